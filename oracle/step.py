@@ -1,0 +1,133 @@
+"""
+Oracle (test infrastructure): ONE whole CutMix mean-teacher training iteration on PyTorch-CPU fp32, restated from
+train_seg_semisup_mask_mt.py:287-467 with the oracle pieces:
+
+    zero grads                                             :290
+    sup:   CE(student(x), y[:,0]).backward()               :296-301
+    unsup: paste images / validity masks                   :346-351   (mix)   |  x*m   :389 (cut)
+           teacher(x0), teacher(x1) under no_grad          :354-356
+           student(x_mix)                                  :358
+           paste teacher logits, softmax, confidence, loss :363-458
+           backward                                        :459
+    optimizer step (k-fold updates on duplicated entries)  :465   (deeplab2.py:208-230 duplicates)
+    EMA step over every float state tensor                 :466-467 (optim_weight_ema.py:21-25)
+
+This is what `bench.py` times as `cpu_baseline` (kind "port") and what tests compare the device step against.
+State lives in plain dicts of tensors keyed by the reference's state_dict names.
+
+Pinned by tests/golden/step.npz (three iterations of the reference modules on the tiny network).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import deeplab2 as dl
+from . import losses as L
+
+
+class StepState(object):
+    """Student / teacher state dicts + optimizer slots for the trainable tensors."""
+
+    def __init__(self, student_state, num_classes, layers=dl.LAYERS, opt='adam', lr=1e-4, teacher_alpha=0.99,
+                 sgd_momentum=0.9, sgd_nesterov=False, sgd_weight_decay=5e-4):
+        self.layers = tuple(layers)
+        self.num_classes = num_classes
+        self.student = OrderedDict((k, v.clone()) for k, v in student_state.items())
+        # EMAWeightOptimizer.__init__ copies every float tensor (optim_weight_ema.py:12-13); the int64
+        # num_batches_tracked entries keep the teacher's own values.
+        self.teacher = OrderedDict((k, v.clone()) for k, v in student_state.items())
+        self.opt = opt
+        self.teacher_alpha = teacher_alpha
+        self.sgd = (sgd_momentum, sgd_nesterov, sgd_weight_decay)
+        g0, g1 = dl.param_multiplicity(num_classes, layers)
+        self.entries = [(k, mult, lr * 0.1) for k, mult in g0.items()] + [(k, mult, lr) for k, mult in g1.items()]
+        self.base_lrs = {k: l for k, _, l in self.entries}
+        self.lr_scale = 1.0
+        self.m = {k: torch.zeros_like(self.student[k]) for k, _, _ in self.entries}
+        self.v = {k: torch.zeros_like(self.student[k]) for k, _, _ in self.entries}
+        self.steps = {k: 0 for k, _, _ in self.entries}
+        self.buf = {k: None for k, _, _ in self.entries}
+
+
+def _adam_k(p, g, m, v, step, lr, k, beta1=0.9, beta2=0.999, eps=1e-8):
+    for _ in range(k):
+        step += 1
+        m.lerp_(g, 1 - beta1)
+        v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        bc1 = 1 - beta1 ** step
+        bc2 = 1 - beta2 ** step
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m, denom, value=-(lr / bc1))
+    return step
+
+
+def _sgd_k(p, g, buf, lr, k, momentum, nesterov, wd):
+    first = buf is None       # see oracle/ema_opt.py:sgd_k_updates for the first-step quirk
+    for _ in range(k):
+        d = g
+        if wd != 0:
+            d = d.add(p, alpha=wd)
+        if momentum != 0:
+            if first:
+                buf = d.clone()
+            else:
+                buf.mul_(momentum).add_(d)
+            d = d.add(buf, alpha=momentum) if nesterov else buf
+        p.add_(d, alpha=-lr)
+    return buf
+
+
+def train_iteration(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode='mix', loss_fn='var', conf_thresh=0.97,
+                    conf_per_pixel=False, ramp_val=1.0, rampup=-1, cons_weight=1.0, frozen_bn=True):
+    """
+    One iteration. `sup_y` int64 (N,1,H,W) with 255 = ignore; `masks` float (N,1,H,W) in {0,1}.
+    In cut mode ux1/um1 are ignored. Returns dict(sup_loss, consistency_loss, conf_rate).
+    """
+    if not frozen_bn:
+        raise NotImplementedError('oracle step covers the --freeze_bn configuration (cfg 2/3)')
+    keys = [k for k, _, _ in S.entries]
+    leaves = {k: S.student[k].clone().requires_grad_(True) for k in keys}
+    st = OrderedDict(S.student)
+    st.update(leaves)
+
+    logits_sup = dl.forward(sup_x, st, S.layers, frozen=True)
+    sup_loss = L.supervised_ce(logits_sup, sup_y[:, 0])
+    total = sup_loss
+    closs = None
+    rate = None
+    if cons_weight > 0.0:
+        with torch.no_grad():
+            l0 = dl.forward(ux0, S.teacher, S.layers, frozen=True)
+            l1 = dl.forward(ux1, S.teacher, S.layers, frozen=True) if mode == 'mix' else None
+        kw = dict(loss_fn=loss_fn, conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, ramp_val=ramp_val,
+                  rampup=rampup, cons_weight=cons_weight)
+        if mode == 'mix':
+            l_stu = dl.forward(L.paste(ux0, ux1, masks), st, S.layers, frozen=True)
+            r = L.mix_mode_loss(l_stu, l0, l1, masks, um0, um1, **kw)
+        else:
+            l_stu = dl.forward(ux0 * masks, st, S.layers, frozen=True)
+            r = L.cut_mode_loss(l_stu, l0, masks, um0, **kw)
+        total = total + r['unsup_loss']
+        closs, rate = r['consistency_loss'], r['conf_rate']
+    total.backward()       # the reference back-props the two losses separately; the gradients add
+
+    with torch.no_grad():
+        for k, mult, base_lr in S.entries:
+            g = leaves[k].grad
+            if g is None:      # ASPP d18/d24 never receive gradients and are skipped by the optimizer
+                continue
+            lr = base_lr * S.lr_scale
+            if S.opt == 'adam':
+                S.steps[k] = _adam_k(S.student[k], g, S.m[k], S.v[k], S.steps[k], lr, mult)
+            else:
+                mom, nest, wd = S.sgd
+                S.buf[k] = _sgd_k(S.student[k], g, S.buf[k], lr, mult, mom, nest, wd)
+        a = S.teacher_alpha
+        for k, t in S.teacher.items():
+            if t.dtype == torch.float32:
+                t.mul_(a)
+                t.add_(S.student[k] * (1.0 - a))
+    return dict(sup_loss=float(sup_loss.detach()),
+                consistency_loss=None if closs is None else float(closs.detach()),
+                conf_rate=None if rate is None else float(rate))
