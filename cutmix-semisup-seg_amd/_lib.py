@@ -1,0 +1,118 @@
+"""
+ctypes binding of libcutmixseg_hip.so (C ABI: include/cutmixseg.h).
+
+There is deliberately NO fallback: if the shared object has not been built (python cutmix-semisup-seg_amd/build.py,
+or __graft_entry__.build()) importing this module raises, and every op in the package fails with it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libcutmixseg_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError('libcutmixseg_hip.so not found at {} -- build it with '
+                      '`python cutmix-semisup-seg_amd/build.py` (hipcc, gfx950); there is no CPU fallback'.format(LIB_PATH))
+
+lib = C.CDLL(LIB_PATH)
+
+F32, BF16 = 0, 1
+LABEL_U8, LABEL_I64 = 0, 1
+LOSS_IDS = {'var': 0, 'logits_var': 1, 'logits_smoothl1': 2, 'bce': 3, 'kld': 4}
+MODE_MIX, MODE_CUT = 0, 1
+OPT_CHUNK = 2048
+
+c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class ConsistencyDesc(C.Structure):
+    _fields_ = [('l_stu', c_void_p), ('l_tea0', c_void_p), ('l_tea1', c_void_p), ('ranges', c_void_p),
+                ('mask', c_void_p), ('um0', c_void_p), ('um1', c_void_p),
+                ('n', c_int), ('c', c_int), ('h', c_int), ('w', c_int), ('H', c_int), ('W', c_int),
+                ('align_corners', c_int), ('n_boxes', c_int), ('invert', c_int), ('mode', c_int),
+                ('loss_fn', c_int), ('conf_thresh', c_float), ('conf_per_pixel', c_int)]
+
+
+class CeDesc(C.Structure):
+    _fields_ = [('logits', c_void_p), ('labels', c_void_p), ('label_dtype', c_int), ('ignore_index', c_int),
+                ('n', c_int), ('c', c_int), ('h', c_int), ('w', c_int), ('H', c_int), ('W', c_int),
+                ('align_corners', c_int)]
+
+
+class ParamSegment(C.Structure):
+    _fields_ = [('offset', C.c_uint64), ('count', C.c_uint64), ('k_updates', C.c_int32), ('lr_group', C.c_int32)]
+
+
+class OptimDesc(C.Structure):
+    _fields_ = [('param', c_void_p), ('grad', c_void_p), ('slot0', c_void_p), ('slot1', c_void_p),
+                ('ema_param', c_void_p), ('param_bf16', c_void_p), ('ema_bf16', c_void_p),
+                ('segments', c_void_p), ('chunk_seg', c_void_p), ('chunk_off', c_void_p), ('n_chunks', C.c_uint32),
+                ('lrs', c_void_p), ('step_count', c_void_p),
+                ('grad_scale', c_float), ('ema_alpha', c_float), ('ema_one_minus_alpha', c_float),
+                ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
+                ('momentum', c_float), ('weight_decay', c_float), ('nesterov', c_int)]
+
+
+_P = C.POINTER
+
+
+def _proto(name, restype, argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+# every symbol include/cutmixseg.h declares (tests/test_abi.py checks the header against this table)
+PROTOTYPES = {
+    'cms_version': (c_int, []),
+    'cms_last_error': (C.c_char_p, []),
+    'cms_device_info': (c_int, [_P(c_int), C.c_char_p, c_size_t]),
+    'cms_boxmask_rasterize': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'cms_cutmix_paste': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, c_void_p]),
+    'cms_cutmix_paste_mask': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_void_p]),
+    'cms_consistency_workspace_bytes': (c_size_t, [_P(ConsistencyDesc)]),
+    'cms_consistency_fwd': (c_int, [_P(ConsistencyDesc), c_void_p, c_void_p, c_void_p]),
+    'cms_consistency_finalize': (c_int, [c_void_p, c_void_p, c_float, c_int, c_float, c_float, c_void_p, c_void_p]),
+    'cms_consistency_bwd': (c_int, [_P(ConsistencyDesc), c_void_p, c_void_p, c_void_p]),
+    'cms_ce_workspace_bytes': (c_size_t, [_P(CeDesc)]),
+    'cms_ce_fwd': (c_int, [_P(CeDesc), c_void_p, c_void_p, c_void_p]),
+    'cms_ce_finalize': (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
+    'cms_ce_bwd': (c_int, [_P(CeDesc), c_void_p, c_void_p, c_void_p]),
+    'cms_upsample_bilinear_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p]),
+    'cms_upsample_bilinear_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p]),
+    'cms_ema_flat': (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p, c_void_p]),
+    'cms_adam_ema_step': (c_int, [_P(OptimDesc), c_void_p]),
+    'cms_sgd_ema_step': (c_int, [_P(OptimDesc), c_void_p]),
+    'cms_increment_counter': (c_int, [c_void_p, c_void_p]),
+    'cms_argmax_confusion': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_void_p, c_void_p, c_void_p]),
+    'cms_confusion': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
+}
+
+fn = {}
+for _name, (_res, _args) in PROTOTYPES.items():
+    fn[_name] = _proto(_name, _res, _args)
+
+
+class CmsError(RuntimeError):
+    pass
+
+
+def check(rc, what=''):
+    """Raise on a negative return code. CMS_EINVAL maps to ValueError (the reference raises ValueError for bad
+    configuration), everything else to CmsError."""
+    if rc == 0:
+        return
+    msg = fn['cms_last_error']().decode(errors='replace')
+    if rc == -1:
+        raise ValueError('{}: {}'.format(what or 'cutmixseg', msg))
+    raise CmsError('{} failed (code {}): {}'.format(what or 'cutmixseg', rc, msg))
+
+
+def version():
+    return fn['cms_version']()

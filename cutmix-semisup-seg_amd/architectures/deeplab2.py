@@ -1,0 +1,304 @@
+"""
+Mirror of the reference's architectures/deeplab2.py: DeepLab v2 on ResNet-101 (the network of BASELINE configs 2
+and 3), same constructor / attributes / state_dict keys, executed MI355X-first.
+
+Kept from the reference (file:line relative to upstream):
+  * structure: 7x7/2 stem, max-pool 3x3/2 ceil_mode (deeplab2.py:140-146); bottlenecks with the stride on the FIRST
+    1x1 (Caffe style, :70) and a dilated 3x3 (:76-77); layers [3,4,23,3] with layer3 dilation 2 and layer4 dilation 4
+    at stride 1 (:147-150); a downsample branch on every first block (:163-168)
+  * ASPP head of four 3x3 convs 2048->C with dilations 6/12/18/24 of which only the first two are ever summed
+    because of the early `return` in the reference's loop (:124-128)  [SURVEY Appendix A, Q1]
+  * every BatchNorm affine parameter has requires_grad=False (:72-84, 143-144, 170-171); `freeze_batchnorm()` puts
+    BN layers in eval mode (:244-245)
+  * initialisation: conv weights ~ N(0, 0.01), BN gamma 1 / beta 0 (:153-159)
+  * `pretrained_parameters()` yields each backbone conv weight once per enclosing module of the walk (3x for block
+    convs, 4x for downsample convs, 1x for the stem) and `new_parameters()` yields the ASPP tensors (:208-242)
+  * BLOCK_SIZE / MEAN / STD attributes, the three factory functions and `_load_state_into_model` (:248-322)
+  * `forward(x)` returns logits at the input resolution through a bilinear upsample with align_corners=True (:204)
+
+MI355X-first:
+  * activations are bf16 NHWC (channels-last) between layers, fp32 accumulation, logits leave the head in fp32
+  * frozen BatchNorm is an affine epilogue of the convolution that produced its input (scale/shift folded per
+    forward from the fp32 BN tensors) instead of a separate pass over the activation
+  * `forward_lowres(x)` exposes the (N,C,h,w) head output so that the loss / evaluation kernels can fuse the
+    upsample (ops.py) -- the training step never materialises (N,C,H,W) logits
+  * weights are read from the bf16 copy the fused optimizer maintains in the parameter arena when present
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .util import freeze_bn_module
+
+affine_par = True
+
+_RESNET_101_DEEPLAB_COCO_URL = 'http://vllab1.ucmerced.edu/~whung/adv-semi-seg/resnet101COCO-41f33a49.pth'
+_RESNET_101_IMAGENET_URL = 'https://download.pytorch.org/models/resnet101-5d3b4d8f.pth'
+
+ASPP_DILATIONS = (6, 12, 18, 24)
+ASPP_LIVE = 2          # number of branches the reference's forward actually sums
+
+
+def _frozen_bn(n):
+    bn = nn.BatchNorm2d(n, affine=affine_par)
+    for p in bn.parameters():
+        p.requires_grad = False
+    return bn
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+        super(Bottleneck, self).__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride, bias=False)
+        self.bn1 = _frozen_bn(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=dilation, bias=False,
+                               dilation=dilation)
+        self.bn2 = _frozen_bn(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = _frozen_bn(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x, eng=None):
+        eng = eng or _default_engine(x)
+        out = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        out = eng.conv_bn_act(out, self.conv2, self.bn2, relu=True)
+        if self.downsample is not None:
+            residual = eng.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        else:
+            residual = x
+        return eng.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=residual)
+
+
+class Classifier_Module(nn.Module):
+    def __init__(self, dilation_series, padding_series, num_classes):
+        super(Classifier_Module, self).__init__()
+        self.conv2d_list = nn.ModuleList()
+        for dilation, padding in zip(dilation_series, padding_series):
+            self.conv2d_list.append(nn.Conv2d(2048, num_classes, kernel_size=3, stride=1, padding=padding,
+                                              dilation=dilation, bias=True))
+        for m in self.conv2d_list:
+            m.weight.data.normal_(0, 0.01)
+
+    def forward(self, x, eng=None):
+        eng = eng or _default_engine(x)
+        # conv_d6(x) + conv_d12(x): the reference returns from inside its accumulation loop after one iteration
+        return eng.aspp_head(x, [self.conv2d_list[i] for i in range(ASPP_LIVE)])
+
+
+class TorchEngine(object):
+    """
+    Executes conv(+frozen-BN affine)(+residual)(+ReLU) units with library kernels (MIOpen / hipBLASLt via torch) in
+    `dtype`, channels-last. Interim executor for the backbone until the hand-written MFMA implicit-GEMM kernels
+    (csrc/conv.hip) cover a layer; numerics reference for them on the GPU.
+    """
+
+    def __init__(self, dtype=torch.bfloat16):
+        self.dtype = dtype
+
+    def _weight(self, conv):
+        w = conv.weight
+        if w.dtype != self.dtype:
+            w = w.to(self.dtype)
+        return w
+
+    def prepare_input(self, x):
+        return x.to(dtype=self.dtype, memory_format=torch.channels_last)
+
+    def conv_bn_act(self, x, conv, bn, relu, residual=None):
+        y = F.conv2d(x, self._weight(conv), None, conv.stride, conv.padding, conv.dilation)
+        if bn is not None:
+            if bn.training:
+                y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+            else:
+                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                shift = bn.bias - bn.running_mean * scale
+                y = torch.addcmul(shift.to(y.dtype).view(1, -1, 1, 1), y, scale.to(y.dtype).view(1, -1, 1, 1))
+        if residual is not None:
+            y = y + residual
+        if relu:
+            y = F.relu(y, inplace=True)
+        return y
+
+    def aspp_head(self, x, convs):
+        out = None
+        for conv in convs:
+            y = F.conv2d(x, self._weight(conv), None, conv.stride, conv.padding, conv.dilation)
+            out = y if out is None else out + y
+        bias = sum(c.bias for c in convs)
+        return out.float() + bias.view(1, -1, 1, 1)
+
+    def maxpool(self, x):
+        return F.max_pool2d(x, kernel_size=3, stride=2, padding=1, ceil_mode=True)
+
+
+_ENGINES = {}
+
+
+def _default_engine(x):
+    if not x.is_cuda:
+        raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
+                           'fallback'.format(x.device))
+    key = ('torch', x.dtype if x.dtype in (torch.bfloat16, torch.float32) else torch.bfloat16)
+    if key not in _ENGINES:
+        _ENGINES[key] = TorchEngine(key[1])
+    return _ENGINES[key]
+
+
+class ResNetDeepLab(nn.Module):
+    BLOCK_SIZE = (1, 1)
+
+    def __init__(self, block, layers, num_classes, mean, std):
+        self.MEAN = mean
+        self.STD = std
+        self.inplanes = 64
+        super(ResNetDeepLab, self).__init__()
+        self.num_classes = num_classes
+        self.compute_dtype = torch.bfloat16
+        self.engine = None          # set to an engine object to override the default executor
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = _frozen_bn(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1, ceil_mode=True)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=1, dilation=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=1, dilation=4)
+        self.layer5 = Classifier_Module(list(ASPP_DILATIONS), list(ASPP_DILATIONS), num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data.normal_(0, 0.01)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilation=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion or dilation == 2 or dilation == 4:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                _frozen_bn(planes * block.expansion))
+        stages = [block(self.inplanes, planes, stride, dilation=dilation, downsample=downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            stages.append(block(self.inplanes, planes, dilation=dilation))
+        return nn.Sequential(*stages)
+
+    # ------------------------------------------------------------------------------------------ execution
+    def _engine(self, x):
+        if self.engine is not None:
+            return self.engine
+        if not x.is_cuda:
+            raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
+                               'fallback'.format(x.device))
+        key = ('torch', self.compute_dtype)
+        if key not in _ENGINES:
+            _ENGINES[key] = TorchEngine(self.compute_dtype)
+        return _ENGINES[key]
+
+    def forward_lowres(self, x):
+        """(N,3,H,W) -> (N,C,h,w) fp32 head output (the reference's `x` just before its interpolate, :193)."""
+        eng = self._engine(x)
+        x = eng.prepare_input(x)
+        x = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        x = eng.maxpool(x)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                x = blk(x, eng)
+        return self.layer5(x, eng)
+
+    def forward(self, x, use_dropout=False):
+        lo = self.forward_lowres(x)
+        return ops.upsample_bilinear(lo, x.shape[2:4], align_corners=True)
+
+    upsample_align_corners = True
+
+    # ------------------------------------------------------------------------------------------ parameter groups
+    def pretrained_parameters(self):
+        """
+        Trainable parameters of everything except the classification head. As in the reference, the walk visits
+        every module nested under conv1 / bn1 / layer1..4 and yields each visited module's (recursive) trainable
+        parameters, so a tensor comes out once per enclosing module: block conv weights 3x, downsample convs 4x,
+        the stem conv once. BatchNorm parameters never appear (requires_grad is False).
+        """
+        for top in (self.conv1, self.bn1, self.layer1, self.layer2, self.layer3, self.layer4):
+            for sub in top.modules():
+                for p in sub.parameters():
+                    if p.requires_grad:
+                        yield p
+
+    def new_parameters(self):
+        """The parameters of the classification head (all four ASPP branches)."""
+        for p in self.layer5.parameters():
+            yield p
+
+    def unused_parameter_keys(self):
+        """state_dict keys of parameters that never receive a gradient (ASPP d18 / d24): torch's optimizers skip
+        them (grad is None); the fused optimizer needs to be told."""
+        keys = []
+        for i in range(ASPP_LIVE, len(self.layer5.conv2d_list)):
+            keys += ['layer5.conv2d_list.{}.weight'.format(i), 'layer5.conv2d_list.{}.bias'.format(i)]
+        return keys
+
+    def freeze_batchnorm(self):
+        self.apply(freeze_bn_module)
+
+
+def _hung_mean_std():
+    # BGR ImageNet means of the Caffe model flipped to RGB and scaled to [0,1]; std 1/255 re-expands to [0,255]
+    mean = np.array((104.00698793, 116.66876762, 122.67891434))[::-1] / 255.0
+    std = np.array([1, 1, 1]) / 255.0
+    return mean, std
+
+
+def _load_url(url):
+    from torch.utils.model_zoo import load_url
+    return load_url(url)
+
+
+def resnet101_deeplab_coco(num_classes=21, pretrained=True):
+    mean, std = _hung_mean_std()
+    model = ResNetDeepLab(Bottleneck, [3, 4, 23, 3], num_classes, mean, std)
+    if pretrained:
+        _load_state_into_model(model, _load_url(_RESNET_101_DEEPLAB_COCO_URL))
+    return model
+
+
+def resnet101_deeplab_imagenet(num_classes=21, pretrained=True):
+    mean = np.array([0.485, 0.456, 0.406])
+    std = np.array([0.229, 0.224, 0.225])
+    model = ResNetDeepLab(Bottleneck, [3, 4, 23, 3], num_classes, mean, std)
+    if pretrained:
+        _load_state_into_model(model, _load_url(_RESNET_101_IMAGENET_URL))
+    return model
+
+
+def resnet101_deeplab_imagenet_mittal_std(num_classes=21, pretrained=True):
+    mean, std = _hung_mean_std()
+    model = ResNetDeepLab(Bottleneck, [3, 4, 23, 3], num_classes, mean, std)
+    if pretrained:
+        _load_state_into_model(model, _load_url(_RESNET_101_IMAGENET_URL))
+    return model
+
+
+def _load_state_into_model(model, state_dict, verbose=False):
+    """Copy every tensor of `state_dict` whose name and shape match into the model (others keep their init)."""
+    own = model.state_dict()
+    with torch.no_grad():
+        for name, param in own.items():
+            if name not in state_dict:
+                if verbose:
+                    print('Could not find {}'.format(name))
+            elif param.size() != state_dict[name].size():
+                if verbose:
+                    print('{} -> {}'.format(state_dict[name].shape, param.shape))
+            else:
+                param.copy_(state_dict[name])
+    model.load_state_dict(own)

@@ -1,0 +1,120 @@
+"""
+Flat fp32 parameter arenas.
+
+The reference keeps 528 separate float state tensors per network and walks them from Python for the optimizer
+(314 + 8 entries) and the EMA (528 x 3 launches), optim_weight_ema.py:21-25 / train_seg_semisup_mask_mt.py:465-467.
+Here every float tensor of a module's state_dict (parameters AND buffers, in state_dict order, each aligned to 64
+elements) is re-homed into ONE contiguous fp32 CUDA buffer; the module's tensors become views into it. That gives
+
+  * one fused optimizer + EMA launch per step (csrc/optim.hip),
+  * one gradient buffer (`grad`) -> a single large all-reduce over RCCL instead of per-tensor buckets,
+  * bf16 copies of student / teacher weights written by the same kernel for the bf16 conv path.
+
+int64 `num_batches_tracked` buffers are left alone (the reference's EMA never touches them).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+ALIGN = 64   # elements (256 B)
+
+
+class Segment(object):
+    __slots__ = ('key', 'offset', 'count', 'shape', 'is_param', 'requires_grad')
+
+    def __init__(self, key, offset, count, shape, is_param, requires_grad):
+        self.key, self.offset, self.count, self.shape = key, offset, count, tuple(shape)
+        self.is_param, self.requires_grad = is_param, requires_grad
+
+
+class ParamArena(object):
+    """Re-homes the float32 state of `module` into one flat CUDA buffer (in place; tensor values preserved)."""
+
+    def __init__(self, module, with_grad=True, with_bf16=False):
+        self.module = module
+        named = OrderedDict()
+        params = dict(module.named_parameters())
+        for key, t in module.state_dict(keep_vars=True).items():
+            if t.dtype == torch.float32:
+                named[key] = t
+        if not named:
+            raise ValueError('module has no float32 state')
+        dev = next(iter(named.values())).device
+        if dev.type != 'cuda':
+            raise RuntimeError('ParamArena needs the module on the GPU (got {}); no CPU fallback'.format(dev))
+        self.device = dev
+        self.segments = []
+        off = 0
+        for key, t in named.items():
+            cnt = t.numel()
+            self.segments.append(Segment(key, off, cnt, t.shape, key in params,
+                                         bool(key in params and params[key].requires_grad)))
+            off += (cnt + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.by_key = {s.key: s for s in self.segments}
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev) if with_grad else None
+        self.bf16 = torch.zeros(self.total, dtype=torch.bfloat16, device=dev) if with_bf16 else None
+        with torch.no_grad():
+            for s in self.segments:
+                t = named[s.key]
+                view = self.flat[s.offset:s.offset + s.count].view(s.shape)
+                view.copy_(t)
+                t.data = view            # parameters and buffers alike keep their identity, storage moves
+                if with_grad and s.requires_grad:
+                    t.grad = self.grad[s.offset:s.offset + s.count].view(s.shape)
+        if with_bf16:
+            self.refresh_bf16()
+
+    def view(self, key, buf=None):
+        s = self.by_key[key]
+        buf = self.flat if buf is None else buf
+        return buf[s.offset:s.offset + s.count].view(s.shape)
+
+    def refresh_bf16(self):
+        if self.bf16 is not None:
+            self.bf16.copy_(self.flat)
+
+    def zero_grad(self):
+        if self.grad is not None:
+            self.grad.zero_()
+
+    def keys(self):
+        return [s.key for s in self.segments]
+
+    def same_layout(self, other):
+        return (self.total == other.total and len(self.segments) == len(other.segments) and
+                all(a.key == b.key and a.offset == b.offset and a.count == b.count
+                    for a, b in zip(self.segments, other.segments)))
+
+
+def arena_of(module):
+    return getattr(module, '_cms_arena', None)
+
+
+def ensure_arena(module, with_grad=True, with_bf16=False):
+    a = arena_of(module)
+    if a is None:
+        a = ParamArena(module, with_grad=with_grad, with_bf16=with_bf16)
+        module._cms_arena = a
+    else:
+        if with_bf16 and a.bf16 is None:
+            a.bf16 = torch.zeros(a.total, dtype=torch.bfloat16, device=a.device)
+            a.refresh_bf16()
+        if with_grad and a.grad is None:
+            a.grad = torch.zeros(a.total, dtype=torch.float32, device=a.device)
+            for s in a.segments:
+                if s.requires_grad:
+                    dict(module.named_parameters())[s.key].grad = a.grad[s.offset:s.offset + s.count].view(s.shape)
+    return a
+
+
+def build_chunk_table(segments_kcount, chunk):
+    """[(count), ...] per segment -> (chunk_seg uint32[], chunk_off uint32[]) covering every element once."""
+    seg_ids, offs = [], []
+    for i, cnt in enumerate(segments_kcount):
+        n = (cnt + chunk - 1) // chunk
+        seg_ids.append(np.full(n, i, dtype=np.uint32))
+        offs.append(np.arange(n, dtype=np.uint32) * np.uint32(chunk))
+    return np.concatenate(seg_ids), np.concatenate(offs)

@@ -1,0 +1,711 @@
+// Fused loss kernels of the CutMix mean-teacher step (gfx950).
+//
+//   consistency:  bilinear upsample of low-res logits + paste of the two teacher predictions with the box mask
+//                 (rasterised in-kernel) + softmax x2 + confidence threshold + one of five per-pixel losses +
+//                 masked mean, forward and backward.           train_seg_semisup_mask_mt.py:363-367, 407-459
+//   supervised:   bilinear upsample + log-softmax + NLL(ignore_index), forward and backward.    :126, 299-301
+//
+// Design (MI355X-first): the (N,C,H,W) full-resolution logits / probabilities / per-pixel loss maps of the
+// reference (12+ elementwise kernels and their autograd twins, (5C+4)*P*4 bytes of HBM traffic) are never
+// materialised. One thread owns one output pixel, lanes of a wave are consecutive x so the hi-res validity masks
+// are read fully coalesced, the low-res logits (a few MB, L2-resident) are gathered with the 4 bilinear taps, the
+// class axis lives in registers (compile-time C for 2/5/19/21) so the channel reductions need no cross-lane
+// traffic; the only cross-lane work is the wave-shuffle + LDS block reduction of the three loss sums.
+// Backward: the per-pixel gradient vector is scattered to the low-res logits through an LDS-tiled separable
+// adjoint of the bilinear upsample (x-reduce, then y-reduce, fixed order inside a tile), so global atomics are
+// issued per low-res cell per tile instead of per pixel per tap.
+#include "common.hpp"
+
+namespace cms {
+
+// ------------------------------------------------------------------------------------------------ accessors
+template <bool IDENT>
+struct Gather {
+    const float* base;  // class-0 plane of sample n
+    size_t plane;       // h*w
+    int w_in;
+    Tap ty, tx;
+    size_t off;  // y*w + x, IDENT only
+    __device__ __forceinline__ float operator()(int c) const {
+        if (IDENT) return base[c * plane + off];
+        return bilin_gather(base + c * plane, w_in, ty, tx);
+    }
+};
+
+template <int CT>
+struct RegVec {
+    float v[CT > 0 ? CT : 1];
+    __device__ __forceinline__ float operator()(int c) const { return v[c]; }
+};
+
+template <int CT, bool IDENT>
+__device__ __forceinline__ void fill(RegVec<CT>& r, const Gather<IDENT>& g) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) r.v[c] = g(c);
+}
+
+struct Geo {
+    int n, c, h, w, H, W, align;
+    float sy, sx;
+};
+
+// ------------------------------------------------------------------------------------------------ consistency
+struct ConsArgs {
+    cms_consistency_desc d;
+    Geo g;
+    float tau, inv_root_c;
+};
+
+struct ConsPixel {
+    bool m;
+    float um;
+    const float* tea;
+};
+
+__device__ __forceinline__ ConsPixel cons_pixel_inputs(const ConsArgs& a, int n, int y, int x) {
+    const cms_consistency_desc& d = a.d;
+    const size_t pix = ((size_t)n * d.H + y) * d.W + x;
+    ConsPixel p;
+    if (d.mask) {
+        p.m = d.mask[pix] >= 0.5f;
+    } else {
+        p.m = box_mask_bit(d.ranges + (size_t)n * d.n_boxes * 4, d.n_boxes, y, x, d.invert != 0);
+    }
+    const size_t sample = (size_t)n * d.c * d.h * d.w;
+    if (d.mode == MODE_MIX) {
+        // paste of teacher logits and of the validity masks with the same box mask (:351, :363)
+        p.tea = (p.m ? d.l_tea1 : d.l_tea0) + sample;
+        const float* um = p.m ? d.um1 : d.um0;
+        p.um = um ? um[pix] : 1.0f;
+    } else {
+        // cut mode: loss_mask = cut_mask * um (:401)
+        p.tea = d.l_tea0 + sample;
+        p.um = p.m ? (d.um0 ? d.um0[pix] : 1.0f) : 0.0f;
+    }
+    return p;
+}
+
+template <int CT, bool IDENT>
+__global__ __launch_bounds__(256) void cons_fwd_kernel(ConsArgs a, float* __restrict__ partials) {
+    const Geo& g = a.g;
+    const size_t P = (size_t)g.n * g.H * g.W;
+    const size_t plane = (size_t)g.h * g.w;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % g.W);
+        const size_t t = idx / g.W;
+        const int y = (int)(t % g.H);
+        const int n = (int)(t / g.H);
+        const ConsPixel px = cons_pixel_inputs(a, n, y, x);
+        Gather<IDENT> gs, gt;
+        gs.base = a.d.l_stu + (size_t)n * g.c * plane;
+        gt.base = px.tea;
+        gs.plane = gt.plane = plane;
+        gs.w_in = gt.w_in = g.w;
+        if (IDENT) {
+            gs.off = gt.off = (size_t)y * g.w + x;
+        } else {
+            gs.ty = gt.ty = bilin_tap(y, g.sy, g.h, g.align != 0);
+            gs.tx = gt.tx = bilin_tap(x, g.sx, g.w, g.align != 0);
+        }
+        PixelFwd r;
+        if (CT > 0) {
+            RegVec<CT> rs, rt;
+            fill<CT, IDENT>(rs, gs);
+            fill<CT, IDENT>(rt, gt);
+            r = consistency_pixel_fwd<CT>(rs, rt, g.c, a.d.loss_fn, a.inv_root_c);
+        } else {
+            r = consistency_pixel_fwd<0>(gs, gt, g.c, a.d.loss_fn, a.inv_root_c);
+        }
+        const float lm = r.loss * px.um;
+        const float cf = (a.tau > 0.0f && r.conf >= a.tau) ? 1.0f : 0.0f;
+        acc[0] += lm;
+        acc[1] += lm * cf;
+        acc[2] += cf;
+    }
+    __shared__ float red[3 * 16];
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 3 + 0] = acc[0];
+        partials[blockIdx.x * 3 + 1] = acc[1];
+        partials[blockIdx.x * 3 + 2] = acc[2];
+    }
+}
+
+// second stage: fixed-order sum of the per-workgroup partials in double
+template <int K>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nblocks,
+                                                              double* __restrict__ out, double extra, int extra_slot) {
+    __shared__ double sm[K][256];
+    double loc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) loc[k] = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) loc[k] += (double)partials[i * K + k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) sm[k][threadIdx.x] = loc[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) sm[k][threadIdx.x] += sm[k][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = sm[k][0];
+        if (extra_slot >= 0) out[extra_slot] = extra;
+    }
+}
+
+__global__ void cons_finalize_kernel(const double* __restrict__ sl, const double* __restrict__ sg, float tau,
+                                     int per_pixel, float ramp, float weight, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double Pl = sl[3];
+    double closs, gs, rate;
+    if (tau > 0.0f) {
+        rate = sg[2] / sg[3];
+        if (per_pixel) {
+            closs = sl[1] / Pl;
+            gs = 1.0 / Pl;
+        } else {
+            // default mode: the confidence mask is replaced by its scalar mean (:415-418)
+            closs = rate * (sl[0] / Pl);
+            gs = rate / Pl;
+        }
+    } else {
+        rate = NAN;
+        closs = sl[0] / Pl;
+        gs = 1.0 / Pl;
+    }
+    closs *= (double)ramp;                      // :454-455
+    out[0] = (float)closs;                      // logged value, :461
+    out[1] = (float)rate;                       // :413
+    out[2] = (float)(gs * (double)ramp * (double)weight);
+    out[3] = (float)(closs * (double)weight);   // :458
+}
+
+// ---- backward, identity geometry (h == H, w == W): gradients land directly on their own pixel
+template <int CT>
+__global__ __launch_bounds__(256) void cons_bwd_ident_kernel(ConsArgs a, const float* __restrict__ scalars,
+                                                             float* __restrict__ grad) {
+    const Geo& g = a.g;
+    const size_t P = (size_t)g.n * g.H * g.W;
+    const size_t plane = (size_t)g.h * g.w;
+    const float gscale = scalars[2];
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % g.W);
+        const size_t t = idx / g.W;
+        const int y = (int)(t % g.H);
+        const int n = (int)(t / g.H);
+        const ConsPixel px = cons_pixel_inputs(a, n, y, x);
+        Gather<true> gs, gt;
+        gs.base = a.d.l_stu + (size_t)n * g.c * plane;
+        gt.base = px.tea;
+        gs.plane = gt.plane = plane;
+        gs.w_in = gt.w_in = g.w;
+        gs.off = gt.off = (size_t)y * g.w + x;
+        float* gp = grad + (size_t)n * g.c * plane + gs.off;
+        const float base_f = gscale * px.um;
+        const bool pp = a.tau > 0.0f && a.d.conf_per_pixel;
+        if (base_f == 0.0f) continue;
+        if (CT > 0) {
+            RegVec<CT> rs, rt;
+            fill<CT, true>(rs, gs);
+            fill<CT, true>(rt, gt);
+            float gv[CT > 0 ? CT : 1];
+            const float conf = consistency_pixel_bwd<CT>(rs, rt, g.c, a.d.loss_fn, a.inv_root_c,
+                                                        [&](int k, float v) { gv[k] = v; });
+            const float f = (pp && !(conf >= a.tau)) ? 0.0f : base_f;
+#pragma unroll
+            for (int k = 0; k < CT; ++k) gp[k * plane] += f * gv[k];
+        } else {
+            float ms, zs, mt, zt;
+            softmax_stats<0>(gt, g.c, mt, zt);
+            (void)ms; (void)zs;
+            const float conf = 1.0f / zt;
+            const float f = (pp && !(conf >= a.tau)) ? 0.0f : base_f;
+            consistency_pixel_bwd<0>(gs, gt, g.c, a.d.loss_fn, a.inv_root_c,
+                                     [&](int k, float v) { gp[k * plane] += f * v; });
+        }
+    }
+}
+
+// ---- backward with upsampling: LDS-tiled adjoint of the bilinear interpolation ---------------------------------
+// Workgroup = 256 threads = one tile of TILE_H x TILE_W output pixels of one sample.
+//   phase 1  every thread computes the gradient vector of its 2 pixels -> G[row][class][col]        (LDS)
+//   phase 2  x-adjoint:  R[row][class][j] = sum_col wx(col -> cell j) * G[row][class][col]          (LDS)
+//   phase 3  y-adjoint:  out[class][i][j] = sum_row wy(row -> cell i) * R[row][class][j]  -> one global atomicAdd
+// Summation order inside a tile is fixed; only the few tiles that share a low-res cell meet in the atomics.
+constexpr int TILE_W = 64;
+constexpr int TILE_H = 8;
+constexpr int G_LD = TILE_W + 1;  // +1 float: conflict-free column access for class-major readers
+
+struct TileTables {
+    int xi0[TILE_W], xi1[TILE_W];
+    float xw1[TILE_W];
+    int yi0[TILE_H], yi1[TILE_H];
+    float yw1[TILE_H];
+    int x_lo, n_cols, y_lo, n_rows;
+    int xbeg[TILE_W + 2], xend[TILE_W + 2];
+};
+
+inline int tile_max_cols(float sx) { return (int)((TILE_W - 1) * sx) + 3; }
+inline int tile_max_rows(float sy) { return (int)((TILE_H - 1) * sy) + 3; }
+
+inline size_t tile_lds_bytes(int C, float sy, float sx) {
+    size_t g = (size_t)TILE_H * C * G_LD;
+    size_t r = (size_t)TILE_H * C * tile_max_cols(sx);
+    return (g + r) * sizeof(float);
+}
+
+template <class PixelGrad>
+__device__ __forceinline__ void tiled_scatter(const Geo& g, PixelGrad pixel_grad, float* __restrict__ grad_lo,
+                                              float* smem) {
+    __shared__ TileTables tb;
+    const int tiles_x = (g.W + TILE_W - 1) / TILE_W;
+    const int tiles_y = (g.H + TILE_H - 1) / TILE_H;
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x;
+    b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int x0 = tx_i * TILE_W, y0 = ty_i * TILE_H;
+    const int tw = min(TILE_W, g.W - x0), th = min(TILE_H, g.H - y0);
+    const int C = g.c;
+    const int tid = threadIdx.x;
+
+    if (tid < TILE_W) {
+        Tap t = bilin_tap(min(x0 + tid, g.W - 1), g.sx, g.w, g.align != 0);
+        tb.xi0[tid] = t.i0;
+        tb.xi1[tid] = t.i1;
+        tb.xw1[tid] = t.w1;
+    } else if (tid < TILE_W + TILE_H) {
+        const int r = tid - TILE_W;
+        Tap t = bilin_tap(min(y0 + r, g.H - 1), g.sy, g.h, g.align != 0);
+        tb.yi0[r] = t.i0;
+        tb.yi1[r] = t.i1;
+        tb.yw1[r] = t.w1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        tb.x_lo = tb.xi0[0];
+        tb.n_cols = tb.xi1[tw - 1] - tb.xi0[0] + 1;
+        tb.y_lo = tb.yi0[0];
+        tb.n_rows = tb.yi1[th - 1] - tb.yi0[0] + 1;
+    }
+    __syncthreads();
+    if (tid < tb.n_cols) {
+        // contiguous range of tile columns that touch low-res column x_lo + tid (i0 is monotone in x)
+        const int X = tb.x_lo + tid;
+        int lo = tw, hi = 0;
+        for (int c = 0; c < tw; ++c) {
+            if (tb.xi0[c] == X || tb.xi1[c] == X) {
+                lo = min(lo, c);
+                hi = c + 1;
+            }
+        }
+        tb.xbeg[tid] = lo;
+        tb.xend[tid] = hi;
+    }
+
+    float* G = smem;                                 // [TILE_H][C][G_LD]
+    float* R = smem + (size_t)TILE_H * C * G_LD;     // [TILE_H][C][n_cols]
+
+    // phase 1
+    const int col = tid & (TILE_W - 1);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int row = (tid >> 6) + rr * 4;
+        float* gcol = G + ((size_t)row * C) * G_LD + col;
+        const bool valid = col < tw && row < th;
+        bool wrote = false;
+        if (valid) {
+            Tap ty, tx;
+            ty.i0 = tb.yi0[row]; ty.i1 = tb.yi1[row]; ty.w1 = tb.yw1[row]; ty.w0 = 1.0f - ty.w1;
+            tx.i0 = tb.xi0[col]; tx.i1 = tb.xi1[col]; tx.w1 = tb.xw1[col]; tx.w0 = 1.0f - tx.w1;
+            wrote = pixel_grad(n, y0 + row, x0 + col, ty, tx, [&](int k, float v) { gcol[(size_t)k * G_LD] = v; });
+        }
+        if (!wrote) {
+            for (int k = 0; k < C; ++k) gcol[(size_t)k * G_LD] = 0.0f;
+        }
+    }
+    __syncthreads();
+
+    // phase 2: items (row, j, class), class fastest across lanes -> stride G_LD reads, conflict-free
+    const int n_cols = tb.n_cols, n_rows = tb.n_rows;
+    const int items2 = th * n_cols * C;
+    for (int it = tid; it < items2; it += blockDim.x) {
+        const int k = it % C;
+        const int rj = it / C;
+        const int j = rj % n_cols;
+        const int row = rj / n_cols;
+        const int X = tb.x_lo + j;
+        const float* gr = G + ((size_t)row * C + k) * G_LD;
+        float s = 0.0f;
+        for (int c = tb.xbeg[j]; c < tb.xend[j]; ++c) {
+            const float w1 = tb.xw1[c];
+            float wgt = (tb.xi0[c] == X ? 1.0f - w1 : 0.0f) + (tb.xi1[c] == X ? w1 : 0.0f);
+            s += wgt * gr[c];
+        }
+        R[((size_t)row * C + k) * n_cols + j] = s;
+    }
+    __syncthreads();
+
+    // phase 3: items (class, i, j), j fastest -> coalesced atomics
+    const int items3 = C * n_rows * n_cols;
+    const size_t plane = (size_t)g.h * g.w;
+    float* out_n = grad_lo + (size_t)n * C * plane;
+    for (int it = tid; it < items3; it += blockDim.x) {
+        const int j = it % n_cols;
+        const int ki = it / n_cols;
+        const int i = ki % n_rows;
+        const int k = ki / n_rows;
+        const int Y = tb.y_lo + i;
+        float s = 0.0f;
+        for (int row = 0; row < th; ++row) {
+            const float w1 = tb.yw1[row];
+            float wgt = (tb.yi0[row] == Y ? 1.0f - w1 : 0.0f) + (tb.yi1[row] == Y ? w1 : 0.0f);
+            s += wgt * R[((size_t)row * C + k) * n_cols + j];
+        }
+        if (s != 0.0f) atomicAdd(out_n + (size_t)k * plane + (size_t)Y * g.w + (tb.x_lo + j), s);
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void cons_bwd_tiled_kernel(ConsArgs a, const float* __restrict__ scalars,
+                                                             float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Geo& g = a.g;
+    const float gscale = scalars[2];
+    const size_t plane = (size_t)g.h * g.w;
+    const bool pp = a.tau > 0.0f && a.d.conf_per_pixel;
+    auto pixel_grad = [&](int n, int y, int x, const Tap& ty, const Tap& tx, auto emit) -> bool {
+        const ConsPixel px = cons_pixel_inputs(a, n, y, x);
+        const float base_f = gscale * px.um;
+        if (base_f == 0.0f) return false;
+        Gather<false> gs, gt;
+        gs.base = a.d.l_stu + (size_t)n * g.c * plane;
+        gt.base = px.tea;
+        gs.plane = gt.plane = plane;
+        gs.w_in = gt.w_in = g.w;
+        gs.ty = gt.ty = ty;
+        gs.tx = gt.tx = tx;
+        if (CT > 0) {
+            RegVec<CT> rs, rt;
+            fill<CT, false>(rs, gs);
+            fill<CT, false>(rt, gt);
+            float gv[CT > 0 ? CT : 1];
+            const float conf = consistency_pixel_bwd<CT>(rs, rt, g.c, a.d.loss_fn, a.inv_root_c,
+                                                        [&](int k, float v) { gv[k] = v; });
+            const float f = (pp && !(conf >= a.tau)) ? 0.0f : base_f;
+#pragma unroll
+            for (int k = 0; k < CT; ++k) emit(k, f * gv[k]);
+        } else {
+            float mt, zt;
+            softmax_stats<0>(gt, g.c, mt, zt);
+            const float conf = 1.0f / zt;
+            const float f = (pp && !(conf >= a.tau)) ? 0.0f : base_f;
+            consistency_pixel_bwd<0>(gs, gt, g.c, a.d.loss_fn, a.inv_root_c, [&](int k, float v) { emit(k, f * v); });
+        }
+        return true;
+    };
+    tiled_scatter(g, pixel_grad, grad, smem);
+}
+
+// ------------------------------------------------------------------------------------------------ cross entropy
+struct CeArgs {
+    cms_ce_desc d;
+    Geo g;
+};
+
+__device__ __forceinline__ int load_label(const CeArgs& a, size_t pix) {
+    if (a.d.label_dtype == CMS_LABEL_U8) return (int)((const uint8_t*)a.d.labels)[pix];
+    const int64_t v = ((const int64_t*)a.d.labels)[pix];
+    return (v < 0 || v > 0x7fffffff) ? -1 : (int)v;
+}
+
+template <int CT, bool IDENT>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(CeArgs a, float* __restrict__ partials) {
+    const Geo& g = a.g;
+    const size_t P = (size_t)g.n * g.H * g.W;
+    const size_t plane = (size_t)g.h * g.w;
+    float acc[2] = {0.0f, 0.0f};
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += (size_t)gridDim.x * blockDim.x) {
+        const int label = load_label(a, idx);
+        if (label == a.d.ignore_index || label < 0 || label >= g.c) continue;
+        const int x = (int)(idx % g.W);
+        const size_t t = idx / g.W;
+        const int y = (int)(t % g.H);
+        const int n = (int)(t / g.H);
+        Gather<IDENT> gl;
+        gl.base = a.d.logits + (size_t)n * g.c * plane;
+        gl.plane = plane;
+        gl.w_in = g.w;
+        if (IDENT) {
+            gl.off = (size_t)y * g.w + x;
+        } else {
+            gl.ty = bilin_tap(y, g.sy, g.h, g.align != 0);
+            gl.tx = bilin_tap(x, g.sx, g.w, g.align != 0);
+        }
+        float v;
+        if (CT > 0) {
+            RegVec<CT> r;
+            fill<CT, IDENT>(r, gl);
+            float mx, z;
+            softmax_stats<CT>(r, g.c, mx, z);
+            v = -((gl(label) - mx) - logf(z));   // label is a run-time index: re-gather instead of indexing registers
+        } else {
+            v = ce_pixel_fwd<0>(gl, g.c, label);
+        }
+        acc[0] += v;
+        acc[1] += 1.0f;
+    }
+    __shared__ float red[2 * 16];
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 2 + 0] = acc[0];
+        partials[blockIdx.x * 2 + 1] = acc[1];
+    }
+}
+
+__global__ void ce_finalize_kernel(const double* __restrict__ stats, float weight, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out[0] = (float)(stats[0] / stats[1]);
+    out[1] = (float)((double)weight / stats[1]);
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void ce_bwd_ident_kernel(CeArgs a, const float* __restrict__ scalars,
+                                                           float* __restrict__ grad) {
+    const Geo& g = a.g;
+    const size_t P = (size_t)g.n * g.H * g.W;
+    const size_t plane = (size_t)g.h * g.w;
+    const float gscale = scalars[1];
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += (size_t)gridDim.x * blockDim.x) {
+        const int label = load_label(a, idx);
+        if (label == a.d.ignore_index || label < 0 || label >= g.c) continue;
+        const int x = (int)(idx % g.W);
+        const size_t t = idx / g.W;
+        const int y = (int)(t % g.H);
+        const int n = (int)(t / g.H);
+        Gather<true> gl;
+        gl.base = a.d.logits + (size_t)n * g.c * plane;
+        gl.plane = plane;
+        gl.w_in = g.w;
+        gl.off = (size_t)y * g.w + x;
+        float* gp = grad + (size_t)n * g.c * plane + gl.off;
+        if (CT > 0) {
+            RegVec<CT> r;
+            fill<CT, true>(r, gl);
+            ce_pixel_bwd<CT>(r, g.c, label, [&](int k, float v) { gp[k * plane] += gscale * v; });
+        } else {
+            ce_pixel_bwd<0>(gl, g.c, label, [&](int k, float v) { gp[k * plane] += gscale * v; });
+        }
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void ce_bwd_tiled_kernel(CeArgs a, const float* __restrict__ scalars,
+                                                           float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Geo& g = a.g;
+    const float gscale = scalars[1];
+    const size_t plane = (size_t)g.h * g.w;
+    auto pixel_grad = [&](int n, int y, int x, const Tap& ty, const Tap& tx, auto emit) -> bool {
+        const size_t pix = ((size_t)n * g.H + y) * g.W + x;
+        const int label = load_label(a, pix);
+        if (label == a.d.ignore_index || label < 0 || label >= g.c) return false;
+        Gather<false> gl;
+        gl.base = a.d.logits + (size_t)n * g.c * plane;
+        gl.plane = plane;
+        gl.w_in = g.w;
+        gl.ty = ty;
+        gl.tx = tx;
+        if (CT > 0) {
+            RegVec<CT> r;
+            fill<CT, false>(r, gl);
+            ce_pixel_bwd<CT>(r, g.c, label, [&](int k, float v) { emit(k, gscale * v); });
+        } else {
+            ce_pixel_bwd<0>(gl, g.c, label, [&](int k, float v) { emit(k, gscale * v); });
+        }
+        return true;
+    };
+    tiled_scatter(g, pixel_grad, grad, smem);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static Geo make_geo(int n, int c, int h, int w, int H, int W, int align) {
+    Geo g;
+    g.n = n; g.c = c; g.h = h; g.w = w; g.H = H; g.W = W; g.align = align;
+    g.sy = bilin_scale(h, H, align != 0);
+    g.sx = bilin_scale(w, W, align != 0);
+    return g;
+}
+
+static int check_cons(const cms_consistency_desc* d) {
+    CMS_REQUIRE(d != nullptr, "consistency: null descriptor");
+    CMS_REQUIRE(d->l_stu && d->l_tea0, "consistency: l_stu / l_tea0 must not be NULL");
+    CMS_REQUIRE(d->mode == CMS_MODE_MIX || d->mode == CMS_MODE_CUT, "consistency: unknown mode %d", d->mode);
+    CMS_REQUIRE(d->mode != CMS_MODE_MIX || d->l_tea1, "consistency: mix mode needs l_tea1");
+    CMS_REQUIRE((d->ranges != nullptr) != (d->mask != nullptr), "consistency: give exactly one of ranges / mask");
+    CMS_REQUIRE(d->ranges == nullptr || d->n_boxes >= 0, "consistency: n_boxes < 0");
+    CMS_REQUIRE(d->n > 0 && d->c > 0 && d->h > 0 && d->w > 0 && d->H > 0 && d->W > 0, "consistency: bad geometry");
+    CMS_REQUIRE(d->h <= d->H && d->w <= d->W, "consistency: logits larger than the loss geometry");
+    CMS_REQUIRE(d->loss_fn >= CMS_LOSS_VAR && d->loss_fn <= CMS_LOSS_KLD, "Unknown consistency loss function %d",
+                d->loss_fn);
+    return CMS_OK;
+}
+
+static ConsArgs make_cons_args(const cms_consistency_desc* d) {
+    ConsArgs a;
+    a.d = *d;
+    a.g = make_geo(d->n, d->c, d->h, d->w, d->H, d->W, d->align_corners);
+    a.tau = d->conf_thresh;
+    a.inv_root_c = (float)(1.0 / sqrt((double)d->c));
+    return a;
+}
+
+static int fwd_grid(size_t P) { return grid_for(P, 256, 2048); }
+
+#define CMS_DISPATCH_C(C, ...)                    \
+    switch (C) {                                  \
+        case 2: { constexpr int CT = 2; __VA_ARGS__; } break;   \
+        case 5: { constexpr int CT = 5; __VA_ARGS__; } break;   \
+        case 19: { constexpr int CT = 19; __VA_ARGS__; } break; \
+        case 21: { constexpr int CT = 21; __VA_ARGS__; } break; \
+        default: { constexpr int CT = 0; __VA_ARGS__; } break;  \
+    }
+
+}  // namespace cms
+
+using namespace cms;
+
+extern "C" size_t cms_consistency_workspace_bytes(const cms_consistency_desc* d) {
+    if (!d) return 0;
+    return (size_t)fwd_grid((size_t)d->n * d->H * d->W) * 3 * sizeof(float);
+}
+
+extern "C" int cms_consistency_fwd(const cms_consistency_desc* d, void* workspace, double* stats_out, void* stream) {
+    int rc = check_cons(d);
+    if (rc) return rc;
+    CMS_REQUIRE(workspace && stats_out, "consistency_fwd: workspace / stats_out NULL");
+    ConsArgs a = make_cons_args(d);
+    const size_t P = (size_t)d->n * d->H * d->W;
+    const int grid = fwd_grid(P);
+    hipStream_t s = (hipStream_t)stream;
+    const bool ident = d->h == d->H && d->w == d->W;
+    float* partials = (float*)workspace;
+    CMS_DISPATCH_C(d->c, {
+        if (ident) hipLaunchKernelGGL((cons_fwd_kernel<CT, true>), dim3(grid), dim3(256), 0, s, a, partials);
+        else hipLaunchKernelGGL((cons_fwd_kernel<CT, false>), dim3(grid), dim3(256), 0, s, a, partials);
+    });
+    hipLaunchKernelGGL((reduce_partials_kernel<3>), dim3(1), dim3(256), 0, s, partials, grid, stats_out, (double)P, 3);
+    return launch_status("cms_consistency_fwd");
+}
+
+extern "C" int cms_consistency_finalize(const double* stats_local, const double* stats_global, float conf_thresh,
+                                        int conf_per_pixel, float ramp_val, float cons_weight, float* scalars_out,
+                                        void* stream) {
+    CMS_REQUIRE(stats_local && stats_global && scalars_out, "consistency_finalize: NULL argument");
+    hipLaunchKernelGGL(cons_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats_local, stats_global,
+                       conf_thresh, conf_per_pixel, ramp_val, cons_weight, scalars_out);
+    return launch_status("cms_consistency_finalize");
+}
+
+extern "C" int cms_consistency_bwd(const cms_consistency_desc* d, const float* scalars, float* grad_l_stu,
+                                   void* stream) {
+    int rc = check_cons(d);
+    if (rc) return rc;
+    CMS_REQUIRE(scalars && grad_l_stu, "consistency_bwd: scalars / grad NULL");
+    ConsArgs a = make_cons_args(d);
+    hipStream_t s = (hipStream_t)stream;
+    const bool ident = d->h == d->H && d->w == d->W;
+    if (ident) {
+        const int grid = fwd_grid((size_t)d->n * d->H * d->W);
+        CMS_DISPATCH_C(d->c, {
+            hipLaunchKernelGGL((cons_bwd_ident_kernel<CT>), dim3(grid), dim3(256), 0, s, a, scalars, grad_l_stu);
+        });
+    } else {
+        const size_t lds = tile_lds_bytes(d->c, a.g.sy, a.g.sx);
+        CMS_REQUIRE(lds <= 160 * 1024 - 4096, "consistency_bwd: %d classes at this scale need %zu B of LDS", d->c, lds);
+        const int tiles = ((d->W + TILE_W - 1) / TILE_W) * ((d->H + TILE_H - 1) / TILE_H) * d->n;
+        CMS_DISPATCH_C(d->c, {
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute((const void*)cons_bwd_tiled_kernel<CT>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((cons_bwd_tiled_kernel<CT>), dim3(tiles), dim3(256), lds, s, a, scalars, grad_l_stu);
+        });
+    }
+    return launch_status("cms_consistency_bwd");
+}
+
+static int check_ce(const cms_ce_desc* d) {
+    CMS_REQUIRE(d != nullptr, "ce: null descriptor");
+    CMS_REQUIRE(d->logits && d->labels, "ce: logits / labels NULL");
+    CMS_REQUIRE(d->label_dtype == CMS_LABEL_U8 || d->label_dtype == CMS_LABEL_I64, "ce: bad label dtype");
+    CMS_REQUIRE(d->n > 0 && d->c > 0 && d->h > 0 && d->w > 0 && d->H > 0 && d->W > 0, "ce: bad geometry");
+    CMS_REQUIRE(d->h <= d->H && d->w <= d->W, "ce: logits larger than the label geometry");
+    return CMS_OK;
+}
+
+extern "C" size_t cms_ce_workspace_bytes(const cms_ce_desc* d) {
+    if (!d) return 0;
+    return (size_t)fwd_grid((size_t)d->n * d->H * d->W) * 2 * sizeof(float);
+}
+
+extern "C" int cms_ce_fwd(const cms_ce_desc* d, void* workspace, double* stats_out, void* stream) {
+    int rc = check_ce(d);
+    if (rc) return rc;
+    CMS_REQUIRE(workspace && stats_out, "ce_fwd: workspace / stats_out NULL");
+    CeArgs a;
+    a.d = *d;
+    a.g = make_geo(d->n, d->c, d->h, d->w, d->H, d->W, d->align_corners);
+    const int grid = fwd_grid((size_t)d->n * d->H * d->W);
+    hipStream_t s = (hipStream_t)stream;
+    const bool ident = d->h == d->H && d->w == d->W;
+    float* partials = (float*)workspace;
+    CMS_DISPATCH_C(d->c, {
+        if (ident) hipLaunchKernelGGL((ce_fwd_kernel<CT, true>), dim3(grid), dim3(256), 0, s, a, partials);
+        else hipLaunchKernelGGL((ce_fwd_kernel<CT, false>), dim3(grid), dim3(256), 0, s, a, partials);
+    });
+    hipLaunchKernelGGL((reduce_partials_kernel<2>), dim3(1), dim3(256), 0, s, partials, grid, stats_out, 0.0, -1);
+    return launch_status("cms_ce_fwd");
+}
+
+extern "C" int cms_ce_finalize(const double* stats, float loss_weight, float* scalars_out, void* stream) {
+    CMS_REQUIRE(stats && scalars_out, "ce_finalize: NULL argument");
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, loss_weight, scalars_out);
+    return launch_status("cms_ce_finalize");
+}
+
+extern "C" int cms_ce_bwd(const cms_ce_desc* d, const float* scalars, float* grad_logits, void* stream) {
+    int rc = check_ce(d);
+    if (rc) return rc;
+    CMS_REQUIRE(scalars && grad_logits, "ce_bwd: scalars / grad NULL");
+    CeArgs a;
+    a.d = *d;
+    a.g = make_geo(d->n, d->c, d->h, d->w, d->H, d->W, d->align_corners);
+    hipStream_t s = (hipStream_t)stream;
+    const bool ident = d->h == d->H && d->w == d->W;
+    if (ident) {
+        const int grid = fwd_grid((size_t)d->n * d->H * d->W);
+        CMS_DISPATCH_C(d->c, {
+            hipLaunchKernelGGL((ce_bwd_ident_kernel<CT>), dim3(grid), dim3(256), 0, s, a, scalars, grad_logits);
+        });
+    } else {
+        const size_t lds = tile_lds_bytes(d->c, a.g.sy, a.g.sx);
+        CMS_REQUIRE(lds <= 160 * 1024 - 4096, "ce_bwd: %d classes at this scale need %zu B of LDS", d->c, lds);
+        const int tiles = ((d->W + TILE_W - 1) / TILE_W) * ((d->H + TILE_H - 1) / TILE_H) * d->n;
+        CMS_DISPATCH_C(d->c, {
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute((const void*)ce_bwd_tiled_kernel<CT>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((ce_bwd_tiled_kernel<CT>), dim3(tiles), dim3(256), lds, s, a, scalars, grad_logits);
+        });
+    }
+    return launch_status("cms_ce_bwd");
+}

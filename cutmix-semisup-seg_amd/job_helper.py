@@ -1,0 +1,105 @@
+"""
+Mirror of the reference's job_helper.py: the `@job(name)` decorator that gives a training function a
+`.submit(**kwargs)` entry point, creates `results/<job>/log_<desc>.txt` + `results/<job>/<desc>/`, tees
+stdout/stderr into the log and skips a job whose log already exists (job_helper.py:28-146). Host-side plumbing only.
+"""
+import os
+import re
+import sys
+
+LOG_PREFIX = re.compile(r'log_(\d+)')
+JOB_DIR_PREFIX = re.compile(r'(\d+)')
+
+
+class LogAlreadyExistsError(Exception):
+    pass
+
+
+class Logger(object):
+    """File + stream tee (appends, like the reference)."""
+
+    def __init__(self, path, stream):
+        self.path = path
+        self.stream = stream
+
+    def write(self, x):
+        with open(self.path, 'a+') as f_out:
+            f_out.write(x)
+        self.stream.write(x)
+
+    def flush(self):
+        self.stream.flush()
+
+
+class SubmitConfig(object):
+    def __init__(self, job_name, job_desc, enumerate_job_names):
+        res_dir = os.path.join('results', job_name)
+        os.makedirs(res_dir, exist_ok=True)
+        if job_desc == 'none':
+            self.log_path = None
+            self.job_out_dir = None
+        elif enumerate_job_names:
+            index = 0
+            for name in os.listdir(res_dir):
+                for rx in (LOG_PREFIX, JOB_DIR_PREFIX):
+                    m = rx.match(name)
+                    if m is not None:
+                        index = max(index, int(m.group(1)) + 1)
+            self.log_path = os.path.join(res_dir, 'log_{:04d}_{}.txt'.format(index, job_desc))
+            self.job_out_dir = os.path.join(res_dir, '{:04d}_{}'.format(index, job_desc))
+        else:
+            self.log_path = os.path.join(res_dir, 'log_{}.txt'.format(job_desc))
+            self.job_out_dir = os.path.join(res_dir, job_desc)
+            if os.path.exists(self.log_path) or os.path.exists(self.job_out_dir):
+                raise LogAlreadyExistsError
+        self._run_dir = None
+        if self.log_path is not None:
+            self._stdout = Logger(self.log_path, sys.stdout)
+            self._stderr = Logger(self.log_path, sys.stderr)
+
+    @property
+    def run_dir(self):
+        if self._run_dir is None and self.job_out_dir is not None:
+            self._run_dir = self.job_out_dir
+            os.makedirs(self._run_dir, exist_ok=True)
+        return self._run_dir
+
+    def connect_streams(self):
+        if self.log_path is not None:
+            sys.stdout = self._stdout
+            sys.stderr = self._stderr
+
+    def disconnect_streams(self):
+        if self.log_path is not None:
+            sys.stdout = self._stdout.stream
+            sys.stderr = self._stderr.stream
+
+
+def job(job_name, enumerate_job_names=True):
+    """Decorator: `fn.submit(job_desc=..., **kwargs)` runs `fn(submit_config, **kwargs)` under the job's log."""
+
+    def decorate(job_fn):
+        def run_job(**kwargs):
+            specific = kwargs.pop('job_name', None) or job_name
+            quota_group = kwargs.pop('quota_group', None)
+            if quota_group is not None and quota_group != '':
+                raise ValueError('quota_group not supported when dnnlib is not available')
+            desc = kwargs.pop('job_desc', None)
+            if desc is None or desc == '':
+                desc = specific
+            try:
+                submit_config = SubmitConfig(specific, desc, enumerate_job_names)
+            except LogAlreadyExistsError:
+                print('Job {}:{} already executed; skipping'.format(specific, desc))
+                return
+            print('[NO dnnlib] logging to {}'.format(submit_config.log_path))
+            submit_config.connect_streams()
+            try:
+                job_fn(submit_config, **kwargs)
+            finally:
+                submit_config.disconnect_streams()
+
+        job_fn.submit = run_job
+        return job_fn
+
+    return decorate

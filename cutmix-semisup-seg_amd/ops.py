@@ -1,0 +1,373 @@
+"""
+Tensor-level wrappers over the C ABI (include/cutmixseg.h). PyTorch is used for device memory, streams and
+autograd plumbing only; all arithmetic happens in the HIP kernels. Every function requires CUDA(HIP) tensors and
+raises otherwise -- there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import fn, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('cutmix-semisup-seg_amd ops run on the GPU only (got a {} tensor); there is no CPU '
+                               'fallback'.format(t.device))
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return _lib.F32
+    if t.dtype == torch.bfloat16:
+        return _lib.BF16
+    raise TypeError('unsupported dtype {}'.format(t.dtype))
+
+
+# ---------------------------------------------------------------------------------------------- box masks / paste
+def ranges_to_device(ranges, device):
+    """int32 (N, n_boxes, 4) numpy / tensor -> contiguous int32 CUDA tensor."""
+    if isinstance(ranges, np.ndarray):
+        ranges = torch.from_numpy(np.ascontiguousarray(ranges, dtype=np.int32))
+    return ranges.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
+
+
+def boxmask_rasterize(ranges, mask_shape, invert, out=None):
+    """ranges int32 CUDA (N, nb, 4) -> f32 (N,1,H,W). mask_gen.py:110-116 on the device."""
+    _need_cuda(ranges)
+    n, nb = int(ranges.shape[0]), int(ranges.shape[1])
+    H, W = int(mask_shape[0]), int(mask_shape[1])
+    if out is None:
+        out = torch.empty((n, 1, H, W), dtype=torch.float32, device=ranges.device)
+    check(fn['cms_boxmask_rasterize'](_ptr(ranges), n, nb, H, W, int(bool(invert)), _ptr(out), _stream()),
+          'cms_boxmask_rasterize')
+    return out
+
+
+def cutmix_paste(x0, x1, ranges=None, invert=True, mask=None, out=None):
+    """
+    out = x0*(1-m) + x1*m  (train_seg_semisup_mask_mt.py:350-351, 363); x0=None gives x1*m (:389).
+    Give either int32 `ranges` (mask rasterised in-kernel) or a materialised f32 `mask` (N,1,H,W).
+    """
+    _need_cuda(x0, x1, ranges, mask)
+    x1 = x1.contiguous()
+    if x0 is not None:
+        x0 = x0.contiguous()
+        if x0.shape != x1.shape or x0.dtype != x1.dtype:
+            raise ValueError('cutmix_paste: x0/x1 shape or dtype mismatch')
+    n, c, h, w = (int(s) for s in x1.shape)
+    if out is None:
+        out = torch.empty_like(x1)
+    dt = _dtype_code(x1)
+    if (ranges is None) == (mask is None):
+        raise ValueError('cutmix_paste: give exactly one of ranges / mask')
+    if ranges is not None:
+        check(fn['cms_cutmix_paste'](_ptr(x0), _ptr(x1), _ptr(out), dt, _ptr(ranges), n, int(ranges.shape[1]), c, h, w,
+                                     int(bool(invert)), _stream()), 'cms_cutmix_paste')
+    else:
+        mask = _f32c(mask)
+        check(fn['cms_cutmix_paste_mask'](_ptr(x0), _ptr(x1), _ptr(out), dt, _ptr(mask), n, c, h, w, _stream()),
+              'cms_cutmix_paste_mask')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- consistency loss
+class ConsistencyConfig(object):
+    """Static configuration of the unsupervised loss (train_seg_semisup_mask_mt.py CLI flags)."""
+
+    def __init__(self, mode='mix', loss_fn='var', conf_thresh=0.97, conf_per_pixel=False, align_corners=True,
+                 invert=True):
+        if mode not in ('mix', 'cut'):
+            raise ValueError('Unknown mask_mode {}'.format(mode))
+        if loss_fn not in _lib.LOSS_IDS:
+            raise ValueError('Unknown consistency loss function {}'.format(loss_fn))
+        self.mode = mode
+        self.loss_fn = loss_fn
+        self.conf_thresh = float(conf_thresh)
+        self.conf_per_pixel = bool(conf_per_pixel)
+        self.align_corners = bool(align_corners)
+        self.invert = bool(invert)
+
+
+def _cons_desc(cfg, l_stu, l_tea0, l_tea1, ranges, mask, um0, um1, out_size):
+    n, c, h, w = (int(s) for s in l_stu.shape)
+    d = _lib.ConsistencyDesc()
+    d.l_stu, d.l_tea0, d.l_tea1 = l_stu.data_ptr(), l_tea0.data_ptr(), (l_tea1.data_ptr() if l_tea1 is not None else None)
+    d.ranges = ranges.data_ptr() if ranges is not None else None
+    d.mask = mask.data_ptr() if mask is not None else None
+    d.um0 = um0.data_ptr() if um0 is not None else None
+    d.um1 = um1.data_ptr() if um1 is not None else None
+    d.n, d.c, d.h, d.w = n, c, h, w
+    d.H, d.W = int(out_size[0]), int(out_size[1])
+    d.align_corners = int(cfg.align_corners)
+    d.n_boxes = int(ranges.shape[1]) if ranges is not None else 0
+    d.invert = int(cfg.invert)
+    d.mode = _lib.MODE_MIX if cfg.mode == 'mix' else _lib.MODE_CUT
+    d.loss_fn = _lib.LOSS_IDS[cfg.loss_fn]
+    d.conf_thresh = cfg.conf_thresh
+    d.conf_per_pixel = int(cfg.conf_per_pixel)
+    return d
+
+
+def _allreduce_sum(t, group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return True
+    return False
+
+
+def consistency_forward(cfg, l_stu, l_tea0, l_tea1, out_size, ranges=None, mask=None, um0=None, um1=None,
+                        ramp_val=1.0, cons_weight=1.0, group=None, sync_conf_rate=True):
+    """
+    Fused forward. Returns (scalars, ctx): scalars = f32[4] device tensor
+    [consistency_loss, conf_rate, grad_scale, unsup_loss]; ctx feeds consistency_backward. No host sync.
+    Under torch.distributed the confidence count is all-reduced so that the rate is the global one.
+    """
+    _need_cuda(l_stu, l_tea0, l_tea1, ranges, mask, um0, um1)
+    l_stu, l_tea0, l_tea1 = _f32c(l_stu), _f32c(l_tea0), _f32c(l_tea1)
+    mask, um0, um1 = _f32c(mask), _f32c(um0), _f32c(um1)
+    if l_tea0.shape != l_stu.shape or (l_tea1 is not None and l_tea1.shape != l_stu.shape):
+        raise ValueError('consistency: student / teacher logits shapes differ')
+    d = _cons_desc(cfg, l_stu, l_tea0, l_tea1, ranges, mask, um0, um1, out_size)
+    dev = l_stu.device
+    ws = torch.empty(max(int(fn['cms_consistency_workspace_bytes'](C.byref(d))), 16), dtype=torch.uint8, device=dev)
+    stats = torch.empty(4, dtype=torch.float64, device=dev)
+    check(fn['cms_consistency_fwd'](C.byref(d), _ptr(ws), _ptr(stats), _stream()), 'cms_consistency_fwd')
+    stats_g = stats
+    if sync_conf_rate and cfg.conf_thresh > 0.0:
+        g = stats.clone()
+        if _allreduce_sum(g, group):
+            stats_g = g
+    scalars = torch.empty(4, dtype=torch.float32, device=dev)
+    check(fn['cms_consistency_finalize'](_ptr(stats), _ptr(stats_g), cfg.conf_thresh, int(cfg.conf_per_pixel),
+                                         float(ramp_val), float(cons_weight), _ptr(scalars), _stream()),
+          'cms_consistency_finalize')
+    keep = (l_stu, l_tea0, l_tea1, ranges, mask, um0, um1)
+    return scalars, (d, keep, stats)
+
+
+def consistency_backward(ctx, scalars, grad_out=None):
+    """grad wrt the (low-res) student logits; `grad_out` f32 (N,C,h,w) is accumulated into when given."""
+    d, keep, _ = ctx
+    l_stu = keep[0]
+    if grad_out is None:
+        grad_out = torch.zeros_like(l_stu)
+    check(fn['cms_consistency_bwd'](C.byref(d), _ptr(scalars), _ptr(grad_out), _stream()), 'cms_consistency_bwd')
+    return grad_out
+
+
+class _ConsistencyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, l_stu, l_tea0, l_tea1, ranges, mask, um0, um1, cfg, out_size, ramp_val, cons_weight, group):
+        scalars, c = consistency_forward(cfg, l_stu.detach(), l_tea0, l_tea1, out_size, ranges, mask, um0, um1,
+                                         ramp_val, cons_weight, group)
+        ctx.c = c
+        ctx.scalars = scalars
+        ctx.in_dtype = l_stu.dtype
+        closs, rate, unsup = scalars[0], scalars[1], scalars[3]
+        ctx.mark_non_differentiable(closs, rate)
+        return unsup, closs, rate
+
+    @staticmethod
+    def backward(ctx, g_unsup, g_closs, g_rate):
+        sc = ctx.scalars.clone()
+        sc[2] = sc[2] * g_unsup
+        grad = consistency_backward(ctx.c, sc)
+        return (grad.to(ctx.in_dtype),) + (None,) * 11
+
+
+def consistency_loss(l_stu, l_tea0, l_tea1, out_size, cfg, ranges=None, mask=None, um0=None, um1=None, ramp_val=1.0,
+                     cons_weight=1.0, group=None):
+    """autograd entry: returns (unsup_loss [differentiable wrt l_stu], consistency_loss, conf_rate)."""
+    return _ConsistencyFn.apply(l_stu, l_tea0, l_tea1, ranges, mask, um0, um1, cfg, tuple(out_size), ramp_val,
+                                cons_weight, group)
+
+
+# ---------------------------------------------------------------------------------------------- supervised CE
+def _ce_desc(logits, labels, ignore_index, out_size, align_corners):
+    n, c, h, w = (int(s) for s in logits.shape)
+    d = _lib.CeDesc()
+    d.logits, d.labels = logits.data_ptr(), labels.data_ptr()
+    if labels.dtype == torch.uint8:
+        d.label_dtype = _lib.LABEL_U8
+    elif labels.dtype == torch.int64:
+        d.label_dtype = _lib.LABEL_I64
+    else:
+        raise TypeError('labels must be uint8 or int64, got {}'.format(labels.dtype))
+    d.ignore_index = int(ignore_index)
+    d.n, d.c, d.h, d.w = n, c, h, w
+    d.H, d.W = int(out_size[0]), int(out_size[1])
+    d.align_corners = int(bool(align_corners))
+    return d
+
+
+def ce_forward(logits, labels, out_size=None, ignore_index=255, align_corners=True, loss_weight=1.0, group=None,
+               sync_count=False):
+    """labels (N,H,W) uint8/int64. Returns (scalars f32[2] = [loss, grad_scale], ctx)."""
+    _need_cuda(logits, labels)
+    logits = _f32c(logits)
+    labels = labels.contiguous()
+    if labels.dim() == 4:
+        labels = labels[:, 0].contiguous()
+    if out_size is None:
+        out_size = labels.shape[1:3]
+    if tuple(labels.shape) != (logits.shape[0], int(out_size[0]), int(out_size[1])):
+        raise ValueError('ce: labels shape {} does not match (N,H,W)=({}, {}, {})'.format(
+            tuple(labels.shape), logits.shape[0], out_size[0], out_size[1]))
+    d = _ce_desc(logits, labels, ignore_index, out_size, align_corners)
+    dev = logits.device
+    ws = torch.empty(max(int(fn['cms_ce_workspace_bytes'](C.byref(d))), 16), dtype=torch.uint8, device=dev)
+    stats = torch.empty(2, dtype=torch.float64, device=dev)
+    check(fn['cms_ce_fwd'](C.byref(d), _ptr(ws), _ptr(stats), _stream()), 'cms_ce_fwd')
+    if sync_count:
+        # exact global-batch semantics under data parallelism: divide by the mean valid count over ranks
+        import torch.distributed as dist
+        cnt = stats[1:2].clone()
+        if _allreduce_sum(cnt, group):
+            stats = torch.stack([stats[0], cnt[0] / dist.get_world_size(group)])
+    scalars = torch.empty(2, dtype=torch.float32, device=dev)
+    check(fn['cms_ce_finalize'](_ptr(stats), float(loss_weight), _ptr(scalars), _stream()), 'cms_ce_finalize')
+    return scalars, (d, (logits, labels), stats)
+
+
+def ce_backward(ctx, scalars, grad_out=None):
+    d, keep, _ = ctx
+    if grad_out is None:
+        grad_out = torch.zeros_like(keep[0])
+    check(fn['cms_ce_bwd'](C.byref(d), _ptr(scalars), _ptr(grad_out), _stream()), 'cms_ce_bwd')
+    return grad_out
+
+
+class _CeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, out_size, ignore_index, align_corners):
+        scalars, c = ce_forward(logits.detach(), labels, out_size, ignore_index, align_corners)
+        ctx.c = c
+        ctx.scalars = scalars
+        ctx.in_dtype = logits.dtype
+        return scalars[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        sc = ctx.scalars.clone()
+        sc[1] = sc[1] * g
+        return ce_backward(ctx.c, sc).to(ctx.in_dtype), None, None, None, None
+
+
+def cross_entropy(logits, labels, out_size=None, ignore_index=255, align_corners=True):
+    """nn.CrossEntropyLoss(ignore_index)(upsample(logits), labels) with the upsample fused (pass full-res logits for
+    the plain loss)."""
+    return _CeFn.apply(logits, labels, None if out_size is None else tuple(out_size), ignore_index, align_corners)
+
+
+# ---------------------------------------------------------------------------------------------- bilinear upsample
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size, align_corners):
+        _need_cuda(x)
+        xin = _f32c(x)
+        n, c, h, w = (int(s) for s in xin.shape)
+        H, W = int(size[0]), int(size[1])
+        out = torch.empty((n, c, H, W), dtype=torch.float32, device=x.device)
+        check(fn['cms_upsample_bilinear_fwd'](_ptr(xin), _ptr(out), n, c, h, w, H, W, int(bool(align_corners)),
+                                              _stream()), 'cms_upsample_bilinear_fwd')
+        ctx.geo = (n, c, h, w, H, W, int(bool(align_corners)))
+        ctx.in_dtype = x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w, H, W, ac = ctx.geo
+        g = _f32c(g)
+        gi = torch.empty((n, c, h, w), dtype=torch.float32, device=g.device)
+        check(fn['cms_upsample_bilinear_bwd'](_ptr(g), _ptr(gi), n, c, h, w, H, W, ac, _stream()),
+              'cms_upsample_bilinear_bwd')
+        return gi.to(ctx.in_dtype), None, None
+
+
+def upsample_bilinear(x, size, align_corners=True):
+    return _UpsampleFn.apply(x, tuple(size), align_corners)
+
+
+# ---------------------------------------------------------------------------------------------- EMA
+def ema_flat(tgt, src, alpha, tgt_bf16=None):
+    """tgt = tgt*alpha + src*(1-alpha) over flat fp32 CUDA buffers, reference rounding (optim_weight_ema.py:21-25)."""
+    _need_cuda(tgt, src, tgt_bf16)
+    if tgt.dtype != torch.float32 or src.dtype != torch.float32 or not tgt.is_contiguous() or not src.is_contiguous():
+        raise TypeError('ema_flat: contiguous float32 buffers required')
+    if tgt.numel() != src.numel():
+        raise ValueError('ema_flat: size mismatch')
+    one_minus_alpha = 1.0 - float(alpha)      # Python double, cast to fp32 at the ABI like the tensor-scalar mul
+    check(fn['cms_ema_flat'](_ptr(tgt), _ptr(src), tgt.numel(), float(alpha), one_minus_alpha, _ptr(tgt_bf16),
+                             _stream()), 'cms_ema_flat')
+    return tgt
+
+
+# ---------------------------------------------------------------------------------------------- evaluation
+def argmax_confusion(logits, labels, num_classes, out_size=None, ignore_index=255, align_corners=True, cm=None,
+                     want_pred=False):
+    """
+    Fused upsample + argmax + confusion matrix (train_seg_semisup_mask_mt.py:510-514, evaluation.py:6-37).
+    labels (N,H,W) uint8/int64 or None. Returns (cm int64 (C,C) CUDA [accumulated into `cm` when given], pred|None).
+    """
+    _need_cuda(logits, labels, cm)
+    logits = _f32c(logits)
+    n, c, h, w = (int(s) for s in logits.shape)
+    if c != num_classes:
+        raise ValueError('argmax_confusion: logits have {} classes, expected {}'.format(c, num_classes))
+    ldt = _lib.LABEL_U8
+    if labels is not None:
+        if labels.dim() == 4:
+            labels = labels[:, 0]
+        labels = labels.contiguous()
+        ldt = _lib.LABEL_U8 if labels.dtype == torch.uint8 else _lib.LABEL_I64
+        if labels.dtype not in (torch.uint8, torch.int64):
+            raise TypeError('labels must be uint8 or int64')
+        if out_size is None:
+            out_size = labels.shape[1:3]
+    if out_size is None:
+        out_size = (h, w)
+    H, W = int(out_size[0]), int(out_size[1])
+    if labels is not None and cm is None:
+        cm = torch.zeros((c, c), dtype=torch.int64, device=logits.device)
+    pred = torch.empty((n, H, W), dtype=torch.uint8, device=logits.device) if want_pred else None
+    check(fn['cms_argmax_confusion'](_ptr(logits), _ptr(labels), ldt, -1 if ignore_index is None else int(ignore_index),
+                                     n, c, h, w, H, W, int(bool(align_corners)), _ptr(cm), _ptr(pred), _stream()),
+          'cms_argmax_confusion')
+    return cm, pred
+
+
+def confusion(truth, pred, num_classes, ignore_index=None, cm=None):
+    """uint8 CUDA maps of equal shape -> int64 (C,C) confusion matrix (row = truth, column = prediction)."""
+    _need_cuda(truth, pred, cm)
+    truth = truth.contiguous()
+    pred = pred.contiguous()
+    if truth.dtype != torch.uint8 or pred.dtype != torch.uint8:
+        raise TypeError('confusion: uint8 maps required')
+    if truth.numel() != pred.numel():
+        raise ValueError('confusion: size mismatch')
+    if cm is None:
+        cm = torch.zeros((num_classes, num_classes), dtype=torch.int64, device=truth.device)
+    check(fn['cms_confusion'](_ptr(truth), _ptr(pred), truth.numel(), -1 if ignore_index is None else int(ignore_index),
+                              int(num_classes), _ptr(cm), _stream()), 'cms_confusion')
+    return cm

@@ -1,0 +1,162 @@
+"""
+Fused Adam / SGD (+ teacher EMA) over the flat parameter arena -- the device side of
+`torch.optim.Adam([...pretrained @ 0.1 lr..., ...new @ lr...])` / `torch.optim.SGD(...)` in
+train_seg_semisup_mask_mt.py:90-100 and of `student_optim.step(); teacher_optim.step()` at :465-467.
+
+Semantics kept from the reference:
+  * parameter groups with their own `lr` (and `initial_lr`, so lr_schedules work on `param_groups`);
+  * a tensor listed k times in a group (architectures/deeplab2.py:208-230 yields backbone conv weights 3x / 4x)
+    receives k sequential updates per step and Adam's step counter advances by k;
+  * parameters that never receive a gradient (DeepLab v2's ASPP d18 / d24 branches, Q1) are not updated;
+  * a tensor may not sit in two groups (torch raises ValueError).
+One kernel launch per step for all parameters; learning rates travel as a small device array so the launch is
+hipGraph-replayable; the step counter lives on the device.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import fn, check
+from .arena import ensure_arena, build_chunk_table
+
+
+class _FusedOptimizer(object):
+    KIND = None
+
+    def __init__(self, module, param_groups, defaults):
+        self.module = module
+        self.arena = ensure_arena(module, with_grad=True)
+        self.defaults = dict(defaults)
+        a = self.arena
+        ptr2seg = {}
+        base = a.flat.data_ptr()
+        for i, s in enumerate(a.segments):
+            ptr2seg[base + 4 * s.offset] = i
+        self.param_groups = []
+        mult = [0] * len(a.segments)
+        group_of = [-1] * len(a.segments)
+        for gi, g in enumerate(param_groups):
+            g = dict(g)
+            plist = list(g['params'])
+            g['params'] = plist
+            for k, v in self.defaults.items():
+                g.setdefault(k, v)
+            g.setdefault('initial_lr', g['lr'])
+            self.param_groups.append(g)
+            for p in plist:
+                si = ptr2seg.get(p.data_ptr())
+                if si is None:
+                    raise ValueError('optimizer got a parameter that does not live in the module\'s arena')
+                if group_of[si] not in (-1, gi):
+                    raise ValueError('some parameters appear in more than one parameter group')
+                group_of[si] = gi
+                mult[si] += 1
+        unused = set(getattr(module, 'unused_parameter_keys', lambda: [])())
+        if max(mult) > 8:
+            raise ValueError('a parameter is listed more than 8 times')
+        segs = (_lib.ParamSegment * len(a.segments))()
+        for i, s in enumerate(a.segments):
+            segs[i].offset = s.offset
+            segs[i].count = s.count
+            k = mult[i] if (s.requires_grad and s.key not in unused) else 0
+            segs[i].k_updates = k
+            segs[i].lr_group = max(group_of[i], 0)
+        self.k_updates = OrderedDict((s.key, int(segs[i].k_updates)) for i, s in enumerate(a.segments))
+        dev = a.device
+        self._segments = torch.frombuffer(bytearray(bytes(segs)), dtype=torch.uint8).to(dev)
+        cs, co = build_chunk_table([s.count for s in a.segments], _lib.OPT_CHUNK)
+        self._chunk_seg = torch.from_numpy(cs.view(np.int32)).to(dev)
+        self._chunk_off = torch.from_numpy(co.view(np.int32)).to(dev)
+        self._n_chunks = int(cs.shape[0])
+        self.slot0 = torch.zeros_like(a.flat)
+        self.slot1 = torch.zeros_like(a.flat) if self.KIND == 'adam' else None
+        self._lrs_host = torch.zeros(max(len(self.param_groups), 1), dtype=torch.float64).pin_memory() \
+            if torch.cuda.is_available() else torch.zeros(max(len(self.param_groups), 1), dtype=torch.float64)
+        self._lrs_dev = torch.zeros(max(len(self.param_groups), 1), dtype=torch.float64, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.grad_scale = 1.0
+        self._ema = None
+
+    # -- torch.optim-like surface
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    def attach_ema(self, ema_optimizer):
+        if not ema_optimizer.target_arena.same_layout(self.arena):
+            raise ValueError('teacher and student arenas differ')
+        self._ema = ema_optimizer
+
+    def state_dict(self):
+        return dict(kind=self.KIND, step_count=int(self.step_count.item()), slot0=self.slot0, slot1=self.slot1,
+                    param_groups=[{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
+
+    def _desc(self):
+        a = self.arena
+        d = _lib.OptimDesc()
+        d.param, d.grad = a.flat.data_ptr(), a.grad.data_ptr()
+        d.slot0 = self.slot0.data_ptr()
+        d.slot1 = self.slot1.data_ptr() if self.slot1 is not None else None
+        d.param_bf16 = a.bf16.data_ptr() if a.bf16 is not None else None
+        if self._ema is not None:
+            t = self._ema.target_arena
+            d.ema_param = t.flat.data_ptr()
+            d.ema_bf16 = t.bf16.data_ptr() if t.bf16 is not None else None
+            alpha = float(self._ema.ema_alpha)
+            d.ema_alpha = alpha
+            d.ema_one_minus_alpha = 1.0 - alpha
+        else:
+            d.ema_param = None
+            d.ema_bf16 = None
+        d.segments = self._segments.data_ptr()
+        d.chunk_seg = self._chunk_seg.data_ptr()
+        d.chunk_off = self._chunk_off.data_ptr()
+        d.n_chunks = self._n_chunks
+        d.lrs = self._lrs_dev.data_ptr()
+        d.step_count = self.step_count.data_ptr()
+        d.grad_scale = float(self.grad_scale)
+        return d
+
+    def _fill(self, d):
+        raise NotImplementedError
+
+    def step(self):
+        for i, g in enumerate(self.param_groups):
+            self._lrs_host[i] = float(g['lr'])
+        self._lrs_dev.copy_(self._lrs_host, non_blocking=True)
+        d = self._desc()
+        self._fill(d)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(fn['cms_adam_ema_step' if self.KIND == 'adam' else 'cms_sgd_ema_step'](C.byref(d), stream),
+              'cms_{}_ema_step'.format(self.KIND))
+        check(fn['cms_increment_counter'](C.c_void_p(self.step_count.data_ptr()), stream), 'cms_increment_counter')
+        if self._ema is not None:
+            self._ema._mark_fused_step_done()
+
+
+class FusedAdam(_FusedOptimizer):
+    KIND = 'adam'
+
+    def __init__(self, module, param_groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super(FusedAdam, self).__init__(module, param_groups, dict(lr=lr, betas=betas, eps=eps))
+
+    def _fill(self, d):
+        g = self.param_groups[0] if self.param_groups else self.defaults
+        d.beta1, d.beta2 = float(g['betas'][0]), float(g['betas'][1])
+        d.eps = float(g['eps'])
+
+
+class FusedSGD(_FusedOptimizer):
+    KIND = 'sgd'
+
+    def __init__(self, module, param_groups, lr=1e-3, momentum=0.0, nesterov=False, weight_decay=0.0):
+        super(FusedSGD, self).__init__(module, param_groups, dict(lr=lr, momentum=momentum, nesterov=nesterov,
+                                                                  weight_decay=weight_decay))
+
+    def _fill(self, d):
+        g = self.param_groups[0] if self.param_groups else self.defaults
+        d.momentum = float(g['momentum'])
+        d.weight_decay = float(g['weight_decay'])
+        d.nesterov = int(bool(g['nesterov']))

@@ -1,0 +1,180 @@
+"""
+One CutMix mean-teacher training iteration on the GPU -- the body of the reference's hot loop,
+train_seg_semisup_mask_mt.py:287-476, as a reusable object (the trainer and bench.py both drive it).
+
+Reference order (per iteration):                                        here
+  lr scheduler step, zero_grad                         :288-290          caller / arena memset
+  student(x_sup) -> CE(ignore 255) -> backward         :296-301          fused CE kernel on low-res logits
+  paste images + validity masks with the box mask      :346-351          cms_cutmix_paste (mask rasterised in-kernel)
+  teacher(x0), teacher(x1) under no_grad               :354-356          ONE teacher pass over [x0; x1]      (*)
+  student(x_mix)                                       :358              ONE student pass over [x_sup; x_mix] (*)
+  paste teacher logits, softmax x2, confidence, loss   :363-458          fused consistency kernel (fwd, finalize, bwd)
+  unsup_loss.backward()                                :459              one backward for both losses        (*)
+  student_optim.step(); teacher_optim.step()           :465-467          one fused Adam/SGD + EMA kernel
+  float(sup_loss) / float(consistency_loss) / float(conf rate)           device scalars, no host sync
+  NaN bail                                             :469-472          checked one iteration late (async copy)
+
+(*) With frozen BatchNorm (`--freeze_bn`, the configuration of the reference's run_*_experiments.sh) and no dropout
+every sample goes through the networks independently, so concatenating batches and summing the two losses before a
+single backward is the same computation with half the kernel launches and twice the GEMM M dimension. With
+batch-statistics BN the passes are kept separate and in the reference's order (`fuse_batches=False`).
+
+Data parallel: one process per GPU; gradients of the flat arena are summed with ONE all-reduce (RCCL) and scaled by
+1/world inside the optimizer kernel; the confidence count is all-reduced (8 bytes) so that the default
+"scalar confidence rate" mode uses the global rate.
+"""
+import torch
+
+from . import ops
+
+
+class StepConfig(object):
+    def __init__(self, mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.97, conf_per_pixel=False,
+                 rampup=-1, unsup_batch_ratio=1, invert=True, fuse_batches=True, compute_dtype=torch.bfloat16):
+        if mask_mode not in ('mix', 'zero', 'cut'):
+            raise ValueError('Unknown mask_mode {}'.format(mask_mode))
+        self.mix = mask_mode == 'mix'
+        self.cons_weight = float(cons_weight)
+        self.rampup = rampup
+        self.unsup_batch_ratio = int(unsup_batch_ratio)
+        self.fuse_batches = bool(fuse_batches)
+        self.compute_dtype = compute_dtype
+        self.cons = ops.ConsistencyConfig(mode='mix' if self.mix else 'cut', loss_fn=cons_loss_fn,
+                                          conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, invert=invert)
+
+
+class UnsupBatch(object):
+    """
+    One unsupervised batch in the reference's layout. `ranges` replaces the full-resolution
+    `mask_params`; `*_stu` default to the teacher images (no colour augmentation pair).
+    """
+
+    def __init__(self, x0_tea, ranges, um0=None, x1_tea=None, um1=None, x0_stu=None, x1_stu=None):
+        self.x0_tea, self.x1_tea = x0_tea, x1_tea
+        self.x0_stu = x0_tea if x0_stu is None else x0_stu
+        self.x1_stu = x1_tea if x1_stu is None else x1_stu
+        self.um0, self.um1 = um0, um1
+        self.ranges = ranges
+
+
+class CutMixMeanTeacherStep(object):
+    def __init__(self, student_net, teacher_net, student_optim, teacher_optim, cfg, group=None):
+        self.student = student_net
+        self.teacher = teacher_net
+        self.student_optim = student_optim
+        self.teacher_optim = teacher_optim
+        self.cfg = cfg
+        self.group = group
+        self.align_corners = getattr(student_net, 'upsample_align_corners', True)
+        cfg.cons.align_corners = self.align_corners
+        import torch.distributed as dist
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._nan_probe = None
+        self._nan_event = None
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _allreduce_grads(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.student_optim.arena.grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.student_optim.grad_scale = 1.0 / self.world
+
+    def nan_detected(self):
+        """True if the supervised loss of an EARLIER iteration was NaN (checked without stalling the stream)."""
+        if self._nan_probe is None:
+            return False
+        if not self._nan_event.query():
+            return False
+        return bool(torch.isnan(self._nan_probe).any())
+
+    def _post_nan_probe(self, sup_loss):
+        if self._nan_probe is None:
+            self._nan_probe = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._nan_event = torch.cuda.Event()
+        self._nan_probe.copy_(sup_loss.reshape(1), non_blocking=True)
+        self._nan_event.record()
+
+    def _student_inputs(self, ub):
+        cfg = self.cfg
+        if cfg.mix:
+            return ops.cutmix_paste(ub.x0_stu, ub.x1_stu, ranges=ub.ranges, invert=cfg.cons.invert)
+        return ops.cutmix_paste(None, ub.x0_stu, ranges=ub.ranges, invert=cfg.cons.invert)      # x * m
+
+    # ------------------------------------------------------------------------------------------ the iteration
+    def __call__(self, sup_x, sup_y, unsup_batches, ramp_val=1.0):
+        """
+        sup_x (N,3,H,W); sup_y (N,1,H,W) or (N,H,W) uint8/int64 with 255 = ignore; unsup_batches: list of UnsupBatch
+        (len == unsup_batch_ratio; may be empty when cons_weight == 0).
+        Returns device scalars: dict(sup_loss, consistency_loss, conf_rate) (the latter two averaged over the
+        unsupervised batches, None when there are none).
+        """
+        cfg = self.cfg
+        out_size = sup_x.shape[2:4]
+        self.student_optim.zero_grad()
+        use_unsup = cfg.cons_weight > 0.0 and len(unsup_batches) > 0
+        n_sup = sup_x.shape[0]
+        ramp = ramp_val if cfg.rampup > 0 else 1.0
+
+        if cfg.fuse_batches:
+            stu_in = [sup_x]
+            tea_in = []
+            if use_unsup:
+                for ub in unsup_batches:
+                    stu_in.append(self._student_inputs(ub))
+                    tea_in.append(ub.x0_tea)
+                    if cfg.mix:
+                        tea_in.append(ub.x1_tea)
+                with torch.no_grad():
+                    tea_lo = self.teacher.forward_lowres(torch.cat(tea_in, dim=0) if len(tea_in) > 1 else tea_in[0])
+            stu_lo = self.student.forward_lowres(torch.cat(stu_in, dim=0) if len(stu_in) > 1 else stu_in[0])
+            grad_lo = torch.zeros_like(stu_lo, dtype=torch.float32)
+            lo_det = stu_lo.detach()
+            ce_sc, ce_ctx = ops.ce_forward(lo_det[:n_sup], sup_y, out_size, 255, self.align_corners, group=self.group)
+            ops.ce_backward(ce_ctx, ce_sc, grad_lo[:n_sup])
+            cons_vals = []
+            if use_unsup:
+                s_off, t_off = n_sup, 0
+                for ub in unsup_batches:
+                    n = ub.x0_tea.shape[0]
+                    l0 = tea_lo[t_off:t_off + n]
+                    l1 = tea_lo[t_off + n:t_off + 2 * n] if cfg.mix else None
+                    t_off += 2 * n if cfg.mix else n
+                    sc, cctx = ops.consistency_forward(cfg.cons, lo_det[s_off:s_off + n], l0, l1, out_size,
+                                                       ranges=ub.ranges, um0=ub.um0, um1=ub.um1, ramp_val=ramp,
+                                                       cons_weight=cfg.cons_weight, group=self.group)
+                    ops.consistency_backward(cctx, sc, grad_lo[s_off:s_off + n])
+                    s_off += n
+                    cons_vals.append(sc)
+            stu_lo.backward(grad_lo.to(stu_lo.dtype))
+        else:
+            # reference order, separate passes (batch-statistics BN)
+            lo = self.student.forward_lowres(sup_x)
+            ce_sc, ce_ctx = ops.ce_forward(lo.detach(), sup_y, out_size, 255, self.align_corners, group=self.group)
+            lo.backward(ops.ce_backward(ce_ctx, ce_sc).to(lo.dtype))
+            cons_vals = []
+            if use_unsup:
+                for ub in unsup_batches:
+                    x_stu = self._student_inputs(ub)
+                    with torch.no_grad():
+                        l0 = self.teacher.forward_lowres(ub.x0_tea)
+                        l1 = self.teacher.forward_lowres(ub.x1_tea) if cfg.mix else None
+                    ls = self.student.forward_lowres(x_stu)
+                    sc, cctx = ops.consistency_forward(cfg.cons, ls.detach(), l0, l1, out_size, ranges=ub.ranges,
+                                                       um0=ub.um0, um1=ub.um1, ramp_val=ramp,
+                                                       cons_weight=cfg.cons_weight, group=self.group)
+                    ls.backward(ops.consistency_backward(cctx, sc).to(ls.dtype))
+                    cons_vals.append(sc)
+
+        self._allreduce_grads()
+        self.student_optim.step()
+        if self.teacher_optim is not None:
+            self.teacher_optim.step()
+
+        sup_loss = ce_sc[0]
+        self._post_nan_probe(sup_loss)
+        res = dict(sup_loss=sup_loss, consistency_loss=None, conf_rate=None)
+        if cons_vals:
+            stacked = torch.stack(cons_vals)
+            res['consistency_loss'] = stacked[:, 0].mean()
+            res['conf_rate'] = stacked[:, 1].mean()
+        return res

@@ -1,0 +1,218 @@
+/*
+ * cutmixseg.h -- C ABI of libcutmixseg_hip.so: the MI355X (gfx950) kernels behind the CutMix mean-teacher training
+ * step of Britefury/cutmix-semisup-seg (train_seg_semisup_mask_mt.py).
+ *
+ * The reference has no FFI: its boundary is the Python API. Each entry point below names the
+ * reference code (file:line, relative to the upstream repository root) whose device work it replaces; the Python
+ * mirror of the reference interface (cutmix-semisup-seg_amd/) binds these with ctypes -- see INTEGRATION.md for
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless its name ends in `_host`
+ *   - the caller owns every buffer; the library allocates nothing, never synchronises and enqueues all work on
+ *     `stream` (a hipStream_t passed as void*); calls are capturable in a hipGraph
+ *   - tensors are dense NCHW unless stated otherwise
+ *   - returns 0 on success or a negative CMS_E* code; never throws; cms_last_error() gives a thread-local message
+ *   - `dtype` arguments: CMS_F32 or CMS_BF16
+ *   - low-resolution logits + (H, W, align_corners) describe an implicit bilinear upsample that is evaluated inside
+ *     the kernel (full-resolution logits are never materialised); pass h == H and w == W for plain logits
+ */
+#ifndef CUTMIXSEG_H
+#define CUTMIXSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMS_VERSION 100
+
+#define CMS_OK 0
+#define CMS_EINVAL (-1)     /* bad argument */
+#define CMS_ELAUNCH (-2)    /* kernel launch / HIP runtime error */
+#define CMS_EUNSUPPORTED (-3)
+
+#define CMS_F32 0
+#define CMS_BF16 1
+
+#define CMS_LABEL_U8 0
+#define CMS_LABEL_I64 1
+
+/* cons_loss_fn, train_seg_semisup_mask_mt.py:428-446 */
+#define CMS_LOSS_VAR 0
+#define CMS_LOSS_LOGITS_VAR 1
+#define CMS_LOSS_LOGITS_SMOOTHL1 2
+#define CMS_LOSS_BCE 3
+#define CMS_LOSS_KLD 4
+
+/* mask_mode, train_seg_semisup_mask_mt.py:27-33 */
+#define CMS_MODE_MIX 0
+#define CMS_MODE_CUT 1
+
+int cms_version(void);
+const char* cms_last_error(void);
+/* number of compute units / name of the current device (device-props cache) */
+int cms_device_info(int* n_cu, char* name_out, size_t name_cap);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Box masks + CutMix paste      (mask_gen.py:110-120 ; train_seg_semisup_mask_mt.py:346-351, 363, 385-389)
+ *
+ * `ranges`: int32 (N, n_boxes, 4) = [y0, y1, x0, x1] half-open, i.e. the reference's float rectangles after its
+ * `int(y0):int(y1)` slicing rules (done on the host by the Python side). Boxes XOR; `invert` != 0 means box = 1.
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* mask_out f32 (N,1,H,W): what BoxMaskGenerator.generate_params returns / torch_masks_from_params passes through */
+int cms_boxmask_rasterize(const int32_t* ranges, int n, int n_boxes, int h, int w, int invert,
+                          float* mask_out, void* stream);
+
+/* out[n,c,y,x] = m ? x1 : x0, with m rasterised in-kernel from `ranges` (mask never touches HBM).
+ * x0 == NULL means zeros (cut mode: x * m, :389). Exact for m in {0,1} (x0*(1-m) + x1*m, :350). */
+int cms_cutmix_paste(const void* x0, const void* x1, void* out, int dtype, const int32_t* ranges, int n,
+                     int n_boxes, int c, int h, int w, int invert, void* stream);
+
+/* same with a materialised f32 mask (N,1,H,W), computed arithmetically as x0*(1-m) + x1*m (any mask values) */
+int cms_cutmix_paste_mask(const void* x0, const void* x1, void* out, int dtype, const float* mask, int n, int c,
+                          int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Masked consistency loss, fused: bilinear upsample + teacher-logit paste + softmax + confidence + loss
+ *                               (train_seg_semisup_mask_mt.py:363-367, 407-459)
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct cms_consistency_desc {
+    const float* l_stu;    /* (N,C,h,w) student logits (of the pasted / cut image)                          */
+    const float* l_tea0;   /* (N,C,h,w) teacher logits of image 0                                            */
+    const float* l_tea1;   /* (N,C,h,w) teacher logits of image 1 (mix mode) or NULL (cut mode)              */
+    const int32_t* ranges; /* (N,n_boxes,4) box ranges, or NULL when `mask` is given                         */
+    const float* mask;     /* (N,1,H,W) materialised box mask, or NULL when `ranges` is given                */
+    const float* um0;      /* (N,1,H,W) validity mask of image 0, NULL = all ones                            */
+    const float* um1;      /* (N,1,H,W) validity mask of image 1, NULL = all ones (ignored in cut mode)      */
+    int n, c, h, w;        /* logits geometry                                                                */
+    int H, W;              /* loss geometry (crop size); logits are upsampled h x w -> H x W in-kernel       */
+    int align_corners;     /* 1: deeplab2.py:204 ; 0: deeplab3plus.py:77                                     */
+    int n_boxes, invert;
+    int mode;              /* CMS_MODE_MIX / CMS_MODE_CUT                                                    */
+    int loss_fn;           /* CMS_LOSS_*                                                                     */
+    float conf_thresh;     /* <= 0 disables confidence thresholding (:408)                                   */
+    int conf_per_pixel;    /* --conf_per_pixel (:415)                                                        */
+} cms_consistency_desc;
+
+/* bytes of scratch needed by cms_consistency_fwd (per-workgroup partial sums) */
+size_t cms_consistency_workspace_bytes(const cms_consistency_desc* d);
+
+/* stats_out: double[4] = { sum(loss*um), sum(loss*um*conf), count(conf >= thresh), P = N*H*W } (device).
+ * Deterministic (fixed-order second-stage reduction). Under data parallelism the caller all-reduces
+ * stats[2..3] before cms_consistency_finalize. */
+int cms_consistency_fwd(const cms_consistency_desc* d, void* workspace, double* stats_out, void* stream);
+
+/* scalars_out: float[4] = { consistency_loss (the value the reference logs, :461), conf_rate (:413, NaN if
+ * disabled), grad_scale (d unsup_loss / d per-pixel masked loss), unsup_loss (:458) } (device).
+ * `stats_global` = stats used for the confidence rate (== stats_local on one GPU). No host sync. */
+int cms_consistency_finalize(const double* stats_local, const double* stats_global, float conf_thresh,
+                             int conf_per_pixel, float ramp_val, float cons_weight, float* scalars_out,
+                             void* stream);
+
+/* grad_l_stu f32 (N,C,h,w) += d unsup_loss / d l_stu (caller zero-fills when it wants `=`); reads scalars[2] */
+int cms_consistency_bwd(const cms_consistency_desc* d, const float* scalars, float* grad_l_stu, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Supervised cross entropy, fused: bilinear upsample + log-softmax + NLL(ignore_index)
+ *                               (nn.CrossEntropyLoss(ignore_index=255), train_seg_semisup_mask_mt.py:126, 299-301)
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct cms_ce_desc {
+    const float* logits;  /* (N,C,h,w) */
+    const void* labels;   /* (N,H,W) uint8 or int64 */
+    int label_dtype;      /* CMS_LABEL_U8 / CMS_LABEL_I64 */
+    int ignore_index;
+    int n, c, h, w, H, W, align_corners;
+} cms_ce_desc;
+
+size_t cms_ce_workspace_bytes(const cms_ce_desc* d);
+/* stats_out: double[2] = { sum over valid pixels of -log p[label], number of valid pixels } */
+int cms_ce_fwd(const cms_ce_desc* d, void* workspace, double* stats_out, void* stream);
+/* scalars_out: float[2] = { loss = sum / count, grad_scale = loss_weight / count } from (possibly all-reduced)
+ * stats */
+int cms_ce_finalize(const double* stats, float loss_weight, float* scalars_out, void* stream);
+int cms_ce_bwd(const cms_ce_desc* d, const float* scalars, float* grad_logits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Bilinear upsample (F.interpolate(mode='bilinear'), architectures/deeplab2.py:204, deeplab3plus.py:54-55,77)
+ * Stand-alone form for the `forward(x) -> (N,C,H,W)` contract of the reference models.
+ * ------------------------------------------------------------------------------------------------------------ */
+int cms_upsample_bilinear_fwd(const float* lo, float* hi, int n, int c, int h, int w, int H, int W,
+                              int align_corners, void* stream);
+/* grad_lo (N,C,h,w) = adjoint applied to grad_hi (overwrites); deterministic gather */
+int cms_upsample_bilinear_bwd(const float* grad_hi, float* grad_lo, int n, int c, int h, int w, int H, int W,
+                              int align_corners, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Teacher EMA and fused optimizer + EMA over flat fp32 arenas
+ *                               (optim_weight_ema.py:21-25 ; torch.optim.Adam/SGD at
+ *                                train_seg_semisup_mask_mt.py:90-100, 465-467)
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* tgt = tgt*alpha + src*one_minus_alpha with the reference's three fp32 roundings (no FMA). Optional bf16 copy
+ * of the new target. */
+int cms_ema_flat(float* tgt, const float* src, size_t count, float alpha, float one_minus_alpha,
+                 uint16_t* tgt_bf16_out, void* stream);
+
+/* One segment of the parameter arena (a state_dict tensor). `k_updates` = how many times the tensor appears in
+ * the optimizer's parameter list (deeplab2.py:208-230 yields backbone weights 3x/4x): the update is applied k
+ * times in sequence with the same gradient; 0 = not optimised (BN tensors, or tensors that never receive a
+ * gradient such as the ASPP d18/d24 branches) -> only the EMA is applied. */
+typedef struct cms_param_segment {
+    uint64_t offset;     /* first element in the arenas */
+    uint64_t count;      /* number of elements */
+    int32_t k_updates;
+    int32_t lr_group;    /* index into the `lrs` array */
+} cms_param_segment;
+
+typedef struct cms_optim_desc {
+    float* param;              /* student fp32 master arena */
+    const float* grad;         /* gradient arena (same indexing) */
+    float* slot0;              /* Adam exp_avg / SGD momentum buffer */
+    float* slot1;              /* Adam exp_avg_sq (unused for SGD) */
+    float* ema_param;          /* teacher fp32 arena, or NULL (pi model) */
+    uint16_t* param_bf16;      /* optional bf16 copy of the updated student arena */
+    uint16_t* ema_bf16;        /* optional bf16 copy of the updated teacher arena */
+    const cms_param_segment* segments; /* DEVICE array */
+    const uint32_t* chunk_seg; /* DEVICE array: segment index of every CMS_OPT_CHUNK-element chunk of work */
+    const uint32_t* chunk_off; /* DEVICE array: element offset of the chunk inside its segment */
+    uint32_t n_chunks;
+    const double* lrs;         /* DEVICE array: current learning rate per group (double, as Python holds it) */
+    const int64_t* step_count; /* DEVICE scalar: number of optimizer steps already taken */
+    float grad_scale;          /* gradients are multiplied by this first (1/world_size after a sum all-reduce) */
+    float ema_alpha;
+    float ema_one_minus_alpha; /* (float)(1.0 - (double)alpha), as the reference forms it */
+    /* Adam */
+    float beta1, beta2, eps;
+    /* SGD */
+    float momentum, weight_decay;
+    int nesterov;
+} cms_optim_desc;
+
+#define CMS_OPT_CHUNK 2048
+
+int cms_adam_ema_step(const cms_optim_desc* d, void* stream);
+int cms_sgd_ema_step(const cms_optim_desc* d, void* stream);
+/* *counter += 1 on the device (keeps the optimizer step counter graph-replayable) */
+int cms_increment_counter(int64_t* counter, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Evaluation: fused upsample + argmax + confusion matrix   (train_seg_semisup_mask_mt.py:510-514 ; evaluation.py)
+ * I = diag(cm), U = rowsum + colsum - diag so one CxC histogram is all that is needed.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* cm int64 (C,C) += histogram of (truth, argmax) over pixels with truth != ignore_index (ignore_index < 0: none).
+ * pred_out (N,H,W) uint8 optional. */
+int cms_argmax_confusion(const float* logits, const void* labels, int label_dtype, int ignore_index, int n, int c,
+                         int h, int w, int H, int W, int align_corners, int64_t* cm, uint8_t* pred_out,
+                         void* stream);
+/* fast_cm / per_class_i_and_u_cm on integer maps (evaluation.py:6-37): truth, pred uint8 (count) */
+int cms_confusion(const uint8_t* truth, const uint8_t* pred, size_t count, int ignore_index, int c, int64_t* cm,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUTMIXSEG_H */

@@ -1,0 +1,219 @@
+"""
+CPU-only: host-side logic of the drop-in modules (the reference's module names at the repository root) against the
+golden vectors generated from the reference: box-mask RNG draws / slicing rules, LR schedules, architecture
+registry, DeepLab v2 state-dict layout and parameter groups, CLI surface, job helper, error behaviour.
+"""
+import hashlib
+import json
+import os
+from collections import Counter
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, load_golden_json
+
+import mask_gen
+import lr_schedules
+import job_helper
+from architectures import network_architectures, deeplab2
+
+_BM = load_golden_json('boxmask_meta')
+
+
+@pytest.mark.parametrize('case', _BM['cases'], ids=[c['key'] for c in _BM['cases']])
+def test_boxmask_generate_params_bit_exact(case):
+    g = load_golden('boxmask')
+    kw = dict(_BM['flagsets'][case['flagset']])
+    pr = kw.pop('prop_range')
+    gen = mask_gen.BoxMaskGenerator(tuple(pr) if isinstance(pr, list) else pr, **kw)
+    shape = tuple(case['shape'])
+    m = gen.generate_params(_BM['n'], shape, rng=np.random.RandomState(case['seed']))
+    assert m.dtype == np.float64 and m.shape == (_BM['n'], 1) + shape
+    m8 = m.astype(np.uint8)
+    assert hashlib.sha256(m8.tobytes()).hexdigest() == case['sha256']
+    np.testing.assert_array_equal(m8.sum(axis=3)[:, 0], g[case['key'] + '__rowsum'])
+    # the device path carries the same information as int32 ranges
+    r = gen.generate_ranges(_BM['n'], shape, rng=np.random.RandomState(case['seed']))
+    assert r.dtype == np.int32 and r.shape == (_BM['n'], kw['n_boxes'], 4)
+    assert (r[..., 0] <= r[..., 1]).all() and (r[..., 2] <= r[..., 3]).all()
+    assert r.min() >= 0 and r[..., 1].max() <= shape[0] and r[..., 3].max() <= shape[1]
+
+
+def test_boxmask_float_prop_range_and_identity_params():
+    gen = mask_gen.BoxMaskGenerator(0.25)
+    assert gen.prop_range == (0.25, 0.25)
+    t = torch.zeros(2, 1, 8, 8)
+    assert gen.torch_masks_from_params(t, (8, 8), 'cpu') is t       # reference: identity (mask_gen.py:119-120)
+    with pytest.raises(NotImplementedError):
+        mask_gen.MaskGenerator().generate_params(1, (4, 4))
+
+
+def test_add_mask_params_to_batch_layouts():
+    gen = mask_gen.BoxMaskGenerator(0.5, invert=True)
+    batch = [dict(image=np.zeros((3, 16, 20), np.float32)) for _ in range(3)]
+    out = mask_gen.AddMaskParamsToBatch(gen)(batch)
+    assert all(s['mask_params'].shape == (1, 16, 20) and s['mask_params'].dtype == np.float32 for s in out)
+    paired = [dict(sample0=dict(image=np.zeros((3, 16, 20), np.float32)), sample1=dict(image=None)) for _ in range(2)]
+    out = mask_gen.AddMaskParamsToBatch(gen, as_ranges=True)(paired)
+    assert all(s['mask_params'].shape == (1, 4) and s['mask_params'].dtype == np.int32 for s in out)
+
+
+class _Opt(object):
+    def __init__(self, base):
+        self.param_groups = [dict(lr=base * 0.1), dict(lr=base)]
+
+
+def test_lr_schedules_match_reference_sequences():
+    g = load_golden('lr')
+    base = float(g['base_lr'])
+    for sched in ('poly', 'cosine'):
+        opt = _Opt(base)
+        ep, it = lr_schedules.make_lr_schedulers(opt, 40, sched, '', 0.1, poly_power=0.9)
+        assert ep is None and it is not None
+        for i in range(40):
+            it.step(i)
+            np.testing.assert_allclose([gr['lr'] for gr in opt.param_groups], g[sched][i], rtol=1e-12, atol=1e-22)
+    opt = _Opt(base)
+    ep, it = lr_schedules.make_lr_schedulers(opt, 40, 'stepped', '[3, 6]', 0.1)
+    assert it is None and ep is not None
+    for e in range(10):
+        ep.step(e)
+        np.testing.assert_allclose([gr['lr'] for gr in opt.param_groups], g['stepped'][e], rtol=1e-12)
+    assert lr_schedules.make_lr_schedulers(_Opt(base), 40, 'none', '', 0.1) == (None, None)
+    for bad in (('stepped', ''), ('bogus', '')):       # reference quirk: empty milestones -> "Unknown schedule_type"
+        with pytest.raises(ValueError, match='Unknown schedule_type'):
+            lr_schedules.make_lr_schedulers(_Opt(base), 40, bad[0], bad[1], 0.1)
+    for e, R, v in g['rampup']:
+        assert network_architectures.sigmoid_rampup(e, int(R)) == pytest.approx(v, rel=1e-12)
+
+
+def test_lr_schedules_work_on_torch_optimizers_too():
+    p = torch.nn.Parameter(torch.zeros(2))
+    opt = torch.optim.SGD([dict(params=[p], lr=0.1)], lr=0.1)
+    _, it = lr_schedules.make_lr_schedulers(opt, 10, 'poly', '', 0.1)
+    it.step(5)
+    assert opt.param_groups[0]['lr'] == pytest.approx(0.1 * 0.5 ** 0.9)
+
+
+def test_registry_names_and_unavailable_architectures():
+    assert sorted(network_architectures.seg.names()) == load_golden_json('registry_names')
+    with pytest.raises(NotImplementedError):
+        network_architectures.seg.get('resnet101_pspnet_imagenet')(21)
+    with pytest.raises(NotImplementedError):
+        network_architectures.seg.get('resnet50unet_imagenet')(2, pretrained=False)
+    reg = network_architectures.ArchRegistry()
+
+    @reg.register('x')
+    def x():
+        return 1
+    assert reg.get('x') is x and list(reg.names()) == ['x']
+
+
+def test_robust_bce_formula():
+    p = torch.tensor([0.2, 0.9])
+    t = torch.tensor([0.0, 1.0])
+    want = -(t * torch.log(p + 1e-6) + (1 - t) * torch.log(1 - p + 1e-6))
+    torch.testing.assert_close(network_architectures.robust_binary_crossentropy(p, t), want)
+
+
+_DM = load_golden_json('deeplab2_meta')
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'r101'])
+def test_deeplab2_state_dict_and_param_groups(tag):
+    from oracle import deeplab2 as odl
+    meta = _DM[tag]
+    C, layers = meta['num_classes'], meta['layers']
+    if tag == 'r101':
+        net = network_architectures.seg.get('resnet101_deeplab_imagenet')(C, pretrained=False)
+    else:
+        net = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
+    sd = net.state_dict()
+    spec = odl.state_spec(C, layers)
+    assert list(sd.keys()) == list(spec.keys())
+    for k, (shape, dt) in spec.items():
+        assert tuple(sd[k].shape) == tuple(shape) and sd[k].dtype == dt
+    assert len(sd) == meta['n_state']
+    assert sum(p.numel() for p in net.parameters()) == meta['n_params']
+    assert sum(p.numel() for p in net.parameters() if p.requires_grad) == meta['n_trainable']
+    id2key = {id(p): k for k, p in net.named_parameters()}
+    assert [id2key[id(p)] for p in net.pretrained_parameters()] == meta['pretrained_order']
+    assert [id2key[id(p)] for p in net.new_parameters()] == meta['new_order']
+    assert sorted(net.unused_parameter_keys()) == meta['none_grads_in0']
+    assert net.BLOCK_SIZE == (1, 1) and hasattr(net, 'MEAN') and hasattr(net, 'STD')
+    if tag == 'r101':
+        assert Counter(Counter(meta['pretrained_order']).values()) == {1: 1, 3: 99, 4: 4}
+    net.train()
+    net.freeze_batchnorm()
+    assert all(not m.training for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    assert net.layer1.training
+    # loading closed-form state through the reference-style helper
+    deeplab2._load_state_into_model(net, odl.closed_form_state(C, layers))
+    torch.testing.assert_close(net.state_dict()['layer1.0.conv1.weight'],
+                               odl.closed_form_state(C, layers)['layer1.0.conv1.weight'])
+
+
+def test_deeplab2_mean_std_of_the_three_factories():
+    a = deeplab2.resnet101_deeplab_imagenet(3, pretrained=False)
+    b = deeplab2.resnet101_deeplab_coco(3, pretrained=False)
+    c = deeplab2.resnet101_deeplab_imagenet_mittal_std(3, pretrained=False)
+    np.testing.assert_allclose(a.MEAN, [0.485, 0.456, 0.406])
+    np.testing.assert_allclose(a.STD, [0.229, 0.224, 0.225])
+    np.testing.assert_allclose(b.MEAN, np.array([122.67891434, 116.66876762, 104.00698793]) / 255.0)
+    np.testing.assert_allclose(b.STD, np.ones(3) / 255.0)
+    np.testing.assert_allclose(c.MEAN, b.MEAN)
+
+
+def test_networks_refuse_cpu_inputs():
+    net = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, [1, 1, 1, 1], 3, np.zeros(3), np.ones(3))
+    with pytest.raises(RuntimeError, match='GPU only'):
+        net(torch.zeros(1, 3, 33, 33))
+
+
+def test_cli_surface_matches_reference():
+    import train_seg_semisup_mask_mt as trainer
+    ref = load_golden_json('cli_options')
+    mine = {p.name: p for p in trainer.experiment.params}
+    for o in ref:
+        assert o['name'] in mine, 'missing option --{}'.format(o['name'])
+        p = mine[o['name']]
+        assert list(p.opts) == o['opts']
+        assert bool(getattr(p, 'is_flag', False)) == o['is_flag']
+        assert p.default == o['default'] or str(p.default) == str(o['default']), o['name']
+        if o['choices'] is not None:
+            assert list(p.type.choices) == o['choices']
+    extra = set(mine) - {o['name'] for o in ref}
+    assert extra == {'synthetic', 'synthetic_n_classes', 'synthetic_val_batches', 'compute_dtype', 'no_fuse_batches'}
+
+
+def test_job_helper_log_layout_and_skip(tmp_path, monkeypatch, capsys):
+    monkeypatch.chdir(tmp_path)
+    calls = []
+
+    @job_helper.job('myjob', enumerate_job_names=False)
+    def fn(submit_config, a):
+        calls.append(a)
+        print('hello {}'.format(a))
+        assert submit_config.run_dir == os.path.join('results', 'myjob', 'd1')
+
+    fn.submit(job_desc='d1', a=3)
+    assert calls == [3]
+    assert 'hello 3' in open(tmp_path / 'results' / 'myjob' / 'log_d1.txt').read()
+    assert (tmp_path / 'results' / 'myjob' / 'd1').is_dir()
+    fn.submit(job_desc='d1', a=4)                  # log exists -> skipped
+    assert calls == [3]
+    assert 'already executed; skipping' in capsys.readouterr().out
+    with pytest.raises(ValueError):
+        fn.submit(job_desc='d2', a=1, quota_group='x')
+
+
+def test_trainer_config_errors_before_touching_a_gpu(tmp_path, monkeypatch):
+    import train_seg_semisup_mask_mt as trainer
+    monkeypatch.chdir(tmp_path)
+    defaults = {p.name: p.default for p in trainer.experiment.params}
+    defaults['job_desc'] = 'none'
+    bad = dict(defaults, mask_mode='bogus')
+    with pytest.raises(ValueError, match='Unknown mask_mode'):
+        trainer.train_seg_semisup_mask_mt.submit(**bad)
