@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""
+bench.py -- train images/sec of the CutMix mean-teacher step (student + teacher), BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank / GPU)
+
+A "step" is one full iteration of train_seg_semisup_mask_mt.py:287-476 on synthetic inputs already resident in HBM:
+student fwd/bwd on the supervised batch, 2 teacher forwards, student fwd/bwd on the CutMix-mixed batch, fused masked
+consistency + CE losses, fused Adam + EMA, (N > 1) one RCCL all-reduce of the flat gradient arena.
+Workload at N = 1: BASELINE configs[1] -- DeepLab v2 / ResNet-101, 10 x 3 x 321 x 321, 21 classes, CutMix, bf16.
+`--workload cityscapes` selects configs[2] (4 x 3 x 512 x 1024 per GPU, 19 classes, paired colour-aug layout).
+Weak scaling: the per-GPU batch is fixed. Prints ONE JSON line on rank 0.
+
+Extra objects in the line
+  roofline      the dominant hand-written kernel of the step (see --roofline_kernel), timed live with HIP events on
+                the launch stream inside the timed region; algorithmic bytes per launch from DESIGN.md.
+  cpu_baseline  the CPU oracle's restatement of the same step (kind "port"), timed on this box's host cores on a
+                bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    'pascal': dict(name='deeplab2-resnet101 cutmix mean-teacher step, 10x3x321x321, 21 classes (BASELINE configs[1])',
+                   batch=10, H=321, W=321, classes=21, paired=False),
+    'cityscapes': dict(name='deeplab2-resnet101 cutmix mean-teacher step, 4x3x512x1024 per GPU, 19 classes, '
+                            'paired colour-aug layout (BASELINE configs[2])',
+                       batch=4, H=512, W=1024, classes=19, paired=True),
+}
+
+
+def cpu_baseline(workload, seconds_budget=30.0):
+    """Oracle step on the host cores, bounded sample: batch 2 (the GPU run uses the full batch), >= 2 timed iters."""
+    import numpy as np
+    import torch
+    from oracle import deeplab2 as odl, step as ostep, boxmask as obox
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    C, H, W = workload['classes'], workload['H'], workload['W']
+    N = 2 if H * W <= 321 * 321 else 1
+    g = torch.Generator().manual_seed(0)
+    st = odl.closed_form_state(C)
+    S = ostep.StepState(st, C, opt='adam', lr=3e-5)
+    x = torch.randn(N, 3, H, W, generator=g)
+    y = torch.randint(0, C, (N, 1, H, W), generator=g)
+    ux0, ux1 = torch.randn(N, 3, H, W, generator=g), torch.randn(N, 3, H, W, generator=g)
+    ones = torch.ones(N, 1, H, W)
+    m = torch.tensor(obox.generate_params(N, (H, W), 0.5, invert=True, rng=np.random.RandomState(0)).astype(np.float32))
+    ostep.train_iteration(S, x, y, ux0, ux1, ones, ones, m)          # warm-up
+    times = []
+    t_start = time.time()
+    while len(times) < 2 or (time.time() - t_start < seconds_budget * 0.6 and len(times) < 8):
+        t0 = time.time()
+        ostep.train_iteration(S, x, y, ux0, ux1, ones, ones, m)
+        times.append(time.time() - t0)
+    t = sum(times) / len(times)
+    return dict(value=N / t, unit='images/sec', cores=cores, kind='port',
+                sample='oracle/step.py (PyTorch-CPU fp32 restatement of the reference step), batch {} of {}x{} '
+                       '(GPU run: batch {}), {} timed iterations after 1 warm-up, {:.2f} s/iter'.format(
+                           N, H, W, workload['batch'], len(times), t))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='pascal')
+    ap.add_argument('--dtype', choices=['bf16', 'fp32'], default='bf16')
+    ap.add_argument('--roofline_kernel', choices=['adam_ema', 'consistency'], default='adam_ema')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_fuse_batches', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+
+    from cutmix_semisup_seg_amd import ops, optim as fo
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
+    from architectures import network_architectures
+    import mask_gen
+    import optim_weight_ema
+
+    wl = WORKLOADS[args.workload]
+    B, H, W, C = wl['batch'], wl['H'], wl['W'], wl['classes']
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+
+    torch.manual_seed(12345)                       # identical replicas on every rank
+    Net = network_architectures.seg.get('resnet101_deeplab_imagenet')
+    stu, tea = Net(C, pretrained=False).to(dev), Net(C, pretrained=False).to(dev)
+    stu.compute_dtype = tea.compute_dtype = dtype
+    lr = 3e-5                                      # run_pascal_aug_experiments.sh
+    opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=lr * 0.1),
+                             dict(params=list(stu.new_parameters()), lr=lr)])
+    for p in tea.parameters():
+        p.requires_grad = False
+    ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
+    ema.fuse_into(opt)
+    stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()      # --freeze_bn
+    cfg = StepConfig(mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.97, conf_per_pixel=False,
+                     fuse_batches=not args.no_fuse_batches, compute_dtype=dtype)
+    step = CutMixMeanTeacherStep(stu, tea, opt, ema, cfg)
+
+    gen = torch.Generator(device=dev).manual_seed(12345 + rank)
+    mask_rng = np.random.RandomState(12345 + rank)
+    boxgen = mask_gen.BoxMaskGenerator(0.5, invert=True)
+
+    def images():
+        return torch.randn(B, 3, H, W, generator=gen, device=dev).to(dtype)
+
+    # a small pool of resident synthetic batches, cycled (inputs are in HBM before the timed region starts)
+    pool = []
+    for _ in range(2):
+        y = torch.randint(0, C, (B, 1, H, W), generator=gen, device=dev)
+        y[torch.rand(B, 1, H, W, generator=gen, device=dev) < 0.05] = 255
+        pool.append(dict(x=images(), y=y.to(torch.uint8), x0=images(), x1=images(),
+                         x0s=images() if wl['paired'] else None, x1s=images() if wl['paired'] else None))
+
+    # roofline instrumentation: bracket every launch of the chosen kernel with events on the launch stream
+    ev_pairs = []
+    timing_on = [False]
+    if args.roofline_kernel == 'adam_ema':
+        orig_step = opt.step
+
+        def timed_step():
+            if not timing_on[0]:
+                return orig_step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            from cutmix_semisup_seg_amd import optim as _o, _lib
+            # time only the optimizer kernel: lr upload first, then events around the launch
+            for i, gp in enumerate(opt.param_groups):
+                opt._lrs_host[i] = float(gp['lr'])
+            opt._lrs_dev.copy_(opt._lrs_host, non_blocking=True)
+            d = opt._desc()
+            opt._fill(d)
+            import ctypes as Cc
+            s = Cc.c_void_p(torch.cuda.current_stream().cuda_stream)
+            e0.record()
+            _lib.check(_lib.fn['cms_adam_ema_step'](Cc.byref(d), s), 'cms_adam_ema_step')
+            e1.record()
+            _lib.check(_lib.fn['cms_increment_counter'](Cc.c_void_p(opt.step_count.data_ptr()), s))
+            if opt._ema is not None:
+                opt._ema._mark_fused_step_done()
+            ev_pairs.append((e0, e1))
+        opt.step = timed_step
+        n_float = opt.arena.total
+        bytes_per_launch = n_float * 40.0          # 5 fp32 reads + 4 fp32 writes + 2 bf16 copies
+        kname = 'optim_ema_kernel<ADAM> (fused Adam + teacher EMA over the 44.15M-element arena)'
+    else:
+        orig_fwd = ops.consistency_forward
+        orig_bwd = ops.consistency_backward
+
+        def timed_fwd(*a, **k):
+            if not timing_on[0]:
+                return orig_fwd(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_fwd(*a, **k)
+            e1.record()
+            ev_pairs.append((e0, e1))
+            return r
+        ops.consistency_forward = timed_fwd
+        P = B * H * W
+        bytes_per_launch = (2 * C + 2) * P * 4.0    # reference-equivalent traffic of the forward half, SURVEY 8(d)
+        kname = 'cons_fwd_kernel (+ second-stage reduce + finalize)'
+
+    def one_step(i):
+        b = pool[i % len(pool)]
+        ranges = ops.ranges_to_device(boxgen.generate_ranges(B, (H, W), rng=mask_rng), dev)
+        ub = UnsupBatch(b['x0'], ranges, x1_tea=b['x1'], x0_stu=b['x0s'], x1_stu=b['x1s'])
+        return step(b['x'], b['y'], [ub])
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timing_on[0] = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timing_on[0] = False
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+
+    last = {k: (None if v is None else float(v)) for k, v in res.items()}
+    if not np.isfinite(last['sup_loss']):
+        raise SystemExit('non-finite loss in the bench loop: {}'.format(last))
+
+    if rank == 0:
+        ms_kernel = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float('nan')
+        achieved = bytes_per_launch / (ms_kernel * 1e-3) / 1e9
+        out = {
+            'metric': 'train images/sec (student+teacher step)',
+            'value': args.steps * B * world / elapsed,
+            'unit': 'images/sec',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': args.dtype,
+            'data': 'synthetic (N(0,1) images, uniform labels with 5% ignore=255, all-ones validity masks, '
+                    'seeded box masks; random-init weights)',
+            'config': {'workload': wl['name'], 'per_gpu_batch': B, 'global_batch': B * world, 'crop': [H, W],
+                       'classes': C, 'parallelism': 'dp{}'.format(world), 'image_forwards_per_sec':
+                           4 * args.steps * B * world / elapsed,
+                       'fuse_batches': not args.no_fuse_batches, 'last_losses': last},
+            'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'avg_launch_ms': ms_kernel,
+                         'algorithmic_bytes_per_launch': bytes_per_launch, 'launches_timed': len(ev_pairs)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(wl)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
