@@ -44,7 +44,9 @@ def cpu_baseline(workload, seconds_budget=30.0):
     import torch
     from oracle import deeplab2 as odl, step as ostep, boxmask as obox
     torch.manual_seed(0)
-    cores = torch.get_num_threads()
+    # conv-heavy fp32 work stops scaling (and regresses) long before 100+ threads; use at most 32
+    cores = min(torch.get_num_threads(), 32)
+    torch.set_num_threads(cores)
     C, H, W = workload['classes'], workload['H'], workload['W']
     N = 2 if H * W <= 321 * 321 else 1
     g = torch.Generator().manual_seed(0)

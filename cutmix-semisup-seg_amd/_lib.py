@@ -7,6 +7,10 @@ or __graft_entry__.build()) importing this module raises, and every op in the pa
 import ctypes as C
 import os
 
+# PyTorch ships its own libamdhip64.so.7; it must be the HIP runtime instance this library binds to (same SONAME), or
+# kernels would be launched through a second, device-less runtime. Importing torch first guarantees that.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libcutmixseg_hip.so')
 
@@ -49,7 +53,7 @@ class OptimDesc(C.Structure):
                 ('segments', c_void_p), ('chunk_seg', c_void_p), ('chunk_off', c_void_p), ('n_chunks', C.c_uint32),
                 ('lrs', c_void_p), ('step_count', c_void_p),
                 ('grad_scale', c_float), ('ema_alpha', c_float), ('ema_one_minus_alpha', c_float),
-                ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
+                ('beta1', C.c_double), ('beta2', C.c_double), ('eps', C.c_double),
                 ('momentum', c_float), ('weight_decay', c_float), ('nesterov', c_int)]
 
 

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libcutmixseg_hip.so')
 STAMP = os.path.join(CSRC, '.build_stamp')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function', '-Wno-pass-failed',
          '-Wno-unused-result']
 
 
@@ -29,7 +29,7 @@ def _digest():
     deps = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hpp'))
     deps.append(os.path.join(os.path.dirname(HERE), 'include', 'cutmixseg.h'))
     for p in deps:
-        h.update(p.encode())
+        h.update(os.path.basename(p).encode())
         with open(p, 'rb') as f:
             h.update(f.read())
     h.update(' '.join(FLAGS).encode())

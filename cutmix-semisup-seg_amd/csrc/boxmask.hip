@@ -98,7 +98,13 @@ __global__ __launch_bounds__(256) void paste_mask_kernel(const T* __restrict__ x
         const float m = mask[n * hw + i % hw];
         const float a = x0 ? to_f(x0[i]) : 0.0f;
         const float b = to_f(x1[i]);
-        const float r = __fadd_rn(__fmul_rn(a, __fsub_rn(1.0f, m)), __fmul_rn(b, m));
+        float r;
+        {
+#pragma clang fp contract(off)
+            const float t0 = a * (1.0f - m);
+            const float t1 = b * m;
+            r = t0 + t1;
+        }
         from_f(r, out[i]);
     }
 }

@@ -64,15 +64,15 @@ __global__ __launch_bounds__(256) void optim_ema_kernel(cms_optim_desc d) {
         if (ADAM) {
             for (int j = 0; j < k; ++j) {
                 const double t = (double)(steps_done * k + j + 1);
-                coef.step_size[j] = (float)(lr / (1.0 - pow((double)d.beta1, t)));
-                coef.bc2_sqrt[j] = (float)sqrt(1.0 - pow((double)d.beta2, t));
+                coef.step_size[j] = (float)(lr / (1.0 - pow(d.beta1, t)));
+                coef.bc2_sqrt[j] = (float)sqrt(1.0 - pow(d.beta2, t));
             }
         }
     }
     __syncthreads();
     const bool first_step = steps_done == 0;
-    const float b1 = d.beta1, b2 = d.beta2, eps = d.eps;
-    const float w1 = 1.0f - b1, w2 = 1.0f - b2;
+    const float b2 = (float)d.beta2, eps = (float)d.eps;
+    const float w1 = (float)(1.0 - d.beta1), w2 = (float)(1.0 - d.beta2);
     const float lr_f = lr_sh;
 
 #pragma unroll

@@ -218,8 +218,13 @@ CMS_HD void ce_pixel_bwd(L l, int crt, int label, E emit) {
 // ---------------------------------------------------------------------------------------------- EMA (3 roundings)
 // optim_weight_ema.py:23-25: t.mul_(alpha); t.add_(s * (1 - alpha)) -- two products and one sum, each rounded.
 CMS_HD float ema_update(float t, float s, float alpha, float one_minus_alpha) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fadd_rn(__fmul_rn(t, alpha), __fmul_rn(s, one_minus_alpha));
+#if defined(__clang__)
+#pragma clang fp contract(off)
+    // HIP's __fmul_rn / __fadd_rn are plain operators that the optimiser may fuse into an FMA; contraction must be
+    // off for the three roundings of the reference to survive
+    const float a = t * alpha;
+    const float b = s * one_minus_alpha;
+    return a + b;
 #else
     volatile float a = t * alpha;
     volatile float b = s * one_minus_alpha;

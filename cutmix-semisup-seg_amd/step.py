@@ -127,7 +127,8 @@ class CutMixMeanTeacherStep(object):
                 with torch.no_grad():
                     tea_lo = self.teacher.forward_lowres(torch.cat(tea_in, dim=0) if len(tea_in) > 1 else tea_in[0])
             stu_lo = self.student.forward_lowres(torch.cat(stu_in, dim=0) if len(stu_in) > 1 else stu_in[0])
-            grad_lo = torch.zeros_like(stu_lo, dtype=torch.float32)
+            # dense NCHW scratch for the loss kernels (stu_lo itself may be channels-last strided)
+            grad_lo = torch.zeros(stu_lo.shape, dtype=torch.float32, device=stu_lo.device)
             lo_det = stu_lo.detach()
             ce_sc, ce_ctx = ops.ce_forward(lo_det[:n_sup], sup_y, out_size, 255, self.align_corners, group=self.group)
             ops.ce_backward(ce_ctx, ce_sc, grad_lo[:n_sup])

@@ -185,8 +185,8 @@ typedef struct cms_optim_desc {
     float grad_scale;          /* gradients are multiplied by this first (1/world_size after a sum all-reduce) */
     float ema_alpha;
     float ema_one_minus_alpha; /* (float)(1.0 - (double)alpha), as the reference forms it */
-    /* Adam */
-    float beta1, beta2, eps;
+    /* Adam (doubles: torch forms 1-beta and the bias corrections in Python double before the fp32 ops) */
+    double beta1, beta2, eps;
     /* SGD */
     float momentum, weight_decay;
     int nesterov;
