@@ -57,6 +57,16 @@ class OptimDesc(C.Structure):
                 ('momentum', c_float), ('weight_decay', c_float), ('nesterov', c_int)]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [('x', c_void_p), ('w', c_void_p), ('y', c_void_p), ('y32', c_void_p), ('scale', c_void_p),
+                ('bias', c_void_p), ('res', c_void_p), ('mask_src', c_void_p),
+                ('n', c_int), ('h', c_int), ('w_in', c_int), ('cin', c_int),
+                ('ho', c_int), ('wo', c_int), ('cout', c_int), ('cout_real', c_int), ('ntaps', c_int),
+                ('tap_dy', c_int * 18), ('tap_dx', c_int * 18), ('stride', c_int),
+                ('out_h', c_int), ('out_w', c_int), ('out_stride', c_int), ('relu', c_int), ('mode', c_int),
+                ('tile', c_int)]
+
+
 _P = C.POINTER
 
 
@@ -96,6 +106,8 @@ PROTOTYPES = {
     'cms_argmax_confusion': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p, c_void_p, c_void_p]),
     'cms_confusion': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
+    'cms_conv_igemm': (c_int, [_P(ConvDesc), c_void_p]),
+    'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 fn = {}

@@ -1,0 +1,352 @@
+// MFMA implicit-GEMM convolution family for the DeepLab v2 backbone (gfx950 / CDNA4, wave64).
+//
+// Replaces the cuDNN/MIOpen calls the reference issues through nn.Conv2d + nn.BatchNorm2d + ReLU (+ residual add) in
+// architectures/deeplab2.py:89-109 (Bottleneck.forward), :124-128 (ASPP head) and their autograd twins.
+//
+// Data layout: activations bf16 NHWC; weights bf16 [tap][Cout][Cin] (Cin contiguous) -- the physical layout the
+// parameter arena keeps conv weights in, so the bf16 copy written by the fused optimizer IS the forward operand;
+// fp32 accumulation in the MFMA accumulators.
+//
+// GEMM view:  D[co][pixel] = sum_{tap, ci} W[tap][co][ci] * X[pixel shifted by tap][ci]
+//   MFMA "A" operand = weight tile (rows = co), "B" operand = pixel tile (columns = pixels), K = taps * Cin.
+//   v_mfma_f32_32x32x16_bf16: lane l holds A[i = l&31][k = 8*(l>>5)..+7] and B[k = 8*(l>>5)..+7][j = l&31]; both are
+//   one ds_read_b128 of a [row][k] LDS image. Accumulator: column j = l&31 (pixel), row i = (r&3) + 8*(r>>2) + 4*(l>>5)
+//   (co) -> every lane owns runs of 4 consecutive channels of one pixel = 8 contiguous bytes of the NHWC output.
+//
+// Workgroup: 256 threads = 4 waves, tile BN (co) x BM (pixels) x BK=64; global -> registers -> LDS staging with the
+// next tile's global loads issued before the MFMA phase of the current one; LDS rows are 128 B, 16-byte chunks
+// XOR-swizzled with (row>>1)&7 so that the 16-lane groups of ds_read_b128 hit 16 distinct slots (no bank conflicts);
+// zero padding / tile tails are handled in the loader (out-of-range rows load zeros). Each global load instruction of
+// a wave covers 8 rows x 128 contiguous bytes (full cache lines).
+//
+// Epilogues (fused, in registers):
+//   forward   y = relu(acc * scale[co] + bias[co] + residual)      (frozen BN folded to scale/bias, deeplab2.py:92-107)
+//   dgrad     dx = (acc + add_in) * [mask_src > 0]                 (ReLU backward of the producer of this conv's input)
+//   optional fp32 NCHW output for the ASPP head logits.
+//
+// Roofline: dilated 3x3 (layer3: K = 2304, AI ~ 680 FLOP/B) is MFMA-bound; 1x1 (AI ~ 180 FLOP/B) is HBM-bound on the
+// activation stream; DESIGN.md section 4 lists algorithmic FLOPs / bytes per layer shape.
+#include "common.hpp"
+
+namespace cms {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// native vector type for 16-byte staging registers (HIP's uint4 struct copies become memcpy calls that the compiler
+// leaves in scratch memory)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CONV_BK = 64;          // K elements per stage = 128 B per LDS row
+constexpr int CONV_ROW_BYTES = 128;
+
+struct ConvArgs {
+    const uint16_t* x;         // bf16 [N][H][W][Cin]
+    const uint16_t* w;         // bf16 [ntaps][Cout][Cin]
+    uint16_t* y;               // bf16 [N][out_H][out_W][Cout] or NULL
+    float* y32;                // fp32 NCHW [N][cout_real][Ho][Wo] or NULL
+    const float* scale;        // [Cout] or NULL (forward)
+    const float* bias;         // [Cout] or NULL (forward)
+    const uint16_t* res;       // bf16, indexed like y, or NULL
+    const uint16_t* mask_src;  // bf16, indexed like y, or NULL (dgrad)
+    int N, H, W, Cin;
+    int Ho, Wo, Cout, cout_real;
+    int ntaps, stride;
+    int out_H, out_W, out_stride;
+    int relu, mode;            // mode 0 = forward epilogue, 1 = dgrad epilogue
+    int M;                     // N*Ho*Wo
+    short tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
+};
+
+__device__ __forceinline__ uint32_t swz(int row, int chunk) {
+    return (uint32_t)row * CONV_ROW_BYTES + (uint32_t)((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <int WN, int WM, int TN, int TM>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int BN = WN * TN * 32;    // output channels per workgroup
+    constexpr int BM = WM * TM * 32;    // pixels per workgroup
+    constexpr int PA = BM / 32;         // loader passes over the pixel tile
+    constexpr int PB = BN / 32;
+    static_assert(WN * WM == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_x = smem;                          // [BM][128 B]
+    unsigned char* lds_w = smem + BM * CONV_ROW_BYTES;    // [BN][128 B]
+    // tap offsets: a dynamically indexed by-value kernel argument would be spilled to scratch, so park them in LDS
+    short* lds_tap = reinterpret_cast<short*>(smem + (BM + BN) * CONV_ROW_BYTES);    // [2][CMS_CONV_MAX_TAPS]
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < CMS_CONV_MAX_TAPS; ++i) {
+            lds_tap[i] = a.tap_dy[i];
+            lds_tap[CMS_CONV_MAX_TAPS + i] = a.tap_dx[i];
+        }
+    }
+    __syncthreads();
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN;
+
+    // XCD-aware tile order: consecutive logical ids (same pixel tile, different co tiles) stay on one XCD's L2
+    const int ntn = a.Cout / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % ntn, tile_m = bid / ntn;
+    const int co0 = tile_n * BN, m0 = tile_m * BM;
+
+    // ---- loader geometry (fixed for the whole K loop)
+    const int chunk = tid & 7, lrow = tid >> 3;
+    int by[PA], bx[PA], nb[PA];
+    bool okm[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        okm[i] = m < a.M;
+        const int mm = okm[i] ? m : 0;
+        const int ox = mm % a.Wo;
+        const int t = mm / a.Wo;
+        const int oy = t % a.Ho;
+        const int n = t / a.Ho;
+        by[i] = oy * a.stride;
+        bx[i] = ox * a.stride;
+        nb[i] = n * a.H * a.W;
+    }
+    const int kc_per_tap = a.Cin / CONV_BK;
+    const int ksteps = a.ntaps * kc_per_tap;
+
+    u32x4 rx[PA], rw[PB];
+    auto load_tile = [&](int ks) {
+        const int tap = ks / kc_per_tap;
+        const int c0 = (ks - tap * kc_per_tap) * CONV_BK + chunk * 8;
+        const int dy = lds_tap[tap], dx = lds_tap[CMS_CONV_MAX_TAPS + tap];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int iy = by[i] + dy, ix = bx[i] + dx;
+            const bool ok = okm[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            if (ok) {
+                rx[i] = *reinterpret_cast<const u32x4*>(a.x + ((size_t)(nb[i] + iy * a.W + ix)) * a.Cin + c0);
+            } else {
+                rx[i] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        const uint16_t* wt = a.w + ((size_t)tap * a.Cout + co0) * a.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wt + (size_t)(lrow + 32 * i) * a.Cin);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(lds_x + swz(lrow + 32 * i, chunk)) = rx[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<u32x4*>(lds_w + swz(lrow + 32 * i, chunk)) = rw[i];
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    load_tile(0);
+    for (int ks = 0; ks < ksteps; ++ks) {
+        __syncthreads();            // previous stage's fragment reads are done
+        store_tile();
+        __syncthreads();
+        load_tile(ks + 1 < ksteps ? ks + 1 : ks);   // in flight during the MFMA phase (last one is a harmless re-load)
+#pragma unroll
+        for (int kk = 0; kk < CONV_BK / 16; ++kk) {
+            u32x4 fw[TN], fx[TM];     // (arrays of __bf16 vectors are not promoted to registers by the compiler)
+            const int ch = kk * 2 + fhalf;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int row = (wn * TN + i) * 32 + frow;
+                fw[i] = *reinterpret_cast<const u32x4*>(lds_w + swz(row, ch));
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int row = (wm * TM + j) * 32 + frow;
+                fx[j] = *reinterpret_cast<const u32x4*>(lds_x + swz(row, ch));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[i]),
+                                                                        __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue straight from the accumulators: lane owns pixel (l&31) of each pixel tile and, per register
+    // quad, 4 consecutive output channels
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + (wm * TM + j) * 32 + frow;
+        if (m >= a.M) continue;
+        const int ox = m % a.Wo;
+        const int t = m / a.Wo;
+        const int oy = t % a.Ho;
+        const int n = t / a.Ho;
+        const size_t opix = ((size_t)n * a.out_H + (size_t)oy * a.out_stride) * a.out_W + (size_t)ox * a.out_stride;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = co0 + (wn * TN + i) * 32 + 8 * q + 4 * fhalf;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                if (a.mode == 0) {
+                    if (a.scale) {
+                        const float4 s = *reinterpret_cast<const float4*>(a.scale + co);
+                        v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+                    }
+                    if (a.bias) {
+                        const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                }
+                if (a.res) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(a.res + opix * a.Cout + co);
+                    v[0] += bf16_to_f32((uint16_t)(rr.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rr.x >> 16));
+                    v[2] += bf16_to_f32((uint16_t)(rr.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rr.y >> 16));
+                }
+                if (a.mode == 0) {
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                    }
+                } else if (a.mask_src) {
+                    const uint2 mm = *reinterpret_cast<const uint2*>(a.mask_src + opix * a.Cout + co);
+                    // bf16 > 0  <=>  sign bit clear and magnitude non-zero
+                    const uint16_t h[4] = {(uint16_t)(mm.x & 0xffff), (uint16_t)(mm.x >> 16), (uint16_t)(mm.y & 0xffff),
+                                           (uint16_t)(mm.y >> 16)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ((h[e] & 0x8000) == 0 && (h[e] & 0x7fff) != 0) ? v[e] : 0.0f;
+                }
+                if (a.y) {
+                    uint2 o;
+                    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(a.y + opix * a.Cout + co) = o;
+                }
+                if (a.y32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e < a.cout_real)
+                            a.y32[(((size_t)n * a.cout_real + co + e) * a.Ho + oy) * a.Wo + ox] = v[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dgrad operand: wT[tap'][ci][co] = bf16( w[tap][co][ci] * scale[co] ), tap' = ntaps-1-tap when `flip`
+// (32x32 LDS tile transpose; coalesced on both sides). src may be fp32 or bf16.
+template <class T>
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const T* __restrict__ src, uint16_t* __restrict__ dst,
+                                                             const float* __restrict__ scale, int ntaps, int Cout,
+                                                             int Cin, int flip) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const T* s = src + (size_t)tap * Cout * Cin;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        float v = 0.0f;
+        if (co < Cout && ci < Cin) {
+            if constexpr (sizeof(T) == 4) v = (float)s[(size_t)co * Cin + ci];
+            else v = bf16_to_f32((uint16_t)s[(size_t)co * Cin + ci]);
+            if (scale) v *= scale[co];
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    const int otap = flip ? ntaps - 1 - tap : tap;
+    uint16_t* d = dst + (size_t)otap * Cin * Cout;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Cin && co < Cout) d[(size_t)ci * Cout + co] = f32_to_bf16(tile[tx][r]);
+    }
+}
+
+}  // namespace cms
+
+using namespace cms;
+
+static int conv_check(const cms_conv_desc* d) {
+    CMS_REQUIRE(d != nullptr, "conv: null descriptor");
+    CMS_REQUIRE(d->x && d->w && (d->y || d->y32), "conv: NULL tensor");
+    CMS_REQUIRE(d->n > 0 && d->h > 0 && d->w_in > 0 && d->cin > 0 && d->ho > 0 && d->wo > 0 && d->cout > 0,
+                "conv: bad geometry");
+    CMS_REQUIRE(d->cin % CONV_BK == 0, "conv: Cin (%d) must be a multiple of %d", d->cin, CONV_BK);
+    CMS_REQUIRE(d->cout % 32 == 0, "conv: Cout (%d) must be a multiple of 32 (pad the weight tensor)", d->cout);
+    CMS_REQUIRE(d->ntaps > 0 && d->ntaps <= CMS_CONV_MAX_TAPS, "conv: 1..%d taps", CMS_CONV_MAX_TAPS);
+    CMS_REQUIRE(d->stride >= 1 && d->out_stride >= 1, "conv: bad stride");
+    CMS_REQUIRE(d->y == nullptr || d->cout_real == d->cout, "conv: bf16 NHWC output needs cout_real == cout");
+    CMS_REQUIRE((size_t)d->n * d->h * d->w_in < (1u << 31) && (size_t)d->n * d->ho * d->wo < (1u << 31),
+                "conv: too many pixels");
+    return CMS_OK;
+}
+
+template <int WN, int WM, int TN, int TM>
+static void conv_launch(const ConvArgs& a, hipStream_t s) {
+    constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
+    const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM);
+    const size_t lds = (size_t)(BN + BM) * CONV_ROW_BYTES + 2 * CMS_CONV_MAX_TAPS * sizeof(short) + 8;
+    hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM>), dim3(grid), dim3(256), lds, s, a);
+}
+
+extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
+    int rc = conv_check(d);
+    if (rc) return rc;
+    ConvArgs a;
+    a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.y = (uint16_t*)d->y; a.y32 = d->y32;
+    a.scale = d->scale; a.bias = d->bias; a.res = (const uint16_t*)d->res; a.mask_src = (const uint16_t*)d->mask_src;
+    a.N = d->n; a.H = d->h; a.W = d->w_in; a.Cin = d->cin;
+    a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout; a.cout_real = d->cout_real;
+    a.ntaps = d->ntaps; a.stride = d->stride;
+    a.out_H = d->out_h; a.out_W = d->out_w; a.out_stride = d->out_stride;
+    a.relu = d->relu; a.mode = d->mode;
+    a.M = d->n * d->ho * d->wo;
+    for (int i = 0; i < CMS_CONV_MAX_TAPS; ++i) {
+        a.tap_dy[i] = (short)(i < d->ntaps ? d->tap_dy[i] : 0);
+        a.tap_dx[i] = (short)(i < d->ntaps ? d->tap_dx[i] : 0);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int tile = d->tile;   // 0 = auto
+    if ((tile == 0 && d->cout % 128 == 0) || tile == 128) {
+        CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 128 needs Cout %% 128 == 0");
+        conv_launch<2, 2, 2, 2>(a, s);           // 128 co x 128 pixels
+    } else if ((tile == 0 && d->cout % 64 == 0) || tile == 64) {
+        CMS_REQUIRE(d->cout % 64 == 0, "conv: tile 64 needs Cout %% 64 == 0");
+        conv_launch<1, 4, 2, 1>(a, s);           // 64 co x 128 pixels
+    } else {
+        conv_launch<1, 4, 1, 1>(a, s);           // 32 co x 128 pixels
+    }
+    return launch_status("cms_conv_igemm");
+}
+
+extern "C" int cms_conv_pack_transpose(const void* src, int src_dtype, void* dst_bf16, const float* scale, int ntaps,
+                                       int cout, int cin, int flip, void* stream) {
+    CMS_REQUIRE(src && dst_bf16, "conv_pack_transpose: NULL pointer");
+    CMS_REQUIRE(ntaps > 0 && cout > 0 && cin > 0, "conv_pack_transpose: bad geometry");
+    CMS_REQUIRE(src_dtype == CMS_F32 || src_dtype == CMS_BF16, "conv_pack_transpose: bad dtype");
+    dim3 grid((cin + 31) / 32, (cout + 31) / 32, ntaps);
+    hipStream_t s = (hipStream_t)stream;
+    if (src_dtype == CMS_F32)
+        hipLaunchKernelGGL(pack_transpose_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (uint16_t*)dst_bf16,
+                           scale, ntaps, cout, cin, flip);
+    else
+        hipLaunchKernelGGL(pack_transpose_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)src,
+                           (uint16_t*)dst_bf16, scale, ntaps, cout, cin, flip);
+    return launch_status("cms_conv_pack_transpose");
+}

@@ -371,3 +371,67 @@ def confusion(truth, pred, num_classes, ignore_index=None, cm=None):
     check(fn['cms_confusion'](_ptr(truth), _ptr(pred), truth.numel(), -1 if ignore_index is None else int(ignore_index),
                               int(num_classes), _ptr(cm), _stream()), 'cms_confusion')
     return cm
+
+
+# ---------------------------------------------------------------------------------------------- MFMA convolution
+def conv_taps(kh, kw, dilation, padding):
+    """(dy, dx) input offsets of the kh*kw taps in [ky][kx] order."""
+    return [(ky * dilation - padding, kx * dilation - padding) for ky in range(kh) for kx in range(kw)]
+
+
+def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, res=None, relu=False, mode=0,
+               mask_src=None, out=None, out_f32_nchw=None, cout_real=None, out_stride=1, out_full_hw=None, tile=0):
+    """
+    Implicit-GEMM convolution on the MFMA units (csrc/conv.hip).
+      x         bf16 NHWC-contiguous tensor of logical shape (N, H, W, Cin)
+      w_packed  bf16 (ntaps, Cout, Cin)
+      taps      list of (dy, dx) input offsets per tap
+    Returns the bf16 (N, out_h, out_w, Cout) output (or the fp32 NCHW tensor given in `out_f32_nchw`).
+    """
+    _need_cuda(x, w_packed, scale, bias, res, mask_src, out, out_f32_nchw)
+    if x.dtype != torch.bfloat16 or w_packed.dtype != torch.bfloat16 or not x.is_contiguous() \
+            or not w_packed.is_contiguous():
+        raise TypeError('conv_igemm: contiguous bf16 NHWC input and packed weights required')
+    n, h, w_in, cin = (int(s) for s in x.shape)
+    ntaps, cout, cin_w = (int(s) for s in w_packed.shape)
+    if cin_w != cin or ntaps != len(taps):
+        raise ValueError('conv_igemm: weight / tap table does not match the input')
+    ho, wo = (int(out_hw[0]), int(out_hw[1])) if out_hw is not None else (h, w_in)
+    oh, ow = (int(out_full_hw[0]), int(out_full_hw[1])) if out_full_hw is not None else (ho, wo)
+    d = _lib.ConvDesc()
+    d.x, d.w = x.data_ptr(), w_packed.data_ptr()
+    if out_f32_nchw is None:
+        if out is None:
+            out = (torch.zeros if out_stride > 1 else torch.empty)((n, oh, ow, cout), dtype=torch.bfloat16,
+                                                                  device=x.device)
+        d.y, d.y32 = out.data_ptr(), None
+    else:
+        d.y, d.y32 = None, out_f32_nchw.data_ptr()
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.res = res.data_ptr() if res is not None else None
+    d.mask_src = mask_src.data_ptr() if mask_src is not None else None
+    d.n, d.h, d.w_in, d.cin = n, h, w_in, cin
+    d.ho, d.wo, d.cout = ho, wo, cout
+    d.cout_real = cout if cout_real is None else int(cout_real)
+    d.ntaps = ntaps
+    for i, (dy, dx) in enumerate(taps):
+        d.tap_dy[i], d.tap_dx[i] = int(dy), int(dx)
+    d.stride = int(stride)
+    d.out_h, d.out_w, d.out_stride = oh, ow, int(out_stride)
+    d.relu, d.mode, d.tile = int(bool(relu)), int(mode), int(tile)
+    check(fn['cms_conv_igemm'](C.byref(d), _stream()), 'cms_conv_igemm')
+    return out if out_f32_nchw is None else out_f32_nchw
+
+
+def conv_pack_transpose(w_packed, scale=None, flip=True, out=None):
+    """(ntaps, Cout, Cin) fp32/bf16 -> bf16 (ntaps, Cin, Cout) with BN scale folded and taps flipped: dgrad operand."""
+    _need_cuda(w_packed, scale, out)
+    ntaps, cout, cin = (int(s) for s in w_packed.shape)
+    if not w_packed.is_contiguous():
+        raise TypeError('conv_pack_transpose: contiguous weights required')
+    if out is None:
+        out = torch.empty((ntaps, cin, cout), dtype=torch.bfloat16, device=w_packed.device)
+    check(fn['cms_conv_pack_transpose'](_ptr(w_packed), _dtype_code(w_packed), _ptr(out), _ptr(scale), ntaps, cout, cin,
+                                        int(bool(flip)), _stream()), 'cms_conv_pack_transpose')
+    return out

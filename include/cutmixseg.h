@@ -212,6 +212,43 @@ int cms_argmax_confusion(const float* logits, const void* labels, int label_dtyp
 int cms_confusion(const uint8_t* truth, const uint8_t* pred, size_t count, int ignore_index, int c, int64_t* cm,
                   void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * MFMA implicit-GEMM convolution for the backbone   (nn.Conv2d + frozen nn.BatchNorm2d + ReLU (+ residual) of
+ *                               architectures/deeplab2.py:89-109, 124-128, and their backward passes)
+ * Activations bf16 NHWC, weights bf16 [tap][Cout][Cin], fp32 accumulation.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define CMS_CONV_MAX_TAPS 18
+#define CMS_CONV_FWD 0     /* y  = relu(acc * scale[co] + bias[co] + res)                     */
+#define CMS_CONV_DGRAD 1   /* dx = (acc + res) * [mask_src > 0]                               */
+
+typedef struct cms_conv_desc {
+    const void* x;         /* bf16 [N][H][W][Cin]                                                                */
+    const void* w;         /* bf16 [ntaps][Cout][Cin]                                                            */
+    void* y;               /* bf16 [N][out_h][out_w][Cout] or NULL                                               */
+    float* y32;            /* fp32 NCHW [N][cout_real][Ho][Wo] or NULL (ASPP head logits)                         */
+    const float* scale;    /* [Cout] or NULL: frozen-BN gamma/sqrt(var+eps)                                       */
+    const float* bias;     /* [Cout] or NULL: frozen-BN beta - mean*scale, or the conv bias                       */
+    const void* res;       /* bf16, indexed like y: residual (forward) / gradient to add (dgrad), or NULL         */
+    const void* mask_src;  /* bf16, indexed like y: dgrad output is zeroed where this activation is <= 0, or NULL */
+    int n, h, w_in, cin;   /* input geometry                                                                     */
+    int ho, wo, cout;      /* GEMM pixel grid (N*ho*wo rows) and channel count (multiple of 32)                   */
+    int cout_real;         /* channels actually written to y32 (<= cout); must equal cout for the bf16 output     */
+    int ntaps;             /* kernel taps; tap t reads input pixel (oy*stride + tap_dy[t], ox*stride + tap_dx[t]) */
+    int tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
+    int stride;            /* input gather stride                                                                */
+    int out_h, out_w, out_stride; /* output tensor geometry; pixel (oy,ox) is written at (oy*out_stride, ...)      */
+    int relu;              /* forward epilogue ReLU                                                              */
+    int mode;              /* CMS_CONV_FWD / CMS_CONV_DGRAD                                                      */
+    int tile;              /* 0 = auto, else channels per workgroup: 128 / 64 / 32                               */
+} cms_conv_desc;
+
+int cms_conv_igemm(const cms_conv_desc* d, void* stream);
+
+/* dst[tap'][ci][co] = bf16(src[tap][co][ci] * scale[co]) with tap' = ntaps-1-tap when flip != 0: the operand of
+ * the dgrad pass (which is cms_conv_igemm on the transposed, tap-flipped, BN-scale-folded weights). */
+int cms_conv_pack_transpose(const void* src, int src_dtype, void* dst_bf16, const float* scale, int ntaps, int cout,
+                            int cin, int flip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,148 @@
+"""
+GPU parity of the MFMA implicit-GEMM convolution (csrc/conv.hip, through the C ABI) against a plain PyTorch fp32
+reference of the same op on identical bf16-rounded inputs (F.conv2d in fp32 on the device + folded-BN affine +
+residual + ReLU; autograd for the data gradient). Tolerance: bf16 output rounding (2^-8 relative) on top of fp32
+accumulation-order differences.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from cutmix_semisup_seg_amd import ops as _ops
+    return _ops
+
+
+def _mk(shape, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen, device=DEV) * scale).bfloat16()
+
+
+def _pack(w):          # (Cout, Cin, kh, kw) bf16 -> (taps, Cout, Cin)
+    co, ci, kh, kw = w.shape
+    return w.permute(2, 3, 0, 1).reshape(kh * kw, co, ci).contiguous()
+
+
+CASES = [
+    # name, N, H, W, Cin, Cout, k, stride, dil
+    ('l3_conv3_1x1', 2, 41, 41, 256, 1024, 1, 1, 1),
+    ('l3_conv2_3x3_d2', 2, 41, 41, 256, 256, 3, 1, 2),
+    ('l4_conv2_3x3_d4', 1, 41, 41, 512, 512, 3, 1, 4),
+    ('l2_conv1_1x1_s2', 2, 81, 81, 256, 128, 1, 2, 1),
+    ('l1_conv1_1x1_c64', 2, 33, 47, 256, 64, 1, 1, 1),
+    ('l1_conv2_3x3_c64', 1, 33, 47, 64, 64, 3, 1, 1),
+    ('tail_1x1', 1, 7, 9, 64, 128, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize('epi', ['plain', 'bn_relu', 'bn_res_relu'])
+def test_conv_forward(ops, case, epi):
+    name, N, H, W, Cin, Cout, k, stride, dil = case
+    g = torch.Generator(device=DEV).manual_seed(hash(name) % 1000)
+    pad = dil * (k - 1) // 2
+    x = _mk((N, H, W, Cin), g)
+    w = _mk((Cout, Cin, k, k), g, (2.0 / (Cin * k * k)) ** 0.5)
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    scale = (torch.rand(Cout, generator=g, device=DEV) + 0.5) if epi != 'plain' else None
+    bias = torch.randn(Cout, generator=g, device=DEV) * 0.1 if epi != 'plain' else None
+    res = _mk((N, Ho, Wo, Cout), g) if epi == 'bn_res_relu' else None
+    relu = epi != 'plain'
+    y = ops.conv_igemm(x, _pack(w), ops.conv_taps(k, k, dil, pad), stride=stride, out_hw=(Ho, Wo), scale=scale,
+                       bias=bias, res=res, relu=relu)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, stride, pad, dil)
+    if scale is not None:
+        ref = ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    if res is not None:
+        ref = ref + res.float().permute(0, 3, 1, 2)
+    if relu:
+        ref = F.relu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    assert y.shape == ref.shape
+    err = (y.float() - ref).abs()
+    tol = 1e-2 * ref.abs() + 2e-2
+    assert bool((err <= tol).all()), 'max err {} at scale {}'.format(float(err.max()), float(ref.abs().max()))
+    assert float(err.mean()) <= 4e-3 * float(ref.abs().mean() + 1e-6) + 1e-4
+
+
+@pytest.mark.parametrize('tile', [128, 64, 32])
+def test_conv_tile_variants_agree(ops, tile):
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = _mk((2, 20, 23, 128), g)
+    w = _mk((128, 128, 3, 3), g, 0.03)
+    taps = ops.conv_taps(3, 3, 2, 2)
+    a = ops.conv_igemm(x, _pack(w), taps, tile=tile)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, 1, 2, 2).permute(0, 2, 3, 1)
+    assert float((a.float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max()) + 1e-2
+
+
+def test_aspp_head_two_dilations_fp32_nchw(ops):
+    """conv_d6(x) + conv_d12(x) + bias as ONE 18-tap implicit GEMM with the class axis padded to 32."""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    N, H, W, Cin, C = 2, 41, 41, 2048, 21
+    x = _mk((N, H, W, Cin), g)
+    w6 = _mk((C, Cin, 3, 3), g, 0.01)
+    w12 = _mk((C, Cin, 3, 3), g, 0.01)
+    b = torch.randn(C, generator=g, device=DEV)
+    wp = torch.zeros(18, 32, Cin, dtype=torch.bfloat16, device=DEV)
+    wp[:9, :C] = _pack(w6)
+    wp[9:, :C] = _pack(w12)
+    bias = torch.zeros(32, device=DEV)
+    bias[:C] = b
+    taps = ops.conv_taps(3, 3, 6, 6) + ops.conv_taps(3, 3, 12, 12)
+    out = torch.empty(N, C, H, W, device=DEV)
+    ops.conv_igemm(x, wp, taps, bias=bias, out_f32_nchw=out, cout_real=C)
+    xf = x.float().permute(0, 3, 1, 2)
+    ref = F.conv2d(xf, w6.float(), None, 1, 6, 6) + F.conv2d(xf, w12.float(), None, 1, 12, 12) + b.view(1, -1, 1, 1)
+    assert float((out - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize('case', [('1x1', 2, 41, 41, 256, 1024, 1, 1), ('3x3_d2', 2, 41, 41, 256, 256, 3, 2),
+                                  ('3x3_d4_tail', 1, 19, 21, 512, 512, 3, 4)], ids=lambda c: c[0])
+def test_conv_dgrad_with_relu_mask(ops, case):
+    """dX = conv^T(dU * scale) then masked by the producer's ReLU, via the same kernel on packed-transposed weights."""
+    name, N, H, W, Cin, Cout, k, dil = case
+    g = torch.Generator(device=DEV).manual_seed(11)
+    pad = dil * (k - 1) // 2
+    x = _mk((N, H, W, Cin), g)                   # saved input activation (post-ReLU of its producer)
+    x = torch.relu(x)
+    w = _mk((Cout, Cin, k, k), g, (2.0 / (Cin * k * k)) ** 0.5)
+    scale = torch.rand(Cout, generator=g, device=DEV) + 0.5
+    dU = _mk((N, H, W, Cout), g)                 # gradient wrt the pre-activation of this conv's BN output
+    add = _mk((N, H, W, Cin), g)                 # gradient arriving through a residual branch
+    wT = ops.conv_pack_transpose(_pack(w), scale=scale, flip=True)      # (taps, Cin, Cout)
+    assert wT.shape == (k * k, Cin, Cout)
+    dx = ops.conv_igemm(dU, wT, ops.conv_taps(k, k, dil, pad), res=add, mode=1, mask_src=x)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    y = F.conv2d(xr, w.float(), None, 1, pad, dil) * scale.view(1, -1, 1, 1)
+    y.backward(dU.float().permute(0, 3, 1, 2))
+    ref = (xr.grad + add.float().permute(0, 3, 1, 2)) * (x.float().permute(0, 3, 1, 2) > 0)
+    ref = ref.permute(0, 2, 3, 1)
+    err = (dx.float() - ref).abs()
+    assert bool((err <= 1.5e-2 * ref.abs() + 3e-2 * float(ref.abs().mean())).all()), float(err.max())
+
+
+def test_conv_dgrad_stride2_scatter(ops):
+    g = torch.Generator(device=DEV).manual_seed(12)
+    N, H, W, Cin, Cout = 2, 81, 81, 256, 128
+    w = _mk((Cout, Cin, 1, 1), g, 0.06)
+    dU = _mk((N, 41, 41, Cout), g)
+    wT = ops.conv_pack_transpose(_pack(w), flip=True)
+    dx = ops.conv_igemm(dU, wT, [(0, 0)], mode=1, out_hw=(41, 41), out_stride=2, out_full_hw=(H, W))
+    xr = torch.zeros(N, Cin, H, W, device=DEV, requires_grad=True)
+    F.conv2d(xr, w.float(), None, 2).backward(dU.float().permute(0, 3, 1, 2))
+    ref = xr.grad.permute(0, 2, 3, 1)
+    assert float((dx.float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max()) + 1e-3
+
+
+def test_conv_rejects_bad_shapes(ops):
+    x = torch.zeros(1, 4, 4, 48, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(1, 64, 48, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError, match='multiple of 64'):
+        ops.conv_igemm(x, w, [(0, 0)])
