@@ -67,6 +67,13 @@ class ConvDesc(C.Structure):
                 ('tile', c_int)]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [('du', c_void_p), ('x', c_void_p), ('dw', c_void_p), ('scale', c_void_p),
+                ('n', c_int), ('h', c_int), ('w_in', c_int), ('cin', c_int), ('ho', c_int), ('wo', c_int),
+                ('cout', c_int), ('cout_real', c_int), ('ntaps', c_int), ('tap_dy', c_int * 18), ('tap_dx', c_int * 18),
+                ('stride', c_int), ('ksplit', c_int)]
+
+
 _P = C.POINTER
 
 
@@ -107,6 +114,7 @@ PROTOTYPES = {
                                      c_int, c_void_p, c_void_p, c_void_p]),
     'cms_confusion': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
     'cms_conv_igemm': (c_int, [_P(ConvDesc), c_void_p]),
+    'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 

@@ -350,3 +350,204 @@ extern "C" int cms_conv_pack_transpose(const void* src, int src_dtype, void* dst
                            (uint16_t*)dst_bf16, scale, ntaps, cout, cin, flip);
     return launch_status("cms_conv_pack_transpose");
 }
+
+// =================================================================================================================
+// Weight gradient:  dW[tap][co][ci] += scale[co] * sum_pixels dU[pix][co] * X[pix shifted by tap][ci]
+//
+// GEMM with K = pixels: both operands are stored pixel-major (NHWC), i.e. K-major, while the MFMA wants each lane to
+// hold 8 consecutive k for one row. gfx950's LDS transpose read does that conversion: ds_read_b64_tr_b16 over a
+// 16-lane group turns a [4 pixels][16 channels] block (source lane s supplies the 8-byte chunk
+// pixel = s>>2, channels 4*(s&3)..+3) into "lane i holds channel i for the 4 pixels" (probed on hardware:
+// result(lane i, j) = chunk[4j + (i>>2)][i&3], tools/tr_probe.hip). Two such reads give one MFMA operand fragment.
+//
+// LDS image: [64 pixels][128 channels] bf16 per operand (256-byte rows, 64-byte slots XOR-swizzled with pixel&3 so the
+// four pixel rows of a half-wave's read land in different bank windows). Workgroup = 4 waves, 128 (co) x 128 (ci)
+// outputs of one tap over one slice of the pixel axis (split-K); results are accumulated into the fp32 gradient arena
+// with atomics (the arena is zeroed once per step, so both backward passes of an iteration simply add up).
+// MFMA-bound for Cin*Cout >= 256*256 (AI = 2*64*128*128 / 32 KB per stage = 64 FLOP/B from L2/HBM per workgroup stage).
+namespace cms {
+
+struct WgradArgs {
+    const uint16_t* du;    // bf16 [N][Ho][Wo][Cout]
+    const uint16_t* x;     // bf16 [N][H][W][Cin]
+    float* dw;             // fp32 [ntaps][Cout][Cin]
+    const float* scale;    // [Cout] or NULL
+    int N, H, W, Cin, Ho, Wo, Cout;
+    int ntaps, stride;
+    int M;                 // N*Ho*Wo
+    int ksplit, pix_per_split;   // pixel slice per workgroup (multiple of 64)
+    int cout_real;         // rows >= cout_real are not written (padded class axis)
+    short tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t wg_off(int pix, int ch) {     // byte offset of channel `ch` (multiple of 4) of row `pix`
+    const int slot = (ch >> 5) ^ (pix & 3);
+    return (uint32_t)pix * 256u + (uint32_t)slot * 64u + (uint32_t)(ch & 31) * 2u;
+}
+
+template <int TCO, int TCI>      // 32x32 MFMA tiles per wave along co / ci; waves are 2 x 2
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int BCO = 2 * TCO * 32, BCI = 2 * TCI * 32;       // <= 128 each
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_u = smem;                  // [64][256 B]  dU tile (only the first BCO channels are used)
+    unsigned char* lds_x = smem + 64 * 256;       // [64][256 B]  X tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = wave & 1, wci = wave >> 1;
+    const int nco = a.Cout / BCO, nci = a.Cin / BCI;
+    int b = blockIdx.x;
+    const int tco = b % nco; b /= nco;
+    const int tci = b % nci; b /= nci;
+    const int tap = b % a.ntaps; b /= a.ntaps;
+    const int ks = b;
+    const int co0 = tco * BCO, ci0 = tci * BCI;
+    int dy = 0, dx = 0;
+#pragma unroll
+    for (int i = 0; i < CMS_CONV_MAX_TAPS; ++i) {       // constant-index scan (no dynamic indexing of kernel arguments)
+        if (i == tap) { dy = a.tap_dy[i]; dx = a.tap_dx[i]; }
+    }
+    const int p_begin = ks * a.pix_per_split;
+    const int p_end = min(a.M, p_begin + a.pix_per_split);
+    if (p_begin >= p_end) return;      // empty slice (uniform for the whole workgroup)
+
+    // loader: 64 pixels x 16 chunks of 16 B per operand; thread -> chunk (tid & 15), pixel rows (tid >> 4) + 16*i
+    const int c16 = tid & 15, prow = tid >> 4;
+    const bool load_u = c16 * 8 < BCO, load_x = c16 * 8 < BCI;
+    u32x4 ru[4], rxx[4];
+    auto load_tile = [&](int p0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = p0 + prow + 16 * i;
+            const bool ok = m < p_end;
+            ru[i] = u32x4{0u, 0u, 0u, 0u};
+            rxx[i] = u32x4{0u, 0u, 0u, 0u};
+            if (ok) {
+                const int ox = m % a.Wo;
+                const int t = m / a.Wo;
+                const int oy = t % a.Ho;
+                const int n = t / a.Ho;
+                if (load_u) ru[i] = *reinterpret_cast<const u32x4*>(a.du + (size_t)m * a.Cout + co0 + c16 * 8);
+                const int iy = oy * a.stride + dy, ix = ox * a.stride + dx;
+                if (load_x && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                    rxx[i] = *reinterpret_cast<const u32x4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + ci0 + c16 * 8);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = prow + 16 * i;
+            *reinterpret_cast<u32x4*>(lds_u + wg_off(p, c16 * 8)) = ru[i];
+            *reinterpret_cast<u32x4*>(lds_x + wg_off(p, c16 * 8)) = rxx[i];
+        }
+    };
+
+    f32x16 acc[TCO][TCI];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TCI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // transpose-read geometry of this lane: 16-lane group g, lane-in-group li
+    const int g = lane >> 4, li = lane & 15;
+    const int ch_in_tile = 16 * (g & 1) + 4 * (li & 3);     // channel chunk this lane SUPPLIES (within a 32-wide tile)
+    const int pix_in_blk = 8 * (g >> 1) + (li >> 2);        // pixel row this lane supplies (within a 16-pixel k-step)
+
+    if (p_begin < p_end) load_tile(p_begin);
+    for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        load_tile(p0 + 64 < p_end ? p0 + 64 : p0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {                    // 16 pixels per MFMA
+            u32x4 fu[TCO], fx[TCI];
+            const int pr0 = kk * 16 + pix_in_blk;           // first read: pixels +0..3 of this lane group's 8
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) {
+                const int ch = (wco * TCO + i) * 32 + ch_in_tile;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(lds_u + wg_off(pr0, ch)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(lds_u + wg_off(pr0 + 4, ch)));
+                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                fu[i] = u32x4{l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int j = 0; j < TCI; ++j) {
+                const int ch = (wci * TCI + j) * 32 + ch_in_tile;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(lds_x + wg_off(pr0, ch)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(lds_x + wg_off(pr0 + 4, ch)));
+                uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                fx[j] = u32x4{l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                for (int j = 0; j < TCI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fu[i]),
+                                                                        __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: acc rows = co, columns = ci (lane&31) -> 128-byte contiguous atomics per row
+    float* dwt = a.dw + (size_t)tap * a.Cout * a.Cin;
+    const int fcol = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TCO; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+            if (co >= a.cout_real) continue;
+            const float s = a.scale ? a.scale[co] : 1.0f;
+#pragma unroll
+            for (int j = 0; j < TCI; ++j) {
+                const int ci = ci0 + (wci * TCI + j) * 32 + fcol;
+                atomicAdd(dwt + (size_t)co * a.Cin + ci, acc[i][j][r] * s);
+            }
+        }
+    }
+}
+
+}  // namespace cms
+
+extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
+    CMS_REQUIRE(d && d->du && d->x && d->dw, "conv_wgrad: NULL pointer");
+    CMS_REQUIRE(d->cin % 64 == 0 && d->cout % 64 == 0, "conv_wgrad: Cin (%d) and Cout (%d) must be multiples of 64", d->cin,
+                d->cout);
+    CMS_REQUIRE(d->ntaps > 0 && d->ntaps <= CMS_CONV_MAX_TAPS, "conv_wgrad: 1..%d taps", CMS_CONV_MAX_TAPS);
+    CMS_REQUIRE(d->n > 0 && d->h > 0 && d->w_in > 0 && d->ho > 0 && d->wo > 0 && d->stride >= 1, "conv_wgrad: bad geometry");
+    WgradArgs a;
+    a.du = (const uint16_t*)d->du; a.x = (const uint16_t*)d->x; a.dw = d->dw; a.scale = d->scale;
+    a.N = d->n; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
+    a.ntaps = d->ntaps; a.stride = d->stride;
+    a.M = d->n * d->ho * d->wo;
+    a.cout_real = d->cout_real > 0 ? d->cout_real : d->cout;
+    for (int i = 0; i < CMS_CONV_MAX_TAPS; ++i) {
+        a.tap_dy[i] = (short)(i < d->ntaps ? d->tap_dy[i] : 0);
+        a.tap_dx[i] = (short)(i < d->ntaps ? d->tap_dx[i] : 0);
+    }
+    const int bco = d->cout % 128 == 0 ? 128 : 64, bci = d->cin % 128 == 0 ? 128 : 64;
+    const int tiles = (d->cout / bco) * (d->cin / bci) * d->ntaps;
+    // split the pixel axis so that the grid has ~3 workgroups per CU, each slice a multiple of 64 pixels
+    int ksplit = d->ksplit > 0 ? d->ksplit : (768 + tiles - 1) / tiles;
+    int per = ((a.M + ksplit - 1) / ksplit + 63) / 64 * 64;
+    if (per < 64) per = 64;
+    ksplit = (a.M + per - 1) / per;
+    a.ksplit = ksplit;
+    a.pix_per_split = per;
+    const size_t lds = 2 * 64 * 256;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(tiles * ksplit);
+    if (bco == 128 && bci == 128) hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), lds, s, a);
+    else if (bco == 128) hipLaunchKernelGGL((conv_wgrad_kernel<2, 1>), grid, dim3(256), lds, s, a);
+    else if (bci == 128) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), lds, s, a);
+    return launch_status("cms_conv_wgrad");
+}

@@ -435,3 +435,31 @@ def conv_pack_transpose(w_packed, scale=None, flip=True, out=None):
     check(fn['cms_conv_pack_transpose'](_ptr(w_packed), _dtype_code(w_packed), _ptr(out), _ptr(scale), ntaps, cout, cin,
                                         int(bool(flip)), _stream()), 'cms_conv_pack_transpose')
     return out
+
+
+def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0):
+    """
+    dw (fp32 (ntaps, Cout, Cin), accumulated into) += scale[co] * sum_pixels du[pix][co] * x[pix + tap][ci].
+    du bf16 (N, Ho, Wo, Cout), x bf16 (N, H, W, Cin), both NHWC-contiguous.
+    """
+    _need_cuda(du, x, dw, scale)
+    if du.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dw.dtype != torch.float32:
+        raise TypeError('conv_wgrad: bf16 activations and an fp32 gradient buffer required')
+    if not (du.is_contiguous() and x.is_contiguous() and dw.is_contiguous()):
+        raise TypeError('conv_wgrad: contiguous tensors required')
+    n, ho, wo, cout = (int(s) for s in du.shape)
+    n2, h, w_in, cin = (int(s) for s in x.shape)
+    if n2 != n or tuple(dw.shape) != (len(taps), cout, cin):
+        raise ValueError('conv_wgrad: shape mismatch')
+    d = _lib.WgradDesc()
+    d.du, d.x, d.dw = du.data_ptr(), x.data_ptr(), dw.data_ptr()
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.n, d.h, d.w_in, d.cin, d.ho, d.wo, d.cout = n, h, w_in, cin, ho, wo, cout
+    d.cout_real = 0 if cout_real is None else int(cout_real)
+    d.ntaps = len(taps)
+    for i, (dy, dx) in enumerate(taps):
+        d.tap_dy[i], d.tap_dx[i] = int(dy), int(dx)
+    d.stride = int(stride)
+    d.ksplit = int(ksplit)
+    check(fn['cms_conv_wgrad'](C.byref(d), _stream()), 'cms_conv_wgrad')
+    return dw

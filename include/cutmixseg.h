@@ -249,6 +249,23 @@ int cms_conv_igemm(const cms_conv_desc* d, void* stream);
 int cms_conv_pack_transpose(const void* src, int src_dtype, void* dst_bf16, const float* scale, int ntaps, int cout,
                             int cin, int flip, void* stream);
 
+/* dW[tap][co][ci] (fp32) += scale[co] * sum over pixels of dU[pix][co] * X[pix shifted by tap][ci]; K = pixels,
+ * split across workgroups and accumulated with atomics (zero the gradient buffer once per step). */
+typedef struct cms_wgrad_desc {
+    const void* du;        /* bf16 [N][ho][wo][cout]: gradient wrt the conv+BN output (pre-activation)            */
+    const void* x;         /* bf16 [N][h][w_in][cin]: the conv's input                                             */
+    float* dw;             /* fp32 [ntaps][cout][cin]                                                              */
+    const float* scale;    /* [cout] frozen-BN scale or NULL                                                       */
+    int n, h, w_in, cin, ho, wo, cout;
+    int cout_real;         /* rows >= cout_real are skipped (padded class axis); 0 = cout                          */
+    int ntaps;
+    int tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
+    int stride;
+    int ksplit;            /* 0 = auto                                                                             */
+} cms_wgrad_desc;
+
+int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,3 +146,50 @@ def test_conv_rejects_bad_shapes(ops):
     w = torch.zeros(1, 64, 48, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(ValueError, match='multiple of 64'):
         ops.conv_igemm(x, w, [(0, 0)])
+
+
+WG_CASES = [('1x1_256_1024', 2, 41, 41, 256, 1024, 1, 1, 1), ('3x3d2_256', 2, 41, 41, 256, 256, 3, 1, 2),
+            ('1x1s2_256_128', 2, 81, 81, 256, 128, 1, 2, 1), ('3x3_64_64', 2, 33, 47, 64, 64, 3, 1, 1),
+            ('1x1_64_256', 1, 33, 47, 64, 256, 1, 1, 1), ('3x3d4_512_tail', 1, 19, 21, 512, 512, 3, 1, 4)]
+
+
+@pytest.mark.parametrize('case', WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_conv_wgrad(ops, case):
+    name, N, H, W, Cin, Cout, k, stride, dil = case
+    g = torch.Generator(device=DEV).manual_seed(21)
+    pad = dil * (k - 1) // 2
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    x = _mk((N, H, W, Cin), g)
+    dU = _mk((N, Ho, Wo, Cout), g)
+    scale = torch.rand(Cout, generator=g, device=DEV) + 0.5
+    dw = torch.zeros(k * k, Cout, Cin, device=DEV)
+    ops.conv_wgrad(dU, x, ops.conv_taps(k, k, dil, pad), dw, stride=stride, scale=scale)
+    w = torch.zeros(Cout, Cin, k, k, device=DEV, requires_grad=True)
+    y = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, stride, pad, dil) * scale.view(1, -1, 1, 1)
+    y.backward(dU.float().permute(0, 3, 1, 2))
+    ref = w.grad.permute(2, 3, 0, 1).reshape(k * k, Cout, Cin)
+    err = (dw - ref).abs()
+    assert float(err.max()) <= 2e-3 * float(ref.abs().max()) + 1e-3, (float(err.max()), float(ref.abs().max()))
+    # accumulation semantics: a second call adds
+    ops.conv_wgrad(dU, x, ops.conv_taps(k, k, dil, pad), dw, stride=stride, scale=scale, ksplit=3)
+    assert float((dw - 2 * ref).abs().max()) <= 4e-3 * float(ref.abs().max()) + 2e-3
+
+
+def test_aspp_wgrad_padded_classes(ops):
+    g = torch.Generator(device=DEV).manual_seed(22)
+    N, H, W, Cin, C = 2, 41, 41, 2048, 21
+    x = _mk((N, H, W, Cin), g)
+    dL = torch.zeros(N, H, W, 64, dtype=torch.bfloat16, device=DEV)
+    dL[..., :C] = _mk((N, H, W, C), g)
+    taps = ops.conv_taps(3, 3, 6, 6) + ops.conv_taps(3, 3, 12, 12)
+    dw = torch.zeros(18, 64, Cin, device=DEV)
+    ops.conv_wgrad(dL, x, taps, dw, cout_real=C)
+    xf = x.float().permute(0, 3, 1, 2)
+    for i, d in enumerate((6, 12)):
+        w = torch.zeros(C, Cin, 3, 3, device=DEV, requires_grad=True)
+        F.conv2d(xf, w, None, 1, d, d).backward(dL[..., :C].float().permute(0, 3, 1, 2))
+        ref = w.grad.permute(2, 3, 0, 1).reshape(9, C, Cin)
+        got = dw[9 * i:9 * i + 9, :C]
+        assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-3
+    assert float(dw[:, C:].abs().max()) == 0.0
