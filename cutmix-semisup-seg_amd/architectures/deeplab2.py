@@ -114,7 +114,9 @@ class TorchEngine(object):
         y = F.conv2d(x, self._weight(conv), None, conv.stride, conv.padding, conv.dilation)
         if bn is not None:
             if bn.training:
-                y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+                # batch-statistics BN in fp32 (the library's bf16 channels-last training kernel faults on gfx950)
+                y = F.batch_norm(y.float(), bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum,
+                                 bn.eps).to(y.dtype)
                 if bn.num_batches_tracked is not None:
                     bn.num_batches_tracked += 1
             else:
@@ -163,6 +165,10 @@ class ResNetDeepLab(nn.Module):
         self.num_classes = num_classes
         self.compute_dtype = torch.bfloat16
         self.engine = None          # set to an engine object to override the default executor
+        # 'auto': hand-written MFMA executor (backbone_hip.py) whenever BatchNorm is frozen and compute is bf16,
+        # library engine otherwise; 'torch' / 'hip' force one
+        self.engine_kind = 'auto'
+        self._hip_executor = None
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = _frozen_bn(64)
         self.relu = nn.ReLU(inplace=True)
@@ -203,12 +209,32 @@ class ResNetDeepLab(nn.Module):
             _ENGINES[key] = TorchEngine(self.compute_dtype)
         return _ENGINES[key]
 
+    def _use_hip_body(self):
+        if self.engine_kind == 'torch' or self.engine is not None:
+            return False
+        frozen = all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        ok = frozen and self.compute_dtype == torch.bfloat16 and self.num_classes <= 32
+        if self.engine_kind == 'hip' and not ok:
+            raise RuntimeError('the MFMA executor needs frozen BatchNorm (freeze_batchnorm()), bf16 compute and '
+                               '<= 32 classes')
+        return ok
+
+    def hip_executor(self):
+        if self._hip_executor is None:
+            from ..backbone_hip import DeepLabHipExecutor
+            self._hip_executor = DeepLabHipExecutor(self)
+        return self._hip_executor
+
     def forward_lowres(self, x):
         """(N,3,H,W) -> (N,C,h,w) fp32 head output (the reference's `x` just before its interpolate, :193)."""
         eng = self._engine(x)
+        use_hip = self._use_hip_body()
         x = eng.prepare_input(x)
         x = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         x = eng.maxpool(x)
+        if use_hip:
+            from ..backbone_hip import run_body
+            return run_body(self.hip_executor(), x.permute(0, 2, 3, 1).contiguous())
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 x = blk(x, eng)

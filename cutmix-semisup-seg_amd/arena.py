@@ -10,6 +10,12 @@ elements) is re-homed into ONE contiguous fp32 CUDA buffer; the module's tensors
   * one gradient buffer (`grad`) -> a single large all-reduce over RCCL instead of per-tensor buckets,
   * bf16 copies of student / teacher weights written by the same kernel for the bf16 conv path.
 
+Convolution weights (4-D tensors, logical shape (Cout, Cin, kh, kw) as in the reference's state_dict) are stored
+PHYSICALLY as [kh][kw][Cout][Cin]: the module sees a strided view with the reference's shape, while the flat
+buffers hold exactly the [tap][Cout][Cin] operand layout of the MFMA convolution kernels (csrc/conv.hip). The bf16
+copy written by the optimizer kernel is therefore directly the forward weight operand, and the weight-gradient
+kernel accumulates straight into the fp32 gradient arena. Element-wise consumers (Adam, EMA, all-reduce) do not care.
+
 int64 `num_batches_tracked` buffers are left alone (the reference's EMA never touches them).
 """
 from collections import OrderedDict
@@ -26,6 +32,14 @@ class Segment(object):
     def __init__(self, key, offset, count, shape, is_param, requires_grad):
         self.key, self.offset, self.count, self.shape = key, offset, count, tuple(shape)
         self.is_param, self.requires_grad = is_param, requires_grad
+
+
+def _logical_view(flat_slice, shape):
+    """View of a flat segment with logical `shape`; 4-D tensors use the physical order (kh, kw, co, ci)."""
+    if len(shape) == 4:
+        co, ci, kh, kw = shape
+        return flat_slice.view(kh, kw, co, ci).permute(2, 3, 0, 1)
+    return flat_slice.view(shape)
 
 
 class ParamArena(object):
@@ -59,18 +73,26 @@ class ParamArena(object):
         with torch.no_grad():
             for s in self.segments:
                 t = named[s.key]
-                view = self.flat[s.offset:s.offset + s.count].view(s.shape)
+                view = _logical_view(self.flat[s.offset:s.offset + s.count], s.shape)
                 view.copy_(t)
                 t.data = view            # parameters and buffers alike keep their identity, storage moves
                 if with_grad and s.requires_grad:
-                    t.grad = self.grad[s.offset:s.offset + s.count].view(s.shape)
+                    t.grad = _logical_view(self.grad[s.offset:s.offset + s.count], s.shape)
         if with_bf16:
             self.refresh_bf16()
 
     def view(self, key, buf=None):
+        """Logical-shape view of `key` in `buf` (default: the fp32 master arena)."""
         s = self.by_key[key]
         buf = self.flat if buf is None else buf
-        return buf[s.offset:s.offset + s.count].view(s.shape)
+        return _logical_view(buf[s.offset:s.offset + s.count], s.shape)
+
+    def packed(self, key, buf=None):
+        """Physical (ntaps, Cout, Cin) view of a convolution weight in `buf` -- the kernels' operand layout."""
+        s = self.by_key[key]
+        co, ci, kh, kw = s.shape
+        buf = self.flat if buf is None else buf
+        return buf[s.offset:s.offset + s.count].view(kh * kw, co, ci)
 
     def refresh_bf16(self):
         if self.bf16 is not None:
@@ -106,7 +128,8 @@ def ensure_arena(module, with_grad=True, with_bf16=False):
             a.grad = torch.zeros(a.total, dtype=torch.float32, device=a.device)
             for s in a.segments:
                 if s.requires_grad:
-                    dict(module.named_parameters())[s.key].grad = a.grad[s.offset:s.offset + s.count].view(s.shape)
+                    dict(module.named_parameters())[s.key].grad = _logical_view(
+                        a.grad[s.offset:s.offset + s.count], s.shape)
     return a
 
 

@@ -1,0 +1,231 @@
+"""
+Static executor of the DeepLab v2 body (layer1..layer4 + ASPP head) on the hand-written MFMA convolution kernels
+(csrc/conv.hip) -- forward AND backward, replacing the autograd graph of ~450 library ops per pass that
+`Bottleneck.forward` / `Classifier_Module.forward` of architectures/deeplab2.py:89-128 expand to.
+
+Per bottleneck (frozen BatchNorm folded into scale/bias, deeplab2.py:92-107):
+
+    forward      a   = relu(conv1(x)*s1 + b1)                 1x1 (stride on this conv, deeplab2.py:70)
+                 b   = relu(conv2(a)*s2 + b2)                 3x3 dilated
+                 out = relu(conv3(b)*s3 + b3 + res)           res = x  or  conv_d(x)*sd + bd
+    backward     given dC = d loss / d (pre-ReLU sum), already masked by [out > 0]:
+                 dW3 += wgrad(b, dC)*s3      dU2 = dgrad3(dC) * [b > 0]
+                 dW2 += wgrad(a, dU2)*s2     dU1 = dgrad2(dU2) * [a > 0]
+                 dWd += wgrad(x, dC)*sd      dres = dgrad_d(dC)           (or dres = dC for an identity shortcut)
+                 dW1 += wgrad(x, dU1)*s1     dC_prev = (dgrad1(dU1) + dres) * [x > 0]
+    Every ReLU mask, residual add, BN affine and bf16 rounding happens in a convolution epilogue; weight gradients
+    are accumulated straight into the fp32 gradient arena. dgrad is the forward kernel on the transposed weights
+    (BN scale folded, cms_conv_pack_transpose) with negated tap offsets.
+
+Only valid with frozen BatchNorm (`--freeze_bn`; BN layers in eval mode) -- with batch statistics the networks run on
+the library engine instead (architectures/deeplab2.py: TorchEngine).
+"""
+import torch
+
+from . import ops
+from .arena import ensure_arena
+
+
+class _Conv(object):
+    __slots__ = ('wkey', 'bn', 'taps', 'ntaps', 'neg_taps', 'stride', 'cin', 'cout', 'scale', 'bias', 'wT')
+
+    def __init__(self, wkey, bn, conv):
+        self.wkey, self.bn = wkey, bn
+        kh, kw = conv.kernel_size
+        self.taps = ops.conv_taps(kh, kw, conv.dilation[0], conv.padding[0])
+        self.neg_taps = [(-dy, -dx) for dy, dx in self.taps]
+        self.stride = conv.stride[0]
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.scale = self.bias = self.wT = None
+
+
+class _Block(object):
+    __slots__ = ('c1', 'c2', 'c3', 'cd')
+
+
+class DeepLabHipExecutor(object):
+    def __init__(self, net):
+        self.net = net
+        self.trainable = any(p.requires_grad for p in net.parameters())
+        self.arena = ensure_arena(net, with_grad=self.trainable, with_bf16=True)
+        self.num_classes = net.num_classes
+        self.blocks = []
+        for li in range(1, 5):
+            layer = getattr(net, 'layer{}'.format(li))
+            for bi, blk in enumerate(layer):
+                pre = 'layer{}.{}'.format(li, bi)
+                b = _Block()
+                b.c1 = _Conv(pre + '.conv1.weight', pre + '.bn1', blk.conv1)
+                b.c2 = _Conv(pre + '.conv2.weight', pre + '.bn2', blk.conv2)
+                b.c3 = _Conv(pre + '.conv3.weight', pre + '.bn3', blk.conv3)
+                b.cd = None
+                if blk.downsample is not None:
+                    b.cd = _Conv(pre + '.downsample.0.weight', pre + '.downsample.1', blk.downsample[0])
+                self.blocks.append(b)
+        head = net.layer5.conv2d_list
+        self.aspp_keys = ['layer5.conv2d_list.0', 'layer5.conv2d_list.1']
+        self.aspp_taps = []
+        for i in range(2):
+            self.aspp_taps += ops.conv_taps(3, 3, head[i].dilation[0], head[i].padding[0])
+        self.aspp_neg_taps = [(-dy, -dx) for dy, dx in self.aspp_taps]
+        dev = self.arena.device
+        C = self.num_classes
+        if C > 32:
+            raise NotImplementedError('ASPP head kernel is specialised for <= 32 classes')
+        self.aspp_w = torch.zeros(18, 64, 2048, dtype=torch.bfloat16, device=dev)     # class axis padded to 64 (dgrad K)
+        self.aspp_w32 = torch.zeros(18, 32, 2048, dtype=torch.bfloat16, device=dev)   # forward operand (padded to 32)
+        self.aspp_wT = torch.zeros(18, 2048, 64, dtype=torch.bfloat16, device=dev)
+        self.aspp_bias = torch.zeros(32, dtype=torch.float32, device=dev)
+        self._affine_ready = False
+        self._wT_version = -1
+        self.version = 0          # bumped whenever the weights change (optimizer step / load_state_dict)
+        net.register_load_state_dict_post_hook(lambda module, incompatible: self.invalidate())
+
+    # ------------------------------------------------------------------------------------------ weights / affine
+    def invalidate(self):
+        """Call after the fp32 weights changed outside the fused optimizer (load_state_dict, manual edits)."""
+        self.arena.refresh_bf16()
+        self._affine_ready = False
+        self.version += 1
+
+    def _all_convs(self):
+        for b in self.blocks:
+            for c in (b.c1, b.c2, b.c3, b.cd):
+                if c is not None:
+                    yield c
+
+    def _refresh_affine(self):
+        a = self.arena
+        for c in self._all_convs():
+            w, bta = a.view(c.bn + '.weight'), a.view(c.bn + '.bias')
+            rm, rv = a.view(c.bn + '.running_mean'), a.view(c.bn + '.running_var')
+            eps = 1e-5
+            c.scale = (w * torch.rsqrt(rv + eps)).contiguous()
+            c.bias = (bta - rm * c.scale).contiguous()
+        self._affine_ready = True
+
+    def _w(self, c):
+        return self.arena.packed(c.wkey, self.arena.bf16)
+
+    def _refresh_aspp_fwd(self):
+        C = self.num_classes
+        a = self.arena
+        for i, k in enumerate(self.aspp_keys):
+            wk = a.packed(k + '.weight', a.bf16)
+            self.aspp_w[9 * i:9 * i + 9, :C].copy_(wk)
+            self.aspp_w32[9 * i:9 * i + 9, :C].copy_(wk)
+        self.aspp_bias[:C] = a.view(self.aspp_keys[0] + '.bias') + a.view(self.aspp_keys[1] + '.bias')
+
+    def _refresh_backward_weights(self):
+        for c in self._all_convs():
+            c.wT = ops.conv_pack_transpose(self._w(c), scale=c.scale, flip=False, out=c.wT)
+        ops.conv_pack_transpose(self.aspp_w, flip=False, out=self.aspp_wT)
+
+    # ------------------------------------------------------------------------------------------ forward
+    @staticmethod
+    def _out_hw(h, w, stride):
+        return (h - 1) // stride + 1, (w - 1) // stride + 1
+
+    def _fwd(self, x, c, relu, res=None):
+        n, h, w, _ = x.shape
+        ho, wo = self._out_hw(h, w, c.stride)
+        return ops.conv_igemm(x, self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), scale=c.scale, bias=c.bias,
+                              res=res, relu=relu)
+
+    def forward(self, x, save):
+        """x: bf16 NHWC (N, h, w, 64) = stem + max-pool output. Returns (logits fp32 NCHW, saved)."""
+        if not self._affine_ready:
+            self._refresh_affine()
+        saved = [] if save else None
+        cur = x
+        for b in self.blocks:
+            a1 = self._fwd(cur, b.c1, True)
+            a2 = self._fwd(a1, b.c2, True)
+            res = cur if b.cd is None else self._fwd(cur, b.cd, False)
+            out = self._fwd(a2, b.c3, True, res=res)
+            if save:
+                saved.append((cur, a1, a2))
+            cur = out
+        self._refresh_aspp_fwd()
+        n, h, w, _ = cur.shape
+        logits = torch.empty((n, self.num_classes, h, w), dtype=torch.float32, device=cur.device)
+        ops.conv_igemm(cur, self.aspp_w32, self.aspp_taps, bias=self.aspp_bias, out_f32_nchw=logits,
+                       cout_real=self.num_classes)
+        if save:
+            saved.append(cur)
+        return logits, saved
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _wgrad(self, du, x, c):
+        ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride, scale=c.scale)
+
+    def _dgrad(self, du, c, res=None, mask=None, in_hw=None):
+        """gradient wrt the input of conv `c`; `in_hw` = spatial size of that input (needed for stride 2)."""
+        n, ho, wo, _ = du.shape
+        if c.stride == 1:
+            return ops.conv_igemm(du, c.wT, c.neg_taps, res=res, mode=1, mask_src=mask)
+        return ops.conv_igemm(du, c.wT, c.neg_taps, res=res, mode=1, mask_src=mask, out_hw=(ho, wo),
+                              out_stride=c.stride, out_full_hw=in_hw)
+
+    def backward(self, saved, dlogits):
+        """dlogits fp32 (N,C,h,w). Accumulates weight gradients into the arena; returns d loss / d x (bf16 NHWC)."""
+        if self._wT_version != self.version or self.blocks[0].c1.wT is None:
+            self._refresh_backward_weights()
+            self._wT_version = self.version
+        a = self.arena
+        C = self.num_classes
+        x4 = saved[-1]
+        n, _, h, w = dlogits.shape
+        dl = torch.zeros((n, h, w, 64), dtype=torch.bfloat16, device=dlogits.device)
+        dl[..., :C] = dlogits.permute(0, 2, 3, 1)
+        # ASPP head: weight / bias gradients of the two live branches, then the data gradient
+        for i, k in enumerate(self.aspp_keys):
+            gw = a.packed(k + '.weight', a.grad)                     # fp32 (9, C, 2048)
+            tmp = torch.zeros((9, 64, 2048), dtype=torch.float32, device=dl.device)
+            ops.conv_wgrad(dl, x4, self.aspp_taps[9 * i:9 * i + 9], tmp, cout_real=C)
+            gw.add_(tmp[:, :C])
+            a.view(k + '.bias', a.grad).add_(dlogits.sum(dim=(0, 2, 3)))
+        dC = ops.conv_igemm(dl, self.aspp_wT, self.aspp_neg_taps, mode=1, mask_src=x4)
+        capture = getattr(self, 'debug_capture', None)
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            if capture is not None:
+                capture[bi] = dC
+            b = self.blocks[bi]
+            xin, a1, a2 = saved[bi]
+            in_hw = (xin.shape[1], xin.shape[2])
+            self._wgrad(dC, a2, b.c3)
+            dU2 = self._dgrad(dC, b.c3, mask=a2)
+            self._wgrad(dU2, a1, b.c2)
+            dU1 = self._dgrad(dU2, b.c2, mask=a1)
+            if b.cd is not None:
+                self._wgrad(dC, xin, b.cd)
+                dres = self._dgrad(dC, b.cd, in_hw=in_hw)
+            else:
+                dres = dC
+            self._wgrad(dU1, xin, b.c1)
+            dC = self._dgrad(dU1, b.c1, res=dres, mask=None if bi == 0 else xin, in_hw=in_hw)
+        return dC
+
+
+class _BodyFn(torch.autograd.Function):
+    """The whole body as one autograd node: forward keeps the activations, backward runs the hand-written chain."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, executor, need_grad):
+        logits, saved = executor.forward(x_nhwc, save=need_grad)
+        ctx.executor = executor
+        ctx.saved_acts = saved
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        dx = ctx.executor.backward(ctx.saved_acts, dlogits.contiguous().float())
+        ctx.saved_acts = None
+        return dx, None, None
+
+
+def run_body(executor, x_nhwc):
+    need_grad = torch.is_grad_enabled() and executor.trainable
+    if need_grad and not x_nhwc.requires_grad:
+        x_nhwc = x_nhwc.detach().requires_grad_(True)     # make sure autograd calls our backward
+    return _BodyFn.apply(x_nhwc, executor, need_grad)

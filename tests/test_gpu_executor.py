@@ -1,0 +1,183 @@
+"""
+GPU: the hand-written MFMA executor of the DeepLab v2 body (backbone_hip.py: fused conv/BN/ReLU/residual forward,
+dgrad/wgrad backward) against the library engine (same network, same bf16 weights) and the fp32 CPU oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _cf_input(n, h, w, phase):
+    idx = torch.arange(n * 3 * h * w, dtype=torch.float64)
+    return torch.sin(phase + 0.61803398875 * idx).reshape(n, 3, h, w).float() * 1.5
+
+
+def _state(layers, C, active_relus):
+    """
+    Seeded random weights with a healthy gradient flow (He-initialised convolutions, BN scale in [0.6, 1.4], small
+    running statistics). With `active_relus` every BN bias is pushed up so that (almost) all ReLUs are in their linear
+    region -- the backward pass then has no ReLU-mask ambiguity between bf16 and fp32 activations.
+    (The closed-form weights of the golden fixtures make early-layer gradients cancel by 2-3 orders of magnitude per
+    stage, which turns any bf16 backward -- library or hand-written -- into noise; not a useful yardstick here.)
+    """
+    from oracle import deeplab2 as odl
+    g = torch.Generator().manual_seed(1234)
+    st = {}
+    for k, (shape, dt) in odl.state_spec(C, layers).items():
+        if dt == torch.int64:
+            st[k] = torch.zeros(shape, dtype=torch.int64)
+        elif len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            st[k] = torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5
+        elif k.endswith('running_var'):
+            st[k] = 0.8 + 0.4 * torch.rand(shape, generator=g)
+        elif k.endswith('running_mean'):
+            st[k] = 0.1 * torch.randn(shape, generator=g)
+        elif k.endswith('.weight'):
+            st[k] = 0.6 + 0.8 * torch.rand(shape, generator=g)
+        else:
+            st[k] = 0.1 * torch.randn(shape, generator=g) + (1.5 if (active_relus and not k.startswith('layer5')) else 0.0)
+    return st
+
+
+def _build(layers, C, kind, active_relus=False):
+    from architectures import deeplab2
+    net = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
+    net.load_state_dict(_state(layers, C, active_relus))
+    net = net.to(DEV)
+    net.engine_kind = kind
+    net.train()
+    net.freeze_batchnorm()
+    return net
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize('active', [True, False], ids=['linear_regime', 'relu_regime'])
+@pytest.mark.parametrize('layers,C,shape', [([1, 1, 1, 1], 5, (2, 65, 81)), ([3, 4, 23, 3], 21, (2, 65, 65)),
+                                            ([3, 4, 23, 3], 19, (1, 97, 129))], ids=['tiny', 'r101_21', 'r101_19'])
+def test_executor_forward_backward_matches_library_engine(layers, C, shape, active):
+    from oracle import deeplab2 as odl
+    n, H, W = shape
+    x = _cf_input(n, H, W, 0.7).bfloat16().to(DEV)
+    hip, ref = _build(layers, C, 'hip', active), _build(layers, C, 'torch', active)
+    lo_h = hip.forward_lowres(x)
+    lo_r = ref.forward_lowres(x)
+    assert lo_h.shape == lo_r.shape and lo_h.dtype == torch.float32 and lo_h.is_contiguous()
+    # fp32 CPU oracle on the same bf16-rounded conv weights: the hand-written path (one rounding per layer) must be at
+    # least as close to it as the library path (several roundings per layer)
+    st = _state(layers, C, active)
+    st_bf = {k: (v.bfloat16().float() if (v.dtype == torch.float32 and v.dim() == 4) else v) for k, v in st.items()}
+    want = odl.forward_lowres(x.float().cpu(), st_bf, layers, frozen=True)
+    e_h, e_r = _rel(lo_h.cpu(), want), _rel(lo_r.cpu(), want)
+    assert e_h <= 6e-2, (e_h, e_r)
+    assert e_h <= 1.5 * e_r + 5e-3, (e_h, e_r)
+    # backward with the same upstream gradient; truth = the fp32 library engine, yardstick = the bf16 library engine
+    ref32 = _build(layers, C, 'torch', active)
+    ref32.compute_dtype = torch.float32
+    lo_32 = ref32.forward_lowres(x)
+    g = torch.randn(lo_h.shape, generator=torch.Generator(device=DEV).manual_seed(1), device=DEV)
+    hip._cms_arena.zero_grad()
+    lo_h.backward(g)
+    lo_r.backward(g)
+    lo_32.backward(g)
+    named_h, named_r, named_t = dict(hip.named_parameters()), dict(ref.named_parameters()), dict(ref32.named_parameters())
+    keys = ['conv1.weight', 'layer1.0.conv1.weight', 'layer1.0.conv2.weight', 'layer1.0.downsample.0.weight',
+            'layer2.0.conv1.weight', 'layer2.0.downsample.0.weight', 'layer3.0.conv2.weight', 'layer4.0.conv3.weight',
+            'layer5.conv2d_list.0.weight', 'layer5.conv2d_list.1.weight', 'layer5.conv2d_list.0.bias']
+    errs = {}
+    for k in keys:
+        gh, gr, gt = named_h[k].grad, named_r[k].grad, named_t[k].grad
+        assert gh is not None and gr is not None, k
+        errs[k] = (round(_rel(gh, gt), 4), round(_rel(gr.float(), gt), 4))
+    print('gradient rel. errors vs fp32 (hand-written, library bf16):', errs)
+    # bf16 activations / gradients through up to 101 layers: both bf16 paths deviate from the fp32 gradients by the
+    # same order (a few % at the head, tens of % at the stem); the hand-written executor must not be worse than the
+    # library's bf16 path (in practice it is slightly better: one rounding per fused layer instead of three)
+    assert all(eh <= max(1.75 * er, 5e-2) for eh, er in errs.values()), errs
+    assert np.mean([eh for eh, _ in errs.values()]) <= 1.15 * np.mean([er for _, er in errs.values()]) + 1e-2, errs
+    assert errs['layer5.conv2d_list.0.weight'][0] <= 2e-2 and errs['layer4.0.conv3.weight'][0] <= 0.15, errs
+    assert float(named_h['layer5.conv2d_list.2.weight'].grad.abs().max()) == 0.0     # never receives a gradient
+
+
+def test_executor_teacher_forward_only_and_weight_refresh():
+    from oracle import deeplab2 as odl
+    net = _build([1, 1, 1, 1], 5, 'hip')
+    for p in net.parameters():
+        p.requires_grad = False
+    x = _cf_input(1, 33, 47, 0.1).bfloat16().to(DEV)
+    with torch.no_grad():
+        a = net.forward_lowres(x)
+        st = odl.closed_form_state(5, [1, 1, 1, 1])
+        st2 = {k: (v * 0.5 if k == 'layer5.conv2d_list.0.weight' else v) for k, v in st.items()}
+        net.load_state_dict(st2)           # the post-hook refreshes the bf16 operands
+        b = net.forward_lowres(x)
+    assert float((a - b).abs().max()) > 1e-3
+    assert net._hip_executor.arena.grad is None
+
+
+def test_hip_engine_needs_frozen_bn():
+    from architectures import deeplab2
+    net = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, [1, 1, 1, 1], 5, np.zeros(3), np.ones(3)).to(DEV)
+    net.engine_kind = 'hip'
+    net.train()
+    with pytest.raises(RuntimeError, match='frozen BatchNorm'):
+        net.forward_lowres(torch.zeros(1, 3, 33, 33, device=DEV))
+
+
+def test_whole_step_bf16_hip_engine_tracks_fp32_library_engine():
+    """Three iterations: bf16 / MFMA executor vs fp32 / library engine on identical data."""
+    from architectures import deeplab2
+    from oracle import deeplab2 as odl
+    import mask_gen
+    import optim_weight_ema
+    from cutmix_semisup_seg_amd import ops, optim as fo
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
+    C, layers, N, H, W = 5, [1, 1, 1, 1], 2, 65, 65
+    logs = {}
+    for tag, dtype in (('hip', torch.bfloat16), ('lib', torch.float32)):
+        mk = lambda: deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
+        stu, tea = mk(), mk()
+        stu.load_state_dict(odl.closed_form_state(C, layers))
+        stu, tea = stu.to(DEV), tea.to(DEV)
+        stu.compute_dtype = tea.compute_dtype = dtype
+        opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=1e-4),
+                                 dict(params=list(stu.new_parameters()), lr=1e-3)])
+        for p in tea.parameters():
+            p.requires_grad = False
+        ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
+        ema.fuse_into(opt)
+        stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()
+        step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=0.3, compute_dtype=dtype))
+        gen_m = mask_gen.BoxMaskGenerator(0.5, invert=True)
+        rng = np.random.RandomState(3)
+        out = []
+        for it in range(3):
+            g = torch.Generator().manual_seed(50 + it)
+            x = torch.randn(N, 3, H, W, generator=g).to(DEV).to(dtype)
+            y = torch.randint(0, C, (N, 1, H, W), generator=g).to(torch.uint8).to(DEV)
+            ux0 = torch.randn(N, 3, H, W, generator=g).to(DEV).to(dtype)
+            ux1 = torch.randn(N, 3, H, W, generator=g).to(DEV).to(dtype)
+            ranges = ops.ranges_to_device(gen_m.generate_ranges(N, (H, W), rng=rng), DEV)
+            r = step(x, y, [UnsupBatch(ux0, ranges, x1_tea=ux1)])
+            out.append([float(r['sup_loss']), float(r['consistency_loss']), float(r['conf_rate'])])
+        logs[tag] = np.array(out)
+        if tag == 'hip':
+            assert stu._hip_executor is not None and tea._hip_executor is not None
+            w_hip = stu.state_dict()['layer3.0.conv2.weight'].float().cpu()
+        else:
+            w_lib = stu.state_dict()['layer3.0.conv2.weight'].float().cpu()
+    np.testing.assert_allclose(logs['hip'][:, 0], logs['lib'][:, 0], rtol=8e-2)
+    np.testing.assert_allclose(logs['hip'][:, 1], logs['lib'][:, 1], rtol=0.25, atol=1e-6)
+    np.testing.assert_allclose(logs['hip'][:, 2], logs['lib'][:, 2], atol=3e-2)
+    # Adam takes lr-sized steps: after 3 iterations the two weight sets moved the same way
+    st0 = odl.closed_form_state(C, layers)['layer3.0.conv2.weight']
+    dh, dl = (w_hip - st0).flatten(), (w_lib - st0).flatten()
+    cos = float((dh * dl).sum() / (dh.norm() * dl.norm() + 1e-30))
+    assert cos > 0.9, cos
