@@ -148,9 +148,11 @@ class DeepLabHipExecutor(object):
             cur = out
         self._refresh_aspp_fwd()
         n, h, w, _ = cur.shape
-        logits = torch.empty((n, self.num_classes, h, w), dtype=torch.float32, device=cur.device)
+        # 18 taps x 2048 channels = a K of 36864 against only ~260 pixel tiles: split the taps over 6x more workgroups
+        # and accumulate the (tiny) fp32 logits with atomics
+        logits = torch.zeros((n, self.num_classes, h, w), dtype=torch.float32, device=cur.device)
         ops.conv_igemm(cur, self.aspp_w32, self.aspp_taps, bias=self.aspp_bias, out_f32_nchw=logits,
-                       cout_real=self.num_classes)
+                       cout_real=self.num_classes, ksplit=6)
         if save:
             saved.append(cur)
         return logits, saved

@@ -54,12 +54,28 @@ struct ConvArgs {
     int out_H, out_W, out_stride;
     int relu, mode;            // mode 0 = forward epilogue, 1 = dgrad epilogue
     int M;                     // N*Ho*Wo
+    int ksplit;                // > 1: the taps are split across workgroups, fp32 output accumulated with atomics
     short tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
 };
 
 __device__ __forceinline__ uint32_t swz(int row, int chunk) {
     return (uint32_t)row * CONV_ROW_BYTES + (uint32_t)((chunk ^ ((row >> 1) & 7)) << 4);
 }
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    // plain conversions: the compiler emits v_cvt_pk_bf16_f32 (round-to-nearest-even) instead of ~8 integer ops each
+    bf16x2 p = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, p);
+}
+
+struct RowInfo {            // one per pixel row of the workgroup tile, computed once (2 integer divisions per row)
+    uint32_t in_off;        // element offset of input pixel (oy*stride, ox*stride), channel 0
+    uint32_t yx;            // (oy*stride) << 16 | (ox*stride); 0x70007000 for rows past M (every bounds test fails)
+    uint32_t opix;          // output pixel index, 0xffffffff for rows past M
+    uint32_t m;             // GEMM row
+};
 
 template <int WN, int WM, int TN, int TM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -69,18 +85,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int PB = BN / 32;
     static_assert(WN * WM == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int EPI_LD = BN * 2 + 16;                   // epilogue tile row pitch (bytes): +16 B breaks bank aliasing
+    constexpr int STAGE_BYTES = (BM + BN) * CONV_ROW_BYTES;
+    constexpr int EPI_BYTES = BM * EPI_LD;
+    constexpr int UNION_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
     unsigned char* lds_x = smem;                          // [BM][128 B]
     unsigned char* lds_w = smem + BM * CONV_ROW_BYTES;    // [BN][128 B]
-    // tap offsets: a dynamically indexed by-value kernel argument would be spilled to scratch, so park them in LDS
-    short* lds_tap = reinterpret_cast<short*>(smem + (BM + BN) * CONV_ROW_BYTES);    // [2][CMS_CONV_MAX_TAPS]
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < CMS_CONV_MAX_TAPS; ++i) {
-            lds_tap[i] = a.tap_dy[i];
-            lds_tap[CMS_CONV_MAX_TAPS + i] = a.tap_dx[i];
-        }
-    }
-    __syncthreads();
+    unsigned char* lds_epi = smem;                        // [BM][EPI_LD] bf16 output tile (reuses the staging area)
+    short* lds_tap = reinterpret_cast<short*>(smem + UNION_BYTES);                       // [2][CMS_CONV_MAX_TAPS]
+    RowInfo* lds_row = reinterpret_cast<RowInfo*>(smem + UNION_BYTES + 80);              // [BM]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN;
@@ -93,53 +106,89 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int ntiles = nblk / a.ksplit;
+    const int split = bid / ntiles;
+    bid -= split * ntiles;
     const int tile_n = bid % ntn, tile_m = bid / ntn;
     const int co0 = tile_n * BN, m0 = tile_m * BM;
 
-    // ---- loader geometry (fixed for the whole K loop)
+    // ---- one-time tables in LDS: tap offsets (a dynamically indexed by-value kernel argument would go to scratch)
+    // and the per-row geometry
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < CMS_CONV_MAX_TAPS; ++i) {
+            lds_tap[i] = a.tap_dy[i];
+            lds_tap[CMS_CONV_MAX_TAPS + i] = a.tap_dx[i];
+        }
+    }
+    if (tid < BM) {
+        const int m = m0 + tid;
+        RowInfo ri;
+        ri.m = (uint32_t)m;
+        if (m < a.M) {
+            const int ox = m % a.Wo;
+            const int t = m / a.Wo;
+            const int oy = t % a.Ho;
+            const int n = t / a.Ho;
+            const int iy = oy * a.stride, ix = ox * a.stride;
+            ri.in_off = (uint32_t)(((n * a.H + iy) * a.W + ix) * a.Cin);
+            ri.yx = ((uint32_t)iy << 16) | (uint32_t)ix;
+            ri.opix = (uint32_t)((n * a.out_H + oy * a.out_stride) * a.out_W + ox * a.out_stride);
+        } else {
+            ri.in_off = 0;
+            ri.yx = 0x70007000u;
+            ri.opix = 0xffffffffu;
+        }
+        lds_row[tid] = ri;
+    }
+    __syncthreads();
+
+    // ---- loader geometry (fixed for the whole K loop): thread -> 16-byte chunk (tid & 7) of rows (tid >> 3) + 32*i
     const int chunk = tid & 7, lrow = tid >> 3;
-    int by[PA], bx[PA], nb[PA];
-    bool okm[PA];
+    uint32_t xoff[PA], xyx[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int m = m0 + lrow + 32 * i;
-        okm[i] = m < a.M;
-        const int mm = okm[i] ? m : 0;
-        const int ox = mm % a.Wo;
-        const int t = mm / a.Wo;
-        const int oy = t % a.Ho;
-        const int n = t / a.Ho;
-        by[i] = oy * a.stride;
-        bx[i] = ox * a.stride;
-        nb[i] = n * a.H * a.W;
+        const RowInfo ri = lds_row[lrow + 32 * i];
+        xoff[i] = ri.in_off + (uint32_t)(chunk * 8);
+        xyx[i] = ri.yx;
     }
+    const uint32_t woff0 = (uint32_t)(lrow * a.Cin + chunk * 8);
+    const uint32_t wstep = (uint32_t)(32 * a.Cin);
+    const uint32_t st_off = swz(lrow, chunk);            // rows lrow + 32*i share the swizzle term: + i*4096 bytes
+
     const int kc_per_tap = a.Cin / CONV_BK;
-    const int ksteps = a.ntaps * kc_per_tap;
+    const int taps_per_split = (a.ntaps + a.ksplit - 1) / a.ksplit;
+    const int tap_begin = split * taps_per_split;
+    const int tap_end = min(a.ntaps, tap_begin + taps_per_split);
+    const int ks_begin = tap_begin * kc_per_tap;
+    const int ksteps = tap_end * kc_per_tap;        // exclusive end of this workgroup's K range
 
     u32x4 rx[PA], rw[PB];
     auto load_tile = [&](int ks) {
-        const int tap = ks / kc_per_tap;
-        const int c0 = (ks - tap * kc_per_tap) * CONV_BK + chunk * 8;
-        const int dy = lds_tap[tap], dx = lds_tap[CMS_CONV_MAX_TAPS + tap];
+        const int tap = ks / kc_per_tap;                                  // wave-uniform
+        const int c0 = (ks - tap * kc_per_tap) * CONV_BK;
+        const int dy = __builtin_amdgcn_readfirstlane((int)lds_tap[tap]);
+        const int dx = __builtin_amdgcn_readfirstlane((int)lds_tap[CMS_CONV_MAX_TAPS + tap]);
+        const int delta = (dy * a.W + dx) * a.Cin + c0;                   // scalar element offset of this tap / K chunk
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int iy = by[i] + dy, ix = bx[i] + dx;
-            const bool ok = okm[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const uint32_t iy = (xyx[i] >> 16) + (uint32_t)dy, ix = (xyx[i] & 0xffffu) + (uint32_t)dx;
+            const bool ok = iy < (uint32_t)a.H && ix < (uint32_t)a.W;    // unsigned compare covers the negative side
             if (ok) {
-                rx[i] = *reinterpret_cast<const u32x4*>(a.x + ((size_t)(nb[i] + iy * a.W + ix)) * a.Cin + c0);
+                rx[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(xoff[i] + (uint32_t)delta));
             } else {
                 rx[i] = u32x4{0u, 0u, 0u, 0u};
             }
         }
-        const uint16_t* wt = a.w + ((size_t)tap * a.Cout + co0) * a.Cin + c0;
+        const uint16_t* wt = a.w + ((size_t)tap * a.Cout + co0) * a.Cin + c0;   // scalar base
 #pragma unroll
-        for (int i = 0; i < PB; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wt + (size_t)(lrow + 32 * i) * a.Cin);
+        for (int i = 0; i < PB; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wt + (woff0 + (uint32_t)i * wstep));
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(lds_x + swz(lrow + 32 * i, chunk)) = rx[i];
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(lds_x + st_off + i * 32 * CONV_ROW_BYTES) = rx[i];
 #pragma unroll
-        for (int i = 0; i < PB; ++i) *reinterpret_cast<u32x4*>(lds_w + swz(lrow + 32 * i, chunk)) = rw[i];
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<u32x4*>(lds_w + st_off + i * 32 * CONV_ROW_BYTES) = rw[i];
     };
 
     f32x16 acc[TN][TM];
@@ -150,9 +199,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // fragment read address: row (lane & 31) of a 32-row tile, 16-byte chunk (kk*2 + lane>>5) ^ swizzle(row)
+    //   = lane_frag ^ (kk * 32)   (the K sub-step only flips bits 5..6)
     const int frow = lane & 31, fhalf = lane >> 5;
-    load_tile(0);
-    for (int ks = 0; ks < ksteps; ++ks) {
+    const uint32_t lane_frag = (uint32_t)frow * CONV_ROW_BYTES | (uint32_t)(((fhalf ^ (frow >> 1)) & 7) << 4);
+    const unsigned char* fw_base = lds_w + wn * TN * 32 * CONV_ROW_BYTES;
+    const unsigned char* fx_base = lds_x + wm * TM * 32 * CONV_ROW_BYTES;
+
+    if (ks_begin < ksteps) load_tile(ks_begin);
+    for (int ks = ks_begin; ks < ksteps; ++ks) {
         __syncthreads();            // previous stage's fragment reads are done
         store_tile();
         __syncthreads();
@@ -160,17 +215,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int kk = 0; kk < CONV_BK / 16; ++kk) {
             u32x4 fw[TN], fx[TM];     // (arrays of __bf16 vectors are not promoted to registers by the compiler)
-            const int ch = kk * 2 + fhalf;
+            const uint32_t fo = lane_frag ^ (uint32_t)(kk * 32);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const int row = (wn * TN + i) * 32 + frow;
-                fw[i] = *reinterpret_cast<const u32x4*>(lds_w + swz(row, ch));
-            }
+            for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const u32x4*>(fw_base + fo + i * 32 * CONV_ROW_BYTES);
 #pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                const int row = (wm * TM + j) * 32 + frow;
-                fx[j] = *reinterpret_cast<const u32x4*>(lds_x + swz(row, ch));
-            }
+            for (int j = 0; j < TM; ++j) fx[j] = *reinterpret_cast<const u32x4*>(fx_base + fo + j * 32 * CONV_ROW_BYTES);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -180,66 +229,90 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
     }
 
-    // ---- epilogue straight from the accumulators: lane owns pixel (l&31) of each pixel tile and, per register
-    // quad, 4 consecutive output channels
+    // ---- epilogue. The accumulator layout gives every lane runs of 4 consecutive channels of one pixel; BN affine,
+    // residual / gradient add, ReLU or ReLU-mask are applied in registers (one rounding to bf16), the bf16 tile is
+    // transposed through LDS and written out with 16 bytes per lane, 256 contiguous bytes per pixel row.
+    const bool to_lds = a.y != nullptr;
+    if (to_lds) __syncthreads();                           // all fragment reads of the last stage are done
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int m = m0 + (wm * TM + j) * 32 + frow;
-        if (m >= a.M) continue;
-        const int ox = m % a.Wo;
-        const int t = m / a.Wo;
-        const int oy = t % a.Ho;
-        const int n = t / a.Ho;
-        const size_t opix = ((size_t)n * a.out_H + (size_t)oy * a.out_stride) * a.out_W + (size_t)ox * a.out_stride;
+        const int prow_l = (wm * TM + j) * 32 + frow;
+        const RowInfo ri = lds_row[prow_l];
+        const bool valid = ri.opix != 0xffffffffu;
+        const size_t obase = (size_t)ri.opix * a.Cout;
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int co = co0 + (wn * TN + i) * 32 + 8 * q + 4 * fhalf;
+                const int co_l = (wn * TN + i) * 32 + 8 * q + 4 * fhalf;
+                const int co = co0 + co_l;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
                 if (a.mode == 0) {
                     if (a.scale) {
-                        const float4 s = *reinterpret_cast<const float4*>(a.scale + co);
-                        v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+                        const float4 sc = *reinterpret_cast<const float4*>(a.scale + co);
+                        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
                     }
-                    if (a.bias) {
+                    if (a.bias && split == 0) {
                         const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     }
                 }
-                if (a.res) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(a.res + opix * a.Cout + co);
-                    v[0] += bf16_to_f32((uint16_t)(rr.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rr.x >> 16));
-                    v[2] += bf16_to_f32((uint16_t)(rr.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rr.y >> 16));
+                if (a.res && valid) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(a.res + obase + co);
+                    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
                 }
                 if (a.mode == 0) {
                     if (a.relu) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
                     }
-                } else if (a.mask_src) {
-                    const uint2 mm = *reinterpret_cast<const uint2*>(a.mask_src + opix * a.Cout + co);
-                    // bf16 > 0  <=>  sign bit clear and magnitude non-zero
-                    const uint16_t h[4] = {(uint16_t)(mm.x & 0xffff), (uint16_t)(mm.x >> 16), (uint16_t)(mm.y & 0xffff),
-                                           (uint16_t)(mm.y >> 16)};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ((h[e] & 0x8000) == 0 && (h[e] & 0x7fff) != 0) ? v[e] : 0.0f;
+                } else if (a.mask_src && valid) {
+                    const uint2 mk = *reinterpret_cast<const uint2*>(a.mask_src + obase + co);
+                    // bf16 > 0  <=>  as a signed 16-bit integer it is > 0 (NaNs with the sign bit clear count as > 0,
+                    // like the float comparison the reference's ReLU backward makes on NaN-free activations)
+                    v[0] = (int16_t)(mk.x & 0xffffu) > 0 ? v[0] : 0.0f;
+                    v[1] = (int16_t)(mk.x >> 16) > 0 ? v[1] : 0.0f;
+                    v[2] = (int16_t)(mk.y & 0xffffu) > 0 ? v[2] : 0.0f;
+                    v[3] = (int16_t)(mk.y >> 16) > 0 ? v[3] : 0.0f;
                 }
-                if (a.y) {
+                if (to_lds) {
                     uint2 o;
-                    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(a.y + opix * a.Cout + co) = o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(lds_epi + prow_l * EPI_LD + co_l * 2) = o;
                 }
-                if (a.y32) {
+                if (a.y32 && valid) {
+                    const int m = (int)ri.m;
+                    const int ox = m % a.Wo;
+                    const int t = m / a.Wo;
+                    const int oy = t % a.Ho;
+                    const int n = t / a.Ho;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (co + e < a.cout_real)
-                            a.y32[(((size_t)n * a.cout_real + co + e) * a.Ho + oy) * a.Wo + ox] = v[e];
+                        if (co + e < a.cout_real) {
+                            float* dst = a.y32 + (((size_t)n * a.cout_real + co + e) * a.Ho + oy) * a.Wo + ox;
+                            if (a.ksplit > 1) atomicAdd(dst, v[e]);
+                            else *dst = v[e];
+                        }
                     }
                 }
+            }
+        }
+    }
+    if (to_lds) {
+        __syncthreads();
+        constexpr int CPR = BN / 8;                 // 16-byte chunks per output row of this tile
+        constexpr int RPP = 256 / CPR;              // rows per pass
+        const int ch = tid % CPR, r0 = tid / CPR;
+#pragma unroll
+        for (int r = r0; r < BM; r += RPP) {
+            const uint32_t op = lds_row[r].opix;
+            if (op != 0xffffffffu) {
+                const u32x4 val = *reinterpret_cast<const u32x4*>(lds_epi + r * EPI_LD + ch * 16);
+                *reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + ch * 8) = val;
             }
         }
     }
@@ -292,7 +365,8 @@ static int conv_check(const cms_conv_desc* d) {
     CMS_REQUIRE(d->ntaps > 0 && d->ntaps <= CMS_CONV_MAX_TAPS, "conv: 1..%d taps", CMS_CONV_MAX_TAPS);
     CMS_REQUIRE(d->stride >= 1 && d->out_stride >= 1, "conv: bad stride");
     CMS_REQUIRE(d->y == nullptr || d->cout_real == d->cout, "conv: bf16 NHWC output needs cout_real == cout");
-    CMS_REQUIRE((size_t)d->n * d->h * d->w_in < (1u << 31) && (size_t)d->n * d->ho * d->wo < (1u << 31),
+    CMS_REQUIRE((size_t)d->n * d->h * d->w_in * d->cin < (1u << 31) && (size_t)d->n * d->ho * d->wo < (1u << 31) &&
+                    (size_t)d->n * d->out_h * d->out_w < (1u << 31) && d->h < 0x7000 && d->w_in < 0x7000,
                 "conv: too many pixels");
     return CMS_OK;
 }
@@ -300,8 +374,9 @@ static int conv_check(const cms_conv_desc* d) {
 template <int WN, int WM, int TN, int TM>
 static void conv_launch(const ConvArgs& a, hipStream_t s) {
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
-    const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM);
-    const size_t lds = (size_t)(BN + BM) * CONV_ROW_BYTES + 2 * CMS_CONV_MAX_TAPS * sizeof(short) + 8;
+    const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM) * a.ksplit;
+    const size_t stage = (size_t)(BN + BM) * CONV_ROW_BYTES, epi = (size_t)BM * (BN * 2 + 16);
+    const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16;
     hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM>), dim3(grid), dim3(256), lds, s, a);
 }
 
@@ -317,6 +392,10 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
     a.out_H = d->out_h; a.out_W = d->out_w; a.out_stride = d->out_stride;
     a.relu = d->relu; a.mode = d->mode;
     a.M = d->n * d->ho * d->wo;
+    a.ksplit = d->ksplit > 1 ? d->ksplit : 1;
+    CMS_REQUIRE(a.ksplit == 1 || (d->y == nullptr && d->relu == 0 && d->res == nullptr && d->mode == 0),
+                "conv: ksplit needs the fp32 output without residual / ReLU (pre-zeroed, accumulated with atomics)");
+    CMS_REQUIRE(a.ksplit <= d->ntaps, "conv: ksplit (%d) > taps (%d)", a.ksplit, d->ntaps);
     for (int i = 0; i < CMS_CONV_MAX_TAPS; ++i) {
         a.tap_dy[i] = (short)(i < d->ntaps ? d->tap_dy[i] : 0);
         a.tap_dx[i] = (short)(i < d->ntaps ? d->tap_dx[i] : 0);
@@ -415,24 +494,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     // loader: 64 pixels x 16 chunks of 16 B per operand; thread -> chunk (tid & 15), pixel rows (tid >> 4) + 16*i
     const int c16 = tid & 15, prow = tid >> 4;
     const bool load_u = c16 * 8 < BCO, load_x = c16 * 8 < BCI;
+    // pixel cursor of the 4 rows this thread loads: decoded once (2 divisions), then advanced by 64 pixels per stage
+    int cm[4], cn[4], cy[4], cx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = p_begin + prow + 16 * i;
+        cm[i] = m;
+        cx[i] = m % a.Wo;
+        const int t = m / a.Wo;
+        cy[i] = t % a.Ho;
+        cn[i] = t / a.Ho;
+    }
+    const uint32_t uoff = (uint32_t)(co0 + c16 * 8), xoff = (uint32_t)(ci0 + c16 * 8);
     u32x4 ru[4], rxx[4];
-    auto load_tile = [&](int p0) {
+    auto load_tile = [&]() {           // loads the stage the cursors point at
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = p0 + prow + 16 * i;
-            const bool ok = m < p_end;
             ru[i] = u32x4{0u, 0u, 0u, 0u};
             rxx[i] = u32x4{0u, 0u, 0u, 0u};
-            if (ok) {
-                const int ox = m % a.Wo;
-                const int t = m / a.Wo;
-                const int oy = t % a.Ho;
-                const int n = t / a.Ho;
-                if (load_u) ru[i] = *reinterpret_cast<const u32x4*>(a.du + (size_t)m * a.Cout + co0 + c16 * 8);
-                const int iy = oy * a.stride + dy, ix = ox * a.stride + dx;
-                if (load_x && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                    rxx[i] = *reinterpret_cast<const u32x4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + ci0 + c16 * 8);
+            if (cm[i] < p_end) {
+                if (load_u) ru[i] = *reinterpret_cast<const u32x4*>(a.du + ((size_t)cm[i] * a.Cout + uoff));
+                const uint32_t iy = (uint32_t)(cy[i] * a.stride + dy), ix = (uint32_t)(cx[i] * a.stride + dx);
+                if (load_x && iy < (uint32_t)a.H && ix < (uint32_t)a.W)
+                    rxx[i] = *reinterpret_cast<const u32x4*>(
+                        a.x + ((size_t)((cn[i] * a.H + (int)iy) * a.W + (int)ix) * a.Cin + xoff));
             }
+        }
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cm[i] += 64;
+            cx[i] += 64;
+            while (cx[i] >= a.Wo) { cx[i] -= a.Wo; cy[i] += 1; }
+            while (cy[i] >= a.Ho) { cy[i] -= a.Ho; cn[i] += 1; }
         }
     };
     auto store_tile = [&]() {
@@ -457,12 +552,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int ch_in_tile = 16 * (g & 1) + 4 * (li & 3);     // channel chunk this lane SUPPLIES (within a 32-wide tile)
     const int pix_in_blk = 8 * (g >> 1) + (li >> 2);        // pixel row this lane supplies (within a 16-pixel k-step)
 
-    if (p_begin < p_end) load_tile(p_begin);
+    load_tile();
     for (int p0 = p_begin; p0 < p_end; p0 += 64) {
         __syncthreads();
         store_tile();
         __syncthreads();
-        load_tile(p0 + 64 < p_end ? p0 + 64 : p0);
+        advance();
+        load_tile();                                        // next stage (all-zero past the end of the slice)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {                    // 16 pixels per MFMA
             u32x4 fu[TCO], fx[TCI];

@@ -380,7 +380,8 @@ def conv_taps(kh, kw, dilation, padding):
 
 
 def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, res=None, relu=False, mode=0,
-               mask_src=None, out=None, out_f32_nchw=None, cout_real=None, out_stride=1, out_full_hw=None, tile=0):
+               mask_src=None, out=None, out_f32_nchw=None, cout_real=None, out_stride=1, out_full_hw=None, tile=0,
+               ksplit=1):
     """
     Implicit-GEMM convolution on the MFMA units (csrc/conv.hip).
       x         bf16 NHWC-contiguous tensor of logical shape (N, H, W, Cin)
@@ -420,6 +421,7 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     d.stride = int(stride)
     d.out_h, d.out_w, d.out_stride = oh, ow, int(out_stride)
     d.relu, d.mode, d.tile = int(bool(relu)), int(mode), int(tile)
+    d.ksplit = int(ksplit)
     check(fn['cms_conv_igemm'](C.byref(d), _stream()), 'cms_conv_igemm')
     return out if out_f32_nchw is None else out_f32_nchw
 

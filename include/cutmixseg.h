@@ -240,6 +240,8 @@ typedef struct cms_conv_desc {
     int relu;              /* forward epilogue ReLU                                                              */
     int mode;              /* CMS_CONV_FWD / CMS_CONV_DGRAD                                                      */
     int tile;              /* 0 = auto, else channels per workgroup: 128 / 64 / 32                               */
+    int ksplit;            /* <= 1: off; else the taps are split over workgroups (fp32 y32 output only, which must
+                              be zero-filled: partial sums are accumulated with atomics; bias added once)        */
 } cms_conv_desc;
 
 int cms_conv_igemm(const cms_conv_desc* d, void* stream);

@@ -101,6 +101,10 @@ def test_aspp_head_two_dilations_fp32_nchw(ops):
     xf = x.float().permute(0, 3, 1, 2)
     ref = F.conv2d(xf, w6.float(), None, 1, 6, 6) + F.conv2d(xf, w12.float(), None, 1, 12, 12) + b.view(1, -1, 1, 1)
     assert float((out - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-3
+    for ks in (2, 6, 18):          # taps split over workgroups, partial sums accumulated with atomics
+        out2 = torch.zeros(N, C, H, W, device=DEV)
+        ops.conv_igemm(x, wp, taps, bias=bias, out_f32_nchw=out2, cout_real=C, ksplit=ks)
+        assert float((out2 - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-3
 
 
 @pytest.mark.parametrize('case', [('1x1', 2, 41, 41, 256, 1024, 1, 1), ('3x3_d2', 2, 41, 41, 256, 256, 3, 2),
