@@ -48,6 +48,7 @@ struct ConvArgs {
     const float* bias;         // [Cout] or NULL (forward)
     const uint16_t* res;       // bf16, indexed like y, or NULL
     const uint16_t* mask_src;  // bf16, indexed like y, or NULL (dgrad)
+    const uint16_t* zeros;     // >= 128 B of zeros (source of padded / out-of-range rows for the direct-to-LDS loader)
     int N, H, W, Cin;
     int Ho, Wo, Cout, cout_real;
     int ntaps, stride;
@@ -55,6 +56,7 @@ struct ConvArgs {
     int relu, mode;            // mode 0 = forward epilogue, 1 = dgrad epilogue
     int M;                     // N*Ho*Wo
     int ksplit;                // > 1: the taps are split across workgroups, fp32 output accumulated with atomics
+    int dbg;                   // profiling experiments only: 2 = skip the MFMA phase, 3 = skip the loads after the first
     short tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
 };
 
@@ -77,8 +79,12 @@ struct RowInfo {            // one per pixel row of the workgroup tile, computed
     uint32_t m;             // GEMM row
 };
 
-template <int WN, int WM, int TN, int TM>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+// GLDS = true: operands go global -> LDS directly (global_load_lds_dwordx4, 1 KB per wave instruction, no staging
+// registers, no ds_write); the XOR swizzle is applied on the SOURCE side (the LDS image of a wave instruction is
+// lane-linear), out-of-range rows read a zero page. One LDS buffer per workgroup, up to 4 workgroups per CU: the
+// load latency of a workgroup is covered by the MFMA phases of its neighbours.
+template <int WN, int WM, int TN, int TM, bool GLDS>
+__global__ __launch_bounds__(256, (GLDS && TN * TM == 4) ? 4 : ((GLDS && TN * TM == 8) ? 2 : 1)) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BN = WN * TN * 32;    // output channels per workgroup
     constexpr int BM = WM * TM * 32;    // pixels per workgroup
     constexpr int PA = BM / 32;         // loader passes over the pixel tile
@@ -143,17 +149,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
     __syncthreads();
 
-    // ---- loader geometry (fixed for the whole K loop): thread -> 16-byte chunk (tid & 7) of rows (tid >> 3) + 32*i
+    // ---- loader geometry (fixed for the whole K loop)
+    // register-staged: thread -> 16-byte chunk (tid & 7) of rows (tid >> 3) + 32*i, swizzled on the LDS side.
+    // direct-to-LDS:   wave instruction (pass i, wave w) fills rows (4i+w)*8 .. +7 lane-linearly, so lane l lands on
+    //                  row (4i+w)*8 + (l>>3), physical chunk l&7 and must FETCH logical chunk (l&7) ^ swizzle(row).
     const int chunk = tid & 7, lrow = tid >> 3;
-    uint32_t xoff[PA], xyx[PA];
+    uint32_t xoff[PA], xyx[PA], woff[PB];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const RowInfo ri = lds_row[lrow + 32 * i];
-        xoff[i] = ri.in_off + (uint32_t)(chunk * 8);
+        const int row = GLDS ? (4 * i + wave) * 8 + (lane >> 3) : lrow + 32 * i;
+        const int c = GLDS ? ((lane & 7) ^ ((row >> 1) & 7)) : chunk;
+        const RowInfo ri = lds_row[row];
+        xoff[i] = ri.in_off + (uint32_t)(c * 8);
         xyx[i] = ri.yx;
     }
-    const uint32_t woff0 = (uint32_t)(lrow * a.Cin + chunk * 8);
-    const uint32_t wstep = (uint32_t)(32 * a.Cin);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int row = GLDS ? (4 * i + wave) * 8 + (lane >> 3) : lrow + 32 * i;
+        const int c = GLDS ? ((lane & 7) ^ ((row >> 1) & 7)) : chunk;
+        woff[i] = (uint32_t)(row * a.Cin + c * 8);
+    }
     const uint32_t st_off = swz(lrow, chunk);            // rows lrow + 32*i share the swizzle term: + i*4096 bytes
 
     const int kc_per_tap = a.Cin / CONV_BK;
@@ -163,32 +178,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int ks_begin = tap_begin * kc_per_tap;
     const int ksteps = tap_end * kc_per_tap;        // exclusive end of this workgroup's K range
 
-    u32x4 rx[PA], rw[PB];
+    u32x4 rx[GLDS ? 1 : PA], rw[GLDS ? 1 : PB];
     auto load_tile = [&](int ks) {
         const int tap = ks / kc_per_tap;                                  // wave-uniform
         const int c0 = (ks - tap * kc_per_tap) * CONV_BK;
         const int dy = __builtin_amdgcn_readfirstlane((int)lds_tap[tap]);
         const int dx = __builtin_amdgcn_readfirstlane((int)lds_tap[CMS_CONV_MAX_TAPS + tap]);
         const int delta = (dy * a.W + dx) * a.Cin + c0;                   // scalar element offset of this tap / K chunk
+        const uint16_t* wt = a.w + ((size_t)tap * a.Cout + co0) * a.Cin + c0;   // scalar base
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const uint32_t iy = (xyx[i] >> 16) + (uint32_t)dy, ix = (xyx[i] & 0xffffu) + (uint32_t)dx;
             const bool ok = iy < (uint32_t)a.H && ix < (uint32_t)a.W;    // unsigned compare covers the negative side
-            if (ok) {
-                rx[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(xoff[i] + (uint32_t)delta));
+            if constexpr (GLDS) {
+                const uint16_t* src = ok ? a.x + (size_t)(xoff[i] + (uint32_t)delta) : a.zeros + (lane & 7) * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lds_x + (4 * i + wave) * 1024),
+                                                 16, 0, 0);
             } else {
-                rx[i] = u32x4{0u, 0u, 0u, 0u};
+                if (ok) rx[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(xoff[i] + (uint32_t)delta));
+                else rx[i] = u32x4{0u, 0u, 0u, 0u};
             }
         }
-        const uint16_t* wt = a.w + ((size_t)tap * a.Cout + co0) * a.Cin + c0;   // scalar base
 #pragma unroll
-        for (int i = 0; i < PB; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wt + (woff0 + (uint32_t)i * wstep));
+        for (int i = 0; i < PB; ++i) {
+            if constexpr (GLDS) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + woff[i]),
+                                                 (__attribute__((address_space(3))) void*)(lds_w + (4 * i + wave) * 1024),
+                                                 16, 0, 0);
+            } else {
+                rw[i] = *reinterpret_cast<const u32x4*>(wt + woff[i]);
+            }
+        }
     };
     auto store_tile = [&]() {
+        if constexpr (!GLDS) {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(lds_x + st_off + i * 32 * CONV_ROW_BYTES) = rx[i];
+            for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(lds_x + st_off + i * 32 * CONV_ROW_BYTES) = rx[i];
 #pragma unroll
-        for (int i = 0; i < PB; ++i) *reinterpret_cast<u32x4*>(lds_w + st_off + i * 32 * CONV_ROW_BYTES) = rw[i];
+            for (int i = 0; i < PB; ++i) *reinterpret_cast<u32x4*>(lds_w + st_off + i * 32 * CONV_ROW_BYTES) = rw[i];
+        }
     };
 
     f32x16 acc[TN][TM];
@@ -206,12 +235,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const unsigned char* fw_base = lds_w + wn * TN * 32 * CONV_ROW_BYTES;
     const unsigned char* fx_base = lds_x + wm * TM * 32 * CONV_ROW_BYTES;
 
-    if (ks_begin < ksteps) load_tile(ks_begin);
-    for (int ks = ks_begin; ks < ksteps; ++ks) {
-        __syncthreads();            // previous stage's fragment reads are done
-        store_tile();
-        __syncthreads();
-        load_tile(ks + 1 < ksteps ? ks + 1 : ks);   // in flight during the MFMA phase (last one is a harmless re-load)
+    auto mfma_phase = [&]() {
 #pragma unroll
         for (int kk = 0; kk < CONV_BK / 16; ++kk) {
             u32x4 fw[TN], fx[TM];     // (arrays of __bf16 vectors are not promoted to registers by the compiler)
@@ -227,13 +251,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[i]),
                                                                         __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
         }
+    };
+    if (ks_begin < ksteps) load_tile(ks_begin);
+    if constexpr (GLDS) {
+        for (int ks = ks_begin; ks < ksteps; ++ks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the stage has landed in LDS
+            __syncthreads();                                    // ... and everybody else's
+            if (a.dbg != 2) mfma_phase();
+            __syncthreads();                                    // all fragment reads done: the buffer may be refilled
+            if (ks + 1 < ksteps && a.dbg != 3) load_tile(ks + 1);
+        }
+    } else {
+        for (int ks = ks_begin; ks < ksteps; ++ks) {
+            __syncthreads();            // previous stage's fragment reads are done
+            store_tile();
+            __syncthreads();
+            load_tile(ks + 1 < ksteps ? ks + 1 : ks);   // in flight during the MFMA phase (last one: harmless re-load)
+            mfma_phase();
+        }
     }
 
     // ---- epilogue. The accumulator layout gives every lane runs of 4 consecutive channels of one pixel; BN affine,
     // residual / gradient add, ReLU or ReLU-mask are applied in registers (one rounding to bf16), the bf16 tile is
     // transposed through LDS and written out with 16 bytes per lane, 256 contiguous bytes per pixel row.
     const bool to_lds = a.y != nullptr;
-    if (to_lds) __syncthreads();                           // all fragment reads of the last stage are done
+    if (to_lds && !GLDS) __syncthreads();                  // all fragment reads of the last stage are done
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int prow_l = (wm * TM + j) * 32 + frow;
@@ -372,12 +414,13 @@ static int conv_check(const cms_conv_desc* d) {
 }
 
 template <int WN, int WM, int TN, int TM>
-static void conv_launch(const ConvArgs& a, hipStream_t s) {
+static void conv_launch(const ConvArgs& a, hipStream_t s, bool glds) {
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
     const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM) * a.ksplit;
     const size_t stage = (size_t)(BN + BM) * CONV_ROW_BYTES, epi = (size_t)BM * (BN * 2 + 16);
     const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16;
-    hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM>), dim3(grid), dim3(256), lds, s, a);
+    if (glds) hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, false>), dim3(grid), dim3(256), lds, s, a);
 }
 
 extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
@@ -401,15 +444,21 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
         a.tap_dx[i] = (short)(i < d->ntaps ? d->tap_dx[i] : 0);
     }
     hipStream_t s = (hipStream_t)stream;
+    a.zeros = (const uint16_t*)d->zeros;
+    a.dbg = d->variant >= 2 ? d->variant : 0;
+    const bool glds = d->zeros != nullptr && d->variant != 1;     // variant 1 forces the register-staged loader
     const int tile = d->tile;   // 0 = auto
-    if ((tile == 0 && d->cout % 128 == 0) || tile == 128) {
+    if (tile == 256) {                         // experiment: 128 co x 256 pixels (more reuse of the weight tile)
+        CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 256 needs Cout %% 128 == 0");
+        conv_launch<2, 2, 2, 4>(a, s, glds);
+    } else if ((tile == 0 && d->cout % 128 == 0) || tile == 128) {
         CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 128 needs Cout %% 128 == 0");
-        conv_launch<2, 2, 2, 2>(a, s);           // 128 co x 128 pixels
+        conv_launch<2, 2, 2, 2>(a, s, glds);     // 128 co x 128 pixels
     } else if ((tile == 0 && d->cout % 64 == 0) || tile == 64) {
         CMS_REQUIRE(d->cout % 64 == 0, "conv: tile 64 needs Cout %% 64 == 0");
-        conv_launch<1, 4, 2, 1>(a, s);           // 64 co x 128 pixels
+        conv_launch<1, 4, 2, 1>(a, s, glds);     // 64 co x 128 pixels
     } else {
-        conv_launch<1, 4, 1, 1>(a, s);           // 32 co x 128 pixels
+        conv_launch<1, 4, 1, 1>(a, s, glds);     // 32 co x 128 pixels
     }
     return launch_status("cms_conv_igemm");
 }
@@ -477,6 +526,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int wco = wave & 1, wci = wave >> 1;
     const int nco = a.Cout / BCO, nci = a.Cin / BCI;
     int b = blockIdx.x;
+    {   // XCD-aware order: all (co, ci, tap) tiles of one pixel slice are consecutive logical ids and therefore run
+        // on one XCD, which then fetches that slice of dU / X from HBM once instead of once per XCD
+        const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = b % 8, idx = b / 8;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int tco = b % nco; b /= nco;
     const int tci = b % nci; b /= nci;
     const int tap = b % a.ntaps; b /= a.ntaps;
@@ -513,11 +567,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             ru[i] = u32x4{0u, 0u, 0u, 0u};
             rxx[i] = u32x4{0u, 0u, 0u, 0u};
             if (cm[i] < p_end) {
-                if (load_u) ru[i] = *reinterpret_cast<const u32x4*>(a.du + ((size_t)cm[i] * a.Cout + uoff));
+                if (load_u) ru[i] = *reinterpret_cast<const u32x4*>(a.du + (size_t)((uint32_t)(cm[i] * a.Cout) + uoff));
                 const uint32_t iy = (uint32_t)(cy[i] * a.stride + dy), ix = (uint32_t)(cx[i] * a.stride + dx);
                 if (load_x && iy < (uint32_t)a.H && ix < (uint32_t)a.W)
                     rxx[i] = *reinterpret_cast<const u32x4*>(
-                        a.x + ((size_t)((cn[i] * a.H + (int)iy) * a.W + (int)ix) * a.Cin + xoff));
+                        a.x + (size_t)((uint32_t)(((cn[i] * a.H + (int)iy) * a.W + (int)ix) * a.Cin) + xoff));
             }
         }
     };
@@ -632,7 +686,10 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     const int bco = d->cout % 128 == 0 ? 128 : 64, bci = d->cin % 128 == 0 ? 128 : 64;
     const int tiles = (d->cout / bco) * (d->cin / bci) * d->ntaps;
     // split the pixel axis so that the grid has ~3 workgroups per CU, each slice a multiple of 64 pixels
-    int ksplit = d->ksplit > 0 ? d->ksplit : (768 + tiles - 1) / tiles;
+    CMS_REQUIRE((size_t)d->n * d->h * d->w_in * d->cin < (1u << 31) && (size_t)d->n * d->ho * d->wo * d->cout < (1u << 31),
+                "conv_wgrad: tensors must have < 2^31 elements");
+    // ~1.5 workgroups per CU: more slices only add atomic traffic and per-workgroup prologue/epilogue
+    int ksplit = d->ksplit > 0 ? d->ksplit : (384 + tiles - 1) / tiles;
     int per = ((a.M + ksplit - 1) / ksplit + 63) / 64 * 64;
     if (per < 64) per = 64;
     ksplit = (a.M + per - 1) / per;

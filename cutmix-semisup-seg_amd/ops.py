@@ -374,6 +374,18 @@ def confusion(truth, pred, num_classes, ignore_index=None, cm=None):
 
 
 # ---------------------------------------------------------------------------------------------- MFMA convolution
+_ZERO_PAGES = {}
+
+
+def _zero_page(device):
+    """A small all-zero device buffer: where the direct-to-LDS loader fetches padded / out-of-range rows from."""
+    z = _ZERO_PAGES.get(device)
+    if z is None:
+        z = torch.zeros(1024, dtype=torch.bfloat16, device=device)
+        _ZERO_PAGES[device] = z
+    return z
+
+
 def conv_taps(kh, kw, dilation, padding):
     """(dy, dx) input offsets of the kh*kw taps in [ky][kx] order."""
     return [(ky * dilation - padding, kx * dilation - padding) for ky in range(kh) for kx in range(kw)]
@@ -381,7 +393,7 @@ def conv_taps(kh, kw, dilation, padding):
 
 def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, res=None, relu=False, mode=0,
                mask_src=None, out=None, out_f32_nchw=None, cout_real=None, out_stride=1, out_full_hw=None, tile=0,
-               ksplit=1):
+               ksplit=1, variant=0):
     """
     Implicit-GEMM convolution on the MFMA units (csrc/conv.hip).
       x         bf16 NHWC-contiguous tensor of logical shape (N, H, W, Cin)
@@ -422,6 +434,8 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     d.out_h, d.out_w, d.out_stride = oh, ow, int(out_stride)
     d.relu, d.mode, d.tile = int(bool(relu)), int(mode), int(tile)
     d.ksplit = int(ksplit)
+    d.zeros = _zero_page(x.device).data_ptr()
+    d.variant = int(variant)
     check(fn['cms_conv_igemm'](C.byref(d), _stream()), 'cms_conv_igemm')
     return out if out_f32_nchw is None else out_f32_nchw
 

@@ -242,6 +242,9 @@ typedef struct cms_conv_desc {
     int tile;              /* 0 = auto, else channels per workgroup: 128 / 64 / 32                               */
     int ksplit;            /* <= 1: off; else the taps are split over workgroups (fp32 y32 output only, which must
                               be zero-filled: partial sums are accumulated with atomics; bias added once)        */
+    const void* zeros;     /* >= 128 bytes of zeros in device memory: enables the direct-to-LDS loader (padded and
+                              out-of-range rows are fetched from it); NULL = register-staged loader              */
+    int variant;           /* 0 = auto, 1 = force the register-staged loader                                     */
 } cms_conv_desc;
 
 int cms_conv_igemm(const cms_conv_desc* d, void* stream);

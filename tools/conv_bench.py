@@ -40,7 +40,7 @@ def timeit(fn, iters=10):
 
 
 tot_mine = tot_lib = 0.0
-print('{:<22s} {:>9s} {:>9s} {:>8s} {:>8s} {:>8s}'.format('shape', 'mine_us', 'lib_us', 'TF/s', 'GB/s', 'speedup'))
+print('{:<22s} {:>9s} {:>9s} {:>9s} {:>8s} {:>8s} {:>8s}'.format('shape', 'glds_us', 'regst_us', 'lib_us', 'TF/s', 'GB/s', 'speedup'))
 for name, H, W, Cin, Cout, k, stride, dil, cnt in SHAPES:
     g = torch.Generator(device=DEV).manual_seed(0)
     pad = dil * (k - 1) // 2
@@ -55,12 +55,14 @@ for name, H, W, Cin, Cout, k, stride, dil, cnt in SHAPES:
     out = torch.empty(N, Ho, Wo, Cout, dtype=torch.bfloat16, device=DEV)
     t_m = timeit(lambda: ops.conv_igemm(x, wp, taps, stride=stride, out_hw=(Ho, Wo), scale=scale, bias=bias, relu=True,
                                         out=out))
+    t_r = timeit(lambda: ops.conv_igemm(x, wp, taps, stride=stride, out_hw=(Ho, Wo), scale=scale, bias=bias, relu=True,
+                                        out=out, variant=1))
     xcl = x.permute(0, 3, 1, 2)          # NCHW view with channels-last strides
     wcl = w.contiguous(memory_format=torch.channels_last)
     t_l = timeit(lambda: F.conv2d(xcl, wcl, None, stride, pad, dil))
     flops = 2.0 * N * Ho * Wo * Cout * Cin * k * k
     byts = 2.0 * (N * H * W * Cin / (stride * stride if k == 1 else 1) + N * Ho * Wo * Cout + k * k * Cin * Cout)
-    print('{:<22s} {:9.1f} {:9.1f} {:8.1f} {:8.0f} {:8.2f}'.format(name, t_m * 1e3, t_l * 1e3, flops / t_m / 1e9,
+    print('{:<22s} {:9.1f} {:9.1f} {:9.1f} {:8.1f} {:8.0f} {:8.2f}'.format(name, t_m * 1e3, t_r * 1e3, t_l * 1e3, flops / t_m / 1e9,
                                                                   byts / t_m / 1e6, t_l / t_m))
     tot_mine += cnt * t_m
     tot_lib += cnt * t_l
