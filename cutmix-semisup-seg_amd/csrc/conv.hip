@@ -60,6 +60,16 @@ struct ConvArgs {
     short tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
 };
 
+
+// Branch-free pointer select for the direct-to-LDS loads: `ok ? p : z` written as a ternary makes the compiler
+// duplicate the (side-effecting) load into both arms of a divergent branch, i.e. up to two load instructions where
+// the counted s_waitcnt of the ring kernels expects exactly one.
+__device__ __forceinline__ const uint16_t* select_ptr(bool ok, const uint16_t* p, const uint16_t* z) {
+    const uint64_t a = (uint64_t)p, b = (uint64_t)z;
+    const uint64_t m = (uint64_t)0 - (uint64_t)ok;
+    return (const uint16_t*)(b ^ ((a ^ b) & m));
+}
+
 __device__ __forceinline__ uint32_t swz(int row, int chunk) {
     return (uint32_t)row * CONV_ROW_BYTES + (uint32_t)((chunk ^ ((row >> 1) & 7)) << 4);
 }
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256, (GLDS && TN * TM == 4) ? 4 : ((GLDS && TN * TM
             const uint32_t iy = (xyx[i] >> 16) + (uint32_t)dy, ix = (xyx[i] & 0xffffu) + (uint32_t)dx;
             const bool ok = iy < (uint32_t)a.H && ix < (uint32_t)a.W;    // unsigned compare covers the negative side
             if constexpr (GLDS) {
-                const uint16_t* src = ok ? a.x + (size_t)(xoff[i] + (uint32_t)delta) : a.zeros + (lane & 7) * 8;
+                const uint16_t* src = select_ptr(ok, a.x + (size_t)(xoff[i] + (uint32_t)delta), a.zeros + (lane & 7) * 8);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(lds_x + (4 * i + wave) * 1024),
                                                  16, 0, 0);
@@ -665,6 +675,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
+
 }  // namespace cms
 
 extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
@@ -685,19 +696,19 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     }
     const int bco = d->cout % 128 == 0 ? 128 : 64, bci = d->cin % 128 == 0 ? 128 : 64;
     const int tiles = (d->cout / bco) * (d->cin / bci) * d->ntaps;
-    // split the pixel axis so that the grid has ~3 workgroups per CU, each slice a multiple of 64 pixels
     CMS_REQUIRE((size_t)d->n * d->h * d->w_in * d->cin < (1u << 31) && (size_t)d->n * d->ho * d->wo * d->cout < (1u << 31),
                 "conv_wgrad: tensors must have < 2^31 elements");
-    // ~1.5 workgroups per CU: more slices only add atomic traffic and per-workgroup prologue/epilogue
+    // split the pixel axis so that the grid has ~1.5 workgroups per CU (more slices only add atomic traffic and
+    // per-workgroup prologue / epilogue); each slice is a multiple of 64 pixels
     int ksplit = d->ksplit > 0 ? d->ksplit : (384 + tiles - 1) / tiles;
     int per = ((a.M + ksplit - 1) / ksplit + 63) / 64 * 64;
     if (per < 64) per = 64;
     ksplit = (a.M + per - 1) / per;
     a.ksplit = ksplit;
     a.pix_per_split = per;
-    const size_t lds = 2 * 64 * 256;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(tiles * ksplit);
+    const size_t lds = 2 * 64 * 256;
     if (bco == 128 && bci == 128) hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), lds, s, a);
     else if (bco == 128) hipLaunchKernelGGL((conv_wgrad_kernel<2, 1>), grid, dim3(256), lds, s, a);
     else if (bci == 128) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), grid, dim3(256), lds, s, a);

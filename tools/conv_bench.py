@@ -40,7 +40,7 @@ def timeit(fn, iters=10):
 
 
 tot_mine = tot_lib = 0.0
-print('{:<22s} {:>9s} {:>9s} {:>9s} {:>8s} {:>8s} {:>8s}'.format('shape', 'glds_us', 'regst_us', 'lib_us', 'TF/s', 'GB/s', 'speedup'))
+print('{:<22s} {:>9s} {:>9s} {:>9s} {:>8s} {:>8s} {:>8s}'.format('shape', 'glds_us', 'tile64_us', 'lib_us', 'TF/s', 'GB/s', 'speedup'))
 for name, H, W, Cin, Cout, k, stride, dil, cnt in SHAPES:
     g = torch.Generator(device=DEV).manual_seed(0)
     pad = dil * (k - 1) // 2
@@ -56,7 +56,7 @@ for name, H, W, Cin, Cout, k, stride, dil, cnt in SHAPES:
     t_m = timeit(lambda: ops.conv_igemm(x, wp, taps, stride=stride, out_hw=(Ho, Wo), scale=scale, bias=bias, relu=True,
                                         out=out))
     t_r = timeit(lambda: ops.conv_igemm(x, wp, taps, stride=stride, out_hw=(Ho, Wo), scale=scale, bias=bias, relu=True,
-                                        out=out, variant=1))
+                                        out=out, tile=64)) if Cout % 64 == 0 else float('nan')
     xcl = x.permute(0, 3, 1, 2)          # NCHW view with channels-last strides
     wcl = w.contiguous(memory_format=torch.channels_last)
     t_l = timeit(lambda: F.conv2d(xcl, wcl, None, stride, pad, dil))
