@@ -94,12 +94,15 @@ struct RowInfo {            // one per pixel row of the workgroup tile, computed
 // lane-linear), out-of-range rows read a zero page. One LDS buffer per workgroup, up to 4 workgroups per CU: the
 // load latency of a workgroup is covered by the MFMA phases of its neighbours.
 template <int WN, int WM, int TN, int TM, bool GLDS>
-__global__ __launch_bounds__(256, (GLDS && TN * TM == 4) ? 4 : ((GLDS && TN * TM == 8) ? 2 : 1)) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4) ? 4 : 1) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int NW = WN * WM;         // waves per workgroup (4 or 8)
+    constexpr int NT = 64 * NW;
     constexpr int BN = WN * TN * 32;    // output channels per workgroup
     constexpr int BM = WM * TM * 32;    // pixels per workgroup
-    constexpr int PA = BM / 32;         // loader passes over the pixel tile
-    constexpr int PB = BN / 32;
-    static_assert(WN * WM == 4, "4 waves");
+    constexpr int PA = BM / (8 * NW);   // loader passes over the pixel tile (each pass: 8 rows per wave)
+    constexpr int PB = BN / (8 * NW);
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(BM <= NT && PA >= 1 && PB >= 1, "tile too small for the loader");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int EPI_LD = BN * 2 + 16;                   // epilogue tile row pitch (bytes): +16 B breaks bank aliasing
     constexpr int STAGE_BYTES = (BM + BN) * CONV_ROW_BYTES;
@@ -163,11 +166,12 @@ __global__ __launch_bounds__(256, (GLDS && TN * TM == 4) ? 4 : ((GLDS && TN * TM
     // register-staged: thread -> 16-byte chunk (tid & 7) of rows (tid >> 3) + 32*i, swizzled on the LDS side.
     // direct-to-LDS:   wave instruction (pass i, wave w) fills rows (4i+w)*8 .. +7 lane-linearly, so lane l lands on
     //                  row (4i+w)*8 + (l>>3), physical chunk l&7 and must FETCH logical chunk (l&7) ^ swizzle(row).
-    const int chunk = tid & 7, lrow = tid >> 3;
+    const int chunk = tid & 7, lrow = tid >> 3;      // register-staged mapping: rows lrow + (NT/8)*i
+    constexpr int RSTEP = NT / 8;
     uint32_t xoff[PA], xyx[PA], woff[PB];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int row = GLDS ? (4 * i + wave) * 8 + (lane >> 3) : lrow + 32 * i;
+        const int row = GLDS ? (NW * i + wave) * 8 + (lane >> 3) : lrow + RSTEP * i;
         const int c = GLDS ? ((lane & 7) ^ ((row >> 1) & 7)) : chunk;
         const RowInfo ri = lds_row[row];
         xoff[i] = ri.in_off + (uint32_t)(c * 8);
@@ -175,11 +179,11 @@ __global__ __launch_bounds__(256, (GLDS && TN * TM == 4) ? 4 : ((GLDS && TN * TM
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        const int row = GLDS ? (4 * i + wave) * 8 + (lane >> 3) : lrow + 32 * i;
+        const int row = GLDS ? (NW * i + wave) * 8 + (lane >> 3) : lrow + RSTEP * i;
         const int c = GLDS ? ((lane & 7) ^ ((row >> 1) & 7)) : chunk;
         woff[i] = (uint32_t)(row * a.Cin + c * 8);
     }
-    const uint32_t st_off = swz(lrow, chunk);            // rows lrow + 32*i share the swizzle term: + i*4096 bytes
+    const uint32_t st_off = swz(lrow, chunk);            // rows lrow + RSTEP*i share the swizzle term (RSTEP % 16 == 0)
 
     const int kc_per_tap = a.Cin / CONV_BK;
     const int taps_per_split = (a.ntaps + a.ksplit - 1) / a.ksplit;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256, (GLDS && TN * TM == 4) ? 4 : ((GLDS && TN * TM
             if constexpr (GLDS) {
                 const uint16_t* src = select_ptr(ok, a.x + (size_t)(xoff[i] + (uint32_t)delta), a.zeros + (lane & 7) * 8);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(lds_x + (4 * i + wave) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(lds_x + (NW * i + wave) * 1024),
                                                  16, 0, 0);
             } else {
                 if (ok) rx[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(xoff[i] + (uint32_t)delta));
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256, (GLDS && TN * TM == 4) ? 4 : ((GLDS && TN * TM
         for (int i = 0; i < PB; ++i) {
             if constexpr (GLDS) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + woff[i]),
-                                                 (__attribute__((address_space(3))) void*)(lds_w + (4 * i + wave) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(lds_w + (NW * i + wave) * 1024),
                                                  16, 0, 0);
             } else {
                 rw[i] = *reinterpret_cast<const u32x4*>(wt + woff[i]);
@@ -224,9 +228,9 @@ __global__ __launch_bounds__(256, (GLDS && TN * TM == 4) ? 4 : ((GLDS && TN * TM
     auto store_tile = [&]() {
         if constexpr (!GLDS) {
 #pragma unroll
-            for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(lds_x + st_off + i * 32 * CONV_ROW_BYTES) = rx[i];
+            for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(lds_x + st_off + i * RSTEP * CONV_ROW_BYTES) = rx[i];
 #pragma unroll
-            for (int i = 0; i < PB; ++i) *reinterpret_cast<u32x4*>(lds_w + st_off + i * 32 * CONV_ROW_BYTES) = rw[i];
+            for (int i = 0; i < PB; ++i) *reinterpret_cast<u32x4*>(lds_w + st_off + i * RSTEP * CONV_ROW_BYTES) = rw[i];
         }
     };
 
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256, (GLDS && TN * TM == 4) ? 4 : ((GLDS && TN * TM
     if (to_lds) {
         __syncthreads();
         constexpr int CPR = BN / 8;                 // 16-byte chunks per output row of this tile
-        constexpr int RPP = 256 / CPR;              // rows per pass
+        constexpr int RPP = NT / CPR;               // rows per pass
         const int ch = tid % CPR, r0 = tid / CPR;
 #pragma unroll
         for (int r = r0; r < BM; r += RPP) {
@@ -429,8 +433,9 @@ static void conv_launch(const ConvArgs& a, hipStream_t s, bool glds) {
     const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM) * a.ksplit;
     const size_t stage = (size_t)(BN + BM) * CONV_ROW_BYTES, epi = (size_t)BM * (BN * 2 + 16);
     const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16;
-    if (glds) hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true>), dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, false>), dim3(grid), dim3(256), lds, s, a);
+    constexpr int NT = 64 * WN * WM;
+    if (glds) hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true>), dim3(grid), dim3(NT), lds, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, false>), dim3(grid), dim3(NT), lds, s, a);
 }
 
 extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
@@ -458,12 +463,17 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
     a.dbg = d->variant >= 2 ? d->variant : 0;
     const bool glds = d->zeros != nullptr && d->variant != 1;     // variant 1 forces the register-staged loader
     const int tile = d->tile;   // 0 = auto
-    if (tile == 256) {                         // experiment: 128 co x 256 pixels (more reuse of the weight tile)
+    if (tile == 256) {                         // 8 waves: 128 co x 256 pixels (more reuse of the weight tile)
         CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 256 needs Cout %% 128 == 0");
-        conv_launch<2, 2, 2, 4>(a, s, glds);
+        conv_launch<2, 4, 2, 2>(a, s, glds);
+    } else if (tile == 1128) {                 // 8 waves on the 128 x 128 tile (each wave 64 co x 32 pixels)
+        CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 1128 needs Cout %% 128 == 0");
+        conv_launch<2, 4, 2, 1>(a, s, glds);
     } else if ((tile == 0 && d->cout % 128 == 0) || tile == 128) {
+        // default: 128 co x 128 pixels, 4 waves of 64 x 64 (the 8-wave layouts above measured within +-5 % of it on
+        // the DeepLab v2 layer shapes and no better end to end, tools/conv_ablate.py)
         CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 128 needs Cout %% 128 == 0");
-        conv_launch<2, 2, 2, 2>(a, s, glds);     // 128 co x 128 pixels
+        conv_launch<2, 2, 2, 2>(a, s, glds);
     } else if ((tile == 0 && d->cout % 64 == 0) || tile == 64) {
         CMS_REQUIRE(d->cout % 64 == 0, "conv: tile 64 needs Cout %% 64 == 0");
         conv_launch<1, 4, 2, 1>(a, s, glds);     // 64 co x 128 pixels

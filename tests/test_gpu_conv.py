@@ -71,13 +71,14 @@ def test_conv_forward(ops, case, epi):
     assert float(err.mean()) <= 4e-3 * float(ref.abs().mean() + 1e-6) + 1e-4
 
 
-@pytest.mark.parametrize('tile', [128, 64, 32])
-def test_conv_tile_variants_agree(ops, tile):
+@pytest.mark.parametrize('variant', [0, 1], ids=['direct_to_lds', 'register_staged'])
+@pytest.mark.parametrize('tile', [0, 128, 1128, 256, 64, 32])
+def test_conv_tile_variants_agree(ops, tile, variant):
     g = torch.Generator(device=DEV).manual_seed(5)
     x = _mk((2, 20, 23, 128), g)
     w = _mk((128, 128, 3, 3), g, 0.03)
     taps = ops.conv_taps(3, 3, 2, 2)
-    a = ops.conv_igemm(x, _pack(w), taps, tile=tile)
+    a = ops.conv_igemm(x, _pack(w), taps, tile=tile, variant=variant)
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, 1, 2, 2).permute(0, 2, 3, 1)
     assert float((a.float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max()) + 1e-2
 
