@@ -181,3 +181,47 @@ def test_whole_step_bf16_hip_engine_tracks_fp32_library_engine():
     dh, dl = (w_hip - st0).flatten(), (w_lib - st0).flatten()
     cos = float((dh * dl).sum() / (dh.norm() * dl.norm() + 1e-30))
     assert cos > 0.9, cos
+
+
+def test_trainer_cli_synthetic_end_to_end(tmp_path, monkeypatch, capsys):
+    """The reference's command line (run_pascal_aug_experiments.sh flag set) on synthetic data: 2 epochs x 2 iterations
+    of the ResNet-101 DeepLab v2 at a small crop; checks the job/log layout and the epoch log line format."""
+    import re
+    from click.testing import CliRunner
+    import train_seg_semisup_mask_mt as trainer
+    monkeypatch.chdir(tmp_path)
+    args = ['--job_desc', 'smoke', '--synthetic', '--arch', 'resnet101_deeplab_imagenet', '--freeze_bn', '--batch_size', '2',
+            '--crop_size', '65,65', '--learning_rate', '3e-5', '--lr_sched', 'poly', '--mask_prop_range', '0.5',
+            '--conf_thresh', '0.97', '--num_epochs', '2', '--iters_per_epoch', '2', '--synthetic_val_batches', '1']
+    res = CliRunner().invoke(trainer.experiment, args, catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    log = open(tmp_path / 'results' / 'train_seg_semisup_mask_mt' / 'log_smoke.txt').read()
+    lines = [l for l in log.splitlines() if l.startswith('Epoch ')]
+    assert len(lines) == 2
+    pat = re.compile(r'Epoch \d+: took [\d.]+s, TRAIN clf loss=[\d.]+, consistency loss=[\d.]+, conf rate=[\d.]+%, '
+                     r'VAL mIoU=[\d.]+%')
+    assert all(pat.match(l) for l in lines), lines
+    assert 'Built network' in log and 'Training...' in log and 'Settings:' in log
+    clf = [float(re.search(r'clf loss=([\d.]+)', l).group(1)) for l in lines]
+    assert all(np.isfinite(v) and 0 < v < 10 for v in clf)
+
+
+def test_eval_and_full_resolution_forward_with_hip_engine():
+    import evaluation
+    from cutmix_semisup_seg_amd import ops
+    net = _build([1, 1, 1, 1], 5, 'hip')
+    net.eval()
+    x = _cf_input(2, 65, 65, 0.2).bfloat16().to(DEV)
+    with torch.no_grad():
+        lo = net.forward_lowres(x)
+        full = net(x)                                   # the reference's forward contract: logits at input size
+    assert full.shape == (2, 5, 65, 65)
+    torch.testing.assert_close(full, ops.upsample_bilinear(lo, (65, 65), True))
+    y = torch.randint(0, 5, (2, 1, 65, 65), device=DEV).to(torch.uint8)
+    ev = evaluation.EvaluatorIoU(5)
+    ev.sample_logits(lo, y, (65, 65), ignore_value=255, align_corners=True)
+    ev2 = evaluation.EvaluatorIoU(5)
+    pred = full.argmax(dim=1)
+    for i in range(2):
+        ev2.sample(y[i, 0], pred[i].to(torch.uint8), ignore_value=255)
+    assert abs(ev.score().mean() - ev2.score().mean()) < 2e-3     # fused vs materialised path (fp ties aside)
