@@ -82,6 +82,8 @@ def main():
     ap.add_argument('--roofline_kernel', choices=['conv', 'adam_ema', 'consistency'], default='conv')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_fuse_batches', action='store_true')
+    ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')
+    ap.add_argument('--no_roofline_events', action='store_true', help='skip the per-launch event brackets')
     args = ap.parse_args()
 
     import numpy as np
@@ -124,8 +126,11 @@ def main():
     ema.fuse_into(opt)
     stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()      # --freeze_bn
     cfg = StepConfig(mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.97, conf_per_pixel=False,
-                     fuse_batches=not args.no_fuse_batches, compute_dtype=dtype)
+                     fuse_batches=not args.no_fuse_batches, compute_dtype=dtype,
+                     overlap_teacher=not args.no_overlap)
     step = CutMixMeanTeacherStep(stu, tea, opt, ema, cfg)
+    if args.no_overlap and hasattr(stu, 'hip_executor') and dtype == torch.bfloat16:
+        stu.hip_executor().overlap_wgrad = False
 
     gen = torch.Generator(device=dev).manual_seed(12345 + rank)
     mask_rng = np.random.RandomState(12345 + rank)
@@ -225,10 +230,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timing_on[0] = True
+    timing_on[0] = not args.no_roofline_events
     t0 = time.perf_counter()
     for i in range(args.steps):
         res = one_step(i)
+    t_enqueue = time.perf_counter() - t0         # host time to enqueue the K steps (== elapsed when launch-bound)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -267,7 +273,9 @@ def main():
             'config': {'workload': wl['name'], 'per_gpu_batch': B, 'global_batch': B * world, 'crop': [H, W],
                        'classes': C, 'parallelism': 'dp{}'.format(world), 'image_forwards_per_sec':
                            4 * args.steps * B * world / elapsed,
-                       'fuse_batches': not args.no_fuse_batches, 'last_losses': last},
+                       'fuse_batches': not args.no_fuse_batches, 'stream_overlap': not args.no_overlap,
+                       'host_enqueue_ms_per_step': 1e3 * t_enqueue / args.steps,
+                       'last_losses': last},
             'roofline': {'bound': roof['bound'], 'kernel': kname, 'achieved': achieved, 'peak': roof['peak'],
                          'unit': roof['unit'], 'frac': achieved / roof['peak'], 'traffic': None,
                          'avg_launch_ms': ms_kernel,

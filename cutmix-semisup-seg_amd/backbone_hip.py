@@ -77,6 +77,9 @@ class DeepLabHipExecutor(object):
         self.aspp_wT = torch.zeros(18, 2048, 64, dtype=torch.bfloat16, device=dev)
         self.aspp_bias = torch.zeros(32, dtype=torch.float32, device=dev)
         self._affine_ready = False
+        self._bn_idx = None
+        self._side = None
+        self.overlap_wgrad = True
         self._wT_version = -1
         self.version = 0          # bumped whenever the weights change (optimizer step / load_state_dict)
         net.register_load_state_dict_post_hook(lambda module, incompatible: self.invalidate())
@@ -88,20 +91,47 @@ class DeepLabHipExecutor(object):
         self._affine_ready = False
         self.version += 1
 
+    def weights_changed(self, bn_too=False):
+        """The fp32 AND bf16 arenas were updated by an optimizer / EMA kernel. `bn_too`: BatchNorm state moved as well
+        (the EMA runs over the running statistics and affine parameters too, optim_weight_ema.py:21-25; even for
+        equal source and target its three roundings can move a value by an ulp) -> re-fold scale / bias."""
+        self.version += 1
+        if bn_too:
+            self._affine_ready = False
+
     def _all_convs(self):
         for b in self.blocks:
             for c in (b.c1, b.c2, b.c3, b.cd):
                 if c is not None:
                     yield c
 
-    def _refresh_affine(self):
+    def _build_affine_tables(self):
+        """Gather indices of every BatchNorm (weight, bias, running_mean, running_var) element in the arena, in the
+        order of `_all_convs()`, so that folding all 104 layers is a handful of launches instead of ~600."""
         a = self.arena
+        idx = {k: [] for k in ('weight', 'bias', 'running_mean', 'running_var')}
+        off = 0
+        spans = []
         for c in self._all_convs():
-            w, bta = a.view(c.bn + '.weight'), a.view(c.bn + '.bias')
-            rm, rv = a.view(c.bn + '.running_mean'), a.view(c.bn + '.running_var')
-            eps = 1e-5
-            c.scale = (w * torch.rsqrt(rv + eps)).contiguous()
-            c.bias = (bta - rm * c.scale).contiguous()
+            for k in idx:
+                s = a.by_key[c.bn + '.' + k]
+                idx[k].append(torch.arange(s.offset, s.offset + s.count, dtype=torch.int64))
+            spans.append((c, off, off + c.cout))
+            off += c.cout
+        dev = a.device
+        self._bn_idx = {k: torch.cat(v).to(dev) for k, v in idx.items()}
+        self._scale_all = torch.zeros(off, dtype=torch.float32, device=dev)
+        self._bias_all = torch.zeros(off, dtype=torch.float32, device=dev)
+        for c, lo, hi in spans:
+            c.scale, c.bias = self._scale_all[lo:hi], self._bias_all[lo:hi]
+
+    def _refresh_affine(self):
+        """scale = gamma / sqrt(var + eps), bias = beta - mean * scale  (frozen BN, deeplab2.py:92-107)."""
+        if self._bn_idx is None:
+            self._build_affine_tables()
+        flat, ix = self.arena.flat, self._bn_idx
+        torch.mul(flat[ix['weight']], torch.rsqrt(flat[ix['running_var']] + 1e-5), out=self._scale_all)
+        torch.sub(flat[ix['bias']], flat[ix['running_mean']] * self._scale_all, out=self._bias_all)
         self._affine_ready = True
 
     def _w(self, c):
@@ -189,24 +219,44 @@ class DeepLabHipExecutor(object):
             a.view(k + '.bias', a.grad).add_(dlogits.sum(dim=(0, 2, 3)))
         dC = ops.conv_igemm(dl, self.aspp_wT, self.aspp_neg_taps, mode=1, mask_src=x4)
         capture = getattr(self, 'debug_capture', None)
+        # Weight gradients only feed the optimizer, the data-gradient chain never waits for them: they run on a second
+        # HIP stream, one bottleneck behind the chain, and fill the tail / memory-wait gaps of the dgrad launches.
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_wgrad else None
+        keep = []                 # tensors read on the side stream must outlive the python scope that made them
         for bi in range(len(self.blocks) - 1, -1, -1):
             if capture is not None:
                 capture[bi] = dC
             b = self.blocks[bi]
             xin, a1, a2 = saved[bi]
             in_hw = (xin.shape[1], xin.shape[2])
-            self._wgrad(dC, a2, b.c3)
             dU2 = self._dgrad(dC, b.c3, mask=a2)
-            self._wgrad(dU2, a1, b.c2)
             dU1 = self._dgrad(dU2, b.c2, mask=a1)
-            if b.cd is not None:
-                self._wgrad(dC, xin, b.cd)
-                dres = self._dgrad(dC, b.cd, in_hw=in_hw)
+            if side is not None:
+                side.wait_stream(main)
+                keep.append((dC, dU2, dU1))
+                with torch.cuda.stream(side):
+                    self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
             else:
-                dres = dC
-            self._wgrad(dU1, xin, b.c1)
+                self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
+            dres = dC if b.cd is None else self._dgrad(dC, b.cd, in_hw=in_hw)
             dC = self._dgrad(dU1, b.c1, res=dres, mask=None if bi == 0 else xin, in_hw=in_hw)
+        if side is not None:
+            main.wait_stream(side)
+        del keep
         return dC
+
+    def _block_wgrads(self, b, dC, dU2, dU1, xin, a1, a2):
+        self._wgrad(dC, a2, b.c3)
+        self._wgrad(dU2, a1, b.c2)
+        if b.cd is not None:
+            self._wgrad(dC, xin, b.cd)
+        self._wgrad(dU1, xin, b.c1)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.arena.device)
+        return self._side
 
 
 class _BodyFn(torch.autograd.Function):

@@ -132,10 +132,11 @@ class _FusedOptimizer(object):
         check(fn['cms_adam_ema_step' if self.KIND == 'adam' else 'cms_sgd_ema_step'](C.byref(d), stream),
               'cms_{}_ema_step'.format(self.KIND))
         check(fn['cms_increment_counter'](C.c_void_p(self.step_count.data_ptr()), stream), 'cms_increment_counter')
-        for net in (self.module, None if self._ema is None else self._ema.target_net):
-            ex = getattr(net, '_hip_executor', None)
-            if ex is not None:
-                ex.version += 1            # packed backward weights are stale now
+        ex = getattr(self.module, '_hip_executor', None)
+        if ex is not None:
+            ex.weights_changed()           # packed backward weights are stale now
+        if self._ema is not None:
+            self._ema._touch_target()
         if self._ema is not None:
             self._ema._mark_fused_step_done()
 

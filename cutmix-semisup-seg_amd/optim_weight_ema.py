@@ -32,6 +32,7 @@ class EMAWeightOptimizer(object):
                 for tgt_p, src_p in zip(self.target_params, self.source_params):
                     tgt_p[...] = src_p[...]
         self.target_arena.refresh_bf16()
+        self._touch_target()
 
         target_keys = set(target_net.state_dict().keys())
         source_keys = set(source_net.state_dict().keys())
@@ -46,6 +47,12 @@ class EMAWeightOptimizer(object):
         student_optimizer.attach_ema(self)
         self._fused_into = student_optimizer
 
+    def _touch_target(self):
+        # the teacher's weights (and possibly its BN statistics) moved: packed operands of its executor are stale
+        ex = getattr(self.target_net, '_hip_executor', None)
+        if ex is not None:
+            ex.weights_changed(bn_too=True)
+
     def _mark_fused_step_done(self):
         self._fused_pending = True
 
@@ -57,3 +64,4 @@ class EMAWeightOptimizer(object):
         if not self._flat:
             raise RuntimeError('EMAWeightOptimizer: source and target layouts differ')
         ops.ema_flat(self.target_arena.flat, self.source_arena.flat, self.ema_alpha, self.target_arena.bf16)
+        self._touch_target()

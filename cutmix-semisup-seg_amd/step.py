@@ -30,7 +30,8 @@ from . import ops
 
 class StepConfig(object):
     def __init__(self, mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.97, conf_per_pixel=False,
-                 rampup=-1, unsup_batch_ratio=1, invert=True, fuse_batches=True, compute_dtype=torch.bfloat16):
+                 rampup=-1, unsup_batch_ratio=1, invert=True, fuse_batches=True, compute_dtype=torch.bfloat16,
+                 overlap_teacher=True):
         if mask_mode not in ('mix', 'zero', 'cut'):
             raise ValueError('Unknown mask_mode {}'.format(mask_mode))
         self.mix = mask_mode == 'mix'
@@ -38,6 +39,7 @@ class StepConfig(object):
         self.rampup = rampup
         self.unsup_batch_ratio = int(unsup_batch_ratio)
         self.fuse_batches = bool(fuse_batches)
+        self.overlap_teacher = bool(overlap_teacher)
         self.compute_dtype = compute_dtype
         self.cons = ops.ConsistencyConfig(mode='mix' if self.mix else 'cut', loss_fn=cons_loss_fn,
                                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, invert=invert)
@@ -71,6 +73,7 @@ class CutMixMeanTeacherStep(object):
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self._nan_probe = None
         self._nan_event = None
+        self._side = None
 
     # ------------------------------------------------------------------------------------------ helpers
     def _allreduce_grads(self):
@@ -78,6 +81,11 @@ class CutMixMeanTeacherStep(object):
             import torch.distributed as dist
             dist.all_reduce(self.student_optim.arena.grad, op=dist.ReduceOp.SUM, group=self.group)
             self.student_optim.grad_scale = 1.0 / self.world
+
+    def _teacher_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     def nan_detected(self):
         """True if the supervised loss of an EARLIER iteration was NaN (checked without stalling the stream)."""
@@ -124,9 +132,16 @@ class CutMixMeanTeacherStep(object):
                     tea_in.append(ub.x0_tea)
                     if cfg.mix:
                         tea_in.append(ub.x1_tea)
-                with torch.no_grad():
+                # the teacher pass only meets the student at the loss: it runs on its own HIP stream, concurrently
+                # with the student's forward pass (the two fill each other's launch tails and memory stalls)
+                main = torch.cuda.current_stream()
+                side = self._teacher_stream() if cfg.overlap_teacher else main
+                side.wait_stream(main)
+                with torch.cuda.stream(side), torch.no_grad():
                     tea_lo = self.teacher.forward_lowres(torch.cat(tea_in, dim=0) if len(tea_in) > 1 else tea_in[0])
             stu_lo = self.student.forward_lowres(torch.cat(stu_in, dim=0) if len(stu_in) > 1 else stu_in[0])
+            if use_unsup:
+                main.wait_stream(side)
             # dense NCHW scratch for the loss kernels (stu_lo itself may be channels-last strided)
             grad_lo = torch.zeros(stu_lo.shape, dtype=torch.float32, device=stu_lo.device)
             lo_det = stu_lo.detach()
