@@ -84,7 +84,12 @@ def main():
     ap.add_argument('--no_fuse_batches', action='store_true')
     ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')
     ap.add_argument('--no_roofline_events', action='store_true', help='skip the per-launch event brackets')
+    ap.add_argument('--roofline_sample', type=int, default=5,
+                    help='bracket every k-th launch of the conv kernel with events (1 = all; the brackets cost ~3 %% '
+                         'of the step when every launch carries them)')
     args = ap.parse_args()
+    args.roofline_sample = max(1, args.roofline_sample)
+    args.roofline_sample_used = args.roofline_sample
 
     import numpy as np
     import torch
@@ -152,55 +157,59 @@ def main():
     timing_on = [False]
     roof = dict(bound='hbm', peak=HBM_PEAK_GBS, unit='GB/s')
     work_per_launch = []            # algorithmic bytes or FLOPs of every timed launch
+    step_flops = [0.0]              # algorithmic MFMA FLOPs of ALL convolution launches in the timed region
+    launch_no = [0]
     if args.roofline_kernel == 'conv':
         # the dominant kernel of the step: conv_igemm_kernel (csrc/conv.hip) -- every forward and data-gradient
         # convolution of the backbone. Algorithmic FLOPs of a launch = 2 * pixels * Cout * Cin * taps.
         orig_conv = ops.conv_igemm
 
+        def conv_flops(x, w_packed, k):
+            ohw = k.get('out_hw')
+            npix = x.shape[0] * (ohw[0] * ohw[1] if ohw is not None else x.shape[1] * x.shape[2])
+            return 2.0 * npix * w_packed.shape[1] * w_packed.shape[2] * w_packed.shape[0]
+
         def timed_conv(x, w_packed, taps, *a, **k):
             if not timing_on[0]:
+                return orig_conv(x, w_packed, taps, *a, **k)
+            fl = conv_flops(x, w_packed, k)
+            step_flops[0] += fl
+            launch_no[0] += 1
+            if launch_no[0] % args.roofline_sample:
                 return orig_conv(x, w_packed, taps, *a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig_conv(x, w_packed, taps, *a, **k)
             e1.record()
-            ohw = k.get('out_hw')
-            npix = x.shape[0] * (ohw[0] * ohw[1] if ohw is not None else x.shape[1] * x.shape[2])
-            work_per_launch.append(2.0 * npix * w_packed.shape[1] * w_packed.shape[2] * w_packed.shape[0])
+            work_per_launch.append(fl)
             ev_pairs.append((e0, e1))
             return r
+
+        orig_wgrad = ops.conv_wgrad
+
+        def counted_wgrad(du, x, taps, dw, *a, **k):
+            if timing_on[0]:
+                step_flops[0] += 2.0 * du.shape[0] * du.shape[1] * du.shape[2] * du.shape[3] * x.shape[3] * len(taps)
+            return orig_wgrad(du, x, taps, dw, *a, **k)
+        ops.conv_wgrad = counted_wgrad
         ops.conv_igemm = timed_conv
         roof = dict(bound='mfma', peak=MFMA_PEAK_TFLOPS, unit='TFLOP/s')
         kname = 'conv_igemm_kernel (MFMA implicit-GEMM convolution, forward + data-gradient launches of the backbone)'
     elif args.roofline_kernel == 'adam_ema':
-        orig_step = opt.step
+        from cutmix_semisup_seg_amd import _lib
+        orig_launch = _lib.fn['cms_adam_ema_step']          # optim.py launches through this table
 
-        def timed_step():
+        def timed_launch(desc, stream):
             if not timing_on[0]:
-                return orig_step()
+                return orig_launch(desc, stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            from cutmix_semisup_seg_amd import _lib
-            # time only the optimizer kernel: lr upload first, then events around the launch
-            for i, gp in enumerate(opt.param_groups):
-                opt._lrs_host[i] = float(gp['lr'])
-            opt._lrs_dev.copy_(opt._lrs_host, non_blocking=True)
-            d = opt._desc()
-            opt._fill(d)
-            import ctypes as Cc
-            s = Cc.c_void_p(torch.cuda.current_stream().cuda_stream)
             e0.record()
-            _lib.check(_lib.fn['cms_adam_ema_step'](Cc.byref(d), s), 'cms_adam_ema_step')
+            rc = orig_launch(desc, stream)
             e1.record()
-            _lib.check(_lib.fn['cms_increment_counter'](Cc.c_void_p(opt.step_count.data_ptr()), s))
-            for net in (opt.module, None if opt._ema is None else opt._ema.target_net):
-                ex = getattr(net, '_hip_executor', None)
-                if ex is not None:
-                    ex.version += 1
-            if opt._ema is not None:
-                opt._ema._mark_fused_step_done()
             ev_pairs.append((e0, e1))
             work_per_launch.append(opt.arena.total * 40.0)   # 5 fp32 reads + 4 fp32 writes + 2 bf16 copies
-        opt.step = timed_step
+            return rc
+        _lib.fn['cms_adam_ema_step'] = timed_launch
         kname = 'optim_ema_kernel<ADAM> (fused Adam + teacher EMA over the 44.2M-element arena)'
     else:
         orig_fwd = ops.consistency_forward
@@ -250,6 +259,29 @@ def main():
     if not np.isfinite(last['sup_loss']):
         raise SystemExit('non-finite loss in the bench loop: {}'.format(last))
 
+    # Outside the timed region: the same kernel with the GPU to itself (single stream, every launch bracketed). In
+    # the timed region the teacher pass and the weight gradients run concurrently on other streams, so a launch's
+    # event-to-event time there includes the share of the machine the co-running kernels took.
+    isolated = None
+    timed_pairs, timed_work, timed_flops = list(ev_pairs), list(work_per_launch), step_flops[0]
+    if world == 1 and args.roofline_kernel == 'conv' and not args.no_overlap and not args.no_roofline_events \
+            and dtype == torch.bfloat16:
+        del ev_pairs[:], work_per_launch[:]
+        cfg.overlap_teacher = False
+        stu.hip_executor().overlap_wgrad = False
+        args.roofline_sample = 1
+        timing_on[0] = True
+        for i in range(3):
+            one_step(i)
+        torch.cuda.synchronize()
+        timing_on[0] = False
+        ms_iso = [a.elapsed_time(b) for a, b in ev_pairs]
+        ach = sum(work_per_launch) / (sum(ms_iso) * 1e-3) / 1e12
+        isolated = {'achieved': ach, 'frac': ach / roof['peak'], 'avg_launch_ms': float(np.mean(ms_iso)),
+                    'launches_timed': len(ms_iso), 'note': 'same kernel, single stream, 3 extra steps after the '
+                    'timed region (not part of `value`)'}
+    ev_pairs, work_per_launch = timed_pairs, timed_work
+
     if rank == 0:
         ms_all = [a.elapsed_time(b) for a, b in ev_pairs]
         ms_kernel = float(np.mean(ms_all)) if ms_all else float('nan')
@@ -280,8 +312,17 @@ def main():
                          'unit': roof['unit'], 'frac': achieved / roof['peak'], 'traffic': None,
                          'avg_launch_ms': ms_kernel,
                          'algorithmic_{}_per_launch'.format('flops' if roof['bound'] == 'mfma' else 'bytes'): per_launch,
-                         'launches_timed': len(ev_pairs)},
+                         'launches_timed': len(ev_pairs),
+                         'sampling': 'every launch' if args.roofline_sample_used == 1 else
+                                     'every {}th launch'.format(args.roofline_sample_used)},
         }
+        if isolated is not None:
+            out['roofline']['isolated'] = isolated
+        if timed_flops > 0:
+            # all MFMA work of the step (forward, data-gradient AND weight-gradient convolutions) over the step time
+            out['roofline']['step_mfma'] = {
+                'tflop_per_step': timed_flops / args.steps / 1e12,
+                'achieved': timed_flops / elapsed / 1e12, 'frac': timed_flops / elapsed / 1e12 / MFMA_PEAK_TFLOPS}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl)
         print(json.dumps(out))

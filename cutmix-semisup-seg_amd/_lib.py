@@ -74,6 +74,11 @@ class WgradDesc(C.Structure):
                 ('stride', c_int), ('ksplit', c_int)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('scale', c_void_p),
+                ('ntaps', c_int), ('cout', c_int), ('cin', c_int), ('first_block', c_int)]
+
+
 _P = C.POINTER
 
 
@@ -116,6 +121,7 @@ PROTOTYPES = {
     'cms_conv_igemm': (c_int, [_P(ConvDesc), c_void_p]),
     'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'cms_conv_pack_transpose_batch': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
 fn = {}

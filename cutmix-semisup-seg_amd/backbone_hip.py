@@ -79,6 +79,8 @@ class DeepLabHipExecutor(object):
         self._affine_ready = False
         self._bn_idx = None
         self._side = None
+        self._pack_plan = None
+        self.grad_hook = None      # callable(block_index): weight gradients of that bottleneck are enqueued
         self.overlap_wgrad = True
         self._wT_version = -1
         self.version = 0          # bumped whenever the weights change (optimizer step / load_state_dict)
@@ -98,6 +100,17 @@ class DeepLabHipExecutor(object):
         self.version += 1
         if bn_too:
             self._affine_ready = False
+
+    def block_grad_offsets(self):
+        """Arena offset of the first tensor of every bottleneck (state_dict order: conv1.weight comes first)."""
+        return [self.arena.by_key[b.c1.wkey].offset for b in self.blocks]
+
+    def layer_first_blocks(self):
+        out, n = [], 0
+        for li in range(1, 5):
+            out.append(n)
+            n += len(getattr(self.net, 'layer{}'.format(li)))
+        return out
 
     def _all_convs(self):
         for b in self.blocks:
@@ -147,9 +160,18 @@ class DeepLabHipExecutor(object):
         self.aspp_bias[:C] = a.view(self.aspp_keys[0] + '.bias') + a.view(self.aspp_keys[1] + '.bias')
 
     def _refresh_backward_weights(self):
-        for c in self._all_convs():
-            c.wT = ops.conv_pack_transpose(self._w(c), scale=c.scale, flip=False, out=c.wT)
-        ops.conv_pack_transpose(self.aspp_w, flip=False, out=self.aspp_wT)
+        """dgrad operands wT[tap][ci][co] = bf16(w * scale[co]) of all 104 convolutions + the head: one launch."""
+        if not self._affine_ready:
+            self._refresh_affine()
+        if self._pack_plan is None:
+            triples = []
+            for c in self._all_convs():
+                w = self._w(c)
+                c.wT = torch.empty((w.shape[0], w.shape[2], w.shape[1]), dtype=torch.bfloat16, device=w.device)
+                triples.append((w, c.wT, c.scale))
+            triples.append((self.aspp_w, self.aspp_wT, None))
+            self._pack_plan = ops.PackTransposePlan(triples)
+        self._pack_plan.run()
 
     # ------------------------------------------------------------------------------------------ forward
     @staticmethod
@@ -237,8 +259,12 @@ class DeepLabHipExecutor(object):
                 keep.append((dC, dU2, dU1))
                 with torch.cuda.stream(side):
                     self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
+                    if self.grad_hook is not None:
+                        self.grad_hook(bi)
             else:
                 self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
+                if self.grad_hook is not None:
+                    self.grad_hook(bi)
             dres = dC if b.cd is None else self._dgrad(dC, b.cd, in_hw=in_hw)
             dC = self._dgrad(dU1, b.c1, res=dres, mask=None if bi == 0 else xin, in_hw=in_hw)
         if side is not None:

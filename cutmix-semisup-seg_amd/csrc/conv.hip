@@ -93,8 +93,11 @@ struct RowInfo {            // one per pixel row of the workgroup tile, computed
 // registers, no ds_write); the XOR swizzle is applied on the SOURCE side (the LDS image of a wave instruction is
 // lane-linear), out-of-range rows read a zero page. One LDS buffer per workgroup, up to 4 workgroups per CU: the
 // load latency of a workgroup is covered by the MFMA phases of its neighbours.
-template <int WN, int WM, int TN, int TM, bool GLDS>
-__global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4) ? 4 : 1) void conv_igemm_kernel(ConvArgs a) {
+template <int WN, int WM, int TN, int TM, bool GLDS, int NS>
+__global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4) ? (NS == 1 ? 4 : 2) : 1) void conv_igemm_kernel(ConvArgs a) {
+    // NS = LDS stages of the direct-to-LDS loader. 1: load -> barrier -> MFMA -> barrier; memory and MFMA phases only
+    // overlap ACROSS the (up to 4) workgroups of a CU. 2: the loads of K-step k+1 are in flight during the MFMAs of
+    // step k inside one workgroup -- what the DeepLab shapes need, whose grids are only ~2 workgroups per CU.
     constexpr int NW = WN * WM;         // waves per workgroup (4 or 8)
     constexpr int NT = 64 * NW;
     constexpr int BN = WN * TN * 32;    // output channels per workgroup
@@ -107,9 +110,10 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     constexpr int EPI_LD = BN * 2 + 16;                   // epilogue tile row pitch (bytes): +16 B breaks bank aliasing
     constexpr int STAGE_BYTES = (BM + BN) * CONV_ROW_BYTES;
     constexpr int EPI_BYTES = BM * EPI_LD;
-    constexpr int UNION_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-    unsigned char* lds_x = smem;                          // [BM][128 B]
-    unsigned char* lds_w = smem + BM * CONV_ROW_BYTES;    // [BN][128 B]
+    static_assert(NS == 1 || (NS == 2 && GLDS), "two stages only with the direct-to-LDS loader");
+    constexpr int UNION_BYTES = NS * STAGE_BYTES > EPI_BYTES ? NS * STAGE_BYTES : EPI_BYTES;
+    unsigned char* lds_x = smem;                          // [NS][BM][128 B]   (stage s at + s * STAGE_BYTES)
+    unsigned char* lds_w = smem + BM * CONV_ROW_BYTES;    // [NS][BN][128 B]
     unsigned char* lds_epi = smem;                        // [BM][EPI_LD] bf16 output tile (reuses the staging area)
     short* lds_tap = reinterpret_cast<short*>(smem + UNION_BYTES);                       // [2][CMS_CONV_MAX_TAPS]
     RowInfo* lds_row = reinterpret_cast<RowInfo*>(smem + UNION_BYTES + 80);              // [BM]
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     const int ksteps = tap_end * kc_per_tap;        // exclusive end of this workgroup's K range
 
     u32x4 rx[GLDS ? 1 : PA], rw[GLDS ? 1 : PB];
-    auto load_tile = [&](int ks) {
+    auto load_tile = [&](int ks, int buf) {
         const int tap = ks / kc_per_tap;                                  // wave-uniform
         const int c0 = (ks - tap * kc_per_tap) * CONV_BK;
         const int dy = __builtin_amdgcn_readfirstlane((int)lds_tap[tap]);
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
             if constexpr (GLDS) {
                 const uint16_t* src = select_ptr(ok, a.x + (size_t)(xoff[i] + (uint32_t)delta), a.zeros + (lane & 7) * 8);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(lds_x + (NW * i + wave) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(lds_x + buf * STAGE_BYTES + (NW * i + wave) * 1024),
                                                  16, 0, 0);
             } else {
                 if (ok) rx[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(xoff[i] + (uint32_t)delta));
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
         for (int i = 0; i < PB; ++i) {
             if constexpr (GLDS) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + woff[i]),
-                                                 (__attribute__((address_space(3))) void*)(lds_w + (NW * i + wave) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(lds_w + buf * STAGE_BYTES + (NW * i + wave) * 1024),
                                                  16, 0, 0);
             } else {
                 rw[i] = *reinterpret_cast<const u32x4*>(wt + woff[i]);
@@ -249,11 +253,11 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     const unsigned char* fw_base = lds_w + wn * TN * 32 * CONV_ROW_BYTES;
     const unsigned char* fx_base = lds_x + wm * TM * 32 * CONV_ROW_BYTES;
 
-    auto mfma_phase = [&]() {
+    auto mfma_phase = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < CONV_BK / 16; ++kk) {
             u32x4 fw[TN], fx[TM];     // (arrays of __bf16 vectors are not promoted to registers by the compiler)
-            const uint32_t fo = lane_frag ^ (uint32_t)(kk * 32);
+            const uint32_t fo = (lane_frag ^ (uint32_t)(kk * 32)) + (uint32_t)(buf * STAGE_BYTES);
 #pragma unroll
             for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const u32x4*>(fw_base + fo + i * 32 * CONV_ROW_BYTES);
 #pragma unroll
@@ -266,22 +270,32 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
                                                                         __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
         }
     };
-    if (ks_begin < ksteps) load_tile(ks_begin);
-    if constexpr (GLDS) {
+    if (ks_begin < ksteps) load_tile(ks_begin, 0);
+    if constexpr (GLDS && NS == 2) {
+        int buf = 0;
+        for (int ks = ks_begin; ks < ksteps; ++ks, buf ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of stage `buf` has landed in LDS
+            __syncthreads();                                    // ... everybody else's too, and all fragment reads of
+                                                                // the previous step (the other buffer) are done
+            if (ks + 1 < ksteps && a.dbg != 3) load_tile(ks + 1, buf ^ 1);      // in flight during the MFMAs below
+            if (a.dbg != 2) mfma_phase(buf);
+        }
+        __syncthreads();                                        // the epilogue reuses the staging area
+    } else if constexpr (GLDS) {
         for (int ks = ks_begin; ks < ksteps; ++ks) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the stage has landed in LDS
             __syncthreads();                                    // ... and everybody else's
-            if (a.dbg != 2) mfma_phase();
+            if (a.dbg != 2) mfma_phase(0);
             __syncthreads();                                    // all fragment reads done: the buffer may be refilled
-            if (ks + 1 < ksteps && a.dbg != 3) load_tile(ks + 1);
+            if (ks + 1 < ksteps && a.dbg != 3) load_tile(ks + 1, 0);
         }
     } else {
         for (int ks = ks_begin; ks < ksteps; ++ks) {
             __syncthreads();            // previous stage's fragment reads are done
             store_tile();
             __syncthreads();
-            load_tile(ks + 1 < ksteps ? ks + 1 : ks);   // in flight during the MFMA phase (last one: harmless re-load)
-            mfma_phase();
+            load_tile(ks + 1 < ksteps ? ks + 1 : ks, 0);   // in flight during the MFMA phase (last one: harmless re-load)
+            mfma_phase(0);
         }
     }
 
@@ -407,6 +421,48 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const T* __restrict
     }
 }
 
+
+// The same transpose for MANY weight tensors in one launch (the backward pass re-packs all 104 convolutions after
+// every optimizer step): block -> item by binary search over the first_block column of a device-resident table.
+__global__ __launch_bounds__(256) void pack_transpose_batch_kernel(const cms_pack_item* __restrict__ items, int n_items,
+                                                                   int src_is_f32) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n_items - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                                   // last item with first_block <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const cms_pack_item it = items[lo];
+    const int Cout = it.cout, Cin = it.cin;
+    const int nbx = (Cin + 31) / 32, nby = (Cout + 31) / 32;
+    int r0 = b - it.first_block;
+    const int bx = r0 % nbx; r0 /= nbx;
+    const int by = r0 % nby;
+    const int tap = r0 / nby;
+    const int co0 = by * 32, ci0 = bx * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t base = (size_t)tap * Cout * Cin;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        float v = 0.0f;
+        if (co < Cout && ci < Cin) {
+            const size_t e = base + (size_t)co * Cin + ci;
+            v = src_is_f32 ? ((const float*)it.src)[e] : bf16_to_f32(((const uint16_t*)it.src)[e]);
+            if (it.scale) v *= it.scale[co];
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    uint16_t* d = (uint16_t*)it.dst + base;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Cin && co < Cout) d[(size_t)ci * Cout + co] = f32_to_bf16(tile[tx][r]);
+    }
+}
+
 }  // namespace cms
 
 using namespace cms;
@@ -428,14 +484,26 @@ static int conv_check(const cms_conv_desc* d) {
 }
 
 template <int WN, int WM, int TN, int TM>
-static void conv_launch(const ConvArgs& a, hipStream_t s, bool glds) {
+static void conv_launch(const ConvArgs& a, hipStream_t s, int loader) {      // loader: 0 registers, 1 / 2 = glds stages
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
     const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM) * a.ksplit;
-    const size_t stage = (size_t)(BN + BM) * CONV_ROW_BYTES, epi = (size_t)BM * (BN * 2 + 16);
+    const size_t stage = (size_t)(BN + BM) * CONV_ROW_BYTES * (loader == 2 ? 2 : 1), epi = (size_t)BM * (BN * 2 + 16);
     const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16;
     constexpr int NT = 64 * WN * WM;
-    if (glds) hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true>), dim3(grid), dim3(NT), lds, s, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, false>), dim3(grid), dim3(NT), lds, s, a);
+    if (loader == 2) {
+        // two stages of the 128 x 128 tile need 66 KB of dynamic LDS: above the 64 KB a kernel gets without asking
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<WN, WM, TN, TM, true, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+        hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 2>), dim3(grid), dim3(NT), lds, s, a);
+    } else if (loader == 1) {
+        hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 1>), dim3(grid), dim3(NT), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, false, 1>), dim3(grid), dim3(NT), lds, s, a);
+    }
 }
 
 extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
@@ -460,8 +528,12 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     a.zeros = (const uint16_t*)d->zeros;
-    a.dbg = d->variant >= 2 ? d->variant : 0;
-    const bool glds = d->zeros != nullptr && d->variant != 1;     // variant 1 forces the register-staged loader
+    a.dbg = (d->variant == 2 || d->variant == 3) ? d->variant : 0;
+    // variant 0: direct-to-LDS, one stage, up to 4 workgroups per CU (default); 1: register-staged loader;
+    // 4: direct-to-LDS, two stages, 2 workgroups per CU -- measured 10 % faster on grids of exactly <= 2 workgroups per
+    // CU, 20 % slower on everything else (tools/tail_probe.py): co-resident workgroups hide more than the second stage;
+    // 2 / 3: ablation switches of the default kernel (no MFMA / no loads after the first stage)
+    const int glds = (d->zeros == nullptr || d->variant == 1) ? 0 : (d->variant == 4 ? 2 : 1);
     const int tile = d->tile;   // 0 = auto
     if (tile == 256) {                         // 8 waves: 128 co x 256 pixels (more reuse of the weight tile)
         CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 256 needs Cout %% 128 == 0");
@@ -497,6 +569,15 @@ extern "C" int cms_conv_pack_transpose(const void* src, int src_dtype, void* dst
         hipLaunchKernelGGL(pack_transpose_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)src,
                            (uint16_t*)dst_bf16, scale, ntaps, cout, cin, flip);
     return launch_status("cms_conv_pack_transpose");
+}
+
+extern "C" int cms_conv_pack_transpose_batch(const cms_pack_item* items_dev, int n_items, int total_blocks,
+                                             int src_dtype, void* stream) {
+    CMS_REQUIRE(items_dev && n_items > 0 && total_blocks > 0, "conv_pack_transpose_batch: empty table");
+    CMS_REQUIRE(src_dtype == CMS_F32 || src_dtype == CMS_BF16, "conv_pack_transpose_batch: bad dtype");
+    hipLaunchKernelGGL(pack_transpose_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev,
+                       n_items, src_dtype == CMS_F32 ? 1 : 0);
+    return launch_status("cms_conv_pack_transpose_batch");
 }
 
 // =================================================================================================================

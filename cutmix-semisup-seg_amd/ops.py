@@ -453,6 +453,35 @@ def conv_pack_transpose(w_packed, scale=None, flip=True, out=None):
     return out
 
 
+class PackTransposePlan(object):
+    """Device-resident item table for cms_conv_pack_transpose_batch: (src (ntaps,Cout,Cin), dst, scale) triples with
+    fixed addresses, re-packed in ONE launch (`run()`)."""
+
+    def __init__(self, triples):
+        items = (_lib.PackItem * len(triples))()
+        blk = 0
+        self._keep = triples
+        dt = triples[0][0].dtype
+        for i, (src, dst, scale) in enumerate(triples):
+            _need_cuda(src, dst, scale)
+            ntaps, cout, cin = (int(v) for v in src.shape)
+            if src.dtype != dt or not src.is_contiguous() or not dst.is_contiguous() \
+                    or tuple(dst.shape) != (ntaps, cin, cout) or dst.dtype != torch.bfloat16:
+                raise TypeError('PackTransposePlan: contiguous (ntaps,Cout,Cin) sources of one dtype, bf16 '
+                                '(ntaps,Cin,Cout) destinations')
+            items[i].src, items[i].dst = src.data_ptr(), dst.data_ptr()
+            items[i].scale = scale.data_ptr() if scale is not None else None
+            items[i].ntaps, items[i].cout, items[i].cin, items[i].first_block = ntaps, cout, cin, blk
+            blk += ntaps * ((cout + 31) // 32) * ((cin + 31) // 32)
+        self.n_items, self.total_blocks = len(triples), blk
+        self.dtype_code = _dtype_code(triples[0][0])
+        self.table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(triples[0][0].device)
+
+    def run(self):
+        check(fn['cms_conv_pack_transpose_batch'](_ptr(self.table), self.n_items, self.total_blocks, self.dtype_code,
+                                                  _stream()), 'cms_conv_pack_transpose_batch')
+
+
 def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0):
     """
     dw (fp32 (ntaps, Cout, Cin), accumulated into) += scale[co] * sum_pixels du[pix][co] * x[pix + tap][ci].

@@ -31,7 +31,7 @@ from . import ops
 class StepConfig(object):
     def __init__(self, mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.97, conf_per_pixel=False,
                  rampup=-1, unsup_batch_ratio=1, invert=True, fuse_batches=True, compute_dtype=torch.bfloat16,
-                 overlap_teacher=True):
+                 overlap_teacher=True, bucketed_allreduce=True):
         if mask_mode not in ('mix', 'zero', 'cut'):
             raise ValueError('Unknown mask_mode {}'.format(mask_mode))
         self.mix = mask_mode == 'mix'
@@ -40,6 +40,7 @@ class StepConfig(object):
         self.unsup_batch_ratio = int(unsup_batch_ratio)
         self.fuse_batches = bool(fuse_batches)
         self.overlap_teacher = bool(overlap_teacher)
+        self.bucketed_allreduce = bool(bucketed_allreduce)
         self.compute_dtype = compute_dtype
         self.cons = ops.ConsistencyConfig(mode='mix' if self.mix else 'cut', loss_fn=cons_loss_fn,
                                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, invert=invert)
@@ -59,6 +60,51 @@ class UnsupBatch(object):
         self.ranges = ranges
 
 
+class GradBuckets(object):
+    """
+    Bucketed gradient all-reduce overlapped with the backward pass (SURVEY.md 8(e), row "gradients").
+
+    The flat gradient arena is laid out in state_dict order (stem, layer1 .. layer4, head) and the backward pass
+    finishes it from the END towards the start, one bottleneck at a time. `on_block(bi)` is called by the executor
+    right after the weight gradients of bottleneck `bi` were enqueued (on the stream they run on); when `bi` opens a
+    bucket, the finished slice [offset(bi), previous bucket start) is all-reduced asynchronously -- RCCL then works
+    on its own stream while the data-gradient chain continues. `finish()` reduces what is left (the stem, whose
+    gradient comes last) and makes the current stream wait for all of it. Every element is reduced exactly once.
+    """
+
+    def __init__(self, grad, block_offsets, bucket_starts, group=None):
+        self.grad = grad
+        self.block_offsets = list(block_offsets)
+        self.starts = set(int(b) for b in bucket_starts)
+        self.group = group
+        self.hi = int(grad.numel())
+        self.works = []
+
+    def begin(self):
+        self.hi = int(self.grad.numel())
+        self.works = []
+
+    def on_block(self, bi):
+        if bi not in self.starts:
+            return
+        import torch.distributed as dist
+        lo = int(self.block_offsets[bi])
+        if lo < self.hi:
+            self.works.append(dist.all_reduce(self.grad[lo:self.hi], op=dist.ReduceOp.SUM, group=self.group,
+                                              async_op=True))
+            self.hi = lo
+
+    def finish(self):
+        import torch.distributed as dist
+        if self.hi > 0:
+            self.works.append(dist.all_reduce(self.grad[0:self.hi], op=dist.ReduceOp.SUM, group=self.group,
+                                              async_op=True))
+            self.hi = 0
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
 class CutMixMeanTeacherStep(object):
     def __init__(self, student_net, teacher_net, student_optim, teacher_optim, cfg, group=None):
         self.student = student_net
@@ -74,13 +120,38 @@ class CutMixMeanTeacherStep(object):
         self._nan_probe = None
         self._nan_event = None
         self._side = None
+        self._buckets = None
+        self._bucket_obj = None
 
     # ------------------------------------------------------------------------------------------ helpers
     def _allreduce_grads(self):
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.student_optim.arena.grad, op=dist.ReduceOp.SUM, group=self.group)
+            if self._buckets is not None:
+                self._buckets.finish()
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(self.student_optim.arena.grad, op=dist.ReduceOp.SUM, group=self.group)
             self.student_optim.grad_scale = 1.0 / self.world
+
+    def _arm_buckets(self):
+        """Overlap the gradient all-reduce with the (single) backward pass of the fused-batch step on the executor."""
+        self._buckets = None
+        if self.world <= 1 or not self.cfg.fuse_batches or not self.cfg.bucketed_allreduce:
+            return None
+        use_hip = getattr(self.student, '_use_hip_body', None)
+        if use_hip is None or not use_hip():
+            return None
+        ex = self.student.hip_executor()
+        if self._bucket_obj is None:
+            offs = ex.block_grad_offsets()
+            firsts = ex.layer_first_blocks()                 # block index of layerK.0 for K = 1..4
+            l3, l4 = firsts[2], firsts[3]
+            starts = sorted(set([0, l3, (l3 + l4 + 1) // 2, l4]))
+            self._bucket_obj = GradBuckets(self.student_optim.arena.grad, offs, starts, group=self.group)
+        self._buckets = self._bucket_obj
+        self._buckets.begin()
+        ex.grad_hook = self._buckets.on_block
+        return ex
 
     def _teacher_stream(self):
         if self._side is None:
@@ -161,7 +232,12 @@ class CutMixMeanTeacherStep(object):
                     ops.consistency_backward(cctx, sc, grad_lo[s_off:s_off + n])
                     s_off += n
                     cons_vals.append(sc)
-            stu_lo.backward(grad_lo.to(stu_lo.dtype))
+            ex = self._arm_buckets()
+            try:
+                stu_lo.backward(grad_lo.to(stu_lo.dtype))
+            finally:
+                if ex is not None:
+                    ex.grad_hook = None
         else:
             # reference order, separate passes (batch-statistics BN)
             lo = self.student.forward_lowres(sup_x)

@@ -244,7 +244,8 @@ typedef struct cms_conv_desc {
                               be zero-filled: partial sums are accumulated with atomics; bias added once)        */
     const void* zeros;     /* >= 128 bytes of zeros in device memory: enables the direct-to-LDS loader (padded and
                               out-of-range rows are fetched from it); NULL = register-staged loader              */
-    int variant;           /* 0 = auto, 1 = force the register-staged loader                                     */
+    int variant;           /* 0 = auto (direct-to-LDS, 1 stage), 1 = register-staged loader, 4 = direct-to-LDS with
+                              two stages; 2 / 3 = ablation switches (no MFMA / no loads), tools/conv_ablate.py      */
 } cms_conv_desc;
 
 int cms_conv_igemm(const cms_conv_desc* d, void* stream);
@@ -253,6 +254,20 @@ int cms_conv_igemm(const cms_conv_desc* d, void* stream);
  * the dgrad pass (which is cms_conv_igemm on the transposed, tap-flipped, BN-scale-folded weights). */
 int cms_conv_pack_transpose(const void* src, int src_dtype, void* dst_bf16, const float* scale, int ntaps, int cout,
                             int cin, int flip, void* stream);
+
+/* The same for many weight tensors in ONE launch. `items_dev` is a device-resident table (the library reads it on the
+ * device); item i owns blocks [first_block, first_block + ntaps * ceil(cout/32) * ceil(cin/32)), first_block ascending
+ * from 0; total_blocks = the sum. No tap flip. (backbone_hip.py re-packs all dgrad operands after an optimizer step.) */
+typedef struct cms_pack_item {
+    const void* src;       /* (ntaps, cout, cin) fp32 or bf16 (all items the same dtype)                             */
+    void* dst;             /* (ntaps, cin, cout) bf16                                                                 */
+    const float* scale;    /* per output channel (cout) or NULL                                                       */
+    int ntaps, cout, cin;
+    int first_block;
+} cms_pack_item;
+
+int cms_conv_pack_transpose_batch(const cms_pack_item* items_dev, int n_items, int total_blocks, int src_dtype,
+                                  void* stream);
 
 /* dW[tap][co][ci] (fp32) += scale[co] * sum over pixels of dU[pix][co] * X[pix shifted by tap][ci]; K = pixels,
  * split across workgroups and accumulated with atomics (zero the gradient buffer once per step). */

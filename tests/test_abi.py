@@ -35,12 +35,15 @@ def test_struct_layouts_match_the_c_compiler():
     from cutmix_semisup_seg_amd import _lib
     prog = r'''
 #include <stdio.h>
+#include <stddef.h>
 #include "cutmixseg.h"
 int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(cms_consistency_desc), sizeof(cms_ce_desc), sizeof(cms_param_segment),
          sizeof(cms_optim_desc));
   printf("%zu %zu %zu\n", offsetof(cms_consistency_desc, n), offsetof(cms_consistency_desc, conf_thresh),
          offsetof(cms_optim_desc, grad_scale));
+  printf("%zu %zu %zu %zu %zu\n", sizeof(cms_conv_desc), sizeof(cms_wgrad_desc), sizeof(cms_pack_item),
+         offsetof(cms_conv_desc, zeros), offsetof(cms_wgrad_desc, stride));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -57,6 +60,11 @@ int main(void) {
     assert sizes[4] == _lib.ConsistencyDesc.n.offset
     assert sizes[5] == _lib.ConsistencyDesc.conf_thresh.offset
     assert sizes[6] == _lib.OptimDesc.grad_scale.offset
+    assert sizes[7] == ctypes.sizeof(_lib.ConvDesc)
+    assert sizes[8] == ctypes.sizeof(_lib.WgradDesc)
+    assert sizes[9] == ctypes.sizeof(_lib.PackItem)
+    assert sizes[10] == _lib.ConvDesc.zeros.offset
+    assert sizes[11] == _lib.WgradDesc.stride.offset
 
 
 def test_bad_arguments_come_back_as_error_codes_not_crashes():

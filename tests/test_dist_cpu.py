@@ -138,3 +138,51 @@ def _expected_dp_grad(per_sample_grad):
     L = (1/world) * sum_r L_r, so the averaged gradient is exactly dL/dW = sum over all samples of dL/dlogits_n.
     """
     return per_sample_grad.sum(axis=0)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bucketed gradient all-reduce (step.GradBuckets): every element of the flat arena reduced exactly once, in the order
+# the backward pass finishes the buckets
+def _bucket_worker(rank, world, port, out_q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from cutmix_semisup_seg_amd.step import GradBuckets
+        nblocks = 33
+        sizes = [7 + (i * 13) % 29 for i in range(nblocks)]
+        stem, head = 11, 17
+        offs = list(np.cumsum([stem] + sizes[:-1]))
+        total = stem + sum(sizes) + head
+        g = torch.Generator().manual_seed(100 + rank)
+        grad = torch.randn(total, generator=g)
+        local = grad.clone()
+        gb = GradBuckets(grad, offs, [0, 7, 19, 30])
+        for _ in range(2):                       # two iterations: begin() must re-arm the bookkeeping
+            grad.copy_(local)
+            gb.begin()
+            for bi in range(nblocks - 1, -1, -1):
+                gb.on_block(bi)
+            assert gb.hi == stem and len(gb.works) == 4
+            gb.finish()
+            assert gb.hi == 0 and not gb.works
+        out_q.put((rank, local.numpy(), grad.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_covers_the_arena_once():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = res[0][1] + res[1][1]
+    for _, _, got in res:
+        np.testing.assert_array_equal(got, want)

@@ -71,7 +71,7 @@ def test_conv_forward(ops, case, epi):
     assert float(err.mean()) <= 4e-3 * float(ref.abs().mean() + 1e-6) + 1e-4
 
 
-@pytest.mark.parametrize('variant', [0, 1], ids=['direct_to_lds', 'register_staged'])
+@pytest.mark.parametrize('variant', [0, 1, 4], ids=['direct_to_lds', 'register_staged', 'direct_to_lds_2stage'])
 @pytest.mark.parametrize('tile', [0, 128, 1128, 256, 64, 32])
 def test_conv_tile_variants_agree(ops, tile, variant):
     g = torch.Generator(device=DEV).manual_seed(5)

@@ -36,7 +36,8 @@ for name, cin, cout, k, dil in (('3x3d2 256->256', 256, 256, 3, 2), ('1x1 1024->
         taps = ops.conv_taps(k, k, dil, pad)
         out = torch.empty(n, h, w, cout, dtype=torch.bfloat16, device=DEV)
         t = timeit(lambda: ops.conv_igemm(x, wp, taps, scale=scale, bias=bias, relu=True, out=out))
+        t1 = timeit(lambda: ops.conv_igemm(x, wp, taps, scale=scale, bias=bias, relu=True, out=out, variant=4))
         pix = n * h * w
         wgs = ((pix + 127) // 128) * (cout // 128)
-        print('{:<18s} {:5d} {:5d} {:7d} {:6d} {:8.1f} {:8.1f} {:9.1f}'.format(
-            name, h, w, pix, wgs, t, 2.0 * pix * cin * cout * k * k / t / 1e6, t / pix * 1e6))
+        print('{:<18s} {:5d} {:5d} {:7d} {:6d} {:8.1f} {:8.1f} {:9.1f}   2-stage {:8.1f}'.format(
+            name, h, w, pix, wgs, t, 2.0 * pix * cin * cout * k * k / t / 1e6, t / pix * 1e6, t1))
