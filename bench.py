@@ -33,6 +33,9 @@ MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP
 WORKLOADS = {
     'pascal': dict(name='deeplab2-resnet101 cutmix mean-teacher step, 10x3x321x321, 21 classes (BASELINE configs[1])',
                    batch=10, H=321, W=321, classes=21, paired=False),
+    'pascal_v3plus': dict(name='deeplab3plus-resnet101 cutmix mean-teacher step, 10x3x513x513, 21 classes '
+                               '(BASELINE configs[3]); library convolutions, batch-statistics head => separate passes',
+                          batch=10, H=513, W=513, classes=21, paired=False, arch='resnet101_deeplabv3plus_imagenet'),
     'cityscapes': dict(name='deeplab2-resnet101 cutmix mean-teacher step, 4x3x512x1024 per GPU, 19 classes, '
                             'paired colour-aug layout (BASELINE configs[2])',
                        batch=4, H=512, W=1024, classes=19, paired=True),
@@ -51,23 +54,32 @@ def cpu_baseline(workload, seconds_budget=30.0):
     C, H, W = workload['classes'], workload['H'], workload['W']
     N = 2 if H * W <= 321 * 321 else 1
     g = torch.Generator().manual_seed(0)
-    st = odl.closed_form_state(C)
-    S = ostep.StepState(st, C, opt='adam', lr=3e-5)
     x = torch.randn(N, 3, H, W, generator=g)
     y = torch.randint(0, C, (N, 1, H, W), generator=g)
     ux0, ux1 = torch.randn(N, 3, H, W, generator=g), torch.randn(N, 3, H, W, generator=g)
     ones = torch.ones(N, 1, H, W)
     m = torch.tensor(obox.generate_params(N, (H, W), 0.5, invert=True, rng=np.random.RandomState(0)).astype(np.float32))
-    ostep.train_iteration(S, x, y, ux0, ux1, ones, ones, m)          # warm-up
+    if 'v3plus' in workload.get('arch', ''):
+        from oracle import deeplab3plus as o3, step_v3plus as sv
+        N = 2                                   # batch statistics in the head need more than one sample
+        x, y, ux0, ux1, ones, m = (torch.cat([t, t.flip(3)], 0) for t in (x, y, ux0, ux1, ones, m))
+        S = sv.StepStateV3Plus(o3.closed_form_state(C), C, lr=3e-5)
+        run = lambda: sv.train_iteration(S, x, y, ux0, ux1, ones, ones, m)
+        what, min_iters = 'oracle/step_v3plus.py', 1
+    else:
+        S = ostep.StepState(odl.closed_form_state(C), C, opt='adam', lr=3e-5)
+        run = lambda: ostep.train_iteration(S, x, y, ux0, ux1, ones, ones, m)
+        what, min_iters = 'oracle/step.py', 2
+    run()                                                             # warm-up
     times = []
     t_start = time.time()
-    while len(times) < 2 or (time.time() - t_start < seconds_budget * 0.6 and len(times) < 8):
+    while len(times) < min_iters or (time.time() - t_start < seconds_budget * 0.6 and len(times) < 8):
         t0 = time.time()
-        ostep.train_iteration(S, x, y, ux0, ux1, ones, ones, m)
+        run()
         times.append(time.time() - t0)
     t = sum(times) / len(times)
     return dict(value=N / t, unit='images/sec', cores=cores, kind='port',
-                sample='oracle/step.py (PyTorch-CPU fp32 restatement of the reference step), batch {} of {}x{} '
+                sample=what + ' (PyTorch-CPU fp32 restatement of the reference step), batch {} of {}x{} '
                        '(GPU run: batch {}), {} timed iterations after 1 warm-up, {:.2f} s/iter'.format(
                            N, H, W, workload['batch'], len(times), t))
 
@@ -79,7 +91,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='pascal')
     ap.add_argument('--dtype', choices=['bf16', 'fp32'], default='bf16')
-    ap.add_argument('--roofline_kernel', choices=['conv', 'adam_ema', 'consistency'], default='conv')
+    ap.add_argument('--roofline_kernel', choices=['conv', 'adam_ema', 'consistency'], default=None,
+                    help='default: conv (the MFMA convolution) for the DeepLab v2 workloads, adam_ema otherwise')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_fuse_batches', action='store_true')
     ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')
@@ -89,6 +102,8 @@ def main():
                          'of the step when every launch carries them)')
     args = ap.parse_args()
     args.roofline_sample = max(1, args.roofline_sample)
+    if args.roofline_kernel is None:
+        args.roofline_kernel = 'conv' if 'arch' not in WORKLOADS[args.workload] else 'adam_ema'
     args.roofline_sample_used = args.roofline_sample
 
     import numpy as np
@@ -119,7 +134,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
 
     torch.manual_seed(12345)                       # identical replicas on every rank
-    Net = network_architectures.seg.get('resnet101_deeplab_imagenet')
+    Net = network_architectures.seg.get(wl.get('arch', 'resnet101_deeplab_imagenet'))
     stu, tea = Net(C, pretrained=False).to(dev), Net(C, pretrained=False).to(dev)
     stu.compute_dtype = tea.compute_dtype = dtype
     lr = 3e-5                                      # run_pascal_aug_experiments.sh

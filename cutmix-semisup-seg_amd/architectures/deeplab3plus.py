@@ -1,0 +1,270 @@
+"""
+DeepLab v3+ (ResNet-101, output stride 8) with the reference's module tree and state-dict keys
+(architectures/deeplab3plus.py:26-164).
+
+The reference assembles this model from torchvision 0.5.0 parts (`resnet.resnet101(replace_stride_with_dilation=
+[False, True, True])`, `IntermediateLayerGetter`, `segmentation.deeplabv3.ASPP`, deeplab3plus.py:13-15,89-98);
+torchvision is not part of this build, so those parts are restated here from their published structure (parity is
+UNPINNED for this row -- no vectors exist on the reference side; the independent CPU restatement in
+oracle/deeplab3plus.py is the checker):
+
+  backbone   ResNet v1.5 bottlenecks (stride / dilation on the 3x3), layer3 / layer4 dilated instead of strided
+             (first block of a dilated layer keeps the previous dilation), stem max-pool without ceil_mode;
+             taps: layer1 -> 'low_level' (256 ch, 1/4), layer4 -> 'out' (2048 ch, 1/8)
+  head       DeepLabHeadV3Plus (deeplab3plus.py:26-64): project 256->48, ASPP(2048, [12, 24, 36]) incl. the global
+             pooling branch and Dropout(0.5), two 3x3 conv-BN-ReLU, 1x1 -> classes; Kaiming-normal init of every
+             head convolution (:58-64)
+  wrapper    DeepLabv3Wrapper (:104-158): BLOCK_SIZE / MEAN / STD, `freeze_batchnorm()` freezes the BACKBONE only
+             (:120-121), `pretraining=None` => pretrained_parameters() == [] and every parameter trains at the full
+             learning rate (:138-151, factory :162-164)
+
+Execution: bf16 channels-last through the library engine (architectures/deeplab2.py: TorchEngine); the low-resolution
+logits (1/4 of the input) are handed to the fused loss / evaluation kernels, which apply the final bilinear upsample
+(align_corners=False, deeplab3plus.py:77) in-kernel. With batch-statistics BatchNorm and dropout in the head the
+samples of a batch are not independent, so the training step keeps the reference's separate passes
+(step.py: fuse_batches=False). The backbone on the hand-written MFMA convolution kernels is the next step for this
+row.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .util import freeze_bn_module
+from .deeplab2 import TorchEngine, _ENGINES
+
+
+class Bottleneck(nn.Module):
+    """torchvision ResNet v1.5 bottleneck: the 3x3 carries stride and dilation."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+        super(Bottleneck, self).__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=dilation, dilation=dilation,
+                               bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x, eng):
+        out = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        out = eng.conv_bn_act(out, self.conv2, self.bn2, relu=True)
+        res = x if self.downsample is None else eng.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        return eng.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=res)
+
+
+class ResNetTaps(nn.ModuleDict):
+    """ResNet-101 up to layer4 in the child order of IntermediateLayerGetter (keys conv1, bn1, relu, maxpool,
+    layer1..layer4); returns {'low_level': layer1, 'out': layer4} (deeplab3plus.py:96-98)."""
+
+    def __init__(self, layers=(3, 4, 23, 3)):
+        super(ResNetTaps, self).__init__()
+        self.inplanes, self.dilation = 64, 1
+        self['conv1'] = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self['bn1'] = nn.BatchNorm2d(64)
+        self['relu'] = nn.ReLU(inplace=True)
+        self['maxpool'] = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self['layer1'] = self._make_layer(64, layers[0])
+        self['layer2'] = self._make_layer(128, layers[1], stride=2)
+        self['layer3'] = self._make_layer(256, layers[2], stride=2, dilate=True)
+        self['layer4'] = self._make_layer(512, layers[3], stride=2, dilate=True)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride=1, dilate=False):
+        previous_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+        stages = [Bottleneck(self.inplanes, planes, stride, previous_dilation, downsample)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            stages.append(Bottleneck(self.inplanes, planes, dilation=self.dilation))
+        return nn.Sequential(*stages)
+
+    def forward(self, x, eng):
+        x = eng.conv_bn_act(x, self['conv1'], self['bn1'], relu=True)
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        out = {}
+        for name, tap in (('layer1', 'low_level'), ('layer2', None), ('layer3', None), ('layer4', 'out')):
+            for blk in self[name]:
+                x = blk(x, eng)
+            if tap is not None:
+                out[tap] = x
+        return out
+
+
+class ASPP(nn.Module):
+    """torchvision.models.segmentation.deeplabv3.ASPP: keys convs.{0..3}.{0,1}, convs.4.{1,2}, project.{0,1}."""
+
+    def __init__(self, in_channels, atrous_rates, out_channels=256):
+        super(ASPP, self).__init__()
+        mods = [nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, bias=False), nn.BatchNorm2d(out_channels),
+                              nn.ReLU())]
+        for r in atrous_rates:
+            mods.append(nn.Sequential(nn.Conv2d(in_channels, out_channels, 3, padding=r, dilation=r, bias=False),
+                                      nn.BatchNorm2d(out_channels), nn.ReLU()))
+        mods.append(nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(in_channels, out_channels, 1, bias=False),
+                                  nn.BatchNorm2d(out_channels), nn.ReLU()))
+        self.convs = nn.ModuleList(mods)
+        self.project = nn.Sequential(nn.Conv2d(len(mods) * out_channels, out_channels, 1, bias=False),
+                                     nn.BatchNorm2d(out_channels), nn.ReLU(), nn.Dropout(0.5))
+
+    def forward(self, x, eng):
+        br = [eng.conv_bn_act(x, m[0], m[1], relu=True) for m in list(self.convs)[:-1]]
+        pool = self.convs[-1]
+        g = x.float().mean(dim=(2, 3), keepdim=True).to(x.dtype)
+        g = eng.conv_bn_act(g, pool[1], pool[2], relu=True)
+        br.append(F.interpolate(g, size=x.shape[2:4], mode='bilinear', align_corners=False))
+        y = eng.conv_bn_act(torch.cat(br, dim=1), self.project[0], self.project[1], relu=True)
+        drop = self.project[3]
+        return F.dropout(y, drop.p, drop.training)
+
+
+class DeepLabHeadV3Plus(nn.Module):
+    def __init__(self, in_channels, low_level_channels, num_classes, aspp_dilate=(12, 24, 36)):
+        super(DeepLabHeadV3Plus, self).__init__()
+        self.project = nn.Sequential(nn.Conv2d(low_level_channels, 48, 1, bias=False), nn.BatchNorm2d(48),
+                                     nn.ReLU(inplace=True))
+        self.aspp = ASPP(in_channels, list(aspp_dilate))
+        self.classifier = nn.Sequential(
+            nn.Conv2d(304, 256, 3, padding=1, bias=False), nn.BatchNorm2d(256), nn.ReLU(inplace=True),
+            nn.Conv2d(256, 256, 3, padding=1, bias=False), nn.BatchNorm2d(256), nn.ReLU(inplace=True),
+            nn.Conv2d(256, num_classes, 1))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, feature, eng):
+        low = eng.conv_bn_act(feature['low_level'], self.project[0], self.project[1], relu=True)
+        out = self.aspp(feature['out'], eng)
+        out = F.interpolate(out, size=low.shape[2:4], mode='bilinear', align_corners=False)
+        y = torch.cat([low, out], dim=1)
+        y = eng.conv_bn_act(y, self.classifier[0], self.classifier[1], relu=True)
+        y = eng.conv_bn_act(y, self.classifier[3], self.classifier[4], relu=True)
+        last = self.classifier[6]
+        y = F.conv2d(y, last.weight.to(y.dtype), None)
+        return y.float() + last.bias.view(1, -1, 1, 1)
+
+
+class DeepLabV3Plus(nn.Module):
+    def __init__(self, backbone, classifier):
+        super(DeepLabV3Plus, self).__init__()
+        self.backbone = backbone
+        self.classifier = classifier
+
+
+class DeepLabv3Wrapper(nn.Module):
+    BLOCK_SIZE = (1, 1)
+    MEAN = np.array([0.485, 0.456, 0.406])
+    STD = np.array([0.229, 0.224, 0.225])
+    upsample_align_corners = False
+
+    def __init__(self, model, pretraining=None):
+        super(DeepLabv3Wrapper, self).__init__()
+        self.deeplab = model
+        self.pretraining = pretraining
+        self.compute_dtype = torch.bfloat16
+        self.engine = None
+
+    # ------------------------------------------------------------------------------------------ execution
+    def _engine(self, x):
+        if self.engine is not None:
+            return self.engine
+        if not x.is_cuda:
+            raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
+                               'fallback'.format(x.device))
+        key = ('torch', self.compute_dtype)
+        if key not in _ENGINES:
+            _ENGINES[key] = TorchEngine(self.compute_dtype)
+        return _ENGINES[key]
+
+    def forward_lowres(self, x):
+        """(N,3,H,W) -> fp32 (N,C,h,w) logits at the low-level feature size (the reference's tensor just before its
+        final interpolate, deeplab3plus.py:76)."""
+        eng = self._engine(x)
+        feats = self.deeplab.backbone(eng.prepare_input(x), eng)
+        return self.deeplab.classifier(feats, eng)
+
+    def forward(self, x, feature_maps=False, use_dropout=False):
+        lo = self.forward_lowres(x)
+        if lo.is_cuda:
+            return ops.upsample_bilinear(lo, x.shape[2:4], align_corners=False)
+        return F.interpolate(lo, size=x.shape[2:4], mode='bilinear', align_corners=False)
+
+    def samples_are_independent(self):
+        """True when no layer couples the samples of a batch (all BatchNorms frozen, dropout inactive): only then may
+        the training step concatenate batches (step.py). Never the case in the reference's training configuration:
+        the head's BatchNorms use batch statistics (freeze_batchnorm() covers the backbone only)."""
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d) and m.training:
+                return False
+            if isinstance(m, nn.Dropout) and m.training and m.p > 0:
+                return False
+        return True
+
+    # ------------------------------------------------------------------------------------------ reference API
+    def freeze_batchnorm(self):
+        self.deeplab.backbone.apply(freeze_bn_module)
+
+    def _backbone_parameters(self):
+        return list(self.deeplab.backbone.parameters())
+
+    def _classifier_end_parameters(self):
+        return list(self.deeplab.classifier.classifier[-1].parameters())
+
+    def pretrained_parameters(self):
+        if self.pretraining is None:
+            return []
+        elif self.pretraining == 'imagenet':
+            return self._backbone_parameters()
+        elif self.pretraining == 'coco':
+            new_ids = [id(p) for p in self._classifier_end_parameters()]
+            return [p for p in self.parameters() if id(p) not in new_ids]
+        else:
+            raise ValueError('Unknown pretraining {}'.format(self.pretraining))
+
+    def new_parameters(self):
+        if self.pretraining is None:
+            return list(self.parameters())
+        elif self.pretraining == 'imagenet':
+            backbone_ids = [id(p) for p in self._backbone_parameters()]
+            return [p for p in self.parameters() if id(p) not in backbone_ids]
+        elif self.pretraining == 'coco':
+            return self._classifier_end_parameters()
+        else:
+            raise ValueError('Unknown pretraining {}'.format(self.pretraining))
+
+
+def _deeplabv3plus(num_classes, output_stride=8, layers=(3, 4, 23, 3)):
+    if output_stride != 8:
+        raise NotImplementedError('only output stride 8 is used by the reference (deeplab3plus.py:163)')
+    backbone = ResNetTaps(layers)
+    classifier = DeepLabHeadV3Plus(2048, 256, num_classes, (12, 24, 36))
+    return DeepLabV3Plus(backbone, classifier)
+
+
+def resnet101_deeplabv3plus_imagenet(num_classes, pretrained=True):
+    """deeplab3plus.py:162-164. `pretrained=True` would download torchvision's ImageNet ResNet-101 (no network in this
+    build environment): refuse instead of silently training from scratch."""
+    if pretrained:
+        raise NotImplementedError('pretrained ImageNet weights for the torchvision ResNet-101 cannot be downloaded '
+                                  'here; build with pretrained=False and load a state dict (keys '
+                                  '"deeplab.backbone.*")')
+    return DeepLabv3Wrapper(_deeplabv3plus(num_classes, 8))

@@ -3,8 +3,8 @@ Mirror of the reference's architectures/network_architectures.py: the `seg` arch
 (network_architectures.py:15-41), the factory names registered on it (:44-112), `robust_binary_crossentropy`
 (:115-118) and `sigmoid_rampup` (:122-130).
 
-Factories whose backbones are outside the CutMix mean-teacher hot path (U-Nets, DeepLab v3 from torchvision, PSPNet
-from mit_semseg) stay registered under the reference's names and raise NotImplementedError when called, which is
+Factories whose backbones are outside the CutMix mean-teacher hot path (U-Nets, plain DeepLab v3 from torchvision,
+PSPNet from mit_semseg) stay registered under the reference's names and raise NotImplementedError when called, which is
 what the reference itself does when their dependencies are missing (:77-79, mit_csail_semseg.py:24-25).
 """
 import sys
@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import deeplab2
+from . import deeplab3plus
 
 
 class ArchRegistry(object):
@@ -56,7 +57,6 @@ for _name, _needs in (('resnet50unet_imagenet', 'torchvision ResNet-50 U-Net'),
                       ('densenet161unet_imagenet', 'torchvision DenseNet-161 U-Net'),
                       ('resnet101_deeplabv3_coco', 'torchvision DeepLab v3'),
                       ('resnet101_deeplabv3_imagenet', 'torchvision DeepLab v3'),
-                      ('resnet101_deeplabv3plus_imagenet', 'torchvision ResNet-101 + ASPP (DeepLab v3+)'),
                       ('resnet101_pspnet_imagenet', 'the mit_semseg package')):
     seg.register(_name)(_outside_hot_path(_name, _needs))
 
@@ -74,6 +74,11 @@ def resnet101_deeplab_imagenet(num_classes=21, pretrained=True):
 @seg.register('resnet101_deeplab_imagenet_mittal_std')
 def resnet101_deeplab_imagenet_mittal_std(num_classes=21, pretrained=True):
     return deeplab2.resnet101_deeplab_imagenet_mittal_std(num_classes=num_classes, pretrained=pretrained)
+
+
+@seg.register('resnet101_deeplabv3plus_imagenet')
+def resnet101_deeplabv3plus_imagenet(num_classes=21, pretrained=True):
+    return deeplab3plus.resnet101_deeplabv3plus_imagenet(num_classes=num_classes, pretrained=pretrained)
 
 
 def robust_binary_crossentropy(pred, tgt, eps=1e-6):

@@ -153,6 +153,17 @@ class CutMixMeanTeacherStep(object):
         ex.grad_hook = self._buckets.on_block
         return ex
 
+    def _samples_independent(self):
+        """Batches may only be concatenated when no layer couples the samples of a batch: every BatchNorm frozen and
+        no active dropout, in BOTH networks (DeepLab v3+ keeps batch statistics and dropout in its head even under
+        --freeze_bn, deeplab3plus.py:120-121 -> the reference's separate passes are kept for it)."""
+        for net in (self.student, self.teacher):
+            for m in net.modules():
+                name = type(m).__name__
+                if m.training and ('BatchNorm' in name or ('Dropout' in name and getattr(m, 'p', 0) > 0)):
+                    return False
+        return True
+
     def _teacher_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream()
@@ -194,7 +205,7 @@ class CutMixMeanTeacherStep(object):
         n_sup = sup_x.shape[0]
         ramp = ramp_val if cfg.rampup > 0 else 1.0
 
-        if cfg.fuse_batches:
+        if cfg.fuse_batches and self._samples_independent():
             stu_in = [sup_x]
             tea_in = []
             if use_unsup:

@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+( timeout 900 python -m pytest tests/test_gpu_deeplab3plus.py -m gpu -q -x -p no:cacheprovider --timeout 600 ) > gpurun_out/pytest_v3.log 2>&1; echo "pytest rc=$?"
+tail -25 gpurun_out/pytest_v3.log | cut -c1-250
+( timeout 900 python bench.py --workload pascal_v3plus --steps 6 --warmup 3 --no_cpu_baseline ) > gpurun_out/bench_v3.log 2>&1; echo "bench rc=$?"
+grep '^{"metric"' gpurun_out/bench_v3.log | cut -c1-1500; tail -5 gpurun_out/bench_v3.log | grep -v '^{"metric"' | cut -c1-300
