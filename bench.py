@@ -174,6 +174,7 @@ def main():
     work_per_launch = []            # algorithmic bytes or FLOPs of every timed launch
     step_flops = [0.0]              # algorithmic MFMA FLOPs of ALL convolution launches in the timed region
     launch_no = [0]
+    conv_bytes = [0.0]              # algorithmic HBM bytes of the same launches (operands once, output once)
     if args.roofline_kernel == 'conv':
         # the dominant kernel of the step: conv_igemm_kernel (csrc/conv.hip) -- every forward and data-gradient
         # convolution of the backbone. Algorithmic FLOPs of a launch = 2 * pixels * Cout * Cin * taps.
@@ -189,6 +190,10 @@ def main():
                 return orig_conv(x, w_packed, taps, *a, **k)
             fl = conv_flops(x, w_packed, k)
             step_flops[0] += fl
+            npix_out = fl / (2.0 * w_packed.shape[1] * w_packed.shape[2] * w_packed.shape[0])
+            conv_bytes[0] += 2.0 * (x.numel() + w_packed.numel()) + npix_out * w_packed.shape[1] * (
+                (4.0 if k.get('out_f32_nchw') is not None else 2.0) + (2.0 if k.get('res') is not None else 0.0)
+                + (2.0 if k.get('mask_src') is not None else 0.0))
             launch_no[0] += 1
             if launch_no[0] % args.roofline_sample:
                 return orig_conv(x, w_packed, taps, *a, **k)
@@ -331,6 +336,15 @@ def main():
                          'sampling': 'every launch' if args.roofline_sample_used == 1 else
                                      'every {}th launch'.format(args.roofline_sample_used)},
         }
+        if args.roofline_kernel == 'conv' and launch_no[0]:
+            out['roofline']['algorithmic_bytes_per_launch'] = conv_bytes[0] / launch_no[0]
+            pmc = os.path.join(REPO, 'profiles', 'r01d_pmc_traffic.json')
+            if args.workload == 'pascal' and os.path.exists(pmc):
+                # HBM bytes per launch from the TCC memory-side counters (separate FETCH_SIZE / WRITE_SIZE passes of
+                # this command under rocprofv3, gfx950 correction applied; tools/gpu_pmc_traffic.sh)
+                t = json.load(open(pmc))
+                out['roofline']['traffic'] = t['traffic_bytes_per_launch']
+                out['roofline']['traffic_source'] = 'profiles/r01d_pmc_traffic.json (rocprofv3 --pmc, bytes per launch)'
         if isolated is not None:
             out['roofline']['isolated'] = isolated
         if timed_flops > 0:

@@ -107,14 +107,12 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(BM <= NT && PA >= 1 && PB >= 1, "tile too small for the loader");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int EPI_LD = BN * 2 + 16;                   // epilogue tile row pitch (bytes): +16 B breaks bank aliasing
     constexpr int STAGE_BYTES = (BM + BN) * CONV_ROW_BYTES;
-    constexpr int EPI_BYTES = BM * EPI_LD;
+    constexpr int EPI_BYTES = BM * BN * 2;                // epilogue tile (bf16 output / staged residual or mask)
     static_assert(NS == 1 || (NS == 2 && GLDS), "two stages only with the direct-to-LDS loader");
     constexpr int UNION_BYTES = NS * STAGE_BYTES > EPI_BYTES ? NS * STAGE_BYTES : EPI_BYTES;
     unsigned char* lds_x = smem;                          // [NS][BM][128 B]   (stage s at + s * STAGE_BYTES)
     unsigned char* lds_w = smem + BM * CONV_ROW_BYTES;    // [NS][BN][128 B]
-    unsigned char* lds_epi = smem;                        // [BM][EPI_LD] bf16 output tile (reuses the staging area)
     short* lds_tap = reinterpret_cast<short*>(smem + UNION_BYTES);                       // [2][CMS_CONV_MAX_TAPS]
     RowInfo* lds_row = reinterpret_cast<RowInfo*>(smem + UNION_BYTES + 80);              // [BM]
 
@@ -299,11 +297,61 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
         }
     }
 
-    // ---- epilogue. The accumulator layout gives every lane runs of 4 consecutive channels of one pixel; BN affine,
-    // residual / gradient add, ReLU or ReLU-mask are applied in registers (one rounding to bf16), the bf16 tile is
-    // transposed through LDS and written out with 16 bytes per lane, 256 contiguous bytes per pixel row.
+    // ---- epilogue. The accumulator layout gives every lane runs of 4 consecutive channels of one pixel (8 bytes of
+    // NHWC). BN affine, residual / gradient add, ReLU or ReLU-mask are applied in registers (one rounding to bf16).
+    // Global traffic of the epilogue is row-contiguous on BOTH sides: the bf16 output tile is transposed through LDS
+    // and written with 16 bytes per lane, and the residual / mask tiles are fetched global -> LDS with the
+    // direct-to-LDS loader (16 bytes per lane, whole 256-byte rows) and picked up from there in accumulator layout --
+    // 8-byte global reads per lane in that layout cost +50 % on the 256 -> 1024 convolutions (tools/epi_probe.py).
+    // LDS tile: [BM][BN] bf16, 16-byte chunks XOR-swizzled with the row; the staged operand and the output tile share
+    // the layout, so a lane reads its 8 bytes of residual / mask and writes its 8 bytes of output IN PLACE.
+    constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
+    constexpr int EROW = BN * 2;                // tile row pitch (bytes)
+    constexpr int RPI = 64 / CPR;               // tile rows filled by one wave-wide direct-to-LDS instruction
+    static_assert(BM % (NW * RPI) == 0, "epilogue staging passes");
     const bool to_lds = a.y != nullptr;
-    if (to_lds && !GLDS) __syncthreads();                  // all fragment reads of the last stage are done
+    const bool staged = GLDS && to_lds;         // residual / mask through LDS (needs the zero page for dead rows)
+    if (to_lds && !GLDS) __syncthreads();       // all fragment reads of the last stage are done
+    auto stage_tile = [&](const uint16_t* src) {
+#pragma unroll
+        for (int i = 0; i < BM / (NW * RPI); ++i) {
+            const int row = (NW * i + wave) * RPI + lane / CPR;
+            const int clog = (lane % CPR) ^ (row & (CPR - 1));
+            const uint32_t op = lds_row[row].opix;
+            const uint16_t* p = select_ptr(op != 0xffffffffu, src + (size_t)op * a.Cout + co0 + clog * 8,
+                                           a.zeros + (lane & 7) * 8);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                             (__attribute__((address_space(3))) void*)(smem + (NW * i + wave) * 1024),
+                                             16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    auto slot = [&](int prow_l, int co_l) -> uint32_t {
+        return (uint32_t)(prow_l * EROW + ((((co_l >> 3) ^ prow_l) & (CPR - 1)) << 4) + ((co_l & 4) << 1));
+    };
+    uint64_t mbits = 0;                          // ReLU mask of this lane's elements when BOTH operands are staged
+    const bool both = staged && a.res && a.mask_src;
+    if constexpr (GLDS) {
+        if (both) {
+            stage_tile(a.mask_src);
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint2 mk = *reinterpret_cast<const uint2*>(
+                            smem + slot((wm * TM + j) * 32 + frow, (wn * TN + i) * 32 + 8 * q + 4 * fhalf));
+                        const int bit = ((i * TM + j) * 4 + q) * 4;
+                        uint64_t m4 = ((int16_t)(mk.x & 0xffffu) > 0 ? 1u : 0u) | ((int16_t)(mk.x >> 16) > 0 ? 2u : 0u) |
+                                      ((int16_t)(mk.y & 0xffffu) > 0 ? 4u : 0u) | ((int16_t)(mk.y >> 16) > 0 ? 8u : 0u);
+                        mbits |= m4 << bit;
+                    }
+            __syncthreads();                     // everybody has its bits: the tile may be overwritten
+        }
+        if (staged && (a.res || a.mask_src)) stage_tile(a.res ? a.res : a.mask_src);
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int prow_l = (wm * TM + j) * 32 + frow;
@@ -316,6 +364,7 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
             for (int q = 0; q < 4; ++q) {
                 const int co_l = (wn * TN + i) * 32 + 8 * q + 4 * fhalf;
                 const int co = co0 + co_l;
+                unsigned char* cell = smem + slot(prow_l, co_l);
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
@@ -329,8 +378,9 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     }
                 }
-                if (a.res && valid) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(a.res + obase + co);
+                if (a.res && (staged || valid)) {
+                    const uint2 rr = staged ? *reinterpret_cast<const uint2*>(cell)
+                                            : *reinterpret_cast<const uint2*>(a.res + obase + co);
                     v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
                     v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
                 }
@@ -339,8 +389,13 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
                     }
-                } else if (a.mask_src && valid) {
-                    const uint2 mk = *reinterpret_cast<const uint2*>(a.mask_src + obase + co);
+                } else if (both) {
+                    const int bit = ((i * TM + j) * 4 + q) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ((mbits >> (bit + e)) & 1u) ? v[e] : 0.0f;
+                } else if (a.mask_src && (staged || valid)) {
+                    const uint2 mk = staged ? *reinterpret_cast<const uint2*>(cell)
+                                            : *reinterpret_cast<const uint2*>(a.mask_src + obase + co);
                     // bf16 > 0  <=>  as a signed 16-bit integer it is > 0 (NaNs with the sign bit clear count as > 0,
                     // like the float comparison the reference's ReLU backward makes on NaN-free activations)
                     v[0] = (int16_t)(mk.x & 0xffffu) > 0 ? v[0] : 0.0f;
@@ -352,7 +407,7 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
                     uint2 o;
                     o.x = pack_bf16x2(v[0], v[1]);
                     o.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(lds_epi + prow_l * EPI_LD + co_l * 2) = o;
+                    *reinterpret_cast<uint2*>(cell) = o;
                 }
                 if (a.y32 && valid) {
                     const int m = (int)ri.m;
@@ -374,15 +429,15 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     }
     if (to_lds) {
         __syncthreads();
-        constexpr int CPR = BN / 8;                 // 16-byte chunks per output row of this tile
         constexpr int RPP = NT / CPR;               // rows per pass
         const int ch = tid % CPR, r0 = tid / CPR;
 #pragma unroll
         for (int r = r0; r < BM; r += RPP) {
             const uint32_t op = lds_row[r].opix;
             if (op != 0xffffffffu) {
-                const u32x4 val = *reinterpret_cast<const u32x4*>(lds_epi + r * EPI_LD + ch * 16);
-                *reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + ch * 8) = val;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(smem + r * EROW + ch * 16);
+                const int clog = ch ^ (r & (CPR - 1));
+                *reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + clog * 8) = val;
             }
         }
     }
@@ -487,7 +542,7 @@ template <int WN, int WM, int TN, int TM>
 static void conv_launch(const ConvArgs& a, hipStream_t s, int loader) {      // loader: 0 registers, 1 / 2 = glds stages
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
     const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM) * a.ksplit;
-    const size_t stage = (size_t)(BN + BM) * CONV_ROW_BYTES * (loader == 2 ? 2 : 1), epi = (size_t)BM * (BN * 2 + 16);
+    const size_t stage = (size_t)(BN + BM) * CONV_ROW_BYTES * (loader == 2 ? 2 : 1), epi = (size_t)BM * BN * 2;
     const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16;
     constexpr int NT = 64 * WN * WM;
     if (loader == 2) {

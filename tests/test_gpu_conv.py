@@ -198,3 +198,57 @@ def test_aspp_wgrad_padded_classes(ops):
         got = dw[9 * i:9 * i + 9, :C]
         assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-3
     assert float(dw[:, C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('variant', [0, 1], ids=['direct_to_lds', 'register_staged'])
+@pytest.mark.parametrize('tile', [0, 1128, 256, 64, 32])
+@pytest.mark.parametrize('epi', ['res', 'mask', 'mask_res', 'fwd_res_relu'])
+def test_conv_epilogue_operands_through_lds(ops, epi, tile, variant):
+    """Residual / ReLU-mask tiles are staged global -> LDS (swizzled rows) and consumed in accumulator layout; the
+    output tile is written in place. Checked on a ragged pixel count (dead rows) for every tile shape; the element
+    that must come out is exactly bf16(acc [+ res]) [masked], so the comparison is tight."""
+    g = torch.Generator(device=DEV).manual_seed(21)
+    N, H, W, Cin, Cout = 3, 13, 17, 64, 256          # 663 pixels: 5 full 128-pixel tiles + a 23-pixel tail
+    x = _mk((N, H, W, Cin), g)
+    w = _mk((Cout, Cin, 1, 1), g, 0.1)
+    res = _mk((N, H, W, Cout), g)
+    msk = _mk((N, H, W, Cout), g)
+    acc = torch.einsum('nhwc,oc->nhwo', x.float(), w.float()[:, :, 0, 0])
+    kw = dict(tile=tile, variant=variant)
+    if epi == 'res':
+        got, ref = ops.conv_igemm(x, _pack(w), [(0, 0)], mode=1, res=res, **kw), acc + res.float()
+    elif epi == 'mask':
+        got, ref = ops.conv_igemm(x, _pack(w), [(0, 0)], mode=1, mask_src=msk, **kw), acc * (msk.float() > 0)
+    elif epi == 'mask_res':
+        got = ops.conv_igemm(x, _pack(w), [(0, 0)], mode=1, mask_src=msk, res=res, **kw)
+        ref = (acc + res.float()) * (msk.float() > 0)
+    else:
+        scale = torch.rand(Cout, generator=g, device=DEV) + 0.5
+        bias = torch.randn(Cout, generator=g, device=DEV)
+        got = ops.conv_igemm(x, _pack(w), [(0, 0)], scale=scale, bias=bias, res=res, relu=True, **kw)
+        ref = torch.relu(acc * scale + bias + res.float())
+    err = (got.float() - ref).abs()
+    assert bool((err <= 6e-3 * ref.abs() + 2e-3).all()), float(err.max())       # one bf16 rounding + fp32 sum order
+    if 'mask' in epi:
+        assert bool((got[msk <= 0] == 0).all())
+
+
+def test_conv_dgrad_stride2_scatter_with_mask_and_residual(ops):
+    g = torch.Generator(device=DEV).manual_seed(13)
+    N, H, W, Cin, Cout = 2, 21, 23, 256, 128
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    w = _mk((Cout, Cin, 1, 1), g, 0.06)
+    dU = _mk((N, Ho, Wo, Cout), g)
+    res = _mk((N, H, W, Cin), g)
+    xin = _mk((N, H, W, Cin), g)
+    wT = ops.conv_pack_transpose(_pack(w), flip=True)
+    dx = ops.conv_igemm(dU, wT, [(0, 0)], mode=1, out_hw=(Ho, Wo), out_stride=2, out_full_hw=(H, W), res=res,
+                        mask_src=xin)
+    xr = torch.zeros(N, Cin, H, W, device=DEV, requires_grad=True)
+    F.conv2d(xr, w.float(), None, 2).backward(dU.float().permute(0, 3, 1, 2))
+    ref = xr.grad.permute(0, 2, 3, 1)
+    # the strided scatter only visits the even positions: residual and mask apply there, the rest stays zero
+    sel = torch.zeros(N, H, W, 1, dtype=torch.bool, device=DEV)
+    sel[:, ::2, ::2] = True
+    ref = torch.where(sel, (ref + res.float()) * (xin.float() > 0), torch.zeros_like(ref))
+    assert float((dx.float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max()) + 1e-3
