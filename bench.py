@@ -95,6 +95,7 @@ def main():
                     help='default: conv (the MFMA convolution) for the DeepLab v2 workloads, adam_ema otherwise')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_fuse_batches', action='store_true')
+    ap.add_argument('--conv_tile', type=int, default=0, help='experiment: force a conv tile code (256, 1128, 128)')
     ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')
     ap.add_argument('--no_roofline_events', action='store_true', help='skip the per-launch event brackets')
     ap.add_argument('--roofline_sample', type=int, default=5,
@@ -151,6 +152,8 @@ def main():
     step = CutMixMeanTeacherStep(stu, tea, opt, ema, cfg)
     if args.no_overlap and hasattr(stu, 'hip_executor') and dtype == torch.bfloat16:
         stu.hip_executor().overlap_wgrad = False
+    if args.conv_tile and hasattr(stu, 'hip_executor'):
+        stu.hip_executor().conv_tile = tea.hip_executor().conv_tile = args.conv_tile
 
     gen = torch.Generator(device=dev).manual_seed(12345 + rank)
     mask_rng = np.random.RandomState(12345 + rank)

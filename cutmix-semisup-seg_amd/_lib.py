@@ -64,7 +64,7 @@ class ConvDesc(C.Structure):
                 ('ho', c_int), ('wo', c_int), ('cout', c_int), ('cout_real', c_int), ('ntaps', c_int),
                 ('tap_dy', c_int * 18), ('tap_dx', c_int * 18), ('stride', c_int),
                 ('out_h', c_int), ('out_w', c_int), ('out_stride', c_int), ('relu', c_int), ('mode', c_int),
-                ('tile', c_int), ('ksplit', c_int), ('zeros', c_void_p), ('variant', c_int)]
+                ('tile', c_int), ('ksplit', c_int), ('zeros', c_void_p), ('variant', c_int), ('zeros_bytes', c_int)]
 
 
 class WgradDesc(C.Structure):

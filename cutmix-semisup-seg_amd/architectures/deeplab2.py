@@ -225,16 +225,24 @@ class ResNetDeepLab(nn.Module):
             self._hip_executor = DeepLabHipExecutor(self)
         return self._hip_executor
 
+    def stem_nhwc(self, x):
+        """conv1 + bn1 + ReLU + max-pool (:183-186) -> bf16 NHWC, the input of the MFMA executor."""
+        eng = self._engine(x)
+        x = eng.prepare_input(x)
+        x = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        x = eng.maxpool(x)
+        return x.permute(0, 2, 3, 1).contiguous()
+
     def forward_lowres(self, x):
         """(N,3,H,W) -> (N,C,h,w) fp32 head output (the reference's `x` just before its interpolate, :193)."""
         eng = self._engine(x)
         use_hip = self._use_hip_body()
+        if use_hip:
+            from ..backbone_hip import run_body
+            return run_body(self.hip_executor(), self.stem_nhwc(x))
         x = eng.prepare_input(x)
         x = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         x = eng.maxpool(x)
-        if use_hip:
-            from ..backbone_hip import run_body
-            return run_body(self.hip_executor(), x.permute(0, 2, 3, 1).contiguous())
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 x = blk(x, eng)

@@ -82,6 +82,7 @@ class DeepLabHipExecutor(object):
         self._pack_plan = None
         self.grad_hook = None      # callable(block_index): weight gradients of that bottleneck are enqueued
         self.overlap_wgrad = True
+        self.conv_tile = 0         # experiment knob: force a tile shape on the 128-multiple layers (tools, bench)
         self._wT_version = -1
         self.version = 0          # bumped whenever the weights change (optimizer step / load_state_dict)
         net.register_load_state_dict_post_hook(lambda module, incompatible: self.invalidate())
@@ -182,22 +183,31 @@ class DeepLabHipExecutor(object):
         n, h, w, _ = x.shape
         ho, wo = self._out_hw(h, w, c.stride)
         return ops.conv_igemm(x, self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), scale=c.scale, bias=c.bias,
-                              res=res, relu=relu)
+                              res=res, relu=relu, tile=self._tile(c.cout))
 
-    def forward(self, x, save):
-        """x: bf16 NHWC (N, h, w, 64) = stem + max-pool output. Returns (logits fp32 NCHW, saved)."""
+    def _tile(self, cout):
+        """Workgroup tile code for a convolution with `cout` output channels (0 = the library's choice)."""
+        return self.conv_tile if (self.conv_tile and cout % 128 == 0) else 0
+
+    def fwd_begin(self, x, save):
+        """x: bf16 NHWC (N, h, w, 64) = stem + max-pool output. The forward pass in three pieces (begin / one call per
+        bottleneck / end) so that a caller can interleave the launches of two networks on two streams (`_BodyPairFn`)."""
         if not self._affine_ready:
             self._refresh_affine()
-        saved = [] if save else None
-        cur = x
-        for b in self.blocks:
-            a1 = self._fwd(cur, b.c1, True)
-            a2 = self._fwd(a1, b.c2, True)
-            res = cur if b.cd is None else self._fwd(cur, b.cd, False)
-            out = self._fwd(a2, b.c3, True, res=res)
-            if save:
-                saved.append((cur, a1, a2))
-            cur = out
+        return {'cur': x, 'saved': [] if save else None}
+
+    def fwd_block(self, st, bi):
+        b, cur = self.blocks[bi], st['cur']
+        a1 = self._fwd(cur, b.c1, True)
+        a2 = self._fwd(a1, b.c2, True)
+        res = cur if b.cd is None else self._fwd(cur, b.cd, False)
+        st['cur'] = self._fwd(a2, b.c3, True, res=res)
+        if st['saved'] is not None:
+            st['saved'].append((cur, a1, a2))
+
+    def fwd_end(self, st):
+        """-> (logits fp32 NCHW, saved)"""
+        cur, saved = st['cur'], st['saved']
         self._refresh_aspp_fwd()
         n, h, w, _ = cur.shape
         # 18 taps x 2048 channels = a K of 36864 against only ~260 pixel tiles: split the taps over 6x more workgroups
@@ -205,9 +215,15 @@ class DeepLabHipExecutor(object):
         logits = torch.zeros((n, self.num_classes, h, w), dtype=torch.float32, device=cur.device)
         ops.conv_igemm(cur, self.aspp_w32, self.aspp_taps, bias=self.aspp_bias, out_f32_nchw=logits,
                        cout_real=self.num_classes, ksplit=6)
-        if save:
+        if saved is not None:
             saved.append(cur)
         return logits, saved
+
+    def forward(self, x, save):
+        st = self.fwd_begin(x, save)
+        for bi in range(len(self.blocks)):
+            self.fwd_block(st, bi)
+        return self.fwd_end(st)
 
     # ------------------------------------------------------------------------------------------ backward
     def _wgrad(self, du, x, c):
@@ -217,9 +233,9 @@ class DeepLabHipExecutor(object):
         """gradient wrt the input of conv `c`; `in_hw` = spatial size of that input (needed for stride 2)."""
         n, ho, wo, _ = du.shape
         if c.stride == 1:
-            return ops.conv_igemm(du, c.wT, c.neg_taps, res=res, mode=1, mask_src=mask)
+            return ops.conv_igemm(du, c.wT, c.neg_taps, res=res, mode=1, mask_src=mask, tile=self._tile(c.cin))
         return ops.conv_igemm(du, c.wT, c.neg_taps, res=res, mode=1, mask_src=mask, out_hw=(ho, wo),
-                              out_stride=c.stride, out_full_hw=in_hw)
+                              out_stride=c.stride, out_full_hw=in_hw, tile=self._tile(c.cin))
 
     def backward(self, saved, dlogits):
         """dlogits fp32 (N,C,h,w). Accumulates weight gradients into the arena; returns d loss / d x (bf16 NHWC)."""
@@ -300,6 +316,47 @@ class _BodyFn(torch.autograd.Function):
         dx = ctx.executor.backward(ctx.saved_acts, dlogits.contiguous().float())
         ctx.saved_acts = None
         return dx, None, None
+
+
+class _BodyPairFn(torch.autograd.Function):
+    """Student and teacher bodies in ONE node, their launches interleaved bottleneck by bottleneck: student on the
+    current stream, teacher on `side`. Issuing one whole pass after the other leaves the two streams overlapping only
+    where the host happens to run ahead of the GPU; interleaved issue keeps two kernels in flight for the whole
+    forward pass, which is what fills the launch tails of these small grids."""
+
+    @staticmethod
+    def forward(ctx, x_stu, x_tea, ex_stu, ex_tea, side, need_grad):
+        st_s = ex_stu.fwd_begin(x_stu, need_grad)
+        with torch.cuda.stream(side):
+            st_t = ex_tea.fwd_begin(x_tea, False)
+        for bi in range(len(ex_stu.blocks)):
+            ex_stu.fwd_block(st_s, bi)
+            with torch.cuda.stream(side):
+                ex_tea.fwd_block(st_t, bi)
+        logits_s, saved = ex_stu.fwd_end(st_s)
+        with torch.cuda.stream(side):
+            logits_t, _ = ex_tea.fwd_end(st_t)
+        ctx.executor = ex_stu
+        ctx.saved_acts = saved
+        ctx.mark_non_differentiable(logits_t)
+        return logits_s, logits_t
+
+    @staticmethod
+    def backward(ctx, dlogits, _unused):
+        dx = ctx.executor.backward(ctx.saved_acts, dlogits.contiguous().float())
+        ctx.saved_acts = None
+        return dx, None, None, None, None, None
+
+
+def run_body_pair(ex_stu, x_stu, ex_tea, x_tea, side):
+    """(student logits [differentiable], teacher logits). `x_tea` must have been produced on `side`; the caller joins
+    the streams before it reads the teacher logits on the current stream."""
+    if len(ex_stu.blocks) != len(ex_tea.blocks):
+        raise ValueError('student and teacher bodies differ')
+    need_grad = torch.is_grad_enabled() and ex_stu.trainable
+    if need_grad and not x_stu.requires_grad:
+        x_stu = x_stu.detach().requires_grad_(True)
+    return _BodyPairFn.apply(x_stu, x_tea, ex_stu, ex_tea, side, need_grad)
 
 
 def run_body(executor, x_nhwc):

@@ -48,7 +48,7 @@ struct ConvArgs {
     const float* bias;         // [Cout] or NULL (forward)
     const uint16_t* res;       // bf16, indexed like y, or NULL
     const uint16_t* mask_src;  // bf16, indexed like y, or NULL (dgrad)
-    const uint16_t* zeros;     // >= 128 B of zeros (source of padded / out-of-range rows for the direct-to-LDS loader)
+    const uint16_t* zeros;     // >= 2*Cin + 128 B of zeros (source of padded / out-of-range rows for the direct-to-LDS loader)
     int N, H, W, Cin;
     int Ho, Wo, Cout, cout_real;
     int ntaps, stride;
@@ -93,8 +93,9 @@ struct RowInfo {            // one per pixel row of the workgroup tile, computed
 // registers, no ds_write); the XOR swizzle is applied on the SOURCE side (the LDS image of a wave instruction is
 // lane-linear), out-of-range rows read a zero page. One LDS buffer per workgroup, up to 4 workgroups per CU: the
 // load latency of a workgroup is covered by the MFMA phases of its neighbours.
-template <int WN, int WM, int TN, int TM, bool GLDS, int NS>
-__global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4) ? (NS == 1 ? 4 : 2) : 1) void conv_igemm_kernel(ConvArgs a) {
+template <int WN, int WM, int TN, int TM, bool GLDS, int NS, int BK = CONV_BK>
+__global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4) ? ((NS == 1 || BK == 32) ? 4 : 2)
+                                            : ((WN * WM == 4 && TN * TM == 8) ? 2 : 1)) void conv_igemm_kernel(ConvArgs a) {
     // NS = LDS stages of the direct-to-LDS loader. 1: load -> barrier -> MFMA -> barrier; memory and MFMA phases only
     // overlap ACROSS the (up to 4) workgroups of a CU. 2: the loads of K-step k+1 are in flight during the MFMAs of
     // step k inside one workgroup -- what the DeepLab shapes need, whose grids are only ~2 workgroups per CU.
@@ -102,17 +103,25 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     constexpr int NT = 64 * NW;
     constexpr int BN = WN * TN * 32;    // output channels per workgroup
     constexpr int BM = WM * TM * 32;    // pixels per workgroup
-    constexpr int PA = BM / (8 * NW);   // loader passes over the pixel tile (each pass: 8 rows per wave)
-    constexpr int PB = BN / (8 * NW);
+    // BK = K elements per stage. 64: 128-byte LDS rows (8 chunks of 16 B, swizzle (row>>1)&7). 32: 64-byte rows
+    // (4 chunks, swizzle (row>>2)&3) -- two stages of it fit the LDS footprint of one 64-wide stage, i.e. the loads of
+    // step k+1 overlap the MFMAs of step k WITHOUT giving up the 4 workgroups per CU.
+    constexpr int ROWB = BK * 2;        // LDS row pitch (bytes)
+    constexpr int CH = BK / 8;          // 16-byte chunks per row
+    constexpr int LRPI = 64 / CH;       // rows per wave-wide direct-to-LDS instruction (8 or 16)
+    constexpr int WSH = CH == 8 ? 1 : 2;                 // rows per 256-byte bank window = 1 << WSH
+    static_assert(BK == 64 || (BK == 32 && GLDS), "BK = 32 only with the direct-to-LDS loader");
+    constexpr int PA = BM / (LRPI * NW);   // loader passes over the pixel tile
+    constexpr int PB = BN / (LRPI * NW);
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(BM <= NT && PA >= 1 && PB >= 1, "tile too small for the loader");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int STAGE_BYTES = (BM + BN) * CONV_ROW_BYTES;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int EPI_BYTES = BM * BN * 2;                // epilogue tile (bf16 output / staged residual or mask)
     static_assert(NS == 1 || (NS == 2 && GLDS), "two stages only with the direct-to-LDS loader");
     constexpr int UNION_BYTES = NS * STAGE_BYTES > EPI_BYTES ? NS * STAGE_BYTES : EPI_BYTES;
     unsigned char* lds_x = smem;                          // [NS][BM][128 B]   (stage s at + s * STAGE_BYTES)
-    unsigned char* lds_w = smem + BM * CONV_ROW_BYTES;    // [NS][BN][128 B]
+    unsigned char* lds_w = smem + BM * ROWB;              // [NS][BN][128 B]
     short* lds_tap = reinterpret_cast<short*>(smem + UNION_BYTES);                       // [2][CMS_CONV_MAX_TAPS]
     RowInfo* lds_row = reinterpret_cast<RowInfo*>(smem + UNION_BYTES + 80);              // [BM]
 
@@ -170,24 +179,24 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     //                  row (4i+w)*8 + (l>>3), physical chunk l&7 and must FETCH logical chunk (l&7) ^ swizzle(row).
     const int chunk = tid & 7, lrow = tid >> 3;      // register-staged mapping: rows lrow + (NT/8)*i
     constexpr int RSTEP = NT / 8;
-    uint32_t xoff[PA], xyx[PA], woff[PB];
+    uint32_t xoff[GLDS ? 1 : PA], xyx[GLDS ? 1 : PA], woff[PB];
+    if constexpr (!GLDS) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int row = GLDS ? (NW * i + wave) * 8 + (lane >> 3) : lrow + RSTEP * i;
-        const int c = GLDS ? ((lane & 7) ^ ((row >> 1) & 7)) : chunk;
-        const RowInfo ri = lds_row[row];
-        xoff[i] = ri.in_off + (uint32_t)(c * 8);
-        xyx[i] = ri.yx;
+        for (int i = 0; i < PA; ++i) {
+            const RowInfo ri = lds_row[lrow + RSTEP * i];
+            xoff[i] = ri.in_off + (uint32_t)(chunk * 8);
+            xyx[i] = ri.yx;
+        }
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        const int row = GLDS ? (NW * i + wave) * 8 + (lane >> 3) : lrow + RSTEP * i;
-        const int c = GLDS ? ((lane & 7) ^ ((row >> 1) & 7)) : chunk;
+        const int row = GLDS ? (NW * i + wave) * LRPI + lane / CH : lrow + RSTEP * i;
+        const int c = GLDS ? ((lane % CH) ^ ((row >> WSH) & (CH - 1))) : chunk;
         woff[i] = (uint32_t)(row * a.Cin + c * 8);
     }
     const uint32_t st_off = swz(lrow, chunk);            // rows lrow + RSTEP*i share the swizzle term (RSTEP % 16 == 0)
 
-    const int kc_per_tap = a.Cin / CONV_BK;
+    const int kc_per_tap = a.Cin / BK;
     const int taps_per_split = (a.ntaps + a.ksplit - 1) / a.ksplit;
     const int tap_begin = split * taps_per_split;
     const int tap_end = min(a.ntaps, tap_begin + taps_per_split);
@@ -195,36 +204,23 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     const int ksteps = tap_end * kc_per_tap;        // exclusive end of this workgroup's K range
 
     u32x4 rx[GLDS ? 1 : PA], rw[GLDS ? 1 : PB];
-    auto load_tile = [&](int ks, int buf) {
-        const int tap = ks / kc_per_tap;                                  // wave-uniform
-        const int c0 = (ks - tap * kc_per_tap) * CONV_BK;
-        const int dy = __builtin_amdgcn_readfirstlane((int)lds_tap[tap]);
-        const int dx = __builtin_amdgcn_readfirstlane((int)lds_tap[CMS_CONV_MAX_TAPS + tap]);
-        const int delta = (dy * a.W + dx) * a.Cin + c0;                   // scalar element offset of this tap / K chunk
-        const uint16_t* wt = a.w + ((size_t)tap * a.Cout + co0) * a.Cin + c0;   // scalar base
+    auto load_tile = [&](int ks, int) {        // register-staged loader only (the direct-to-LDS cursor is below)
+        if constexpr (!GLDS) {
+            const int tap = ks / kc_per_tap;                                  // wave-uniform
+            const int c0 = (ks - tap * kc_per_tap) * BK;
+            const int dy = __builtin_amdgcn_readfirstlane((int)lds_tap[tap]);
+            const int dx = __builtin_amdgcn_readfirstlane((int)lds_tap[CMS_CONV_MAX_TAPS + tap]);
+            const int delta = (dy * a.W + dx) * a.Cin + c0;                   // scalar element offset of this tap / K chunk
+            const uint16_t* wtp = a.w + ((size_t)tap * a.Cout + co0) * a.Cin + c0;   // scalar base
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const uint32_t iy = (xyx[i] >> 16) + (uint32_t)dy, ix = (xyx[i] & 0xffffu) + (uint32_t)dx;
-            const bool ok = iy < (uint32_t)a.H && ix < (uint32_t)a.W;    // unsigned compare covers the negative side
-            if constexpr (GLDS) {
-                const uint16_t* src = select_ptr(ok, a.x + (size_t)(xoff[i] + (uint32_t)delta), a.zeros + (lane & 7) * 8);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(lds_x + buf * STAGE_BYTES + (NW * i + wave) * 1024),
-                                                 16, 0, 0);
-            } else {
+            for (int i = 0; i < PA; ++i) {
+                const uint32_t iy = (xyx[i] >> 16) + (uint32_t)dy, ix = (xyx[i] & 0xffffu) + (uint32_t)dx;
+                const bool ok = iy < (uint32_t)a.H && ix < (uint32_t)a.W;    // unsigned compare covers the negative side
                 if (ok) rx[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(xoff[i] + (uint32_t)delta));
                 else rx[i] = u32x4{0u, 0u, 0u, 0u};
             }
-        }
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            if constexpr (GLDS) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + woff[i]),
-                                                 (__attribute__((address_space(3))) void*)(lds_w + buf * STAGE_BYTES + (NW * i + wave) * 1024),
-                                                 16, 0, 0);
-            } else {
-                rw[i] = *reinterpret_cast<const u32x4*>(wt + woff[i]);
-            }
+            for (int i = 0; i < PB; ++i) rw[i] = *reinterpret_cast<const u32x4*>(wtp + woff[i]);
         }
     };
     auto store_tile = [&]() {
@@ -233,6 +229,53 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
             for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(lds_x + st_off + i * RSTEP * CONV_ROW_BYTES) = rx[i];
 #pragma unroll
             for (int i = 0; i < PB; ++i) *reinterpret_cast<u32x4*>(lds_w + st_off + i * RSTEP * CONV_ROW_BYTES) = rw[i];
+        }
+    };
+
+    // ---- direct-to-LDS loader as a (tap, K-chunk) cursor. Everything that depends on the tap only -- the tap offsets
+    // (one LDS read), the bounds test of each fetched row, its 64-bit source address or the zero page -- is set up
+    // ONCE per tap; a K step then costs one 64-bit add per wave instruction (the zero page is as long as a pixel's
+    // channel run, so dead rows advance like live ones). This took the load phase from ~125 to ~40 instructions per
+    // stage and removed an LDS round trip from every stage's critical path.
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);            // scalar: LDS destinations live in SGPRs / M0
+    const uint16_t* xaddr[GLDS ? PA : 1];
+    const uint16_t* wt = a.w;
+    int cur_tap = tap_begin, cur_kc = 0;
+    auto setup_tap = [&]() {
+        const int dy = __builtin_amdgcn_readfirstlane((int)lds_tap[cur_tap]);
+        const int dx = __builtin_amdgcn_readfirstlane((int)lds_tap[CMS_CONV_MAX_TAPS + cur_tap]);
+        const int delta = (dy * a.W + dx) * a.Cin;                     // scalar element offset of this tap
+        wt = a.w + ((size_t)cur_tap * a.Cout + co0) * a.Cin;           // scalar base
+#pragma unroll
+        for (int i = 0; i < (GLDS ? PA : 0); ++i) {
+            const int row = (NW * i + wave) * LRPI + lane / CH;
+            const int c = (lane % CH) ^ ((row >> WSH) & (CH - 1));
+            const RowInfo ri = lds_row[row];
+            const uint32_t iy = (ri.yx >> 16) + (uint32_t)dy, ix = (ri.yx & 0xffffu) + (uint32_t)dx;
+            const bool ok = iy < (uint32_t)a.H && ix < (uint32_t)a.W;    // unsigned compare covers the negative side
+            xaddr[i] = select_ptr(ok, a.x + (size_t)(ri.in_off + (uint32_t)(c * 8) + (uint32_t)delta),
+                                  a.zeros + (lane & 7) * 8);
+        }
+    };
+    auto issue_loads = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < (GLDS ? PA : 0); ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xaddr[i],
+                                             (__attribute__((address_space(3))) void*)(lds_x + buf * STAGE_BYTES + (NW * i + wave_s) * 1024),
+                                             16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < (GLDS ? PB : 0); ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + woff[i]),
+                                             (__attribute__((address_space(3))) void*)(lds_w + buf * STAGE_BYTES + (NW * i + wave_s) * 1024),
+                                             16, 0, 0);
+    };
+    auto advance = [&]() {
+        wt += BK;
+#pragma unroll
+        for (int i = 0; i < (GLDS ? PA : 0); ++i) xaddr[i] += BK;
+        if (++cur_kc == kc_per_tap) {
+            cur_kc = 0;
+            if (++cur_tap < tap_end) setup_tap();
         }
     };
 
@@ -247,19 +290,19 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     // fragment read address: row (lane & 31) of a 32-row tile, 16-byte chunk (kk*2 + lane>>5) ^ swizzle(row)
     //   = lane_frag ^ (kk * 32)   (the K sub-step only flips bits 5..6)
     const int frow = lane & 31, fhalf = lane >> 5;
-    const uint32_t lane_frag = (uint32_t)frow * CONV_ROW_BYTES | (uint32_t)(((fhalf ^ (frow >> 1)) & 7) << 4);
-    const unsigned char* fw_base = lds_w + wn * TN * 32 * CONV_ROW_BYTES;
-    const unsigned char* fx_base = lds_x + wm * TM * 32 * CONV_ROW_BYTES;
+    const uint32_t lane_frag = (uint32_t)frow * ROWB | (uint32_t)(((fhalf ^ (frow >> WSH)) & (CH - 1)) << 4);
+    const unsigned char* fw_base = lds_w + wn * TN * 32 * ROWB;
+    const unsigned char* fx_base = lds_x + wm * TM * 32 * ROWB;
 
     auto mfma_phase = [&](int buf) {
 #pragma unroll
-        for (int kk = 0; kk < CONV_BK / 16; ++kk) {
+        for (int kk = 0; kk < BK / 16; ++kk) {
             u32x4 fw[TN], fx[TM];     // (arrays of __bf16 vectors are not promoted to registers by the compiler)
             const uint32_t fo = (lane_frag ^ (uint32_t)(kk * 32)) + (uint32_t)(buf * STAGE_BYTES);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const u32x4*>(fw_base + fo + i * 32 * CONV_ROW_BYTES);
+            for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const u32x4*>(fw_base + fo + i * 32 * ROWB);
 #pragma unroll
-            for (int j = 0; j < TM; ++j) fx[j] = *reinterpret_cast<const u32x4*>(fx_base + fo + j * 32 * CONV_ROW_BYTES);
+            for (int j = 0; j < TM; ++j) fx[j] = *reinterpret_cast<const u32x4*>(fx_base + fo + j * 32 * ROWB);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -268,14 +311,24 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
                                                                         __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
         }
     };
-    if (ks_begin < ksteps) load_tile(ks_begin, 0);
+    if constexpr (GLDS) {
+        if (ks_begin < ksteps) {
+            setup_tap();
+            issue_loads(0);
+        }
+    } else {
+        if (ks_begin < ksteps) load_tile(ks_begin, 0);
+    }
     if constexpr (GLDS && NS == 2) {
         int buf = 0;
         for (int ks = ks_begin; ks < ksteps; ++ks, buf ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of stage `buf` has landed in LDS
             __syncthreads();                                    // ... everybody else's too, and all fragment reads of
                                                                 // the previous step (the other buffer) are done
-            if (ks + 1 < ksteps && a.dbg != 3) load_tile(ks + 1, buf ^ 1);      // in flight during the MFMAs below
+            if (ks + 1 < ksteps && a.dbg != 3) {                // in flight during the MFMAs below
+                advance();
+                issue_loads(buf ^ 1);
+            }
             if (a.dbg != 2) mfma_phase(buf);
         }
         __syncthreads();                                        // the epilogue reuses the staging area
@@ -285,7 +338,10 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
             __syncthreads();                                    // ... and everybody else's
             if (a.dbg != 2) mfma_phase(0);
             __syncthreads();                                    // all fragment reads done: the buffer may be refilled
-            if (ks + 1 < ksteps && a.dbg != 3) load_tile(ks + 1, 0);
+            if (ks + 1 < ksteps && a.dbg != 3) {
+                advance();
+                issue_loads(0);
+            }
         }
     } else {
         for (int ks = ks_begin; ks < ksteps; ++ks) {
@@ -330,7 +386,8 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     auto slot = [&](int prow_l, int co_l) -> uint32_t {
         return (uint32_t)(prow_l * EROW + ((((co_l >> 3) ^ prow_l) & (CPR - 1)) << 4) + ((co_l & 4) << 1));
     };
-    uint64_t mbits = 0;                          // ReLU mask of this lane's elements when BOTH operands are staged
+    uint64_t mbits[2] = {0, 0};                  // ReLU mask of this lane's (<= 128) elements when BOTH operands are staged
+    static_assert(TN * TM * 16 <= 128, "mask bit field");
     const bool both = staged && a.res && a.mask_src;
     if constexpr (GLDS) {
         if (both) {
@@ -346,7 +403,7 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
                         const int bit = ((i * TM + j) * 4 + q) * 4;
                         uint64_t m4 = ((int16_t)(mk.x & 0xffffu) > 0 ? 1u : 0u) | ((int16_t)(mk.x >> 16) > 0 ? 2u : 0u) |
                                       ((int16_t)(mk.y & 0xffffu) > 0 ? 4u : 0u) | ((int16_t)(mk.y >> 16) > 0 ? 8u : 0u);
-                        mbits |= m4 << bit;
+                        mbits[bit >> 6] |= m4 << (bit & 63);
                     }
             __syncthreads();                     // everybody has its bits: the tile may be overwritten
         }
@@ -392,7 +449,7 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
                 } else if (both) {
                     const int bit = ((i * TM + j) * 4 + q) * 4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ((mbits >> (bit + e)) & 1u) ? v[e] : 0.0f;
+                    for (int e = 0; e < 4; ++e) v[e] = ((mbits[bit >> 6] >> ((bit & 63) + e)) & 1u) ? v[e] : 0.0f;
                 } else if (a.mask_src && (staged || valid)) {
                     const uint2 mk = staged ? *reinterpret_cast<const uint2*>(cell)
                                             : *reinterpret_cast<const uint2*>(a.mask_src + obase + co);
@@ -539,8 +596,8 @@ static int conv_check(const cms_conv_desc* d) {
 }
 
 template <int WN, int WM, int TN, int TM>
-static void conv_launch(const ConvArgs& a, hipStream_t s, int loader) {      // loader: 0 registers, 1 / 2 = glds stages
-    constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
+static void conv_launch(const ConvArgs& a, hipStream_t s, int loader) {      // loader: 0 registers, 1 / 2 = glds stages,
+    constexpr int BN = WN * TN * 32, BM = WM * TM * 32;                       //         3 = two glds stages of BK = 32
     const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM) * a.ksplit;
     const size_t stage = (size_t)(BN + BM) * CONV_ROW_BYTES * (loader == 2 ? 2 : 1), epi = (size_t)BM * BN * 2;
     const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16;
@@ -554,7 +611,10 @@ static void conv_launch(const ConvArgs& a, hipStream_t s, int loader) {      // 
             raised = true;
         }
         hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 2>), dim3(grid), dim3(NT), lds, s, a);
-    } else if (loader == 1) {
+    } else if (loader == 3 && BN % (16 * WN * WM) == 0 && BM % (16 * WN * WM) == 0) {
+        if constexpr (BN % (16 * WN * WM) == 0 && BM % (16 * WN * WM) == 0)       // 64-byte rows: 16 rows per wave load
+            hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 2, 32>), dim3(grid), dim3(NT), lds, s, a);
+    } else if (loader == 1 || loader == 3) {
         hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 1>), dim3(grid), dim3(NT), lds, s, a);
     } else {
         hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, false, 1>), dim3(grid), dim3(NT), lds, s, a);
@@ -583,16 +643,22 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     a.zeros = (const uint16_t*)d->zeros;
+    CMS_REQUIRE(d->zeros == nullptr || d->zeros_bytes >= 2 * d->cin + 128,
+                "conv: the zero run (%d bytes) must be at least 2 * Cin + 128 = %d bytes long", d->zeros_bytes, 2 * d->cin + 128);
     a.dbg = (d->variant == 2 || d->variant == 3) ? d->variant : 0;
     // variant 0: direct-to-LDS, one stage, up to 4 workgroups per CU (default); 1: register-staged loader;
     // 4: direct-to-LDS, two stages, 2 workgroups per CU -- measured 10 % faster on grids of exactly <= 2 workgroups per
     // CU, 20 % slower on everything else (tools/tail_probe.py): co-resident workgroups hide more than the second stage;
     // 2 / 3: ablation switches of the default kernel (no MFMA / no loads after the first stage)
-    const int glds = (d->zeros == nullptr || d->variant == 1) ? 0 : (d->variant == 4 ? 2 : 1);
+    // 5: direct-to-LDS, two stages of 32 K-elements each (same LDS footprint and occupancy as the default)
+    const int glds = (d->zeros == nullptr || d->variant == 1) ? 0 : (d->variant == 4 ? 2 : (d->variant == 5 ? 3 : 1));
     const int tile = d->tile;   // 0 = auto
     if (tile == 256) {                         // 8 waves: 128 co x 256 pixels (more reuse of the weight tile)
         CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 256 needs Cout %% 128 == 0");
         conv_launch<2, 4, 2, 2>(a, s, glds);
+    } else if (tile == 2256) {                 // 4 waves, each 64 co x 128 pixels: 6 fragment reads per 8 MFMAs
+        CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 2256 needs Cout %% 128 == 0");
+        conv_launch<2, 2, 2, 4>(a, s, glds);
     } else if (tile == 1128) {                 // 8 waves on the 128 x 128 tile (each wave 64 co x 32 pixels)
         CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 1128 needs Cout %% 128 == 0");
         conv_launch<2, 4, 2, 1>(a, s, glds);

@@ -378,10 +378,11 @@ _ZERO_PAGES = {}
 
 
 def _zero_page(device):
-    """A small all-zero device buffer: where the direct-to-LDS loader fetches padded / out-of-range rows from."""
+    """An all-zero device buffer: where the direct-to-LDS loader fetches padded / out-of-range rows from (it walks
+    through it like through a pixel's channel run, so it must be >= 2 * Cin + 128 bytes: 64 KB covers Cin <= 32704)."""
     z = _ZERO_PAGES.get(device)
     if z is None:
-        z = torch.zeros(1024, dtype=torch.bfloat16, device=device)
+        z = torch.zeros(32768, dtype=torch.bfloat16, device=device)
         _ZERO_PAGES[device] = z
     return z
 
@@ -434,7 +435,8 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     d.out_h, d.out_w, d.out_stride = oh, ow, int(out_stride)
     d.relu, d.mode, d.tile = int(bool(relu)), int(mode), int(tile)
     d.ksplit = int(ksplit)
-    d.zeros = _zero_page(x.device).data_ptr()
+    zp = _zero_page(x.device)
+    d.zeros, d.zeros_bytes = zp.data_ptr(), zp.numel() * 2
     d.variant = int(variant)
     check(fn['cms_conv_igemm'](C.byref(d), _stream()), 'cms_conv_igemm')
     return out if out_f32_nchw is None else out_f32_nchw

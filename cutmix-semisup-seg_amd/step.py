@@ -164,6 +164,13 @@ class CutMixMeanTeacherStep(object):
                     return False
         return True
 
+    def _both_on_executor(self):
+        for net in (self.student, self.teacher):
+            use = getattr(net, '_use_hip_body', None)
+            if use is None or not use() or not hasattr(net, 'stem_nhwc'):
+                return False
+        return self.teacher is not self.student
+
     def _teacher_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream()
@@ -218,11 +225,23 @@ class CutMixMeanTeacherStep(object):
                 # with the student's forward pass (the two fill each other's launch tails and memory stalls)
                 main = torch.cuda.current_stream()
                 side = self._teacher_stream() if cfg.overlap_teacher else main
-                side.wait_stream(main)
+                x_tea = torch.cat(tea_in, dim=0) if len(tea_in) > 1 else tea_in[0]
+                if side is not main:
+                    side.wait_stream(main)              # inputs (and last step's optimizer / EMA writes) are ready
+            x_stu = torch.cat(stu_in, dim=0) if len(stu_in) > 1 else stu_in[0]
+            if use_unsup and side is not main and self._both_on_executor():
+                # both bodies on the MFMA executor: issue them interleaved, bottleneck by bottleneck
+                from .backbone_hip import run_body_pair
                 with torch.cuda.stream(side), torch.no_grad():
-                    tea_lo = self.teacher.forward_lowres(torch.cat(tea_in, dim=0) if len(tea_in) > 1 else tea_in[0])
-            stu_lo = self.student.forward_lowres(torch.cat(stu_in, dim=0) if len(stu_in) > 1 else stu_in[0])
-            if use_unsup:
+                    xt = self.teacher.stem_nhwc(x_tea)
+                xs = self.student.stem_nhwc(x_stu)
+                stu_lo, tea_lo = run_body_pair(self.student.hip_executor(), xs, self.teacher.hip_executor(), xt, side)
+            else:
+                if use_unsup:
+                    with torch.cuda.stream(side), torch.no_grad():
+                        tea_lo = self.teacher.forward_lowres(x_tea)
+                stu_lo = self.student.forward_lowres(x_stu)
+            if use_unsup and side is not main:
                 main.wait_stream(side)
             # dense NCHW scratch for the loss kernels (stu_lo itself may be channels-last strided)
             grad_lo = torch.zeros(stu_lo.shape, dtype=torch.float32, device=stu_lo.device)

@@ -242,10 +242,13 @@ typedef struct cms_conv_desc {
     int tile;              /* 0 = auto, else channels per workgroup: 128 / 64 / 32                               */
     int ksplit;            /* <= 1: off; else the taps are split over workgroups (fp32 y32 output only, which must
                               be zero-filled: partial sums are accumulated with atomics; bias added once)        */
-    const void* zeros;     /* >= 128 bytes of zeros in device memory: enables the direct-to-LDS loader (padded and
-                              out-of-range rows are fetched from it); NULL = register-staged loader              */
+    const void* zeros;     /* a run of zero bytes in device memory, at least 2 * cin + 128 long: enables the
+                              direct-to-LDS loader (padded / out-of-range rows are fetched from it, advancing through
+                              it like a live pixel's channel run); NULL = register-staged loader                 */
     int variant;           /* 0 = auto (direct-to-LDS, 1 stage), 1 = register-staged loader, 4 = direct-to-LDS with
-                              two stages; 2 / 3 = ablation switches (no MFMA / no loads), tools/conv_ablate.py      */
+                              two stages, 5 = two stages of 32 K-elements; 2 / 3 = ablation switches (no MFMA / no
+                              loads), tools/conv_ablate.py                                                       */
+    int zeros_bytes;       /* length of the `zeros` run (checked against 2 * cin + 128)                          */
 } cms_conv_desc;
 
 int cms_conv_igemm(const cms_conv_desc* d, void* stream);

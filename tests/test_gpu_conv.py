@@ -71,8 +71,9 @@ def test_conv_forward(ops, case, epi):
     assert float(err.mean()) <= 4e-3 * float(ref.abs().mean() + 1e-6) + 1e-4
 
 
-@pytest.mark.parametrize('variant', [0, 1, 4], ids=['direct_to_lds', 'register_staged', 'direct_to_lds_2stage'])
-@pytest.mark.parametrize('tile', [0, 128, 1128, 256, 64, 32])
+@pytest.mark.parametrize('variant', [0, 1, 4, 5], ids=['direct_to_lds', 'register_staged', 'direct_to_lds_2stage',
+                                                    'direct_to_lds_2x32'])
+@pytest.mark.parametrize('tile', [0, 128, 1128, 256, 2256, 64, 32])
 def test_conv_tile_variants_agree(ops, tile, variant):
     g = torch.Generator(device=DEV).manual_seed(5)
     x = _mk((2, 20, 23, 128), g)
@@ -200,8 +201,8 @@ def test_aspp_wgrad_padded_classes(ops):
     assert float(dw[:, C:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('variant', [0, 1], ids=['direct_to_lds', 'register_staged'])
-@pytest.mark.parametrize('tile', [0, 1128, 256, 64, 32])
+@pytest.mark.parametrize('variant', [0, 1, 5], ids=['direct_to_lds', 'register_staged', 'direct_to_lds_2x32'])
+@pytest.mark.parametrize('tile', [0, 1128, 256, 2256, 64, 32])
 @pytest.mark.parametrize('epi', ['res', 'mask', 'mask_res', 'fwd_res_relu'])
 def test_conv_epilogue_operands_through_lds(ops, epi, tile, variant):
     """Residual / ReLU-mask tiles are staged global -> LDS (swizzled rows) and consumed in accumulator layout; the

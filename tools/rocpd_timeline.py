@@ -43,5 +43,41 @@ def main(path):
             (loss_end - fwd_end) / 1e6, (t1 - loss_end) / 1e6, len(seg), qs))
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and not (len(sys.argv) > 2 and sys.argv[2] == 'gaps'):
     main(sys.argv[1])
+
+
+def gaps(path, step_index=-2, min_gap_us=15.0, top=40):
+    """Idle gaps (no kernel running on any queue) inside one step + per-queue busy time per phase."""
+    con = sqlite3.connect(path)
+    rows = con.execute('select name, start, end, queue_id, stream_id from kernels order by start').fetchall()
+    opt = [i for i, r in enumerate(rows) if 'optim_ema_kernel' in r[0]]
+    si = step_index if step_index >= 0 else len(opt) + step_index
+    seg = rows[opt[si - 1] + 1:opt[si] + 1]
+    t0 = rows[opt[si - 1]][2]
+    ce = [r for r in seg if 'ce_fwd_kernel' in r[0]]
+    fwd_end = ce[0][1] if ce else seg[-1][2]
+    print('# step', si, 'kernels', len(seg), 'wall_ms', (seg[-1][2] - t0) / 1e6, 'fwd_ms', (fwd_end - t0) / 1e6)
+    for phase, lo, hi in (('fwd', t0, fwd_end), ('bwd', fwd_end, seg[-1][2])):
+        per_q = {}
+        for r in seg:
+            if r[1] >= lo and r[1] < hi:
+                per_q.setdefault((r[3], r[4]), [0.0, 0])
+                per_q[(r[3], r[4])][0] += (r[2] - r[1]) / 1e6
+                per_q[(r[3], r[4])][1] += 1
+        print('# phase', phase, 'wall_ms %.3f' % ((hi - lo) / 1e6), {k: (round(v[0], 3), v[1]) for k, v in per_q.items()})
+    cur_e, last = t0, 'optim_ema_kernel(prev step)'
+    out = []
+    for r in seg:
+        if r[1] > cur_e + min_gap_us * 1e3:
+            out.append(((r[1] - cur_e) / 1e3, (cur_e - t0) / 1e6, last[:60], r[0][:60]))
+        if r[2] > cur_e:
+            cur_e, last = r[2], r[0]
+    out.sort(reverse=True)
+    print('# idle gaps > %g us: %d, total %.3f ms' % (min_gap_us, len(out), sum(g[0] for g in out) / 1e3))
+    for g in out[:top]:
+        print('gap_us %.1f at_ms %.3f after [%s] before [%s]' % g)
+
+
+if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == 'gaps':
+    gaps(sys.argv[1])
