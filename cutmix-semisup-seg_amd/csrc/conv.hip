@@ -737,7 +737,9 @@ __device__ __forceinline__ uint32_t wg_off(int pix, int ch) {     // byte offset
     return (uint32_t)pix * 256u + (uint32_t)slot * 64u + (uint32_t)(ch & 31) * 2u;
 }
 
-template <int TCO, int TCI>      // 32x32 MFMA tiles per wave along co / ci; waves are 2 x 2
+// PLAIN = 1x1, stride 1, no tap offset: the input pixel IS the output pixel, so the loader needs no (n, y, x) cursor and
+// no bounds test -- two thirds of the network's weight-gradient launches.
+template <int TCO, int TCI, bool PLAIN>      // 32x32 MFMA tiles per wave along co / ci; waves are 2 x 2
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int BCO = 2 * TCO * 32, BCI = 2 * TCI * 32;       // <= 128 each
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -776,10 +778,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < 4; ++i) {
         const int m = p_begin + prow + 16 * i;
         cm[i] = m;
-        cx[i] = m % a.Wo;
-        const int t = m / a.Wo;
-        cy[i] = t % a.Ho;
-        cn[i] = t / a.Ho;
+        if constexpr (!PLAIN) {
+            cx[i] = m % a.Wo;
+            const int t = m / a.Wo;
+            cy[i] = t % a.Ho;
+            cn[i] = t / a.Ho;
+        }
     }
     const uint32_t uoff = (uint32_t)(co0 + c16 * 8), xoff = (uint32_t)(ci0 + c16 * 8);
     u32x4 ru[4], rxx[4];
@@ -790,10 +794,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             rxx[i] = u32x4{0u, 0u, 0u, 0u};
             if (cm[i] < p_end) {
                 if (load_u) ru[i] = *reinterpret_cast<const u32x4*>(a.du + (size_t)((uint32_t)(cm[i] * a.Cout) + uoff));
-                const uint32_t iy = (uint32_t)(cy[i] * a.stride + dy), ix = (uint32_t)(cx[i] * a.stride + dx);
-                if (load_x && iy < (uint32_t)a.H && ix < (uint32_t)a.W)
-                    rxx[i] = *reinterpret_cast<const u32x4*>(
-                        a.x + (size_t)((uint32_t)(((cn[i] * a.H + (int)iy) * a.W + (int)ix) * a.Cin) + xoff));
+                if constexpr (PLAIN) {
+                    if (load_x) rxx[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)((uint32_t)(cm[i] * a.Cin) + xoff));
+                } else {
+                    const uint32_t iy = (uint32_t)(cy[i] * a.stride + dy), ix = (uint32_t)(cx[i] * a.stride + dx);
+                    if (load_x && iy < (uint32_t)a.H && ix < (uint32_t)a.W)
+                        rxx[i] = *reinterpret_cast<const u32x4*>(
+                            a.x + (size_t)((uint32_t)(((cn[i] * a.H + (int)iy) * a.W + (int)ix) * a.Cin) + xoff));
+                }
             }
         }
     };
@@ -801,9 +809,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             cm[i] += 64;
-            cx[i] += 64;
-            while (cx[i] >= a.Wo) { cx[i] -= a.Wo; cy[i] += 1; }
-            while (cy[i] >= a.Ho) { cy[i] -= a.Ho; cn[i] += 1; }
+            if constexpr (!PLAIN) {
+                cx[i] += 64;
+                while (cx[i] >= a.Wo) { cx[i] -= a.Wo; cy[i] += 1; }
+                while (cy[i] >= a.Ho) { cy[i] -= a.Ho; cn[i] += 1; }
+            }
         }
     };
     auto store_tile = [&]() {
@@ -921,9 +931,17 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(tiles * ksplit);
     const size_t lds = 2 * 64 * 256;
-    if (bco == 128 && bci == 128) hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), lds, s, a);
-    else if (bco == 128) hipLaunchKernelGGL((conv_wgrad_kernel<2, 1>), grid, dim3(256), lds, s, a);
-    else if (bci == 128) hipLaunchKernelGGL((conv_wgrad_kernel<1, 2>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<1, 1>), grid, dim3(256), lds, s, a);
+    const bool plain = d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho &&
+                       d->w_in == d->wo;
+#define CMS_WGRAD_LAUNCH(TCO, TCI)                                                                                   \
+    do {                                                                                                             \
+        if (plain) hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, true>), grid, dim3(256), lds, s, a);             \
+        else hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, false>), grid, dim3(256), lds, s, a);                  \
+    } while (0)
+    if (bco == 128 && bci == 128) CMS_WGRAD_LAUNCH(2, 2);
+    else if (bco == 128) CMS_WGRAD_LAUNCH(2, 1);
+    else if (bci == 128) CMS_WGRAD_LAUNCH(1, 2);
+    else CMS_WGRAD_LAUNCH(1, 1);
+#undef CMS_WGRAD_LAUNCH
     return launch_status("cms_conv_wgrad");
 }
