@@ -341,13 +341,16 @@ def main():
         }
         if args.roofline_kernel == 'conv' and launch_no[0]:
             out['roofline']['algorithmic_bytes_per_launch'] = conv_bytes[0] / launch_no[0]
-            pmc = os.path.join(REPO, 'profiles', 'r01d_pmc_traffic.json')
-            if args.workload == 'pascal' and os.path.exists(pmc):
+            import glob
+            cands = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_traffic.json')))
+            pmc = cands[-1] if cands else ''
+            if args.workload == 'pascal' and pmc:
                 # HBM bytes per launch from the TCC memory-side counters (separate FETCH_SIZE / WRITE_SIZE passes of
                 # this command under rocprofv3, gfx950 correction applied; tools/gpu_pmc_traffic.sh)
                 t = json.load(open(pmc))
                 out['roofline']['traffic'] = t['traffic_bytes_per_launch']
-                out['roofline']['traffic_source'] = 'profiles/r01d_pmc_traffic.json (rocprofv3 --pmc, bytes per launch)'
+                out['roofline']['traffic_source'] = 'profiles/{} (rocprofv3 --pmc, bytes per launch)'.format(
+                    os.path.basename(pmc))
         if isolated is not None:
             out['roofline']['isolated'] = isolated
         if timed_flops > 0:
