@@ -182,6 +182,8 @@ class DeepLabv3Wrapper(nn.Module):
         self.pretraining = pretraining
         self.compute_dtype = torch.bfloat16
         self.engine = None
+        self.engine_kind = 'auto'          # 'torch' forces the library engine for every pass
+        self._hip_executor = None
 
     # ------------------------------------------------------------------------------------------ execution
     def _engine(self, x):
@@ -195,11 +197,33 @@ class DeepLabv3Wrapper(nn.Module):
             _ENGINES[key] = TorchEngine(self.compute_dtype)
         return _ENGINES[key]
 
+    def _use_hip_backbone(self):
+        """The MFMA executor runs the backbone of every pass that needs no gradient (teacher passes, evaluation) when
+        its BatchNorms are frozen and compute is bf16; passes that train stay on the library engine for now."""
+        if self.engine is not None or self.engine_kind == 'torch' or self.compute_dtype != torch.bfloat16:
+            return False
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        frozen = all(not m.training for m in self.deeplab.backbone.modules() if isinstance(m, nn.BatchNorm2d))
+        return frozen and not need_grad
+
+    def hip_executor(self):
+        if self._hip_executor is None:
+            from ..backbone_hip import DeepLabV3PlusBackboneExecutor
+            self._hip_executor = DeepLabV3PlusBackboneExecutor(self)
+        return self._hip_executor
+
     def forward_lowres(self, x):
         """(N,3,H,W) -> fp32 (N,C,h,w) logits at the low-level feature size (the reference's tensor just before its
         final interpolate, deeplab3plus.py:76)."""
         eng = self._engine(x)
-        feats = self.deeplab.backbone(eng.prepare_input(x), eng)
+        if x.is_cuda and self._use_hip_backbone():
+            bb = self.deeplab.backbone
+            y = eng.conv_bn_act(eng.prepare_input(x), bb['conv1'], bb['bn1'], relu=True)
+            y = F.max_pool2d(y, kernel_size=3, stride=2, padding=1)
+            low, out = self.hip_executor().forward_taps(y.permute(0, 2, 3, 1).contiguous())
+            feats = {'low_level': low.permute(0, 3, 1, 2), 'out': out.permute(0, 3, 1, 2)}    # channels-last views
+        else:
+            feats = self.deeplab.backbone(eng.prepare_input(x), eng)
         return self.deeplab.classifier(feats, eng)
 
     def forward(self, x, feature_maps=False, use_dropout=False):

@@ -45,23 +45,9 @@ class _Block(object):
 
 class DeepLabHipExecutor(object):
     def __init__(self, net):
-        self.net = net
-        self.trainable = any(p.requires_grad for p in net.parameters())
-        self.arena = ensure_arena(net, with_grad=self.trainable, with_bf16=True)
+        self._init_common(net)
         self.num_classes = net.num_classes
-        self.blocks = []
-        for li in range(1, 5):
-            layer = getattr(net, 'layer{}'.format(li))
-            for bi, blk in enumerate(layer):
-                pre = 'layer{}.{}'.format(li, bi)
-                b = _Block()
-                b.c1 = _Conv(pre + '.conv1.weight', pre + '.bn1', blk.conv1)
-                b.c2 = _Conv(pre + '.conv2.weight', pre + '.bn2', blk.conv2)
-                b.c3 = _Conv(pre + '.conv3.weight', pre + '.bn3', blk.conv3)
-                b.cd = None
-                if blk.downsample is not None:
-                    b.cd = _Conv(pre + '.downsample.0.weight', pre + '.downsample.1', blk.downsample[0])
-                self.blocks.append(b)
+        self._add_blocks('', [getattr(net, 'layer{}'.format(li)) for li in range(1, 5)])
         head = net.layer5.conv2d_list
         self.aspp_keys = ['layer5.conv2d_list.0', 'layer5.conv2d_list.1']
         self.aspp_taps = []
@@ -76,6 +62,16 @@ class DeepLabHipExecutor(object):
         self.aspp_w32 = torch.zeros(18, 32, 2048, dtype=torch.bfloat16, device=dev)   # forward operand (padded to 32)
         self.aspp_wT = torch.zeros(18, 2048, 64, dtype=torch.bfloat16, device=dev)
         self.aspp_bias = torch.zeros(32, dtype=torch.float32, device=dev)
+
+    def _init_common(self, net):
+        self.net = net
+        self.trainable = any(p.requires_grad for p in net.parameters())
+        # BatchNorm affine parameters that train (torchvision-style backbones) move with every optimizer step
+        self.bn_trainable = any(p.requires_grad for m in net.modules() if 'BatchNorm' in type(m).__name__
+                                for p in m.parameters())
+        self.arena = ensure_arena(net, with_grad=self.trainable, with_bf16=True)
+        self.blocks = []
+        self._layer_first = []
         self._affine_ready = False
         self._bn_idx = None
         self._side = None
@@ -86,6 +82,21 @@ class DeepLabHipExecutor(object):
         self._wT_version = -1
         self.version = 0          # bumped whenever the weights change (optimizer step / load_state_dict)
         net.register_load_state_dict_post_hook(lambda module, incompatible: self.invalidate())
+
+    def _add_blocks(self, prefix, layers):
+        """`layers`: the four nn.Sequential stages of bottlenecks; `prefix`: state-dict prefix of 'layer1' .. 'layer4'."""
+        for li, layer in enumerate(layers):
+            self._layer_first.append(len(self.blocks))
+            for bi, blk in enumerate(layer):
+                pre = '{}layer{}.{}'.format(prefix, li + 1, bi)
+                b = _Block()
+                b.c1 = _Conv(pre + '.conv1.weight', pre + '.bn1', blk.conv1)
+                b.c2 = _Conv(pre + '.conv2.weight', pre + '.bn2', blk.conv2)
+                b.c3 = _Conv(pre + '.conv3.weight', pre + '.bn3', blk.conv3)
+                b.cd = None
+                if blk.downsample is not None:
+                    b.cd = _Conv(pre + '.downsample.0.weight', pre + '.downsample.1', blk.downsample[0])
+                self.blocks.append(b)
 
     # ------------------------------------------------------------------------------------------ weights / affine
     def invalidate(self):
@@ -99,7 +110,7 @@ class DeepLabHipExecutor(object):
         (the EMA runs over the running statistics and affine parameters too, optim_weight_ema.py:21-25; even for
         equal source and target its three roundings can move a value by an ulp) -> re-fold scale / bias."""
         self.version += 1
-        if bn_too:
+        if bn_too or self.bn_trainable:
             self._affine_ready = False
 
     def block_grad_offsets(self):
@@ -107,11 +118,7 @@ class DeepLabHipExecutor(object):
         return [self.arena.by_key[b.c1.wkey].offset for b in self.blocks]
 
     def layer_first_blocks(self):
-        out, n = [], 0
-        for li in range(1, 5):
-            out.append(n)
-            n += len(getattr(self.net, 'layer{}'.format(li)))
-        return out
+        return list(self._layer_first)
 
     def _all_convs(self):
         for b in self.blocks:
@@ -299,6 +306,35 @@ class DeepLabHipExecutor(object):
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.arena.device)
         return self._side
+
+
+class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
+    """
+    Forward-only executor of the DeepLab v3+ backbone (ResNet-101 v1.5, layer3 / layer4 dilated) on the MFMA
+    convolution kernels: the teacher's passes and evaluation, i.e. every pass that needs no gradient. Returns the two
+    taps the head consumes (architectures/deeplab3plus.py:96-98). The student's passes stay on the library engine
+    until the backward chain learns this network's two extras: a strided 3x3 (`layer2.0.conv2`: a true
+    transposed-convolution data gradient) and trainable BatchNorm affine parameters in a frozen-statistics backbone.
+    """
+
+    def __init__(self, wrapper):
+        self._init_common(wrapper)
+        bb = wrapper.deeplab.backbone
+        self._add_blocks('deeplab.backbone.', [bb['layer{}'.format(li)] for li in range(1, 5)])
+        self.tap_low = self._layer_first[1] - 1          # last bottleneck of layer1
+
+    def forward_taps(self, x):
+        """x: bf16 NHWC stem output -> (low_level (N,h/4,w/4,256), out (N,h/8,w/8,2048)), both bf16 NHWC."""
+        st = self.fwd_begin(x, False)
+        low = None
+        for bi in range(len(self.blocks)):
+            self.fwd_block(st, bi)
+            if bi == self.tap_low:
+                low = st['cur']
+        return low, st['cur']
+
+    def backward(self, saved, dlogits):
+        raise NotImplementedError('the DeepLab v3+ executor is forward-only (teacher / evaluation passes)')
 
 
 class _BodyFn(torch.autograd.Function):

@@ -188,3 +188,62 @@ def test_bf16_step_at_cfg4_geometry_is_finite():
     assert 2.0 < float(r['sup_loss']) < 6.0                    # ~ln(21) at random init
     assert not torch.equal(w0, stu.state_dict()['deeplab.classifier.classifier.6.weight'])
     assert all(torch.isfinite(v).all() for v in tea.state_dict().values() if v.dtype == torch.float32)
+
+
+def test_no_grad_passes_run_the_backbone_on_the_mfma_executor():
+    """Teacher / evaluation passes: backbone on csrc/conv.hip (fused conv + frozen BN + ReLU + residual, incl. the
+    strided 3x3 of layer2.0 and the 1,2,2.. / 2,4,4 dilation pattern), head on the library engine. Compared with the
+    all-library bf16 path on the same weights and with the fp32 oracle."""
+    from oracle import deeplab3plus as o3
+    from cutmix_semisup_seg_amd.backbone_hip import DeepLabV3PlusBackboneExecutor
+    layers, C = (2, 2, 3, 2), 6
+    st = _he_state(C, layers)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 3, 97, 129, generator=g)
+    hip, lib = _net(C, layers, torch.bfloat16, st), _net(C, layers, torch.bfloat16, st)
+    lib.engine_kind = 'torch'
+    for net in (hip, lib):
+        net.train()
+        net.freeze_batchnorm()                     # the teacher's state in the training loop (Q4): head in train mode
+    with torch.no_grad():
+        a = hip.forward_lowres(x.to(DEV)).cpu()
+        b = lib.forward_lowres(x.to(DEV)).cpu()
+    assert isinstance(hip._hip_executor, DeepLabV3PlusBackboneExecutor) and lib._hip_executor is None
+    ref = o3.forward_lowres(x, st, layers, backbone_frozen=True, head_frozen=False)
+    ea, eb = float((a - ref).norm() / ref.norm()), float((b - ref).norm() / ref.norm())
+    assert ea <= max(1.5 * eb, 2e-2), (ea, eb)               # not worse than the library's bf16 path
+    # a pass that trains stays on the library engine
+    y = hip.forward_lowres(x.to(DEV))
+    assert y.requires_grad
+    # The two taps themselves against the fp32 oracle backbone (the random-weight head in eval mode amplifies any input
+    # difference by an order of magnitude, so the logits are no yardstick there): one rounding per fused layer makes
+    # the hand-written path slightly MORE accurate than the library's conv / BN / add / ReLU sequence.
+    from cutmix_semisup_seg_amd.architectures.deeplab2 import TorchEngine
+    import torch.nn.functional as F
+    eng = TorchEngine(torch.bfloat16)
+
+    def taps(net, use_hip):
+        bb = net.deeplab.backbone
+        y = eng.conv_bn_act(eng.prepare_input(x.to(DEV)), bb['conv1'], bb['bn1'], relu=True)
+        y = F.max_pool2d(y, kernel_size=3, stride=2, padding=1)
+        if use_hip:
+            low, out = net.hip_executor().forward_taps(y.permute(0, 2, 3, 1).contiguous())
+            return low.permute(0, 3, 1, 2).float().cpu(), out.permute(0, 3, 1, 2).float().cpu()
+        f = bb(eng.prepare_input(x.to(DEV)), eng)
+        return f['low_level'].float().cpu(), f['out'].float().cpu()
+
+    hip.eval()
+    lib.eval()
+    with torch.no_grad():
+        ref_low, ref_out = o3.backbone(x, st, layers)
+        for (h, l, r) in zip(taps(hip, True), taps(lib, False), (ref_low, ref_out)):
+            eh, el = float((h - r).norm() / r.norm()), float((l - r).norm() / r.norm())
+            assert eh <= 1.5e-2 and eh <= 1.1 * el, (eh, el)
+        # the executor follows weight updates made behind its back (load_state_dict hook)
+        e1 = taps(hip, True)[1]
+        st2 = {k: (v * 1.25 if k.endswith('layer3.1.conv2.weight') else v) for k, v in st.items()}
+        hip.load_state_dict(st2)
+        e2 = taps(hip, True)[1]
+        ref2 = o3.backbone(x, st2, layers)[1]
+        assert float((e2 - ref2).norm() / ref2.norm()) <= 1.5e-2
+        assert float((e2 - e1).norm()) > 10 * float((e2 - ref2).norm())          # the update is what moved it
