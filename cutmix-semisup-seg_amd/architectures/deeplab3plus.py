@@ -182,7 +182,7 @@ class DeepLabv3Wrapper(nn.Module):
         self.pretraining = pretraining
         self.compute_dtype = torch.bfloat16
         self.engine = None
-        self.engine_kind = 'auto'          # 'torch' forces the library engine for every pass
+        self.engine_kind = 'auto'          # 'torch': library engine for every pass; 'hip_nograd': executor only without grad
         self._hip_executor = None
 
     # ------------------------------------------------------------------------------------------ execution
@@ -198,13 +198,14 @@ class DeepLabv3Wrapper(nn.Module):
         return _ENGINES[key]
 
     def _use_hip_backbone(self):
-        """The MFMA executor runs the backbone of every pass that needs no gradient (teacher passes, evaluation) when
-        its BatchNorms are frozen and compute is bf16; passes that train stay on the library engine for now."""
+        """The MFMA executor (backbone_hip.DeepLabV3PlusBackboneExecutor) runs the backbone whenever its BatchNorm
+        statistics are frozen and compute is bf16 -- training passes included; `engine_kind = 'hip_nograd'` restricts
+        it to passes that need no gradient, 'torch' switches it off."""
         if self.engine is not None or self.engine_kind == 'torch' or self.compute_dtype != torch.bfloat16:
             return False
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        frozen = all(not m.training for m in self.deeplab.backbone.modules() if isinstance(m, nn.BatchNorm2d))
-        return frozen and not need_grad
+        if self.engine_kind == 'hip_nograd' and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return False
+        return all(not m.training for m in self.deeplab.backbone.modules() if isinstance(m, nn.BatchNorm2d))
 
     def hip_executor(self):
         if self._hip_executor is None:
@@ -220,7 +221,8 @@ class DeepLabv3Wrapper(nn.Module):
             bb = self.deeplab.backbone
             y = eng.conv_bn_act(eng.prepare_input(x), bb['conv1'], bb['bn1'], relu=True)
             y = F.max_pool2d(y, kernel_size=3, stride=2, padding=1)
-            low, out = self.hip_executor().forward_taps(y.permute(0, 2, 3, 1).contiguous())
+            from ..backbone_hip import run_v3_body
+            low, out = run_v3_body(self.hip_executor(), y.permute(0, 2, 3, 1).contiguous())
             feats = {'low_level': low.permute(0, 3, 1, 2), 'out': out.permute(0, 3, 1, 2)}    # channels-last views
         else:
             feats = self.deeplab.backbone(eng.prepare_input(x), eng)

@@ -27,16 +27,19 @@ from .arena import ensure_arena
 
 
 class _Conv(object):
-    __slots__ = ('wkey', 'bn', 'taps', 'ntaps', 'neg_taps', 'stride', 'cin', 'cout', 'scale', 'bias', 'wT')
+    __slots__ = ('wkey', 'bn', 'taps', 'ntaps', 'neg_taps', 'stride', 'cin', 'cout', 'scale', 'bias', 'wT', 'ksize',
+                 'pad', 'dil', 'wdot', 'dbeta')
 
     def __init__(self, wkey, bn, conv):
         self.wkey, self.bn = wkey, bn
         kh, kw = conv.kernel_size
+        self.ksize, self.pad, self.dil = kh, conv.padding[0], conv.dilation[0]
         self.taps = ops.conv_taps(kh, kw, conv.dilation[0], conv.padding[0])
         self.neg_taps = [(-dy, -dx) for dy, dx in self.taps]
         self.stride = conv.stride[0]
         self.cin, self.cout = conv.in_channels, conv.out_channels
         self.scale = self.bias = self.wT = None
+        self.wdot = self.dbeta = None      # side outputs of the weight gradient when the BN affine trains
 
 
 class _Block(object):
@@ -145,6 +148,11 @@ class DeepLabHipExecutor(object):
         self._bias_all = torch.zeros(off, dtype=torch.float32, device=dev)
         for c, lo, hi in spans:
             c.scale, c.bias = self._scale_all[lo:hi], self._bias_all[lo:hi]
+        if self.bn_trainable and self.trainable:
+            self._wdot_all = torch.zeros(off, dtype=torch.float32, device=dev)
+            self._dbeta_all = torch.zeros(off, dtype=torch.float32, device=dev)
+            for c, lo, hi in spans:
+                c.wdot, c.dbeta = self._wdot_all[lo:hi], self._dbeta_all[lo:hi]
 
     def _refresh_affine(self):
         """scale = gamma / sqrt(var + eps), bias = beta - mean * scale  (frozen BN, deeplab2.py:92-107)."""
@@ -177,7 +185,8 @@ class DeepLabHipExecutor(object):
                 w = self._w(c)
                 c.wT = torch.empty((w.shape[0], w.shape[2], w.shape[1]), dtype=torch.bfloat16, device=w.device)
                 triples.append((w, c.wT, c.scale))
-            triples.append((self.aspp_w, self.aspp_wT, None))
+            if hasattr(self, 'aspp_w'):
+                triples.append((self.aspp_w, self.aspp_wT, None))
             self._pack_plan = ops.PackTransposePlan(triples)
         self._pack_plan.run()
 
@@ -234,7 +243,11 @@ class DeepLabHipExecutor(object):
 
     # ------------------------------------------------------------------------------------------ backward
     def _wgrad(self, du, x, c):
-        ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride, scale=c.scale)
+        if c.wdot is not None:
+            ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride, scale=c.scale,
+                           w_bf16=self._w(c), wdot=c.wdot, dbeta=c.dbeta)
+        else:
+            ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride, scale=c.scale)
 
     def _dgrad(self, du, c, res=None, mask=None, in_hw=None):
         """gradient wrt the input of conv `c`; `in_hw` = spatial size of that input (needed for stride 2)."""
@@ -310,11 +323,18 @@ class DeepLabHipExecutor(object):
 
 class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
     """
-    Forward-only executor of the DeepLab v3+ backbone (ResNet-101 v1.5, layer3 / layer4 dilated) on the MFMA
-    convolution kernels: the teacher's passes and evaluation, i.e. every pass that needs no gradient. Returns the two
-    taps the head consumes (architectures/deeplab3plus.py:96-98). The student's passes stay on the library engine
-    until the backward chain learns this network's two extras: a strided 3x3 (`layer2.0.conv2`: a true
-    transposed-convolution data gradient) and trainable BatchNorm affine parameters in a frozen-statistics backbone.
+    Executor of the DeepLab v3+ backbone (torchvision-style ResNet-101 v1.5, layer3 / layer4 dilated, frozen BatchNorm
+    statistics) on the MFMA convolution kernels, forward and backward. Returns the two taps the head consumes
+    (architectures/deeplab3plus.py:96-98). What differs from the DeepLab v2 body:
+
+      * the 3x3 carries the stride (`layer2.0.conv2`): its data gradient is a true transposed convolution, the one
+        launch of the chain that goes through the library;
+      * the BatchNorm affine parameters TRAIN although the statistics are frozen (torchvision leaves them trainable,
+        `freeze_batchnorm()` only switches the statistics): with G = sum_p dU x the unscaled weight gradient,
+        d(bias) = sum_p dU and d(weight) = (<W, G> - mean * d(bias)) / sqrt(var + eps) -- both come out of the weight
+        gradient kernel as side outputs (cms_wgrad_desc.wdot / dbeta), exact and without dividing by the weight;
+      * two outputs (layer1 -> 'low_level', layer4 -> 'out'), so the backward chain takes a second gradient in at the
+        layer1 / layer2 boundary.
     """
 
     def __init__(self, wrapper):
@@ -323,18 +343,110 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
         self._add_blocks('deeplab.backbone.', [bb['layer{}'.format(li)] for li in range(1, 5)])
         self.tap_low = self._layer_first[1] - 1          # last bottleneck of layer1
 
-    def forward_taps(self, x):
-        """x: bf16 NHWC stem output -> (low_level (N,h/4,w/4,256), out (N,h/8,w/8,2048)), both bf16 NHWC."""
-        st = self.fwd_begin(x, False)
+    def forward_taps(self, x, save=False):
+        """x: bf16 NHWC stem output -> (low_level (N,h/4,w/4,256), out (N,h/8,w/8,2048)) bf16 NHWC [, saved]."""
+        st = self.fwd_begin(x, save)
         low = None
         for bi in range(len(self.blocks)):
             self.fwd_block(st, bi)
             if bi == self.tap_low:
                 low = st['cur']
+        if save:
+            st['saved'].append(st['cur'])
+            return low, st['cur'], st['saved']
         return low, st['cur']
 
+    def _dgrad_strided(self, du, c, mask, in_hw):
+        """Data gradient of a strided k x k convolution (+ ReLU mask of its input) through the library."""
+        n = du.shape[0]
+        w = (self.arena.view(c.wkey) * c.scale.view(-1, 1, 1, 1)).to(torch.bfloat16)
+        g = torch.nn.grad.conv2d_input((n, c.cin, in_hw[0], in_hw[1]), w, du.permute(0, 3, 1, 2), stride=c.stride,
+                                       padding=c.pad, dilation=c.dil)
+        g = g.permute(0, 2, 3, 1)
+        if mask is not None:
+            g = g * (mask > 0)
+        return g.contiguous()
+
+    def backward_taps(self, saved, d_low, d_out):
+        """Gradients wrt the two taps (bf16 NHWC or None) -> gradient wrt the stem output; weight and BatchNorm-affine
+        gradients are accumulated into the arena."""
+        if self._wT_version != self.version or self.blocks[0].c1.wT is None:
+            self._refresh_backward_weights()
+            self._wT_version = self.version
+        x4 = saved[-1]
+        track_bn = self.bn_trainable
+        if track_bn:
+            self._wdot_all.zero_()
+            self._dbeta_all.zero_()
+        if d_out is None:
+            d_out = torch.zeros_like(x4)
+        dC = (d_out * (x4 > 0)).contiguous()
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_wgrad else None
+        keep = []
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            b = self.blocks[bi]
+            xin, a1, a2 = saved[bi]
+            in_hw = (xin.shape[1], xin.shape[2])
+            dU2 = self._dgrad(dC, b.c3, mask=a2)
+            if b.c2.stride == 1:
+                dU1 = self._dgrad(dU2, b.c2, mask=a1)
+            else:
+                dU1 = self._dgrad_strided(dU2, b.c2, a1, (a1.shape[1], a1.shape[2]))
+            if side is not None:
+                side.wait_stream(main)
+                keep.append((dC, dU2, dU1))
+                with torch.cuda.stream(side):
+                    self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
+            else:
+                self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
+            dres = dC if b.cd is None else self._dgrad(dC, b.cd, in_hw=in_hw)
+            if bi == self.tap_low + 1 and d_low is not None:
+                dres = dres + d_low            # second gradient into the layer1 output; masked with it just below
+            dC = self._dgrad(dU1, b.c1, res=dres, mask=None if bi == 0 else xin, in_hw=in_hw)
+        if side is not None:
+            main.wait_stream(side)
+        del keep
+        if track_bn:
+            a, ix = self.arena, self._bn_idx
+            dgamma = (self._wdot_all - a.flat[ix['running_mean']] * self._dbeta_all) * \
+                torch.rsqrt(a.flat[ix['running_var']] + 1e-5)
+            a.grad.index_add_(0, ix['weight'], dgamma)
+            a.grad.index_add_(0, ix['bias'], self._dbeta_all)
+        return dC
+
     def backward(self, saved, dlogits):
-        raise NotImplementedError('the DeepLab v3+ executor is forward-only (teacher / evaluation passes)')
+        raise NotImplementedError('use backward_taps')
+
+
+class _V3BodyFn(torch.autograd.Function):
+    """DeepLab v3+ backbone (after the stem) as one autograd node with two outputs."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, executor, need_grad):
+        if need_grad:
+            low, out, saved = executor.forward_taps(x_nhwc, save=True)
+        else:
+            low, out = executor.forward_taps(x_nhwc, save=False)
+            saved = None
+        ctx.executor = executor
+        ctx.saved_acts = saved
+        return low, out
+
+    @staticmethod
+    def backward(ctx, d_low, d_out):
+        dx = ctx.executor.backward_taps(ctx.saved_acts,
+                                        None if d_low is None else d_low.contiguous().to(torch.bfloat16),
+                                        None if d_out is None else d_out.contiguous().to(torch.bfloat16))
+        ctx.saved_acts = None
+        return dx, None, None
+
+
+def run_v3_body(executor, x_nhwc):
+    need_grad = torch.is_grad_enabled() and executor.trainable
+    if need_grad and not x_nhwc.requires_grad:
+        x_nhwc = x_nhwc.detach().requires_grad_(True)
+    return _V3BodyFn.apply(x_nhwc, executor, need_grad)
 
 
 class _BodyFn(torch.autograd.Function):

@@ -727,6 +727,9 @@ struct WgradArgs {
     int M;                 // N*Ho*Wo
     int ksplit, pix_per_split;   // pixel slice per workgroup (multiple of 64)
     int cout_real;         // rows >= cout_real are not written (padded class axis)
+    const uint16_t* w;     // bf16 [ntaps][Cout][Cin] or NULL   } side outputs for a trainable BN affine:
+    float* wdot;           // [Cout] += <W, G> per output channel } see cms_wgrad_desc
+    float* dbeta;          // [Cout] += sum_p dU[p][co]
     short tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
 };
 
@@ -833,6 +836,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // sum_p dU[p][co] as one more GEMM column: the dU fragments are multiplied with an all-ones operand (bf16 1.0) in
+    // the workgroups of ci-tile 0 / tap 0 (every pixel slice once), waves wci == 0; all 32 columns come out equal
+    const bool do_beta = a.dbeta != nullptr && tci == 0 && tap == 0 && wci == 0;
+    f32x16 accb[TCO];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.0f;
+    const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+
     // transpose-read geometry of this lane: 16-lane group g, lane-in-group li
     const int g = lane >> 4, li = lane & 15;
     const int ch_in_tile = 16 * (g & 1) + 4 * (li & 3);     // channel chunk this lane SUPPLIES (within a 32-wide tile)
@@ -875,6 +888,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 for (int j = 0; j < TCI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fu[i]),
                                                                         __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
+            if (do_beta) {                                  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fu[i]),
+                                                                      __builtin_bit_cast(bf16x8, ones), accb[i], 0, 0, 0);
+            }
         }
     }
 
@@ -888,11 +907,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
             if (co >= a.cout_real) continue;
             const float s = a.scale ? a.scale[co] : 1.0f;
+            float dot = 0.0f;
 #pragma unroll
             for (int j = 0; j < TCI; ++j) {
                 const int ci = ci0 + (wci * TCI + j) * 32 + fcol;
-                atomicAdd(dwt + (size_t)co * a.Cin + ci, acc[i][j][r] * s);
+                const size_t e = (size_t)co * a.Cin + ci;
+                if (a.wdot) dot += acc[i][j][r] * bf16_to_f32(a.w[(size_t)tap * a.Cout * a.Cin + e]);
+                atomicAdd(dwt + e, acc[i][j][r] * s);
             }
+            if (a.wdot) {                                    // row sum over the 32 lanes that share this row
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);
+                if (fcol == 0) atomicAdd(a.wdot + co, dot);
+            }
+            if (do_beta && fcol == 0) atomicAdd(a.dbeta + co, accb[i][r]);
         }
     }
 }
@@ -912,6 +940,8 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     a.ntaps = d->ntaps; a.stride = d->stride;
     a.M = d->n * d->ho * d->wo;
     a.cout_real = d->cout_real > 0 ? d->cout_real : d->cout;
+    a.w = (const uint16_t*)d->w; a.wdot = d->wdot; a.dbeta = d->dbeta;
+    CMS_REQUIRE((d->wdot == nullptr) == (d->w == nullptr), "conv_wgrad: wdot needs the bf16 weights (w) and vice versa");
     for (int i = 0; i < CMS_CONV_MAX_TAPS; ++i) {
         a.tap_dy[i] = (short)(i < d->ntaps ? d->tap_dy[i] : 0);
         a.tap_dx[i] = (short)(i < d->ntaps ? d->tap_dx[i] : 0);

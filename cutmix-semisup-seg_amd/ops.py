@@ -484,7 +484,7 @@ class PackTransposePlan(object):
                                                   _stream()), 'cms_conv_pack_transpose_batch')
 
 
-def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0):
+def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, w_bf16=None, wdot=None, dbeta=None):
     """
     dw (fp32 (ntaps, Cout, Cin), accumulated into) += scale[co] * sum_pixels du[pix][co] * x[pix + tap][ci].
     du bf16 (N, Ho, Wo, Cout), x bf16 (N, H, W, Cin), both NHWC-contiguous.
@@ -508,5 +508,10 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0):
         d.tap_dy[i], d.tap_dx[i] = int(dy), int(dx)
     d.stride = int(stride)
     d.ksplit = int(ksplit)
+    # side outputs for a trainable BatchNorm affine behind this convolution (see cms_wgrad_desc)
+    _need_cuda(w_bf16, wdot, dbeta)
+    d.w = w_bf16.data_ptr() if w_bf16 is not None else None
+    d.wdot = wdot.data_ptr() if wdot is not None else None
+    d.dbeta = dbeta.data_ptr() if dbeta is not None else None
     check(fn['cms_conv_wgrad'](C.byref(d), _stream()), 'cms_conv_wgrad')
     return dw

@@ -285,6 +285,15 @@ typedef struct cms_wgrad_desc {
     int tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
     int stride;
     int ksplit;            /* 0 = auto                                                                             */
+    /* Optional side outputs for a TRAINABLE BatchNorm affine behind the convolution (frozen statistics; torchvision
+     * style backbones, architectures/deeplab3plus.py:89-98): with G = the unscaled weight gradient sum_p dU x,
+     *   wdot[co]  += <W[.][co][.], G[.][co][.]>  (over taps and input channels; W = the bf16 forward operand)
+     *   dbeta[co] += sum over pixels of dU[pix][co]
+     * from which  d(bias) = dbeta  and  d(weight) = (wdot - running_mean * dbeta) / sqrt(running_var + eps)  --
+     * exact, and no division by the BatchNorm weight. All three NULL = off.                                          */
+    const void* w;         /* bf16 [ntaps][cout][cin]                                                              */
+    float* wdot;           /* fp32 [cout], accumulated with atomics                                                */
+    float* dbeta;          /* fp32 [cout], accumulated with atomics                                                */
 } cms_wgrad_desc;
 
 int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream);

@@ -44,6 +44,7 @@ int main(void) {
          offsetof(cms_optim_desc, grad_scale));
   printf("%zu %zu %zu %zu %zu\n", sizeof(cms_conv_desc), sizeof(cms_wgrad_desc), sizeof(cms_pack_item),
          offsetof(cms_conv_desc, zeros), offsetof(cms_wgrad_desc, stride));
+  printf("%zu\n", offsetof(cms_wgrad_desc, dbeta));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -65,6 +66,7 @@ int main(void) {
     assert sizes[9] == ctypes.sizeof(_lib.PackItem)
     assert sizes[10] == _lib.ConvDesc.zeros.offset
     assert sizes[11] == _lib.WgradDesc.stride.offset
+    assert sizes[12] == _lib.WgradDesc.dbeta.offset
 
 
 def test_bad_arguments_come_back_as_error_codes_not_crashes():

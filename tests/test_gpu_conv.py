@@ -253,3 +253,34 @@ def test_conv_dgrad_stride2_scatter_with_mask_and_residual(ops):
     sel[:, ::2, ::2] = True
     ref = torch.where(sel, (ref + res.float()) * (xin.float() > 0), torch.zeros_like(ref))
     assert float((dx.float() - ref).abs().max()) <= 1e-2 * float(ref.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize('case', [('1x1_plain', 2, 19, 23, 128, 256, 1, 1, 1), ('3x3_d2', 2, 17, 19, 128, 128, 3, 2, 1),
+                                  ('3x3_s2', 2, 21, 23, 64, 64, 3, 1, 2), ('1x1_s2', 2, 21, 23, 256, 128, 1, 1, 2)],
+                         ids=lambda c: c[0])
+def test_conv_wgrad_batchnorm_affine_side_outputs(ops, case):
+    """wdot[co] = <W[.][co][.], G[.][co][.]> with G the unscaled weight gradient, dbeta[co] = sum_p dU[p][co]: what the
+    gradient of a trainable BatchNorm affine behind the convolution is assembled from (cms_wgrad_desc)."""
+    name, N, H, W, Cin, Cout, k, dil, stride = case
+    g = torch.Generator(device=DEV).manual_seed(31)
+    pad = dil * (k - 1) // 2
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = _mk((N, H, W, Cin), g)
+    du = _mk((N, Ho, Wo, Cout), g)
+    w = _mk((Cout, Cin, k, k), g, (1.0 / (Cin * k * k)) ** 0.5)
+    scale = torch.rand(Cout, generator=g, device=DEV) + 0.5
+    dw = torch.zeros(k * k, Cout, Cin, device=DEV)
+    wdot = torch.zeros(Cout, device=DEV)
+    dbeta = torch.zeros(Cout, device=DEV)
+    ops.conv_wgrad(du, x, ops.conv_taps(k, k, dil, pad), dw, stride=stride, scale=scale, w_bf16=_pack(w), wdot=wdot,
+                   dbeta=dbeta)
+    xr = x.float().permute(0, 3, 1, 2)
+    wr = w.float().clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride, pad, dil).backward(du.float().permute(0, 3, 1, 2))
+    G = wr.grad                                                       # (Cout, Cin, k, k), unscaled
+    ref_dot = (G * w.float()).sum(dim=(1, 2, 3))
+    ref_beta = du.float().sum(dim=(0, 1, 2))
+    assert float((wdot - ref_dot).abs().max()) <= 2e-3 * float(ref_dot.abs().max()) + 1e-3
+    assert float((dbeta - ref_beta).abs().max()) <= 2e-3 * float(ref_beta.abs().max()) + 1e-3
+    ref_dw = (G * scale.view(-1, 1, 1, 1)).permute(2, 3, 0, 1).reshape(k * k, Cout, Cin)
+    assert float((dw - ref_dw).abs().max()) <= 2e-3 * float(ref_dw.abs().max()) + 1e-3

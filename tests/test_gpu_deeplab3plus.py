@@ -247,3 +247,41 @@ def test_no_grad_passes_run_the_backbone_on_the_mfma_executor():
         ref2 = o3.backbone(x, st2, layers)[1]
         assert float((e2 - ref2).norm() / ref2.norm()) <= 1.5e-2
         assert float((e2 - e1).norm()) > 10 * float((e2 - ref2).norm())          # the update is what moved it
+
+
+def test_training_pass_on_the_executor_matches_the_library_gradients():
+    """Forward + backward of the backbone on the MFMA executor (incl. the library-run strided 3x3 data gradient and the
+    BatchNorm-affine gradients assembled from the weight-gradient side outputs) against the fp32 library engine;
+    yardstick: the library's own bf16 path."""
+    layers, C = (2, 2, 3, 2), 6
+    st = _he_state(C, layers)
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(4, 3, 97, 129, generator=g).to(DEV)
+    tgt = torch.randn(4, C, 25, 33, generator=g).to(DEV)
+
+    def grads(dtype, kind):
+        net = _net(C, layers, dtype, st)
+        net.engine_kind = kind
+        net.eval()                                   # every BatchNorm on running statistics: a clean comparison
+        out = net.forward_lowres(x)
+        ((out - tgt) ** 2).mean().backward()
+        used = net._hip_executor is not None
+        return {k: p.grad.float().cpu() for k, p in net.named_parameters()}, used
+
+    ref, _ = grads(torch.float32, 'torch')
+    lib, used_l = grads(torch.bfloat16, 'torch')
+    hip, used_h = grads(torch.bfloat16, 'auto')
+    assert used_h and not used_l
+    worst = []
+    for k in ref:
+        r = ref[k]
+        eh = float((hip[k] - r).norm() / (r.norm() + 1e-30))
+        el = float((lib[k] - r).norm() / (r.norm() + 1e-30))
+        worst.append((eh / max(el, 1e-3), k, eh, el))
+        assert eh <= max(1.75 * el, 5e-2), (k, eh, el)
+    ratios = sorted(w[0] for w in worst)
+    assert ratios[len(ratios) // 2] <= 1.15, ratios[len(ratios) // 2]      # typically no worse than the library
+    # the BatchNorm affine gradients of the backbone really come from the executor
+    for k in ('deeplab.backbone.layer2.0.bn2.weight', 'deeplab.backbone.layer3.1.bn3.bias',
+              'deeplab.backbone.layer1.0.downsample.1.weight'):
+        assert float(hip[k].abs().max()) > 0
