@@ -14,4 +14,14 @@ Layout
 
 Import as `cutmix_semisup_seg_amd` (alias package next to this directory).
 """
+import os as _os
+
+# The few convolutions still run by the library (stem; the DeepLab v3+ head) go through MIOpen's solver search on
+# their first call. On gfx950 that search also times MIOpen's naive reference kernels -- up to 0.8 s PER CALL, ~45 s of
+# GPU time per process for the DeepLab v3+ head (rocprofv3: naive_conv_ab_nonpacked_*). They can never win; take them
+# out of the search unless the user has said otherwise.
+for _k in ('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', 'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD',
+           'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW'):
+    _os.environ.setdefault(_k, '0')
+
 __version__ = '0.1.0'
