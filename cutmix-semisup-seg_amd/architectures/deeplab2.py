@@ -110,8 +110,11 @@ class TorchEngine(object):
     def prepare_input(self, x):
         return x.to(dtype=self.dtype, memory_format=torch.channels_last)
 
+    def conv2d(self, x, conv):
+        return F.conv2d(x, self._weight(conv), None, conv.stride, conv.padding, conv.dilation)
+
     def conv_bn_act(self, x, conv, bn, relu, residual=None):
-        y = F.conv2d(x, self._weight(conv), None, conv.stride, conv.padding, conv.dilation)
+        y = self.conv2d(x, conv)
         if bn is not None:
             if bn.training:
                 # batch-statistics BN in fp32 (the library's bf16 channels-last training kernel faults on gfx950)

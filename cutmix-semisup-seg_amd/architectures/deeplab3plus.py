@@ -128,7 +128,9 @@ class ASPP(nn.Module):
         pool = self.convs[-1]
         g = x.float().mean(dim=(2, 3), keepdim=True).to(x.dtype)
         g = eng.conv_bn_act(g, pool[1], pool[2], relu=True)
-        br.append(F.interpolate(g, size=x.shape[2:4], mode='bilinear', align_corners=False))
+        # bilinear upsampling of a 1 x 1 map is a broadcast (torchvision's F.interpolate call computes the same values);
+        # the library's channels-last bilinear BACKWARD funnels H*W atomics into one pixel here: 190 ms per call
+        br.append(g.expand(-1, -1, x.shape[2], x.shape[3]))
         y = eng.conv_bn_act(torch.cat(br, dim=1), self.project[0], self.project[1], relu=True)
         drop = self.project[3]
         return F.dropout(y, drop.p, drop.training)
@@ -154,8 +156,9 @@ class DeepLabHeadV3Plus(nn.Module):
     def forward(self, feature, eng):
         low = eng.conv_bn_act(feature['low_level'], self.project[0], self.project[1], relu=True)
         out = self.aspp(feature['out'], eng)
-        out = F.interpolate(out, size=low.shape[2:4], mode='bilinear', align_corners=False)
-        y = torch.cat([low, out], dim=1)
+        # (NCHW-contiguous detour: the library's channels-last bilinear backward is ~100x slower than its NCHW one)
+        out = F.interpolate(out.contiguous(), size=low.shape[2:4], mode='bilinear', align_corners=False)
+        y = torch.cat([low, out.contiguous(memory_format=torch.channels_last)], dim=1)
         y = eng.conv_bn_act(y, self.classifier[0], self.classifier[1], relu=True)
         y = eng.conv_bn_act(y, self.classifier[3], self.classifier[4], relu=True)
         last = self.classifier[6]
@@ -168,6 +171,25 @@ class DeepLabV3Plus(nn.Module):
         super(DeepLabV3Plus, self).__init__()
         self.backbone = backbone
         self.classifier = classifier
+
+
+class HipConvEngine(TorchEngine):
+    """The library engine with its eligible convolutions (stride 1, 'same' padding, channel counts in multiples of 64:
+    the ASPP branches, the ASPP projection, the second classifier 3x3) re-routed to the MFMA kernels; BatchNorm on batch
+    statistics, the 304-channel concat convolution and the 48 / num_classes wide 1x1s stay with the library."""
+
+    def __init__(self, dtype, wrapper):
+        super(HipConvEngine, self).__init__(dtype)
+        from ..arena import ensure_arena
+        self.arena = ensure_arena(wrapper, with_grad=any(p.requires_grad for p in wrapper.parameters()), with_bf16=True)
+        self.keys = {id(m): name + '.weight' for name, m in wrapper.named_modules() if isinstance(m, nn.Conv2d)}
+
+    def conv2d(self, x, conv):
+        from ..backbone_hip import hip_conv2d, hip_conv2d_eligible
+        key = self.keys.get(id(conv))
+        if key is not None and hip_conv2d_eligible(x, conv):
+            return hip_conv2d(x, conv, self.arena, key)
+        return super(HipConvEngine, self).conv2d(x, conv)
 
 
 class DeepLabv3Wrapper(nn.Module):
@@ -184,6 +206,7 @@ class DeepLabv3Wrapper(nn.Module):
         self.engine = None
         self.engine_kind = 'auto'          # 'torch': library engine for every pass; 'hip_nograd': executor only without grad
         self._hip_executor = None
+        self._hip_engine = None
 
     # ------------------------------------------------------------------------------------------ execution
     def _engine(self, x):
@@ -192,6 +215,12 @@ class DeepLabv3Wrapper(nn.Module):
         if not x.is_cuda:
             raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
                                'fallback'.format(x.device))
+        if self.engine_kind != 'torch' and self.compute_dtype == torch.bfloat16:
+            if self._hip_engine is None:
+                self._hip_engine = HipConvEngine(self.compute_dtype, self)
+                # weights loaded behind the arena's back: refresh the bf16 operand copy
+                self.register_load_state_dict_post_hook(lambda module, incompatible: self._hip_engine.arena.refresh_bf16())
+            return self._hip_engine
         key = ('torch', self.compute_dtype)
         if key not in _ENGINES:
             _ENGINES[key] = TorchEngine(self.compute_dtype)

@@ -449,6 +449,51 @@ def run_v3_body(executor, x_nhwc):
     return _V3BodyFn.apply(x_nhwc, executor, need_grad)
 
 
+class _HipConv2dFn(torch.autograd.Function):
+    """One stride-1 'same' convolution (no bias, no folded BatchNorm) on the MFMA kernels as an autograd node: forward
+    cms_conv_igemm, backward cms_conv_igemm (data gradient on the packed-transposed weights) + cms_conv_wgrad straight
+    into the gradient arena. For layers whose BatchNorm runs on batch statistics (the DeepLab v3+ head): the
+    normalisation itself stays with the library, the GEMM -- 95 % of the head's time -- does not."""
+
+    @staticmethod
+    def forward(ctx, x, weight, arena, key, taps):
+        # x: (N, Cin, H, W) channels-last bf16; weight only ties the node to the parameter for autograd
+        xh = x.permute(0, 2, 3, 1).contiguous()
+        y = ops.conv_igemm(xh, arena.packed(key, arena.bf16), taps)
+        ctx.arena, ctx.key, ctx.taps = arena, key, taps
+        ctx.need_w = weight.requires_grad and arena.grad is not None
+        ctx.save_for_backward(xh)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, = ctx.saved_tensors
+        a = ctx.arena
+        dyh = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wT = ops.conv_pack_transpose(a.packed(ctx.key, a.bf16), flip=False)
+            dx = ops.conv_igemm(dyh, wT, [(-dy_, -dx_) for dy_, dx_ in ctx.taps], mode=1).permute(0, 3, 1, 2)
+        if ctx.need_w:
+            ops.conv_wgrad(dyh, xh, ctx.taps, a.packed(ctx.key, a.grad))     # accumulates into the .grad storage
+        return dx, None, None, None, None
+
+
+def hip_conv2d(x, conv, arena, key):
+    """`conv(x)` for a stride-1, 'same'-padded, bias-free nn.Conv2d whose weight lives in `arena` under `key`."""
+    kh, kw = conv.kernel_size
+    taps = ops.conv_taps(kh, kw, conv.dilation[0], conv.padding[0])
+    return _HipConv2dFn.apply(x, conv.weight, arena, key, taps)
+
+
+def hip_conv2d_eligible(x, conv):
+    kh, kw = conv.kernel_size
+    return (x.is_cuda and x.dtype == torch.bfloat16 and conv.bias is None and conv.groups == 1
+            and conv.stride == (1, 1) and kh == kw and kh * kw <= 18
+            and conv.padding == (conv.dilation[0] * (kh - 1) // 2,) * 2 and conv.dilation[0] == conv.dilation[1]
+            and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and x.shape[2] * x.shape[3] >= 64)
+
+
 class _BodyFn(torch.autograd.Function):
     """The whole body as one autograd node: forward keeps the activations, backward runs the hand-written chain."""
 
