@@ -158,7 +158,7 @@ class DeepLabHeadV3Plus(nn.Module):
         out = self.aspp(feature['out'], eng)
         # (NCHW-contiguous detour: the library's channels-last bilinear backward is ~100x slower than its NCHW one)
         out = F.interpolate(out.contiguous(), size=low.shape[2:4], mode='bilinear', align_corners=False)
-        y = torch.cat([low, out.contiguous(memory_format=torch.channels_last)], dim=1)
+        y = torch.cat([low, _ToChannelsLast.apply(out)], dim=1)
         y = eng.conv_bn_act(y, self.classifier[0], self.classifier[1], relu=True)
         y = eng.conv_bn_act(y, self.classifier[3], self.classifier[4], relu=True)
         last = self.classifier[6]
@@ -171,6 +171,19 @@ class DeepLabV3Plus(nn.Module):
         super(DeepLabV3Plus, self).__init__()
         self.backbone = backbone
         self.classifier = classifier
+
+
+class _ToChannelsLast(torch.autograd.Function):
+    """NCHW-contiguous -> channels-last, with the gradient handed back NCHW-contiguous: keeps the library's bilinear
+    upsample on its NCHW kernels in BOTH directions (its channels-last backward is ~100x slower on gfx950)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.contiguous(memory_format=torch.channels_last)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous()
 
 
 class HipConvEngine(TorchEngine):
