@@ -269,18 +269,36 @@ class CutMixMeanTeacherStep(object):
                 if ex is not None:
                     ex.grad_hook = None
         else:
-            # reference order, separate passes (batch-statistics BN)
+            # reference order, separate passes (batch-statistics BN). The teacher's passes depend on nothing the student
+            # does within the iteration (its weights only move in the EMA at the end), so they are issued FIRST, on
+            # the side stream, and run concurrently with the student's supervised forward / backward and mixed
+            # forward; the teacher's own two passes keep their order (they update the same running statistics).
+            main = torch.cuda.current_stream()
+            tea_out = []
+            overlap = use_unsup and cfg.overlap_teacher and self.teacher is not self.student
+            if overlap:
+                side = self._teacher_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side), torch.no_grad():
+                    for ub in unsup_batches:
+                        tea_out.append((self.teacher.forward_lowres(ub.x0_tea),
+                                        self.teacher.forward_lowres(ub.x1_tea) if cfg.mix else None))
             lo = self.student.forward_lowres(sup_x)
             ce_sc, ce_ctx = ops.ce_forward(lo.detach(), sup_y, out_size, 255, self.align_corners, group=self.group)
             lo.backward(ops.ce_backward(ce_ctx, ce_sc).to(lo.dtype))
             cons_vals = []
             if use_unsup:
-                for ub in unsup_batches:
+                for bi, ub in enumerate(unsup_batches):
                     x_stu = self._student_inputs(ub)
-                    with torch.no_grad():
-                        l0 = self.teacher.forward_lowres(ub.x0_tea)
-                        l1 = self.teacher.forward_lowres(ub.x1_tea) if cfg.mix else None
+                    if overlap:
+                        l0, l1 = tea_out[bi]
+                    else:
+                        with torch.no_grad():
+                            l0 = self.teacher.forward_lowres(ub.x0_tea)
+                            l1 = self.teacher.forward_lowres(ub.x1_tea) if cfg.mix else None
                     ls = self.student.forward_lowres(x_stu)
+                    if overlap and bi == 0:
+                        main.wait_stream(side)
                     sc, cctx = ops.consistency_forward(cfg.cons, ls.detach(), l0, l1, out_size, ranges=ub.ranges,
                                                        um0=ub.um0, um1=ub.um1, ramp_val=ramp,
                                                        cons_weight=cfg.cons_weight, group=self.group)
