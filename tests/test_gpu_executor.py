@@ -183,15 +183,18 @@ def test_whole_step_bf16_hip_engine_tracks_fp32_library_engine():
     assert cos > 0.9, cos
 
 
-def test_trainer_cli_synthetic_end_to_end(tmp_path, monkeypatch, capsys):
-    """The reference's command line (run_pascal_aug_experiments.sh flag set) on synthetic data: 2 epochs x 2 iterations
-    of the ResNet-101 DeepLab v2 at a small crop; checks the job/log layout and the epoch log line format."""
+@pytest.mark.parametrize('arch,crop', [('resnet101_deeplab_imagenet', '65,65'),
+                                       ('resnet101_deeplabv3plus_imagenet', '129,129')])
+def test_trainer_cli_synthetic_end_to_end(tmp_path, monkeypatch, capsys, arch, crop):
+    """The reference's command line (run_pascal_aug_experiments.sh / ..._deeplab3plus_experiments.sh flag sets) on
+    synthetic data: 2 epochs x 2 iterations of the ResNet-101 networks at a small crop; checks the job/log layout and
+    the epoch log line format."""
     import re
     from click.testing import CliRunner
     import train_seg_semisup_mask_mt as trainer
     monkeypatch.chdir(tmp_path)
-    args = ['--job_desc', 'smoke', '--synthetic', '--arch', 'resnet101_deeplab_imagenet', '--freeze_bn', '--batch_size', '2',
-            '--crop_size', '65,65', '--learning_rate', '3e-5', '--lr_sched', 'poly', '--mask_prop_range', '0.5',
+    args = ['--job_desc', 'smoke', '--synthetic', '--arch', arch, '--freeze_bn', '--batch_size', '2',
+            '--crop_size', crop, '--learning_rate', '3e-5', '--lr_sched', 'poly', '--mask_prop_range', '0.5',
             '--conf_thresh', '0.97', '--num_epochs', '2', '--iters_per_epoch', '2', '--synthetic_val_batches', '1']
     res = CliRunner().invoke(trainer.experiment, args, catch_exceptions=False)
     assert res.exit_code == 0, res.output
