@@ -479,19 +479,60 @@ class _HipConv2dFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+class _HipConv2dPaddedFn(torch.autograd.Function):
+    """The same for an input-channel count that is not a multiple of 64 (the 48 + 256 = 304-channel concat convolution
+    of the DeepLab v3+ head): activations and the bf16 weight operand are zero-padded along Cin to the next multiple of
+    64 for the call; the weight gradient comes back through a padded fp32 scratch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, arena, key, taps):
+        n, cin, h, w = x.shape
+        cpad = (cin + 63) // 64 * 64
+        xh = torch.zeros((n, h, w, cpad), dtype=torch.bfloat16, device=x.device)
+        xh[..., :cin] = x.permute(0, 2, 3, 1)
+        wp = arena.packed(key, arena.bf16)                            # (taps, Cout, Cin)
+        wpad = torch.zeros((wp.shape[0], wp.shape[1], cpad), dtype=torch.bfloat16, device=x.device)
+        wpad[..., :cin] = wp
+        y = ops.conv_igemm(xh, wpad, taps)
+        ctx.arena, ctx.key, ctx.taps, ctx.cin = arena, key, taps, cin
+        ctx.need_w = weight.requires_grad and arena.grad is not None
+        ctx.save_for_backward(xh, wpad)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, wpad = ctx.saved_tensors
+        a, cin = ctx.arena, ctx.cin
+        dyh = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wT = ops.conv_pack_transpose(wpad, flip=False)
+            dxp = ops.conv_igemm(dyh, wT, [(-dy_, -dx_) for dy_, dx_ in ctx.taps], mode=1)
+            dx = dxp[..., :cin].permute(0, 3, 1, 2)
+        if ctx.need_w:
+            tmp = torch.zeros(wpad.shape, dtype=torch.float32, device=dyh.device)
+            ops.conv_wgrad(dyh, xh, ctx.taps, tmp)
+            a.packed(ctx.key, a.grad).add_(tmp[..., :cin])
+        return dx, None, None, None, None
+
+
 def hip_conv2d(x, conv, arena, key):
     """`conv(x)` for a stride-1, 'same'-padded, bias-free nn.Conv2d whose weight lives in `arena` under `key`."""
     kh, kw = conv.kernel_size
     taps = ops.conv_taps(kh, kw, conv.dilation[0], conv.padding[0])
-    return _HipConv2dFn.apply(x, conv.weight, arena, key, taps)
+    fn = _HipConv2dFn if conv.in_channels % 64 == 0 else _HipConv2dPaddedFn
+    return fn.apply(x, conv.weight, arena, key, taps)
 
 
 def hip_conv2d_eligible(x, conv):
+    """Stride 1, 'same' padding, no bias, >= 128 input channels (padded to a multiple of 64 if need be), output
+    channels in multiples of 64."""
     kh, kw = conv.kernel_size
     return (x.is_cuda and x.dtype == torch.bfloat16 and conv.bias is None and conv.groups == 1
             and conv.stride == (1, 1) and kh == kw and kh * kw <= 18
             and conv.padding == (conv.dilation[0] * (kh - 1) // 2,) * 2 and conv.dilation[0] == conv.dilation[1]
-            and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and x.shape[2] * x.shape[3] >= 64)
+            and (conv.in_channels % 64 == 0 or conv.in_channels >= 128) and conv.out_channels % 64 == 0
+            and x.shape[2] * x.shape[3] >= 64)
 
 
 class _BodyFn(torch.autograd.Function):
