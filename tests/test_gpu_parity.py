@@ -548,3 +548,54 @@ def test_whole_step_three_iterations_vs_golden(ops, cfg_name, cfg, fuse):
         np.testing.assert_allclose(tea.state_dict()[k].cpu().numpy().reshape(-1)[:2048],
                                    g['{}__tea__{}'.format(cfg_name, k)], rtol=5e-3, atol=5e-6)
     assert not step.nan_detected()
+
+
+@pytest.mark.parametrize('fuse', [True, False])
+def test_pi_model_step_teacher_is_the_student(ops, fuse):
+    """`--model pi` (train_seg_semisup_mask_mt.py:110-113): the teacher IS the student, there is no EMA. In the first
+    iteration a mean teacher starts as a copy of the student, so losses and the updated student must coincide with the
+    mean-teacher step on the same data; the step must neither touch a second network nor fork a stream race on one."""
+    from architectures import deeplab2
+    from oracle import deeplab2 as odl
+    import mask_gen
+    import optim_weight_ema
+    from cutmix_semisup_seg_amd import optim as fo
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
+    C, layers, N, H, W, lr = 5, [1, 1, 1, 1], 2, 33, 33, 1e-3
+
+    def build(pi):
+        stu = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
+        stu.load_state_dict(odl.closed_form_state(C, layers))
+        stu = stu.to(DEV)
+        stu.compute_dtype = torch.float32
+        opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=lr * 0.1),
+                                 dict(params=list(stu.new_parameters()), lr=lr)])
+        if pi:
+            tea, ema = stu, None
+        else:
+            tea = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3)).to(DEV)
+            tea.compute_dtype = torch.float32
+            for p in tea.parameters():
+                p.requires_grad = False
+            ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
+            ema.fuse_into(opt)
+        stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()
+        cfg = StepConfig(mask_mode='mix', cons_loss_fn='var', conf_thresh=0.3, fuse_batches=fuse,
+                         compute_dtype=torch.float32)
+        return stu, CutMixMeanTeacherStep(stu, tea, opt, ema, cfg)
+
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(N, 3, H, W, generator=gen)
+    y = torch.randint(0, C, (N, 1, H, W), generator=gen)
+    ux0, ux1 = torch.randn(N, 3, H, W, generator=gen), torch.randn(N, 3, H, W, generator=gen)
+    rn = mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(N, (H, W), rng=np.random.RandomState(3))
+    res, weights = [], []
+    for pi in (True, False):
+        stu, step = build(pi)
+        ub = UnsupBatch(cu(ux0), ops.ranges_to_device(rn, DEV), x1_tea=cu(ux1))
+        r = step(cu(x), cu(y).to(torch.uint8), [ub])
+        res.append([float(r[k]) for k in ('sup_loss', 'consistency_loss', 'conf_rate')])
+        weights.append({k: v.clone() for k, v in stu.state_dict().items() if v.dtype == torch.float32})
+    assert res[0] == pytest.approx(res[1], rel=1e-4, abs=1e-6)
+    for k in weights[0]:
+        torch.testing.assert_close(weights[0][k], weights[1][k], rtol=1e-3, atol=2e-5)     # (library conv run-to-run noise through the first Adam update: lr * g / (|g| + eps))
