@@ -217,3 +217,68 @@ def test_trainer_config_errors_before_touching_a_gpu(tmp_path, monkeypatch):
     bad = dict(defaults, mask_mode='bogus')
     with pytest.raises(ValueError, match='Unknown mask_mode'):
         trainer.train_seg_semisup_mask_mt.submit(**bad)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# host-side decisions of the training step and the engines (no GPU needed: nothing is launched)
+def test_step_fuses_batches_only_when_samples_are_independent():
+    """Concatenating [x_sup; x_mix] / [x0; x1] is only the same computation when no layer couples the samples of a
+    batch: every BatchNorm frozen and no active dropout, in both networks (step.py)."""
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig
+    from cutmix_semisup_seg_amd.architectures import deeplab3plus as d3
+    v2 = lambda: deeplab2.ResNetDeepLab(deeplab2.Bottleneck, [1, 1, 1, 1], 3, np.zeros(3), np.ones(3))
+    stu, tea = v2(), v2()
+    step = CutMixMeanTeacherStep(stu, tea, None, None, StepConfig())
+    stu.train(); tea.train()
+    assert not step._samples_independent()                 # batch-statistics BatchNorm
+    stu.freeze_batchnorm()
+    assert not step._samples_independent()                 # ... still in the teacher
+    tea.freeze_batchnorm()
+    assert step._samples_independent()
+    # DeepLab v3+: freeze_batchnorm() covers the backbone only, the head keeps batch statistics and dropout
+    w = d3.DeepLabv3Wrapper(d3._deeplabv3plus(3, 8, (1, 1, 1, 1)))
+    w.train(); w.freeze_batchnorm()
+    step3 = CutMixMeanTeacherStep(w, w, None, None, StepConfig())
+    assert not step3._samples_independent()
+    w.eval()
+    assert step3._samples_independent()
+
+
+def test_which_convolutions_of_the_v3plus_head_are_routed_to_the_mfma_kernels():
+    from cutmix_semisup_seg_amd.backbone_hip import hip_conv2d_eligible
+    from cutmix_semisup_seg_amd.architectures import deeplab3plus as d3
+
+    class FakeCuda(object):                      # shape / dtype / device facts only -- nothing is computed
+        def __init__(self, shape, dtype=torch.bfloat16, cuda=True):
+            self.shape, self.dtype, self.is_cuda = shape, dtype, cuda
+
+    head = d3.DeepLabHeadV3Plus(2048, 256, 21)
+    x65 = lambda c: FakeCuda((10, c, 65, 65))
+    assert all(hip_conv2d_eligible(x65(2048), head.aspp.convs[i][0]) for i in range(4))     # 1x1 + three dilated 3x3
+    assert hip_conv2d_eligible(x65(1280), head.aspp.project[0])
+    assert hip_conv2d_eligible(FakeCuda((10, 304, 129, 129)), head.classifier[0])            # padded to 320 channels
+    assert hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.classifier[3])
+    assert not hip_conv2d_eligible(FakeCuda((10, 2048, 1, 1)), head.aspp.convs[4][1])        # pooled branch: 1 pixel
+    assert not hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.project[0])           # 48 output channels
+    assert not hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.classifier[6])        # bias, 21 outputs
+    assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), torch.float32), head.aspp.convs[1][0])
+    assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), cuda=False), head.aspp.convs[1][0])
+    stem = torch.nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+    assert not hip_conv2d_eligible(FakeCuda((10, 3, 513, 513)), stem)
+
+
+def test_v3plus_engine_selection_flags():
+    from cutmix_semisup_seg_amd.architectures import deeplab3plus as d3
+    w = d3.DeepLabv3Wrapper(d3._deeplabv3plus(3, 8, (1, 1, 1, 1)))
+    w.train()
+    assert not w._use_hip_backbone()                       # backbone BatchNorm on batch statistics
+    w.freeze_batchnorm()
+    assert w._use_hip_backbone()                           # training passes included
+    w.engine_kind = 'hip_nograd'
+    assert not w._use_hip_backbone()
+    with torch.no_grad():
+        assert w._use_hip_backbone()
+    w.engine_kind = 'torch'
+    assert not w._use_hip_backbone()
+    w.engine_kind, w.compute_dtype = 'auto', torch.float32
+    assert not w._use_hip_backbone()
