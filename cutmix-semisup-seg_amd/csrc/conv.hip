@@ -645,13 +645,15 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
     a.zeros = (const uint16_t*)d->zeros;
     CMS_REQUIRE(d->zeros == nullptr || d->zeros_bytes >= 2 * d->cin + 128,
                 "conv: the zero run (%d bytes) must be at least 2 * Cin + 128 = %d bytes long", d->zeros_bytes, 2 * d->cin + 128);
-    a.dbg = (d->variant == 2 || d->variant == 3) ? d->variant : 0;
+    a.dbg = (d->variant == 2 || d->variant == 3) ? d->variant : (d->variant == 6 ? 2 : (d->variant == 7 ? 3 : 0));
     // variant 0: direct-to-LDS, one stage, up to 4 workgroups per CU (default); 1: register-staged loader;
     // 4: direct-to-LDS, two stages, 2 workgroups per CU -- measured 10 % faster on grids of exactly <= 2 workgroups per
     // CU, 20 % slower on everything else (tools/tail_probe.py): co-resident workgroups hide more than the second stage;
     // 2 / 3: ablation switches of the default kernel (no MFMA / no loads after the first stage)
     // 5: direct-to-LDS, two stages of 32 K-elements each (same LDS footprint and occupancy as the default)
-    const int glds = (d->zeros == nullptr || d->variant == 1) ? 0 : (d->variant == 4 ? 2 : (d->variant == 5 ? 3 : 1));
+    // 6 / 7: the ablation switches applied to the two-stage kernel (variant 4)
+    const int glds = (d->zeros == nullptr || d->variant == 1) ? 0
+                     : ((d->variant == 4 || d->variant == 6 || d->variant == 7) ? 2 : (d->variant == 5 ? 3 : 1));
     const int tile = d->tile;   // 0 = auto
     if (tile == 256) {                         // 8 waves: 128 co x 256 pixels (more reuse of the weight tile)
         CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 256 needs Cout %% 128 == 0");
