@@ -247,7 +247,7 @@ typedef struct cms_conv_desc {
                               it like a live pixel's channel run); NULL = register-staged loader                 */
     int variant;           /* 0 = auto (direct-to-LDS, 1 stage), 1 = register-staged loader, 4 = direct-to-LDS with
                               two stages, 5 = two stages of 32 K-elements; 2 / 3 = ablation switches (no MFMA / no
-                              loads), tools/conv_ablate.py                                                       */
+                              loads) of variant 0, 6 / 7 = the same of variant 4 (tools/conv_ablate*.py)         */
     int zeros_bytes;       /* length of the `zeros` run (checked against 2 * cin + 128)                          */
 } cms_conv_desc;
 
