@@ -96,6 +96,7 @@ def main():
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_fuse_batches', action='store_true')
     ap.add_argument('--conv_tile', type=int, default=0, help='experiment: force a conv tile code (256, 1128, 128)')
+    ap.add_argument('--tile_rule', default='', help='experiment: cout:tile[,cout:tile...] per-layer tile codes')
     ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')
     ap.add_argument('--no_roofline_events', action='store_true', help='skip the per-launch event brackets')
     ap.add_argument('--roofline_sample', type=int, default=5,
@@ -154,6 +155,9 @@ def main():
         stu.hip_executor().overlap_wgrad = False
     if args.conv_tile and hasattr(stu, 'hip_executor'):
         stu.hip_executor().conv_tile = tea.hip_executor().conv_tile = args.conv_tile
+    if args.tile_rule and hasattr(stu, 'hip_executor'):
+        rules = {int(a): int(b) for a, b in (kv.split(':') for kv in args.tile_rule.split(','))}
+        stu.hip_executor().tile_rules = tea.hip_executor().tile_rules = rules
 
     gen = torch.Generator(device=dev).manual_seed(12345 + rank)
     mask_rng = np.random.RandomState(12345 + rank)

@@ -82,6 +82,7 @@ class DeepLabHipExecutor(object):
         self.grad_hook = None      # callable(block_index): weight gradients of that bottleneck are enqueued
         self.overlap_wgrad = True
         self.conv_tile = 0         # experiment knob: force a tile shape on the 128-multiple layers (tools, bench)
+        self.tile_rules = {}       # output channels -> tile code (per-layer choice against the workgroup-count staircase)
         self._wT_version = -1
         self.version = 0          # bumped whenever the weights change (optimizer step / load_state_dict)
         net.register_load_state_dict_post_hook(lambda module, incompatible: self.invalidate())
@@ -203,6 +204,8 @@ class DeepLabHipExecutor(object):
 
     def _tile(self, cout):
         """Workgroup tile code for a convolution with `cout` output channels (0 = the library's choice)."""
+        if cout in self.tile_rules:
+            return self.tile_rules[cout]
         return self.conv_tile if (self.conv_tile and cout % 128 == 0) else 0
 
     def fwd_begin(self, x, save):
