@@ -744,7 +744,9 @@ __device__ __forceinline__ uint32_t wg_off(int pix, int ch) {     // byte offset
 
 // PLAIN = 1x1, stride 1, no tap offset: the input pixel IS the output pixel, so the loader needs no (n, y, x) cursor and
 // no bounds test -- two thirds of the network's weight-gradient launches.
-template <int TCO, int TCI, bool PLAIN>      // 32x32 MFMA tiles per wave along co / ci; waves are 2 x 2
+// BETA = also accumulate sum_p dU[p][co] (cms_wgrad_desc.dbeta). A compile-time switch: as a run-time one its extra
+// accumulators sat in the main loop of EVERY launch (32 v_accvgpr moves per stage, +3-5 % on the DeepLab v2 step).
+template <int TCO, int TCI, bool PLAIN, bool BETA>      // 32x32 MFMA tiles per wave along co / ci; waves are 2 x 2
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int BCO = 2 * TCO * 32, BCI = 2 * TCI * 32;       // <= 128 each
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -793,6 +795,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const uint32_t uoff = (uint32_t)(co0 + c16 * 8), xoff = (uint32_t)(ci0 + c16 * 8);
     u32x4 ru[4], rxx[4];
     auto load_tile = [&]() {           // loads the stage the cursors point at
+        if constexpr (PLAIN) {
+            if (cm[0] - prow + 64 <= p_end) {      // whole 64-pixel stage inside the slice (uniform): straight loads
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (load_u) ru[i] = *reinterpret_cast<const u32x4*>(a.du + (size_t)((uint32_t)(cm[i] * a.Cout) + uoff));
+                    if (load_x) rxx[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)((uint32_t)(cm[i] * a.Cin) + xoff));
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             ru[i] = u32x4{0u, 0u, 0u, 0u};
@@ -840,10 +852,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
     // sum_p dU[p][co] as one more GEMM column: the dU fragments are multiplied with an all-ones operand (bf16 1.0) in
     // the workgroups of ci-tile 0 / tap 0 (every pixel slice once), waves wci == 0; all 32 columns come out equal
-    const bool do_beta = a.dbeta != nullptr && tci == 0 && tap == 0 && wci == 0;
-    f32x16 accb[TCO];
+    const bool do_beta = BETA && tci == 0 && tap == 0 && wci == 0;
+    f32x16 accb[BETA ? TCO : 1];
 #pragma unroll
-    for (int i = 0; i < TCO; ++i)
+    for (int i = 0; i < (BETA ? TCO : 1); ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accb[i][r] = 0.0f;
     const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
@@ -890,11 +902,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 for (int j = 0; j < TCI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fu[i]),
                                                                         __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
-            if (do_beta) {                                  // wave-uniform
+            if constexpr (BETA) {
+                if (do_beta) {                              // wave-uniform
 #pragma unroll
-                for (int i = 0; i < TCO; ++i)
-                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fu[i]),
-                                                                      __builtin_bit_cast(bf16x8, ones), accb[i], 0, 0, 0);
+                    for (int i = 0; i < TCO; ++i)
+                        accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fu[i]),
+                                                                          __builtin_bit_cast(bf16x8, ones), accb[i], 0, 0, 0);
+                }
             }
         }
     }
@@ -922,7 +936,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 for (int off = 16; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);
                 if (fcol == 0) atomicAdd(a.wdot + co, dot);
             }
-            if (do_beta && fcol == 0) atomicAdd(a.dbeta + co, accb[i][r]);
+            if constexpr (BETA) {
+                if (do_beta && fcol == 0) atomicAdd(a.dbeta + co, accb[i][r]);
+            }
         }
     }
 }
@@ -963,12 +979,15 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(tiles * ksplit);
     const size_t lds = 2 * 64 * 256;
+    const bool beta = d->dbeta != nullptr;
     const bool plain = d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho &&
                        d->w_in == d->wo;
 #define CMS_WGRAD_LAUNCH(TCO, TCI)                                                                                   \
     do {                                                                                                             \
-        if (plain) hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, true>), grid, dim3(256), lds, s, a);             \
-        else hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, false>), grid, dim3(256), lds, s, a);                  \
+        if (plain && beta) hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, true, true>), grid, dim3(256), lds, s, a);  \
+        else if (plain) hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, true, false>), grid, dim3(256), lds, s, a);   \
+        else if (beta) hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, false, true>), grid, dim3(256), lds, s, a);    \
+        else hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, false, false>), grid, dim3(256), lds, s, a);             \
     } while (0)
     if (bco == 128 && bci == 128) CMS_WGRAD_LAUNCH(2, 2);
     else if (bco == 128) CMS_WGRAD_LAUNCH(2, 1);
