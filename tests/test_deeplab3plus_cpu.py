@@ -131,3 +131,28 @@ def test_oracle_step_runs_and_moves_the_statistics_it_should():
     assert torch.equal(S.student[k_bb], st[k_bb])                      # frozen backbone
     assert not torch.equal(S.student['deeplab.backbone.layer1.0.bn1.weight'], st['deeplab.backbone.layer1.0.bn1.weight'])
     assert all(v == 1 for v in S.steps.values())
+
+
+def test_batchnorm_affine_gradient_from_the_weight_gradient_side_outputs():
+    """The identity the executor uses for a TRAINABLE affine behind frozen statistics (cms_wgrad_desc.wdot / dbeta):
+    with y = g * (conv(x, W) - mean) / sigma + b and G = the unscaled weight gradient sum_p dY x,
+        d b = sum_p dY,        d g = (<W, G> - mean * d b) / sigma            (per output channel)
+    checked against autograd on a dilated 3x3 and a strided 1x1 convolution."""
+    g = torch.Generator().manual_seed(2)
+    for (cin, cout, k, dil, stride) in ((6, 5, 3, 2, 1), (7, 4, 1, 1, 2)):
+        x = torch.randn(3, cin, 11, 13, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g, requires_grad=True)
+        gamma = (torch.rand(cout, generator=g) + 0.5).requires_grad_(True)
+        beta = torch.randn(cout, generator=g, requires_grad=True)
+        mean, var = torch.randn(cout, generator=g), torch.rand(cout, generator=g) + 0.5
+        u = torch.nn.functional.conv2d(x, w, None, stride, dil * (k - 1) // 2, dil)
+        y = torch.nn.functional.batch_norm(u, mean, var, gamma, beta, False, 0.0, 1e-5)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        sigma = torch.sqrt(var + 1e-5)
+        scale = (gamma / sigma).detach()
+        G = w.grad / scale.view(-1, 1, 1, 1)                       # the kernel holds G before it applies `scale`
+        dbeta = dy.sum(dim=(0, 2, 3))
+        wdot = (w.detach() * G).sum(dim=(1, 2, 3))
+        torch.testing.assert_close(dbeta, beta.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close((wdot - mean * dbeta) / sigma, gamma.grad, rtol=1e-3, atol=1e-3)
