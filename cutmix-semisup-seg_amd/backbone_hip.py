@@ -80,6 +80,7 @@ class DeepLabHipExecutor(object):
         self._side = None
         self._pack_plan = None
         self.grad_hook = None      # callable(block_index): weight gradients of that bottleneck are enqueued
+        self.data_grad_only = False   # backward computes d/d input only (VAT direction: torch.autograd.grad wrt eps)
         self.overlap_wgrad = True
         self.conv_tile = 0         # experiment knob: force a tile shape on the 128-multiple layers (tools, bench)
         self.tile_rules = {}       # output channels -> tile code (per-layer choice against the workgroup-count staircase)
@@ -271,8 +272,9 @@ class DeepLabHipExecutor(object):
         n, _, h, w = dlogits.shape
         dl = torch.zeros((n, h, w, 64), dtype=torch.bfloat16, device=dlogits.device)
         dl[..., :C] = dlogits.permute(0, 2, 3, 1)
+        want_w = self.trainable and not self.data_grad_only and a.grad is not None
         # ASPP head: weight / bias gradients of the two live branches, then the data gradient
-        for i, k in enumerate(self.aspp_keys):
+        for i, k in enumerate(self.aspp_keys if want_w else []):
             gw = a.packed(k + '.weight', a.grad)                     # fp32 (9, C, 2048)
             tmp = torch.zeros((9, 64, 2048), dtype=torch.float32, device=dl.device)
             ops.conv_wgrad(dl, x4, self.aspp_taps[9 * i:9 * i + 9], tmp, cout_real=C)
@@ -283,7 +285,7 @@ class DeepLabHipExecutor(object):
         # Weight gradients only feed the optimizer, the data-gradient chain never waits for them: they run on a second
         # HIP stream, one bottleneck behind the chain, and fill the tail / memory-wait gaps of the dgrad launches.
         main = torch.cuda.current_stream()
-        side = self._side_stream() if self.overlap_wgrad else None
+        side = self._side_stream() if (self.overlap_wgrad and want_w) else None
         keep = []                 # tensors read on the side stream must outlive the python scope that made them
         for bi in range(len(self.blocks) - 1, -1, -1):
             if capture is not None:
@@ -293,7 +295,9 @@ class DeepLabHipExecutor(object):
             in_hw = (xin.shape[1], xin.shape[2])
             dU2 = self._dgrad(dC, b.c3, mask=a2)
             dU1 = self._dgrad(dU2, b.c2, mask=a1)
-            if side is not None:
+            if not want_w:
+                pass
+            elif side is not None:
                 side.wait_stream(main)
                 keep.append((dC, dU2, dU1))
                 with torch.cuda.stream(side):
@@ -597,7 +601,9 @@ def run_body_pair(ex_stu, x_stu, ex_tea, x_tea, side):
 
 
 def run_body(executor, x_nhwc):
-    need_grad = torch.is_grad_enabled() and executor.trainable
+    # a gradient is needed for the weights (a trainable network) or for the INPUT alone (VAT direction through a frozen
+    # teacher: torch.autograd.grad wrt the perturbation)
+    need_grad = torch.is_grad_enabled() and (executor.trainable or x_nhwc.requires_grad)
     if need_grad and not x_nhwc.requires_grad:
         x_nhwc = x_nhwc.detach().requires_grad_(True)     # make sure autograd calls our backward
     return _BodyFn.apply(x_nhwc, executor, need_grad)

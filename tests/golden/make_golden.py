@@ -589,7 +589,23 @@ def gen_cli():
     print('wrote cli_options.json ({} options)'.format(len(opts)))
 
 
+def gen_cli_vat():
+    """command-line surface of the VAT trainer (train_seg_semisup_vat_mt.py:592-644)"""
+    import click
+    import train_seg_semisup_vat_mt as ref_trainer
+    assert ref_trainer.__file__.startswith(REF)
+    opts = []
+    for prm in ref_trainer.experiment.params:
+        kind = type(prm.type).__name__
+        choices = list(prm.type.choices) if isinstance(prm.type, click.Choice) else None
+        opts.append(dict(name=prm.name, opts=list(prm.opts), is_flag=bool(getattr(prm, 'is_flag', False)),
+                         default=prm.default if not callable(prm.default) else None, type=kind, choices=choices))
+    with open(os.path.join(HERE, 'cli_options_vat.json'), 'w') as f:
+        json.dump(opts, f, indent=0, default=str)
+    print('wrote cli_options_vat.json ({} options)'.format(len(opts)))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['boxmask', 'ema', 'evaluation', 'lr', 'losses', 'deeplab2', 'optim', 'step', 'cli']
+    which = sys.argv[1:] or ['boxmask', 'ema', 'evaluation', 'lr', 'losses', 'deeplab2', 'optim', 'step', 'cli', 'cli_vat']
     for w in which:
         globals()['gen_' + w]()

@@ -282,3 +282,67 @@ def test_v3plus_engine_selection_flags():
     assert not w._use_hip_backbone()
     w.engine_kind, w.compute_dtype = 'auto', torch.float32
     assert not w._use_hip_backbone()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# VAT trainer
+def test_vat_cli_surface_matches_reference():
+    import train_seg_semisup_vat_mt as trainer
+    ref = load_golden_json('cli_options_vat')
+    mine = {p.name: p for p in trainer.experiment.params}
+    for o in ref:
+        assert o['name'] in mine, 'missing option --{}'.format(o['name'])
+        p = mine[o['name']]
+        assert list(p.opts) == o['opts']
+        assert bool(getattr(p, 'is_flag', False)) == o['is_flag']
+        assert p.default == o['default'] or str(p.default) == str(o['default']), o['name']
+        if o['choices'] is not None:
+            assert list(p.type.choices) == o['choices']
+    assert set(mine) - {o['name'] for o in ref} == {'synthetic', 'synthetic_n_classes', 'synthetic_val_batches',
+                                                     'compute_dtype'}
+
+
+def test_vat_oracle_math_on_a_linear_network():
+    """oracle/vat.py on a network whose Jacobian is known: logits = conv(x, W). With the 'logits_var' distance and
+    x_hat == x the power-iteration step is d/d eps |W eps|^2 = 2 W^T W eps, i.e. the normalised W^T W eps0."""
+    from oracle import vat as ov
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(4)
+    # float64: with x_hat == x the step differentiates |f(x + eps) - f(x)|^2 at eps ~ 1e-9 per pixel, which float32
+    # (the reference's precision) resolves to mostly zeros -- in unpaired mode the reference's direction is largely
+    # rounding noise; the identity itself is exact
+    w = torch.randn(5, 3, 3, 3, generator=g, dtype=torch.float64)
+    net = lambda x: F.conv2d(x, w, padding=1)
+    x = torch.randn(2, 3, 9, 11, generator=g, dtype=torch.float64)
+    eps0 = ov.normalize_eps(torch.randn(x.shape, generator=g, dtype=torch.float64)) * ov.noise_scale(x.shape)
+    assert ov.noise_scale(x.shape) == pytest.approx(1e-6 * 9 * 11 / 1000)
+    d, y = ov.vat_direction(net, x, x, eps0, 'logits_var')
+    want = ov.normalize_eps(F.conv_transpose2d(F.conv2d(eps0, w, padding=1), w, padding=1))
+    assert float((d - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    torch.testing.assert_close(d.reshape(2, -1).norm(dim=1), torch.ones(2, dtype=torch.float64), rtol=1e-5, atol=1e-5)   # (the + 1e-12)
+    torch.testing.assert_close(y, net(x))
+    # radius: global (:298-299) and adaptive (:277-296)
+    assert ov.vat_radius_of(x, 0.5, False) == pytest.approx(0.5 * (3 * 9 * 11) ** 0.5)
+    r = ov.vat_radius_of(x, 0.5, True)
+    man = [0.25 * float(((x[i, :, 2:, :] - x[i, :, :-2, :]) ** 2).sum() + ((x[i, :, :, 2:] - x[i, :, :, :-2]) ** 2).sum()) ** 0.5
+           for i in range(2)]
+    np.testing.assert_allclose(r.reshape(-1).numpy(), man, rtol=1e-5)
+    p, _ = ov.vat_perturbation(net, x, x, eps0, 0.5, False, 'logits_var')
+    torch.testing.assert_close(p.reshape(2, -1).norm(dim=1), torch.full((2,), 0.5 * (3 * 9 * 11) ** 0.5, dtype=torch.float64),
+                               rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        ov.direction_loss(y, y, 'logits_smoothl1')
+
+
+def test_vat_host_helpers_match_the_oracle():
+    from oracle import vat as ov
+    from cutmix_semisup_seg_amd import vat
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 3, 10, 12, generator=g)
+    torch.testing.assert_close(vat.normalize_eps(x), ov.normalize_eps(x))
+    torch.testing.assert_close(vat.vat_radius_of(x, 0.7, True), ov.vat_radius_of(x, 0.7, True))
+    assert vat.vat_radius_of(x, 0.7, False) == ov.vat_radius_of(x, 0.7, False)
+    n = vat.normalized_noise_like(x, 2.5, generator=torch.Generator().manual_seed(1))
+    torch.testing.assert_close(n.reshape(3, -1).norm(dim=1), torch.full((3,), 2.5))
+    with pytest.raises(ValueError):
+        vat.VATConfig(cons_loss_fn='logits_smoothl1')
