@@ -1,6 +1,6 @@
 """
 Mirror of the reference's train_seg_semisup_mask_mt.py: CutMix / Cutout mean-teacher (or Pi-model) trainer with the
-same 57 command-line options (names and defaults, train_seg_semisup_mask_mt.py:581-638), the same job/log layout
+same 56 command-line options (names and defaults, train_seg_semisup_mask_mt.py:581-638), the same job/log layout
 (job_helper) and the same per-epoch log lines (:521-530, :576-577), driving the MI355X step (step.py).
 
 Differences, all additive:
