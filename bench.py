@@ -1,21 +1,31 @@
 #!/usr/bin/env python
 """
-bench.py -- train images/sec of the CutMix mean-teacher step (student + teacher), BASELINE.json's metric.
+bench.py -- train images/sec of the CutMix mean-teacher step (student + teacher), BASELINE.json's metric
+("train images/sec (student+teacher step) at 321x321 and 512x1024, 1/2/4/8 GPU").
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank / GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL. The driver launches the ranks through torch.distributed.run; started WITHOUT
+WORLD_SIZE in the environment, `--gpus N` re-executes itself under `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1`, so the line always reports the number of ranks that really ran.
 
 A "step" is one full iteration of train_seg_semisup_mask_mt.py:287-476 on synthetic inputs already resident in HBM:
 student fwd/bwd on the supervised batch, 2 teacher forwards, student fwd/bwd on the CutMix-mixed batch, fused masked
-consistency + CE losses, fused Adam + EMA, (N > 1) one RCCL all-reduce of the flat gradient arena.
-Workload at N = 1: BASELINE configs[1] -- DeepLab v2 / ResNet-101, 10 x 3 x 321 x 321, 21 classes, CutMix, bf16.
-`--workload cityscapes` selects configs[2] (4 x 3 x 512 x 1024 per GPU, 19 classes, paired colour-aug layout).
-Weak scaling: the per-GPU batch is fixed. Prints ONE JSON line on rank 0.
+consistency + CE losses, fused Adam + EMA, (N > 1) bucketed RCCL all-reduce of the flat gradient arena.
 
-Extra objects in the line
-  roofline      the dominant hand-written kernel of the step (see --roofline_kernel), timed live with HIP events on
-                the launch stream inside the timed region; algorithmic bytes per launch from DESIGN.md.
-  cpu_baseline  the CPU oracle's restatement of the same step (kind "port"), timed on this box's host cores on a
-                bounded sample (rank 0, N = 1 only).
+Default run = BOTH shapes of the metric, one after the other, in ONE JSON line (rank 0):
+  headline `value`            BASELINE configs[1]: DeepLab v2 / ResNet-101, 10 x 3 x 321 x 321, 21 classes, bf16
+  `configs[1]` of the line    BASELINE configs[2]: 4 x 3 x 512 x 1024 per GPU, 19 classes, paired colour-aug layout
+                              (also as `value_512x1024`); `--workload pascal|cityscapes|pascal_v3plus` runs one only.
+Weak scaling: the per-GPU batch is fixed.
+
+Extra objects per workload
+  roofline      the dominant hand-written kernel of the step, conv_igemm_kernel (bound: MFMA), timed live with HIP events
+                on its launch stream inside the timed region; algorithmic FLOPs per launch = 2 * pixels * Cout * Cin * taps.
+  roofline_hbm  the HBM-bound group the north star names -- CutMix paste + masked consistency fwd/bwd + cross entropy
+                fwd/bwd + ASPP head convolution -- timed the same way; bytes per SURVEY.md 8(d).
+  cpu_baseline  the CPU oracle's restatement of the same step (kind "port"), timed on this box's host cores on a bounded
+                sample (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -29,12 +39,13 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # f32-input MFMA = the fp32 vector rate
 
 WORKLOADS = {
     'pascal': dict(name='deeplab2-resnet101 cutmix mean-teacher step, 10x3x321x321, 21 classes (BASELINE configs[1])',
                    batch=10, H=321, W=321, classes=21, paired=False),
     'pascal_v3plus': dict(name='deeplab3plus-resnet101 cutmix mean-teacher step, 10x3x513x513, 21 classes '
-                               '(BASELINE configs[3]); library convolutions, batch-statistics head => separate passes',
+                               '(BASELINE configs[3]); batch-statistics head => separate passes',
                           batch=10, H=513, W=513, classes=21, paired=False, arch='resnet101_deeplabv3plus_imagenet'),
     'cityscapes': dict(name='deeplab2-resnet101 cutmix mean-teacher step, 4x3x512x1024 per GPU, 19 classes, '
                             'paired colour-aug layout (BASELINE configs[2])',
@@ -43,7 +54,7 @@ WORKLOADS = {
 
 
 def cpu_baseline(workload, seconds_budget=30.0):
-    """Oracle step on the host cores, bounded sample: batch 2 (the GPU run uses the full batch), >= 2 timed iters."""
+    """Oracle step on the host cores, bounded sample: batch 2 (1 at 512x1024; the GPU run uses the full batch)."""
     import numpy as np
     import torch
     from oracle import deeplab2 as odl, step as ostep, boxmask as obox
@@ -69,7 +80,7 @@ def cpu_baseline(workload, seconds_budget=30.0):
     else:
         S = ostep.StepState(odl.closed_form_state(C), C, opt='adam', lr=3e-5)
         run = lambda: ostep.train_iteration(S, x, y, ux0, ux1, ones, ones, m)
-        what, min_iters = 'oracle/step.py', 2
+        what, min_iters = 'oracle/step.py', (2 if N == 2 else 1)
     run()                                                             # warm-up
     times = []
     t_start = time.time()
@@ -84,56 +95,58 @@ def cpu_baseline(workload, seconds_budget=30.0):
                            N, H, W, workload['batch'], len(times), t))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='pascal')
-    ap.add_argument('--dtype', choices=['bf16', 'fp32'], default='bf16')
-    ap.add_argument('--roofline_kernel', choices=['conv', 'adam_ema', 'consistency'], default=None,
-                    help='default: conv (the MFMA convolution) for the DeepLab v2 workloads, adam_ema otherwise')
-    ap.add_argument('--no_cpu_baseline', action='store_true')
-    ap.add_argument('--no_fuse_batches', action='store_true')
-    ap.add_argument('--conv_tile', type=int, default=0, help='experiment: force a conv tile code (256, 1128, 128)')
-    ap.add_argument('--tile_rule', default='', help='experiment: cout:tile[,cout:tile...] per-layer tile codes')
-    ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')
-    ap.add_argument('--no_roofline_events', action='store_true', help='skip the per-launch event brackets')
-    ap.add_argument('--roofline_sample', type=int, default=5,
-                    help='bracket every k-th launch of the conv kernel with events (1 = all; the brackets cost ~3 %% '
-                         'of the step when every launch carries them)')
-    args = ap.parse_args()
-    args.roofline_sample = max(1, args.roofline_sample)
-    if args.roofline_kernel is None:
-        args.roofline_kernel = 'conv' if 'arch' not in WORKLOADS[args.workload] else 'adam_ema'
-    args.roofline_sample_used = args.roofline_sample
+def self_launch(args):
+    """`--gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same flags>`."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL needs on this driver
+    sys.stdout.flush()
+    os.execvp(cmd[0], cmd)
 
+
+def dry_launch(args, world, rank):
+    """Launch-path check that needs no GPU: every rank joins a gloo group, an all-reduce counts the ranks, rank 0
+    prints the JSON skeleton with the world size it saw (tests/test_dist_cpu.py drives `--gpus 2 --dry_launch`)."""
+    import torch
+    import torch.distributed as dist
+    seen = 1
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'metric': 'train images/sec (student+teacher step)', 'value': None, 'unit': 'images/sec',
+                          'n_gpus': world, 'world_size_seen': seen, 'gpus_requested': args.gpus, 'dry_launch': True,
+                          'steps': args.steps, 'warmup': args.warmup}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_workload(key, args, world, rank, dev):
+    """Builds the networks of workload `key`, times K steps, returns the result object (meaningful on rank 0)."""
     import numpy as np
     import torch
     import torch.distributed as dist
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
-
     from cutmix_semisup_seg_amd import ops, optim as fo
     from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
     from architectures import network_architectures
     import mask_gen
     import optim_weight_ema
 
-    wl = WORKLOADS[args.workload]
+    wl = WORKLOADS[key]
     B, H, W, C = wl['batch'], wl['H'], wl['W'], wl['classes']
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    esz = 2.0 if dtype == torch.bfloat16 else 4.0
+    roofline_kernel = args.roofline_kernel or ('conv' if 'arch' not in wl else 'adam_ema')
+    sample_every = max(1, args.roofline_sample)
 
     torch.manual_seed(12345)                       # identical replicas on every rank
     Net = network_architectures.seg.get(wl.get('arch', 'resnet101_deeplab_imagenet'))
@@ -151,11 +164,12 @@ def main():
                      fuse_batches=not args.no_fuse_batches, compute_dtype=dtype,
                      overlap_teacher=not args.no_overlap)
     step = CutMixMeanTeacherStep(stu, tea, opt, ema, cfg)
-    if args.no_overlap and hasattr(stu, 'hip_executor') and dtype == torch.bfloat16:
+    has_ex = hasattr(stu, 'hip_executor')
+    if args.no_overlap and has_ex:
         stu.hip_executor().overlap_wgrad = False
-    if args.conv_tile and hasattr(stu, 'hip_executor'):
+    if args.conv_tile and has_ex:
         stu.hip_executor().conv_tile = tea.hip_executor().conv_tile = args.conv_tile
-    if args.tile_rule and hasattr(stu, 'hip_executor'):
+    if args.tile_rule and has_ex:
         rules = {int(a): int(b) for a, b in (kv.split(':') for kv in args.tile_rule.split(','))}
         stu.hip_executor().tile_rules = tea.hip_executor().tile_rules = rules
 
@@ -174,85 +188,129 @@ def main():
         pool.append(dict(x=images(), y=y.to(torch.uint8), x0=images(), x1=images(),
                          x0s=images() if wl['paired'] else None, x1s=images() if wl['paired'] else None))
 
-    # roofline instrumentation: bracket every launch of the chosen kernel with events on the launch stream
-    ev_pairs = []
+    # ---- roofline instrumentation: HIP events on the launch stream around the launches of the measured kernels
     timing_on = [False]
-    roof = dict(bound='hbm', peak=HBM_PEAK_GBS, unit='GB/s')
-    work_per_launch = []            # algorithmic bytes or FLOPs of every timed launch
-    step_flops = [0.0]              # algorithmic MFMA FLOPs of ALL convolution launches in the timed region
-    launch_no = [0]
-    conv_bytes = [0.0]              # algorithmic HBM bytes of the same launches (operands once, output once)
-    if args.roofline_kernel == 'conv':
-        # the dominant kernel of the step: conv_igemm_kernel (csrc/conv.hip) -- every forward and data-gradient
-        # convolution of the backbone. Algorithmic FLOPs of a launch = 2 * pixels * Cout * Cin * taps.
-        orig_conv = ops.conv_igemm
+    conv = dict(pairs=[], work=[], flops=0.0, bytes=0.0, launches=0)       # conv_igemm_kernel (MFMA)
+    hbm = dict(pairs=[], bytes=0.0, moved=0.0, parts={})                   # the HBM-bound group
+    other = dict(pairs=[], work=[])                                        # --roofline_kernel adam_ema / consistency
+    saved_fns = {}
 
-        def conv_flops(x, w_packed, k):
-            ohw = k.get('out_hw')
-            npix = x.shape[0] * (ohw[0] * ohw[1] if ohw is not None else x.shape[1] * x.shape[2])
-            return 2.0 * npix * w_packed.shape[1] * w_packed.shape[2] * w_packed.shape[0]
+    def ev_pair():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-        def timed_conv(x, w_packed, taps, *a, **k):
-            if not timing_on[0]:
-                return orig_conv(x, w_packed, taps, *a, **k)
-            fl = conv_flops(x, w_packed, k)
-            step_flops[0] += fl
-            npix_out = fl / (2.0 * w_packed.shape[1] * w_packed.shape[2] * w_packed.shape[0])
-            conv_bytes[0] += 2.0 * (x.numel() + w_packed.numel()) + npix_out * w_packed.shape[1] * (
-                (4.0 if k.get('out_f32_nchw') is not None else 2.0) + (2.0 if k.get('res') is not None else 0.0)
-                + (2.0 if k.get('mask_src') is not None else 0.0))
-            launch_no[0] += 1
-            if launch_no[0] % args.roofline_sample:
-                return orig_conv(x, w_packed, taps, *a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    def hbm_timed(part, fn, nbytes, moved):
+        def wrapper(*a, **k):
+            if not timing_on[0] or args.no_roofline_events:
+                return fn(*a, **k)
+            e0, e1 = ev_pair()
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            nb, mv = nbytes(*a, **k), moved(*a, **k)
+            hbm['pairs'].append((part, e0, e1))
+            hbm['bytes'] += nb
+            hbm['moved'] += mv
+            p = hbm['parts'].setdefault(part, [0.0, 0.0, 0])
+            p[0] += nb; p[1] += mv; p[2] += 1
+            return r
+        return wrapper
+
+    P_ = lambda n: float(n) * H * W                           # full-resolution pixels of n images
+
+    def lowres(t):
+        return float(t.shape[0]) * t.shape[2] * t.shape[3]    # low-resolution cells of an (N,C,h,w) tensor
+
+    # SURVEY.md 8(d), compulsory bytes of the reference-equivalent (materialised) formulation / bytes the fused kernels move
+    saved_fns['cutmix_paste'] = ops.cutmix_paste
+    ops.cutmix_paste = hbm_timed('cutmix_paste', saved_fns['cutmix_paste'],
+                                 lambda x0, x1, **k: 9.0 * P_(x1.shape[0]) * esz,      # 2 image reads + 1 write (um all-ones)
+                                 lambda x0, x1, **k: 9.0 * P_(x1.shape[0]) * esz)
+    saved_fns['consistency_forward'] = ops.consistency_forward
+    ops.consistency_forward = hbm_timed('consistency_fwd', saved_fns['consistency_forward'],
+                                        lambda cfg_, ls, *a, **k: (2.0 * C + 2.0) * P_(ls.shape[0]) * 4.0,
+                                        lambda cfg_, ls, *a, **k: 3.0 * C * lowres(ls) * 4.0)
+    saved_fns['consistency_backward'] = ops.consistency_backward
+    ops.consistency_backward = hbm_timed('consistency_bwd', saved_fns['consistency_backward'],
+                                         lambda ctx, sc, *a, **k: (3.0 * C + 2.0) * P_(ctx[1][0].shape[0]) * 4.0,
+                                         lambda ctx, sc, *a, **k: 4.0 * C * lowres(ctx[1][0]) * 4.0)
+    saved_fns['ce_forward'] = ops.ce_forward
+    ops.ce_forward = hbm_timed('ce_fwd', saved_fns['ce_forward'],
+                               lambda lg, lab, *a, **k: C * P_(lg.shape[0]) * 4.0 + P_(lg.shape[0]) * 1.0,
+                               lambda lg, lab, *a, **k: C * lowres(lg) * 4.0 + P_(lg.shape[0]) * 1.0)
+    saved_fns['ce_backward'] = ops.ce_backward
+    ops.ce_backward = hbm_timed('ce_bwd', saved_fns['ce_backward'],
+                                lambda ctx, sc, *a, **k: 2.0 * C * P_(ctx[1][0].shape[0]) * 4.0 + P_(ctx[1][0].shape[0]),
+                                lambda ctx, sc, *a, **k: 2.0 * C * lowres(ctx[1][0]) * 4.0 + P_(ctx[1][0].shape[0]))
+
+    orig_conv = saved_fns['conv_igemm'] = ops.conv_igemm
+    orig_wgrad = saved_fns['conv_wgrad'] = ops.conv_wgrad
+
+    def conv_flops(x, w_packed, k):
+        ohw = k.get('out_hw')
+        npix = x.shape[0] * (ohw[0] * ohw[1] if ohw is not None else x.shape[1] * x.shape[2])
+        return 2.0 * npix * w_packed.shape[1] * w_packed.shape[2] * w_packed.shape[0]
+
+    def timed_conv(x, w_packed, taps, *a, **k):
+        if not timing_on[0]:
+            return orig_conv(x, w_packed, taps, *a, **k)
+        fl = conv_flops(x, w_packed, k)
+        conv['flops'] += fl
+        npix_out = fl / (2.0 * w_packed.shape[1] * w_packed.shape[2] * w_packed.shape[0])
+        head = k.get('out_f32_nchw') is not None
+        nb = esz * (x.numel() + w_packed.numel()) + npix_out * (
+            (4.0 * k.get('cout_real', w_packed.shape[1]) if head else esz * w_packed.shape[1])
+            + (esz * w_packed.shape[1] if k.get('res') is not None else 0.0)
+            + (esz * w_packed.shape[1] if k.get('mask_src') is not None else 0.0))
+        conv['bytes'] += nb
+        conv['launches'] += 1
+        if args.no_roofline_events:
+            return orig_conv(x, w_packed, taps, *a, **k)
+        if head:            # the ASPP head (2048 -> C, dilations 6 + 12): HBM-bound group, every launch timed
+            e0, e1 = ev_pair()
             e0.record()
             r = orig_conv(x, w_packed, taps, *a, **k)
             e1.record()
-            work_per_launch.append(fl)
-            ev_pairs.append((e0, e1))
+            hbm['pairs'].append(('aspp_head_fwd', e0, e1))
+            hbm['bytes'] += nb
+            hbm['moved'] += nb
+            p = hbm['parts'].setdefault('aspp_head_fwd', [0.0, 0.0, 0])
+            p[0] += nb; p[1] += nb; p[2] += 1
             return r
+        if roofline_kernel != 'conv' or conv['launches'] % sample_every:
+            return orig_conv(x, w_packed, taps, *a, **k)
+        e0, e1 = ev_pair()
+        e0.record()
+        r = orig_conv(x, w_packed, taps, *a, **k)
+        e1.record()
+        conv['work'].append(fl)
+        conv['pairs'].append((e0, e1))
+        return r
 
-        orig_wgrad = ops.conv_wgrad
+    def counted_wgrad(du, x, taps, dw, *a, **k):
+        if timing_on[0]:
+            conv['flops'] += 2.0 * du.shape[0] * du.shape[1] * du.shape[2] * du.shape[3] * x.shape[3] * len(taps)
+        return orig_wgrad(du, x, taps, dw, *a, **k)
+    ops.conv_wgrad = counted_wgrad
+    ops.conv_igemm = timed_conv
 
-        def counted_wgrad(du, x, taps, dw, *a, **k):
-            if timing_on[0]:
-                step_flops[0] += 2.0 * du.shape[0] * du.shape[1] * du.shape[2] * du.shape[3] * x.shape[3] * len(taps)
-            return orig_wgrad(du, x, taps, dw, *a, **k)
-        ops.conv_wgrad = counted_wgrad
-        ops.conv_igemm = timed_conv
-        roof = dict(bound='mfma', peak=MFMA_PEAK_TFLOPS, unit='TFLOP/s')
-        kname = 'conv_igemm_kernel (MFMA implicit-GEMM convolution, forward + data-gradient launches of the backbone)'
-    elif args.roofline_kernel == 'adam_ema':
-        from cutmix_semisup_seg_amd import _lib
-        orig_launch = _lib.fn['cms_adam_ema_step']          # optim.py launches through this table
-
+    kname = 'conv_igemm_kernel (MFMA implicit-GEMM convolution, forward + data-gradient launches of the backbone)'
+    roof = dict(bound='mfma', peak=MFMA_PEAK_TFLOPS if dtype == torch.bfloat16 else MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s')
+    from cutmix_semisup_seg_amd import _lib
+    orig_adam = _lib.fn['cms_adam_ema_step']
+    if roofline_kernel == 'adam_ema':
         def timed_launch(desc, stream):
             if not timing_on[0]:
-                return orig_launch(desc, stream)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                return orig_adam(desc, stream)
+            e0, e1 = ev_pair()
             e0.record()
-            rc = orig_launch(desc, stream)
+            rc = orig_adam(desc, stream)
             e1.record()
-            ev_pairs.append((e0, e1))
-            work_per_launch.append(opt.arena.total * 40.0)   # 5 fp32 reads + 4 fp32 writes + 2 bf16 copies
+            other['pairs'].append((e0, e1))
+            other['work'].append(opt.arena.total * 40.0)   # 5 fp32 reads + 4 fp32 writes + 2 bf16 copies
             return rc
         _lib.fn['cms_adam_ema_step'] = timed_launch
         kname = 'optim_ema_kernel<ADAM> (fused Adam + teacher EMA over the 44.2M-element arena)'
-    else:
-        orig_fwd = ops.consistency_forward
-
-        def timed_fwd(*a, **k):
-            if not timing_on[0]:
-                return orig_fwd(*a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = orig_fwd(*a, **k)
-            e1.record()
-            ev_pairs.append((e0, e1))
-            work_per_launch.append((2 * C + 2) * B * H * W * 4.0)   # reference-equivalent traffic, SURVEY 8(d)
-            return r
-        ops.consistency_forward = timed_fwd
-        kname = 'cons_fwd_kernel (+ second-stage reduce + finalize)'
+        roof = dict(bound='hbm', peak=HBM_PEAK_GBS, unit='GB/s')
 
     def one_step(i):
         b = pool[i % len(pool)]
@@ -260,75 +318,78 @@ def main():
         ub = UnsupBatch(b['x0'], ranges, x1_tea=b['x1'], x0_stu=b['x0s'], x1_stu=b['x1s'])
         return step(b['x'], b['y'], [ub])
 
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    timing_on[0] = not args.no_roofline_events
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        res = one_step(i)
-    t_enqueue = time.perf_counter() - t0         # host time to enqueue the K steps (== elapsed when launch-bound)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    timing_on[0] = False
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax)
-
-    last = {k: (None if v is None else float(v)) for k, v in res.items()}
-    if not np.isfinite(last['sup_loss']):
-        raise SystemExit('non-finite loss in the bench loop: {}'.format(last))
-
-    # Outside the timed region: the same kernel with the GPU to itself (single stream, every launch bracketed). In
-    # the timed region the teacher pass and the weight gradients run concurrently on other streams, so a launch's
-    # event-to-event time there includes the share of the machine the co-running kernels took.
-    isolated = None
-    timed_pairs, timed_work, timed_flops = list(ev_pairs), list(work_per_launch), step_flops[0]
-    if world == 1 and args.roofline_kernel == 'conv' and not args.no_overlap and not args.no_roofline_events \
-            and dtype == torch.bfloat16:
-        del ev_pairs[:], work_per_launch[:]
-        cfg.overlap_teacher = False
-        stu.hip_executor().overlap_wgrad = False
-        args.roofline_sample = 1
-        timing_on[0] = True
-        for i in range(3):
+    try:
+        for i in range(args.warmup):
             one_step(i)
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        timing_on[0] = True
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            res = one_step(i)
+        t_enqueue = time.perf_counter() - t0         # host time to enqueue the K steps (== elapsed when launch-bound)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
         timing_on[0] = False
-        ms_iso = [a.elapsed_time(b) for a, b in ev_pairs]
-        ach = sum(work_per_launch) / (sum(ms_iso) * 1e-3) / 1e12
-        isolated = {'achieved': ach, 'frac': ach / roof['peak'], 'avg_launch_ms': float(np.mean(ms_iso)),
-                    'launches_timed': len(ms_iso), 'note': 'same kernel, single stream, 3 extra steps after the '
-                    'timed region (not part of `value`)'}
-    ev_pairs, work_per_launch = timed_pairs, timed_work
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax)
 
+        last = {k: (None if v is None else float(v)) for k, v in res.items()}
+        if not np.isfinite(last['sup_loss']):
+            raise SystemExit('non-finite loss in the bench loop: {}'.format(last))
+
+        # Outside the timed region: the same kernel with the GPU to itself (single stream, every launch bracketed). In
+        # the timed region the teacher pass and the weight gradients run concurrently on other streams, so a launch's
+        # event-to-event time there includes the share of the machine the co-running kernels took.
+        isolated = None
+        timed = dict(pairs=list(conv['pairs']), work=list(conv['work']), flops=conv['flops'], bytes=conv['bytes'],
+                     launches=conv['launches'])
+        hbm_timed_pairs = list(hbm['pairs'])
+        hbm_tot = (hbm['bytes'], hbm['moved'], {k: list(v) for k, v in hbm['parts'].items()})
+        if world == 1 and roofline_kernel == 'conv' and not args.no_overlap and not args.no_roofline_events and has_ex \
+                and 'arch' not in wl:
+            del conv['pairs'][:], conv['work'][:]
+            cfg.overlap_teacher = False
+            stu.hip_executor().overlap_wgrad = False
+            sample_every = 1
+            timing_on[0] = True
+            for i in range(3):
+                one_step(i)
+            torch.cuda.synchronize()
+            timing_on[0] = False
+            ms_iso = [a.elapsed_time(b) for a, b in conv['pairs']]
+            ach = sum(conv['work']) / (sum(ms_iso) * 1e-3) / 1e12
+            isolated = {'achieved': ach, 'frac': ach / roof['peak'], 'avg_launch_ms': float(np.mean(ms_iso)),
+                        'launches_timed': len(ms_iso), 'note': 'same kernel, single stream, 3 extra steps after the '
+                        'timed region (not part of `value`)'}
+    finally:
+        for name, f in saved_fns.items():
+            setattr(ops, name, f)
+        _lib.fn['cms_adam_ema_step'] = orig_adam
+
+    out = None
     if rank == 0:
-        ms_all = [a.elapsed_time(b) for a, b in ev_pairs]
+        if roofline_kernel == 'conv':
+            pairs, work = timed['pairs'], timed['work']
+        else:
+            pairs, work = other['pairs'], other['work']
+        ms_all = [a.elapsed_time(b) for a, b in pairs]
         ms_kernel = float(np.mean(ms_all)) if ms_all else float('nan')
-        per_launch = float(np.mean(work_per_launch)) if work_per_launch else float('nan')
-        rate = (sum(work_per_launch) / (sum(ms_all) * 1e-3)) if ms_all else float('nan')
+        per_launch = float(np.mean(work)) if work else float('nan')
+        rate = (sum(work) / (sum(ms_all) * 1e-3)) if ms_all else float('nan')
         achieved = rate / (1e12 if roof['bound'] == 'mfma' else 1e9)
         out = {
-            'metric': 'train images/sec (student+teacher step)',
+            'workload': key,
             'value': args.steps * B * world / elapsed,
             'unit': 'images/sec',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': args.dtype,
-            'data': 'synthetic (N(0,1) images, uniform labels with 5% ignore=255, all-ones validity masks, '
-                    'seeded box masks; random-init weights)',
             'config': {'workload': wl['name'], 'per_gpu_batch': B, 'global_batch': B * world, 'crop': [H, W],
                        'classes': C, 'parallelism': 'dp{}'.format(world), 'image_forwards_per_sec':
                            4 * args.steps * B * world / elapsed,
@@ -339,16 +400,16 @@ def main():
                          'unit': roof['unit'], 'frac': achieved / roof['peak'], 'traffic': None,
                          'avg_launch_ms': ms_kernel,
                          'algorithmic_{}_per_launch'.format('flops' if roof['bound'] == 'mfma' else 'bytes'): per_launch,
-                         'launches_timed': len(ev_pairs),
-                         'sampling': 'every launch' if args.roofline_sample_used == 1 else
-                                     'every {}th launch'.format(args.roofline_sample_used)},
+                         'launches_timed': len(pairs),
+                         'sampling': 'every launch' if args.roofline_sample <= 1 else
+                                     'every {}th launch'.format(args.roofline_sample)},
         }
-        if args.roofline_kernel == 'conv' and launch_no[0]:
-            out['roofline']['algorithmic_bytes_per_launch'] = conv_bytes[0] / launch_no[0]
+        if roofline_kernel == 'conv' and timed['launches']:
+            out['roofline']['algorithmic_bytes_per_launch'] = timed['bytes'] / timed['launches']
             import glob
             cands = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_traffic.json')))
             pmc = cands[-1] if cands else ''
-            if args.workload == 'pascal' and pmc:
+            if key == 'pascal' and pmc:
                 # HBM bytes per launch from the TCC memory-side counters (separate FETCH_SIZE / WRITE_SIZE passes of
                 # this command under rocprofv3, gfx950 correction applied; tools/gpu_pmc_traffic.sh)
                 t = json.load(open(pmc))
@@ -357,13 +418,117 @@ def main():
                     os.path.basename(pmc))
         if isolated is not None:
             out['roofline']['isolated'] = isolated
-        if timed_flops > 0:
+        if timed['flops'] > 0:
             # all MFMA work of the step (forward, data-gradient AND weight-gradient convolutions) over the step time
             out['roofline']['step_mfma'] = {
-                'tflop_per_step': timed_flops / args.steps / 1e12,
-                'achieved': timed_flops / elapsed / 1e12, 'frac': timed_flops / elapsed / 1e12 / MFMA_PEAK_TFLOPS}
+                'tflop_per_step': timed['flops'] / args.steps / 1e12,
+                'achieved': timed['flops'] / elapsed / 1e12, 'frac': timed['flops'] / elapsed / 1e12 / roof['peak']}
+        if hbm_timed_pairs:
+            ms = {}
+            for part, e0, e1 in hbm_timed_pairs:
+                ms[part] = ms.get(part, 0.0) + e0.elapsed_time(e1)
+            tot_ms = sum(ms.values())
+            nb, mv, parts = hbm_tot
+            out['roofline_hbm'] = {
+                'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'group': 'cutmix paste + masked consistency fwd/bwd + cross entropy fwd/bwd + ASPP head convolution',
+                'achieved': nb / (tot_ms * 1e-3) / 1e9, 'frac': nb / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'basis': 'SURVEY.md 8(d): compulsory bytes of the reference-equivalent formulation (full-resolution '
+                         'logits materialised); the fused kernels evaluate the bilinear upsample in-kernel and move '
+                         '`moved_bytes_per_step` instead',
+                'bytes_per_step': nb / args.steps, 'moved_bytes_per_step': mv / args.steps,
+                'achieved_on_moved_bytes': mv / (tot_ms * 1e-3) / 1e9,
+                'ms_per_step': tot_ms / args.steps,
+                'parts': {k: {'ms_per_step': ms[k] / args.steps, 'GBps': parts[k][0] / (ms[k] * 1e-3) / 1e9,
+                              'launches_per_step': parts[k][2] / args.steps} for k in ms},
+                'traffic': None}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(wl)
+            out['cpu_baseline'] = cpu_baseline(wl, seconds_budget=30.0 if key == 'pascal' else 20.0)
+    del step, opt, ema, stu, tea, pool
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', choices=sorted(WORKLOADS) + ['both'], default='both',
+                    help='both = pascal (321x321, the headline value) then cityscapes (512x1024), one JSON line')
+    ap.add_argument('--dtype', choices=['bf16', 'fp32'], default='bf16')
+    ap.add_argument('--roofline_kernel', choices=['conv', 'adam_ema'], default=None,
+                    help='default: conv (the MFMA convolution) for the DeepLab v2 workloads, adam_ema otherwise')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_fuse_batches', action='store_true')
+    ap.add_argument('--conv_tile', type=int, default=0, help='experiment: force a conv tile code (256, 1128, 128)')
+    ap.add_argument('--tile_rule', default='', help='experiment: cout:tile[,cout:tile...] per-layer tile codes')
+    ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')
+    ap.add_argument('--no_roofline_events', action='store_true', help='skip the per-launch event brackets')
+    ap.add_argument('--roofline_sample', type=int, default=5,
+                    help='bracket every k-th launch of the conv kernel with events (1 = all; the brackets cost ~3 %% '
+                         'of the step when every launch carries them)')
+    ap.add_argument('--dry_launch', action='store_true',
+                    help='launch-path check without a GPU: gloo group, count the ranks, print the JSON skeleton')
+    args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)                          # does not return
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+    if args.dry_launch:
+        return dry_launch(args, world, rank)
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                     # RCCL really spans `world` ranks
+        rccl_world = int(probe.item())
+    else:
+        rccl_world = 1
+
+    keys = ['pascal', 'cityscapes'] if args.workload == 'both' else [args.workload]
+    results = [run_workload(k, args, world, rank, dev) for k in keys]
+    if rank == 0:
+        head = results[0]
+        out = {
+            'metric': 'train images/sec (student+teacher step)',
+            'value': head['value'],
+            'unit': 'images/sec',
+            'n_gpus': world,
+            'rccl_world_size': rccl_world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': head['ms_per_step'],
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': args.dtype,
+            'data': 'synthetic (N(0,1) images, uniform labels with 5% ignore=255, all-ones validity masks, '
+                    'seeded box masks; random-init weights)',
+            'config': head['config'],
+            'roofline': head['roofline'],
+        }
+        for k in ('roofline_hbm', 'cpu_baseline'):
+            if k in head:
+                out[k] = head[k]
+        for r in results:
+            if r['workload'] == 'pascal':
+                out['value_321x321'] = r['value']
+            if r['workload'] == 'cityscapes':
+                out['value_512x1024'] = r['value']
+        out['configs'] = results
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -122,6 +122,10 @@ PROTOTYPES = {
     'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'cms_conv_pack_transpose_batch': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    'cms_conv_igemm_f32': (c_int, [_P(ConvDesc), c_void_p]),
+    'cms_conv_wgrad_f32': (c_int, [_P(WgradDesc), c_void_p]),
+    'cms_conv_pack_transpose_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'cms_conv_pack_transpose_batch_f32': (c_int, [c_void_p, c_int, c_int, c_void_p]),
 }
 
 fn = {}

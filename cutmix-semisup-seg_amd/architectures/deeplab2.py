@@ -168,10 +168,11 @@ class ResNetDeepLab(nn.Module):
         self.num_classes = num_classes
         self.compute_dtype = torch.bfloat16
         self.engine = None          # set to an engine object to override the default executor
-        # 'auto': hand-written MFMA executor (backbone_hip.py) whenever BatchNorm is frozen and compute is bf16,
-        # library engine otherwise; 'torch' / 'hip' force one
+        # 'auto': hand-written MFMA executor (backbone_hip.py) whenever BatchNorm is frozen (bf16 = throughput
+        # configuration, fp32 = parity configuration), library engine otherwise; 'torch' / 'hip' force one
         self.engine_kind = 'auto'
-        self._hip_executor = None
+        self._hip_executor = None       # the executor used last
+        self._hip_executors = {}        # compute dtype -> executor
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = _frozen_bn(64)
         self.relu = nn.ReLU(inplace=True)
@@ -216,17 +217,21 @@ class ResNetDeepLab(nn.Module):
         if self.engine_kind == 'torch' or self.engine is not None:
             return False
         frozen = all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
-        ok = frozen and self.compute_dtype == torch.bfloat16 and self.num_classes <= 32
+        ok = frozen and self.compute_dtype in (torch.bfloat16, torch.float32) and self.num_classes <= 32
         if self.engine_kind == 'hip' and not ok:
-            raise RuntimeError('the MFMA executor needs frozen BatchNorm (freeze_batchnorm()), bf16 compute and '
-                               '<= 32 classes')
+            raise RuntimeError('the MFMA executor needs frozen BatchNorm (freeze_batchnorm()), bf16 or fp32 compute '
+                               'and <= 32 classes')
         return ok
 
     def hip_executor(self):
-        if self._hip_executor is None:
+        # one executor per compute dtype (bf16: throughput configuration; fp32: parity configuration on the f32-input
+        # MFMA, csrc/conv_f32.hip -- also what the VAT direction pass switches to inside a bf16 iteration)
+        ex = self._hip_executors.get(self.compute_dtype)
+        if ex is None:
             from ..backbone_hip import DeepLabHipExecutor
-            self._hip_executor = DeepLabHipExecutor(self)
-        return self._hip_executor
+            ex = self._hip_executors[self.compute_dtype] = DeepLabHipExecutor(self, dtype=self.compute_dtype)
+        self._hip_executor = ex
+        return ex
 
     def stem_nhwc(self, x):
         """conv1 + bn1 + ReLU + max-pool (:183-186) -> bf16 NHWC, the input of the MFMA executor."""

@@ -26,6 +26,15 @@ from . import ops
 from .arena import ensure_arena
 
 
+def executors_of(module):
+    """Every MFMA executor built for `module` (one per compute dtype); empty for networks on the library engine."""
+    exs = getattr(module, '_hip_executors', None)
+    if exs:
+        return list(exs.values())
+    ex = getattr(module, '_hip_executor', None)
+    return [] if ex is None else [ex]
+
+
 class _Conv(object):
     __slots__ = ('wkey', 'bn', 'taps', 'ntaps', 'neg_taps', 'stride', 'cin', 'cout', 'scale', 'bias', 'wT', 'ksize',
                  'pad', 'dil', 'wdot', 'dbeta')
@@ -47,8 +56,11 @@ class _Block(object):
 
 
 class DeepLabHipExecutor(object):
-    def __init__(self, net):
-        self._init_common(net)
+    def __init__(self, net, dtype=torch.bfloat16):
+        """`dtype`: torch.bfloat16 = the throughput configuration (bf16 activations / weights on the bf16 MFMA, fp32
+        accumulation); torch.float32 = the PARITY configuration (fp32 activations, the fp32 master weights themselves as
+        operands, f32-input MFMA -- csrc/conv_f32.hip)."""
+        self._init_common(net, dtype)
         self.num_classes = net.num_classes
         self._add_blocks('', [getattr(net, 'layer{}'.format(li)) for li in range(1, 5)])
         head = net.layer5.conv2d_list
@@ -61,18 +73,22 @@ class DeepLabHipExecutor(object):
         C = self.num_classes
         if C > 32:
             raise NotImplementedError('ASPP head kernel is specialised for <= 32 classes')
-        self.aspp_w = torch.zeros(18, 64, 2048, dtype=torch.bfloat16, device=dev)     # class axis padded to 64 (dgrad K)
-        self.aspp_w32 = torch.zeros(18, 32, 2048, dtype=torch.bfloat16, device=dev)   # forward operand (padded to 32)
-        self.aspp_wT = torch.zeros(18, 2048, 64, dtype=torch.bfloat16, device=dev)
+        self.aspp_w = torch.zeros(18, 64, 2048, dtype=self.dtype, device=dev)     # class axis padded to 64 (dgrad K)
+        self.aspp_w32 = torch.zeros(18, 32, 2048, dtype=self.dtype, device=dev)   # forward operand (padded to 32)
+        self.aspp_wT = torch.zeros(18, 2048, 64, dtype=self.dtype, device=dev)
+        self._aspp_version = -1
         self.aspp_bias = torch.zeros(32, dtype=torch.float32, device=dev)
 
-    def _init_common(self, net):
+    def _init_common(self, net, dtype=torch.bfloat16):
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise TypeError('executor dtype must be torch.bfloat16 or torch.float32')
         self.net = net
+        self.dtype = dtype
         self.trainable = any(p.requires_grad for p in net.parameters())
         # BatchNorm affine parameters that train (torchvision-style backbones) move with every optimizer step
         self.bn_trainable = any(p.requires_grad for m in net.modules() if 'BatchNorm' in type(m).__name__
                                 for p in m.parameters())
-        self.arena = ensure_arena(net, with_grad=self.trainable, with_bf16=True)
+        self.arena = ensure_arena(net, with_grad=self.trainable, with_bf16=(dtype == torch.bfloat16))
         self.blocks = []
         self._layer_first = []
         self._affine_ready = False
@@ -165,17 +181,27 @@ class DeepLabHipExecutor(object):
         torch.sub(flat[ix['bias']], flat[ix['running_mean']] * self._scale_all, out=self._bias_all)
         self._affine_ready = True
 
+    def _wbuf(self):
+        """The flat buffer the convolution operands are views of: the bf16 copy the fused optimizer maintains, or -- in
+        the fp32 parity configuration -- the fp32 master arena itself."""
+        return self.arena.bf16 if self.dtype == torch.bfloat16 else self.arena.flat
+
     def _w(self, c):
-        return self.arena.packed(c.wkey, self.arena.bf16)
+        return self.arena.packed(c.wkey, self._wbuf())
 
     def _refresh_aspp_fwd(self):
+        """Padded operands of the head (class axis -> 32 / 64 rows, the two live dilations stacked to 18 taps). Only
+        when the weights moved since the last refresh (optimizer / EMA step, load_state_dict)."""
+        if self._aspp_version == self.version:
+            return
         C = self.num_classes
         a = self.arena
         for i, k in enumerate(self.aspp_keys):
-            wk = a.packed(k + '.weight', a.bf16)
+            wk = a.packed(k + '.weight', self._wbuf())
             self.aspp_w[9 * i:9 * i + 9, :C].copy_(wk)
             self.aspp_w32[9 * i:9 * i + 9, :C].copy_(wk)
         self.aspp_bias[:C] = a.view(self.aspp_keys[0] + '.bias') + a.view(self.aspp_keys[1] + '.bias')
+        self._aspp_version = self.version
 
     def _refresh_backward_weights(self):
         """dgrad operands wT[tap][ci][co] = bf16(w * scale[co]) of all 104 convolutions + the head: one launch."""
@@ -185,7 +211,7 @@ class DeepLabHipExecutor(object):
             triples = []
             for c in self._all_convs():
                 w = self._w(c)
-                c.wT = torch.empty((w.shape[0], w.shape[2], w.shape[1]), dtype=torch.bfloat16, device=w.device)
+                c.wT = torch.empty((w.shape[0], w.shape[2], w.shape[1]), dtype=self.dtype, device=w.device)
                 triples.append((w, c.wT, c.scale))
             if hasattr(self, 'aspp_w'):
                 triples.append((self.aspp_w, self.aspp_wT, None))
@@ -270,9 +296,10 @@ class DeepLabHipExecutor(object):
         C = self.num_classes
         x4 = saved[-1]
         n, _, h, w = dlogits.shape
-        dl = torch.zeros((n, h, w, 64), dtype=torch.bfloat16, device=dlogits.device)
+        dl = torch.zeros((n, h, w, 64), dtype=self.dtype, device=dlogits.device)
         dl[..., :C] = dlogits.permute(0, 2, 3, 1)
-        want_w = self.trainable and not self.data_grad_only and a.grad is not None
+        data_only = self.data_grad_only or getattr(self.net, '_data_grad_only', False)
+        want_w = self.trainable and not data_only and a.grad is not None
         # ASPP head: weight / bias gradients of the two live branches, then the data gradient
         for i, k in enumerate(self.aspp_keys if want_w else []):
             gw = a.packed(k + '.weight', a.grad)                     # fp32 (9, C, 2048)

@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void cons_bwd_ident_kernel(ConsArgs a, const f
         float* gp = grad + (size_t)n * g.c * plane + gs.off;
         const float base_f = gscale * px.um;
         const bool pp = a.tau > 0.0f && a.d.conf_per_pixel;
-        if (base_f == 0.0f) continue;
+        // no early-out on base_f == 0 (confidence rate 0 at random init, invalid pixels): the masked-consistency
+        // backward always does its full work, SURVEY.md 8(d) -- a zero factor simply contributes zeros
         if (CT > 0) {
             RegVec<CT> rs, rt;
             fill<CT, true>(rs, gs);
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void cons_bwd_tiled_kernel(ConsArgs a, const f
     auto pixel_grad = [&](int n, int y, int x, const Tap& ty, const Tap& tx, auto emit) -> bool {
         const ConsPixel px = cons_pixel_inputs(a, n, y, x);
         const float base_f = gscale * px.um;
-        if (base_f == 0.0f) return false;
+        // (no early-out on base_f == 0, see cons_bwd_ident_kernel)
         Gather<false> gs, gt;
         gs.base = a.d.l_stu + (size_t)n * g.c * plane;
         gt.base = px.tea;

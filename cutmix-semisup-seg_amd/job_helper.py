@@ -15,6 +15,12 @@ class LogAlreadyExistsError(Exception):
     pass
 
 
+class JobNotRun(Exception):
+    """Raised by a job function that refuses to start (e.g. no dataset pipeline and no --synthetic): the log this
+    attempt created is removed again -- otherwise a corrected rerun would be skipped as 'already executed' -- and the
+    process exits non-zero."""
+
+
 class Logger(object):
     """File + stream tee (appends, like the reference)."""
 
@@ -87,15 +93,28 @@ def job(job_name, enumerate_job_names=True):
             desc = kwargs.pop('job_desc', None)
             if desc is None or desc == '':
                 desc = specific
+            # One process per GPU (torchrun): only rank 0 owns the log / run directory; the other ranks run with the
+            # reference's job_desc='none' semantics (no log file, no "already executed" test) so that every rank
+            # enters the collectives of the training function.
+            if int(os.environ.get('RANK', '0')) != 0:
+                desc = 'none'
             try:
                 submit_config = SubmitConfig(specific, desc, enumerate_job_names)
             except LogAlreadyExistsError:
                 print('Job {}:{} already executed; skipping'.format(specific, desc))
+                if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+                    # the other ranks are already on their way into init_process_group: do not leave them hanging
+                    raise SystemExit('Job {}:{} already executed (rank 0 of a multi-process launch)'.format(specific, desc))
                 return
             print('[NO dnnlib] logging to {}'.format(submit_config.log_path))
             submit_config.connect_streams()
             try:
                 job_fn(submit_config, **kwargs)
+            except JobNotRun as e:
+                submit_config.disconnect_streams()
+                if submit_config.log_path is not None and os.path.exists(submit_config.log_path):
+                    os.remove(submit_config.log_path)
+                raise SystemExit(str(e))
             finally:
                 submit_config.disconnect_streams()
 

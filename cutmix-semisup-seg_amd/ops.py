@@ -403,9 +403,13 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     Returns the bf16 (N, out_h, out_w, Cout) output (or the fp32 NCHW tensor given in `out_f32_nchw`).
     """
     _need_cuda(x, w_packed, scale, bias, res, mask_src, out, out_f32_nchw)
-    if x.dtype != torch.bfloat16 or w_packed.dtype != torch.bfloat16 or not x.is_contiguous() \
+    if x.dtype not in (torch.bfloat16, torch.float32) or w_packed.dtype != x.dtype or not x.is_contiguous() \
             or not w_packed.is_contiguous():
-        raise TypeError('conv_igemm: contiguous bf16 NHWC input and packed weights required')
+        raise TypeError('conv_igemm: contiguous NHWC input and packed weights of one dtype (bf16 or fp32) required')
+    for t in (res, mask_src, out):
+        if t is not None and (t.dtype != x.dtype or not t.is_contiguous()):
+            raise TypeError('conv_igemm: residual / mask / output tensors must be contiguous and of the input dtype')
+    f32 = x.dtype == torch.float32          # fp32 parity configuration: csrc/conv_f32.hip
     n, h, w_in, cin = (int(s) for s in x.shape)
     ntaps, cout, cin_w = (int(s) for s in w_packed.shape)
     if cin_w != cin or ntaps != len(taps):
@@ -416,8 +420,7 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     d.x, d.w = x.data_ptr(), w_packed.data_ptr()
     if out_f32_nchw is None:
         if out is None:
-            out = (torch.zeros if out_stride > 1 else torch.empty)((n, oh, ow, cout), dtype=torch.bfloat16,
-                                                                  device=x.device)
+            out = (torch.zeros if out_stride > 1 else torch.empty)((n, oh, ow, cout), dtype=x.dtype, device=x.device)
         d.y, d.y32 = out.data_ptr(), None
     else:
         d.y, d.y32 = None, out_f32_nchw.data_ptr()
@@ -438,16 +441,26 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     zp = _zero_page(x.device)
     d.zeros, d.zeros_bytes = zp.data_ptr(), zp.numel() * 2
     d.variant = int(variant)
-    check(fn['cms_conv_igemm'](C.byref(d), _stream()), 'cms_conv_igemm')
+    name = 'cms_conv_igemm_f32' if f32 else 'cms_conv_igemm'
+    check(fn[name](C.byref(d), _stream()), name)
     return out if out_f32_nchw is None else out_f32_nchw
 
 
-def conv_pack_transpose(w_packed, scale=None, flip=True, out=None):
-    """(ntaps, Cout, Cin) fp32/bf16 -> bf16 (ntaps, Cin, Cout) with BN scale folded and taps flipped: dgrad operand."""
+def conv_pack_transpose(w_packed, scale=None, flip=True, out=None, out_dtype=None):
+    """(ntaps, Cout, Cin) fp32/bf16 -> bf16 (ntaps, Cin, Cout) with BN scale folded and taps flipped: dgrad operand.
+    `out_dtype=torch.float32` (fp32 source only) gives the operand of the fp32 parity configuration."""
     _need_cuda(w_packed, scale, out)
     ntaps, cout, cin = (int(s) for s in w_packed.shape)
     if not w_packed.is_contiguous():
         raise TypeError('conv_pack_transpose: contiguous weights required')
+    if out_dtype == torch.float32 or (out is not None and out.dtype == torch.float32):
+        if w_packed.dtype != torch.float32:
+            raise TypeError('conv_pack_transpose: an fp32 destination needs an fp32 source')
+        if out is None:
+            out = torch.empty((ntaps, cin, cout), dtype=torch.float32, device=w_packed.device)
+        check(fn['cms_conv_pack_transpose_f32'](_ptr(w_packed), _ptr(out), _ptr(scale), ntaps, cout, cin,
+                                                int(bool(flip)), _stream()), 'cms_conv_pack_transpose_f32')
+        return out
     if out is None:
         out = torch.empty((ntaps, cin, cout), dtype=torch.bfloat16, device=w_packed.device)
     check(fn['cms_conv_pack_transpose'](_ptr(w_packed), _dtype_code(w_packed), _ptr(out), _ptr(scale), ntaps, cout, cin,
@@ -464,13 +477,17 @@ class PackTransposePlan(object):
         blk = 0
         self._keep = triples
         dt = triples[0][0].dtype
+        ddt = triples[0][1].dtype
+        if ddt not in (torch.bfloat16, torch.float32) or (ddt == torch.float32 and dt != torch.float32):
+            raise TypeError('PackTransposePlan: bf16 destinations, or fp32 destinations from fp32 sources')
+        self.dst_f32 = ddt == torch.float32
         for i, (src, dst, scale) in enumerate(triples):
             _need_cuda(src, dst, scale)
             ntaps, cout, cin = (int(v) for v in src.shape)
             if src.dtype != dt or not src.is_contiguous() or not dst.is_contiguous() \
-                    or tuple(dst.shape) != (ntaps, cin, cout) or dst.dtype != torch.bfloat16:
-                raise TypeError('PackTransposePlan: contiguous (ntaps,Cout,Cin) sources of one dtype, bf16 '
-                                '(ntaps,Cin,Cout) destinations')
+                    or tuple(dst.shape) != (ntaps, cin, cout) or dst.dtype != ddt:
+                raise TypeError('PackTransposePlan: contiguous (ntaps,Cout,Cin) sources of one dtype, '
+                                '(ntaps,Cin,Cout) destinations of one dtype')
             items[i].src, items[i].dst = src.data_ptr(), dst.data_ptr()
             items[i].scale = scale.data_ptr() if scale is not None else None
             items[i].ntaps, items[i].cout, items[i].cin, items[i].first_block = ntaps, cout, cin, blk
@@ -480,6 +497,10 @@ class PackTransposePlan(object):
         self.table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(triples[0][0].device)
 
     def run(self):
+        if self.dst_f32:
+            check(fn['cms_conv_pack_transpose_batch_f32'](_ptr(self.table), self.n_items, self.total_blocks, _stream()),
+                  'cms_conv_pack_transpose_batch_f32')
+            return
         check(fn['cms_conv_pack_transpose_batch'](_ptr(self.table), self.n_items, self.total_blocks, self.dtype_code,
                                                   _stream()), 'cms_conv_pack_transpose_batch')
 
@@ -490,8 +511,10 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
     du bf16 (N, Ho, Wo, Cout), x bf16 (N, H, W, Cin), both NHWC-contiguous.
     """
     _need_cuda(du, x, dw, scale)
-    if du.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or dw.dtype != torch.float32:
-        raise TypeError('conv_wgrad: bf16 activations and an fp32 gradient buffer required')
+    if du.dtype not in (torch.bfloat16, torch.float32) or x.dtype != du.dtype or dw.dtype != torch.float32:
+        raise TypeError('conv_wgrad: bf16 (or fp32, parity configuration) activations of one dtype and an fp32 '
+                        'gradient buffer required')
+    f32 = du.dtype == torch.float32
     if not (du.is_contiguous() and x.is_contiguous() and dw.is_contiguous()):
         raise TypeError('conv_wgrad: contiguous tensors required')
     n, ho, wo, cout = (int(s) for s in du.shape)
@@ -513,5 +536,6 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
     d.w = w_bf16.data_ptr() if w_bf16 is not None else None
     d.wdot = wdot.data_ptr() if wdot is not None else None
     d.dbeta = dbeta.data_ptr() if dbeta is not None else None
-    check(fn['cms_conv_wgrad'](C.byref(d), _stream()), 'cms_conv_wgrad')
+    name = 'cms_conv_wgrad_f32' if f32 else 'cms_conv_wgrad'
+    check(fn[name](C.byref(d), _stream()), name)
     return dw

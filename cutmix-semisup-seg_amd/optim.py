@@ -25,6 +25,7 @@ from .arena import ensure_arena, build_chunk_table
 
 class _FusedOptimizer(object):
     KIND = None
+    LR_RING = 16
 
     def __init__(self, module, param_groups, defaults):
         self.module = module
@@ -73,9 +74,15 @@ class _FusedOptimizer(object):
         self._n_chunks = int(cs.shape[0])
         self.slot0 = torch.zeros_like(a.flat)
         self.slot1 = torch.zeros_like(a.flat) if self.KIND == 'adam' else None
-        self._lrs_host = torch.zeros(max(len(self.param_groups), 1), dtype=torch.float64).pin_memory() \
-            if torch.cuda.is_available() else torch.zeros(max(len(self.param_groups), 1), dtype=torch.float64)
-        self._lrs_dev = torch.zeros(max(len(self.param_groups), 1), dtype=torch.float64, device=dev)
+        # learning rates travel host -> device through a RING of pinned slots, each guarded by an event: the trainer
+        # never syncs per iteration, so the host may run whole iterations ahead of the GPU and must not rewrite a
+        # slot whose asynchronous copy has not executed yet (a single slot would let step i run with the lr of i+1)
+        ng = max(len(self.param_groups), 1)
+        self._lr_ring = [torch.zeros(ng, dtype=torch.float64).pin_memory() for _ in range(self.LR_RING)]
+        self._lr_events = [None] * self.LR_RING
+        self._lr_slot = 0
+        self._lrs_last = None
+        self._lrs_dev = torch.zeros(ng, dtype=torch.float64, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
         self.grad_scale = 1.0
         self._ema = None
@@ -122,18 +129,42 @@ class _FusedOptimizer(object):
     def _fill(self, d):
         raise NotImplementedError
 
+    def _upload_lrs(self):
+        lrs = tuple(float(g['lr']) for g in self.param_groups)
+        if lrs == self._lrs_last:
+            return                                   # unchanged since the last upload ('none' schedule, stepped epochs)
+        k = self._lr_slot
+        if self._lr_events[k] is not None:
+            self._lr_events[k].synchronize()         # LR_RING uploads ago: practically never blocks
+        host = self._lr_ring[k]
+        for i, v in enumerate(lrs):
+            host[i] = v
+        self._lrs_dev.copy_(host, non_blocking=True)
+        ev = self._lr_events[k] or torch.cuda.Event()
+        ev.record()
+        self._lr_events[k] = ev
+        self._lr_slot = (k + 1) % self.LR_RING
+        self._lrs_last = lrs
+
+    def _check_uniform(self, names):
+        """The kernels take these hyper-parameters once per launch: per-group overrides are an error, not silently
+        group 0's value."""
+        for name in names:
+            vals = [g[name] for g in self.param_groups]
+            if any(v != vals[0] for v in vals[1:]):
+                raise ValueError('{}: parameter groups differ in `{}` ({}); only `lr` may differ per group'.format(
+                    type(self).__name__, name, vals))
+
     def step(self):
-        for i, g in enumerate(self.param_groups):
-            self._lrs_host[i] = float(g['lr'])
-        self._lrs_dev.copy_(self._lrs_host, non_blocking=True)
+        self._upload_lrs()
         d = self._desc()
         self._fill(d)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(fn['cms_adam_ema_step' if self.KIND == 'adam' else 'cms_sgd_ema_step'](C.byref(d), stream),
               'cms_{}_ema_step'.format(self.KIND))
         check(fn['cms_increment_counter'](C.c_void_p(self.step_count.data_ptr()), stream), 'cms_increment_counter')
-        ex = getattr(self.module, '_hip_executor', None)
-        if ex is not None:
+        from .backbone_hip import executors_of
+        for ex in executors_of(self.module):
             ex.weights_changed()           # packed backward weights are stale now
         if self._ema is not None:
             self._ema._touch_target()
@@ -148,6 +179,7 @@ class FusedAdam(_FusedOptimizer):
         super(FusedAdam, self).__init__(module, param_groups, dict(lr=lr, betas=betas, eps=eps))
 
     def _fill(self, d):
+        self._check_uniform(('betas', 'eps'))
         g = self.param_groups[0] if self.param_groups else self.defaults
         d.beta1, d.beta2 = float(g['betas'][0]), float(g['betas'][1])
         d.eps = float(g['eps'])
@@ -161,6 +193,11 @@ class FusedSGD(_FusedOptimizer):
                                                                   weight_decay=weight_decay))
 
     def _fill(self, d):
+        # Duplicated entries (deeplab2.py:208-230) follow torch >= 1.5 semantics -- the torch of this image, 2.10, which
+        # the oracle (oracle/ema_opt.py:sgd_k_updates) pins: on the very first step every visit of a tensor starts its
+        # momentum buffer from the gradient. The reference environment's torch 1.4 looked the buffer up per visit, so
+        # its 2nd / 3rd visit of step 0 already saw one ("Unpinned").
+        self._check_uniform(('momentum', 'weight_decay', 'nesterov'))
         g = self.param_groups[0] if self.param_groups else self.defaults
         d.momentum = float(g['momentum'])
         d.weight_decay = float(g['weight_decay'])

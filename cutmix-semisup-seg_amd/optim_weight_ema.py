@@ -49,8 +49,8 @@ class EMAWeightOptimizer(object):
 
     def _touch_target(self):
         # the teacher's weights (and possibly its BN statistics) moved: packed operands of its executor are stale
-        ex = getattr(self.target_net, '_hip_executor', None)
-        if ex is not None:
+        from .backbone_hip import executors_of
+        for ex in executors_of(self.target_net):
             ex.weights_changed(bn_too=True)
 
     def _mark_fused_step_done(self):

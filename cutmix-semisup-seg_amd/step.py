@@ -224,7 +224,9 @@ class CutMixMeanTeacherStep(object):
                 # the teacher pass only meets the student at the loss: it runs on its own HIP stream, concurrently
                 # with the student's forward pass (the two fill each other's launch tails and memory stalls)
                 main = torch.cuda.current_stream()
-                side = self._teacher_stream() if cfg.overlap_teacher else main
+                # Pi model (teacher IS the student): one network, one executor -- its lazily refreshed operand tables
+                # (BN affine, ASPP weights) must not be rewritten on one stream while the other reads them
+                side = self._teacher_stream() if (cfg.overlap_teacher and self.teacher is not self.student) else main
                 x_tea = torch.cat(tea_in, dim=0) if len(tea_in) > 1 else tea_in[0]
                 if side is not main:
                     side.wait_stream(main)              # inputs (and last step's optimizer / EMA writes) are ready

@@ -60,9 +60,8 @@ def train_seg_semisup_mask_mt(submit_config, dataset, model, arch, freeze_bn,
     crop = None if crop_size == '' else [int(x.strip()) for x in crop_size.split(',')]
 
     if not synthetic:
-        print('This build covers the training step, not the dataset pipeline (datapipe/, cv2, dataset ZIPs are out of '
+        raise job_helper.JobNotRun('This build covers the training step, not the dataset pipeline (datapipe/, cv2, dataset ZIPs are out of '
               'scope and absent); run with --synthetic.')
-        return
     if crop is None:
         raise ValueError('--synthetic needs a --crop_size')
 

@@ -50,15 +50,15 @@ class _DataGradOnly(object):
     """Backward passes inside this context produce input gradients only (no weight gradients into the arenas)."""
 
     def __init__(self, net):
-        self.ex = getattr(net, '_hip_executor', None)
+        self.net = net
 
     def __enter__(self):
-        if self.ex is not None:
-            self.prev, self.ex.data_grad_only = self.ex.data_grad_only, True
+        # read by whichever executor of the network runs the backward pass (backbone_hip.py)
+        self.prev = getattr(self.net, '_data_grad_only', False)
+        self.net._data_grad_only = True
 
     def __exit__(self, *exc):
-        if self.ex is not None:
-            self.ex.data_grad_only = self.prev
+        self.net._data_grad_only = self.prev
 
 
 def vat_direction(net, x, x_hat, cons_loss_fn='kld', eps0=None, generator=None):

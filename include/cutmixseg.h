@@ -298,6 +298,21 @@ typedef struct cms_wgrad_desc {
 
 int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * The same convolution family in fp32 on the f32-input MFMA (v_mfma_f32_32x32x2_f32): the PARITY configuration
+ * (losses / IoU within 1e-4 of the fp32 reference path) and the precision of the VAT direction
+ * pass (train_seg_semisup_vat_mt.py:228-301). Same descriptors; every tensor the bf16 entry points take as bf16 is
+ * fp32 here (x, w, y, res, mask_src; du, x of the weight gradient); Cin % 32 == 0; `tile`, `zeros`, `variant` and the
+ * BatchNorm-affine side outputs of the weight gradient are not used.
+ * ------------------------------------------------------------------------------------------------------------ */
+int cms_conv_igemm_f32(const cms_conv_desc* d, void* stream);
+int cms_conv_wgrad_f32(const cms_wgrad_desc* d, void* stream);
+/* dst[tap'][ci][co] = src[tap][co][ci] * scale[co], fp32 -> fp32 */
+int cms_conv_pack_transpose_f32(const float* src, float* dst, const float* scale, int ntaps, int cout, int cin,
+                                int flip, void* stream);
+/* cms_conv_pack_transpose_batch with fp32 sources AND fp32 destinations */
+int cms_conv_pack_transpose_batch_f32(const cms_pack_item* items_dev, int n_items, int total_blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

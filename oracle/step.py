@@ -79,10 +79,12 @@ def _sgd_k(p, g, buf, lr, k, momentum, nesterov, wd):
 
 
 def train_iteration(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode='mix', loss_fn='var', conf_thresh=0.97,
-                    conf_per_pixel=False, ramp_val=1.0, rampup=-1, cons_weight=1.0, frozen_bn=True):
+                    conf_per_pixel=False, ramp_val=1.0, rampup=-1, cons_weight=1.0, frozen_bn=True, grads_out=None):
     """
     One iteration. `sup_y` int64 (N,1,H,W) with 255 = ignore; `masks` float (N,1,H,W) in {0,1}.
     In cut mode ux1/um1 are ignored. Returns dict(sup_loss, consistency_loss, conf_rate).
+    `grads_out` (dict, optional) receives the autograd gradient of every trainable tensor (what the optimizer consumed)
+    -- the yardstick the tests hold the device backward pass to.
     """
     if not frozen_bn:
         raise NotImplementedError('oracle step covers the --freeze_bn configuration (cfg 2/3)')
@@ -111,6 +113,9 @@ def train_iteration(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode='mix', loss
         total = total + r['unsup_loss']
         closs, rate = r['consistency_loss'], r['conf_rate']
     total.backward()       # the reference back-props the two losses separately; the gradients add
+    if grads_out is not None:
+        for k in keys:
+            grads_out[k] = None if leaves[k].grad is None else leaves[k].grad.detach().clone()
 
     with torch.no_grad():
         for k, mult, base_lr in S.entries:
