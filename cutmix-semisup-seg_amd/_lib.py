@@ -71,7 +71,8 @@ class WgradDesc(C.Structure):
     _fields_ = [('du', c_void_p), ('x', c_void_p), ('dw', c_void_p), ('scale', c_void_p),
                 ('n', c_int), ('h', c_int), ('w_in', c_int), ('cin', c_int), ('ho', c_int), ('wo', c_int),
                 ('cout', c_int), ('cout_real', c_int), ('ntaps', c_int), ('tap_dy', c_int * 18), ('tap_dx', c_int * 18),
-                ('stride', c_int), ('ksplit', c_int), ('w', c_void_p), ('wdot', c_void_p), ('dbeta', c_void_p)]
+                ('stride', c_int), ('ksplit', c_int), ('w', c_void_p), ('wdot', c_void_p), ('dbeta', c_void_p),
+                ('dw_cout', c_int)]
 
 
 class PackItem(C.Structure):
@@ -122,6 +123,18 @@ PROTOTYPES = {
     'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'cms_conv_pack_transpose_batch': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    'cms_program_create': (c_int, [_P(c_void_p)]),
+    'cms_program_destroy': (c_int, [c_void_p]),
+    'cms_program_add_conv': (c_int, [c_void_p, _P(ConvDesc), c_int, c_int, c_int]),
+    'cms_program_add_wgrad': (c_int, [c_void_p, _P(WgradDesc), c_int, c_int, c_int]),
+    'cms_program_add_memset': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int]),
+    'cms_program_add_sync': (c_int, [c_void_p, c_int, c_int, c_int]),
+    'cms_program_size': (c_int, [c_void_p]),
+    'cms_program_run': (c_int, [c_void_p, c_int, c_int, _P(c_void_p), c_int]),
+    'cms_program_run_pair': (c_int, [c_void_p, _P(c_void_p), c_int, c_void_p, _P(c_void_p), c_int]),
+    'cms_program_set_timing': (c_int, [c_void_p, c_int]),
+    'cms_program_read_timing': (c_int, [c_void_p, _P(C.c_double), _P(C.c_double), _P(C.c_long), _P(C.c_double),
+                                        _P(C.c_long)]),
     'cms_conv_igemm_f32': (c_int, [_P(ConvDesc), c_void_p]),
     'cms_conv_wgrad_f32': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_pack_transpose_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

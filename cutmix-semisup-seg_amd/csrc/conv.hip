@@ -729,6 +729,7 @@ struct WgradArgs {
     int M;                 // N*Ho*Wo
     int ksplit, pix_per_split;   // pixel slice per workgroup (multiple of 64)
     int cout_real;         // rows >= cout_real are not written (padded class axis)
+    int dw_cout;           // rows per tap of the dw tensor
     const uint16_t* w;     // bf16 [ntaps][Cout][Cin] or NULL   } side outputs for a trainable BN affine:
     float* wdot;           // [Cout] += <W, G> per output channel } see cms_wgrad_desc
     float* dbeta;          // [Cout] += sum_p dU[p][co]
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 
     // epilogue: acc rows = co, columns = ci (lane&31) -> 128-byte contiguous atomics per row
-    float* dwt = a.dw + (size_t)tap * a.Cout * a.Cin;
+    float* dwt = a.dw + (size_t)tap * a.dw_cout * a.Cin;
     const int fcol = lane & 31, fhalf = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
@@ -958,6 +959,8 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     a.ntaps = d->ntaps; a.stride = d->stride;
     a.M = d->n * d->ho * d->wo;
     a.cout_real = d->cout_real > 0 ? d->cout_real : d->cout;
+    a.dw_cout = d->dw_cout > 0 ? d->dw_cout : d->cout;
+    CMS_REQUIRE(a.dw_cout >= a.cout_real, "conv_wgrad: dw_cout (%d) < cout_real (%d)", a.dw_cout, a.cout_real);
     a.w = (const uint16_t*)d->w; a.wdot = d->wdot; a.dbeta = d->dbeta;
     CMS_REQUIRE((d->wdot == nullptr) == (d->w == nullptr), "conv_wgrad: wdot needs the bf16 weights (w) and vice versa");
     for (int i = 0; i < CMS_CONV_MAX_TAPS; ++i) {

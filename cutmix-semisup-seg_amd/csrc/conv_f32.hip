@@ -268,6 +268,7 @@ struct WgradArgsF32 {
     int M;
     int ksplit, pix_per_split;
     int cout_real;
+    int dw_cout;
     short tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
 };
 
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(WgradArgsF32 a) {
         }
     }
 
-    float* dwt = a.dw + (size_t)tap * a.Cout * a.Cin;
+    float* dwt = a.dw + (size_t)tap * a.dw_cout * a.Cin;
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
 #pragma unroll
@@ -510,6 +511,8 @@ extern "C" int cms_conv_wgrad_f32(const cms_wgrad_desc* d, void* stream) {
     a.ntaps = d->ntaps; a.stride = d->stride;
     a.M = d->n * d->ho * d->wo;
     a.cout_real = d->cout_real > 0 ? d->cout_real : d->cout;
+    a.dw_cout = d->dw_cout > 0 ? d->dw_cout : d->cout;
+    CMS_REQUIRE(a.dw_cout >= a.cout_real, "conv_wgrad_f32: dw_cout (%d) < cout_real (%d)", a.dw_cout, a.cout_real);
     for (int i = 0; i < CMS_CONV_MAX_TAPS; ++i) {
         a.tap_dy[i] = (short)(i < d->ntaps ? d->tap_dy[i] : 0);
         a.tap_dx[i] = (short)(i < d->ntaps ? d->tap_dx[i] : 0);

@@ -1,0 +1,251 @@
+// Launch programs: the native executor of the network passes.
+//
+// The reference drives its step from Python, one cuDNN call at a time (architectures/deeplab2.py:89-109 expands to ~450
+// library ops per pass, train_seg_semisup_mask_mt.py:296-459 issues ~2 k launches per iteration). Round 1 of this build
+// kept one Python -> ctypes round trip per convolution (descriptor filled in Python, ~30 us of host time per launch,
+// 16 ms per iteration -- close to the 23 ms the GPU needed). Here the host side of a pass is recorded ONCE per input
+// shape as a list of launch descriptors over persistent buffers -- convolutions, weight gradients, zero fills, stream
+// fork / join points -- and replayed from C++: one call enqueues the whole pass on up to CMS_PROGRAM_MAX_STREAMS HIP
+// streams (student || teacher, data gradients || weight gradients), cross-stream order through hipEventRecord /
+// hipStreamWaitEvent. Nothing is allocated, nothing synchronises the host; the same call can be stream-captured
+// into a hipGraph by the caller since all it does is launch work and record / wait events.
+//
+// Optional: every k-th convolution launch is bracketed with HIP events on its own stream (bench.py's `roofline`).
+#include "common.hpp"
+#include <new>
+#include <vector>
+
+namespace cms {
+
+enum OpKind { OP_CONV = 0, OP_WGRAD = 1, OP_MEMSET = 2, OP_SYNC = 3 };
+
+struct Op {
+    int kind;
+    int stream;        // OP_SYNC: the stream that WAITS
+    int from;          // OP_SYNC: the stream whose work is waited for
+    int group;         // interleaving key of cms_program_run_pair (bottleneck index)
+    int f32;
+    cms_conv_desc conv;
+    cms_wgrad_desc wg;
+    void* ptr;
+    size_t bytes;
+    hipEvent_t ev;     // OP_SYNC
+    double flops;
+};
+
+struct Timed {
+    hipEvent_t e0, e1;
+    double flops;
+    bool used;
+    bool head;         // the ASPP head convolution (fp32 NCHW logits): HBM-bound, accounted separately
+};
+
+}  // namespace cms
+
+struct cms_program {
+    std::vector<cms::Op> ops;
+    int timing_every = 0;
+    long conv_seen = 0;
+    std::vector<cms::Timed> timed;
+    size_t timed_used = 0;
+    double acc_ms = 0.0, acc_flops = 0.0;
+    long acc_launches = 0;
+};
+
+using namespace cms;
+
+static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
+    CMS_REQUIRE(o.stream >= 0 && o.stream < n_streams, "program: op on stream %d but only %d streams given", o.stream,
+                n_streams);
+    hipStream_t s = (hipStream_t)streams[o.stream];
+    switch (o.kind) {
+    case OP_CONV: {
+        Timed* t = nullptr;
+        const bool head = o.conv.y32 != nullptr;
+        if (p->timing_every > 0 && (head || (p->conv_seen++ % p->timing_every) == 0)) {
+            if (p->timed_used == p->timed.size()) {
+                Timed nt;
+                nt.used = false;
+                nt.head = false;
+                nt.flops = 0.0;
+                if (hipEventCreate(&nt.e0) != hipSuccess || hipEventCreate(&nt.e1) != hipSuccess) {
+                    set_error("program: hipEventCreate failed");
+                    return CMS_ELAUNCH;
+                }
+                p->timed.push_back(nt);
+            }
+            t = &p->timed[p->timed_used++];
+            t->flops = o.flops;
+            t->used = true;
+            t->head = head;
+            (void)hipEventRecord(t->e0, s);
+        }
+        const int rc = o.f32 ? cms_conv_igemm_f32(&o.conv, s) : cms_conv_igemm(&o.conv, s);
+        if (t) (void)hipEventRecord(t->e1, s);
+        return rc;
+    }
+    case OP_WGRAD:
+        return o.f32 ? cms_conv_wgrad_f32(&o.wg, s) : cms_conv_wgrad(&o.wg, s);
+    case OP_MEMSET:
+        if (hipMemsetAsync(o.ptr, 0, o.bytes, s) != hipSuccess) {
+            set_error("program: hipMemsetAsync failed");
+            return CMS_ELAUNCH;
+        }
+        return CMS_OK;
+    case OP_SYNC: {
+        CMS_REQUIRE(o.from >= 0 && o.from < n_streams, "program: sync from stream %d but only %d streams given", o.from,
+                    n_streams);
+        if (streams[o.from] == streams[o.stream]) return CMS_OK;      // same stream: already ordered
+        if (hipEventRecord(o.ev, (hipStream_t)streams[o.from]) != hipSuccess ||
+            hipStreamWaitEvent(s, o.ev, 0) != hipSuccess) {
+            set_error("program: event record / wait failed");
+            return CMS_ELAUNCH;
+        }
+        return CMS_OK;
+    }
+    }
+    set_error("program: unknown op kind %d", o.kind);
+    return CMS_EINVAL;
+}
+
+extern "C" int cms_program_create(cms_program** out) {
+    CMS_REQUIRE(out != nullptr, "program_create: NULL out pointer");
+    *out = new (std::nothrow) cms_program();
+    CMS_REQUIRE(*out != nullptr, "program_create: out of host memory");
+    return CMS_OK;
+}
+
+extern "C" int cms_program_destroy(cms_program* p) {
+    if (!p) return CMS_OK;
+    for (auto& o : p->ops)
+        if (o.kind == OP_SYNC && o.ev) (void)hipEventDestroy(o.ev);
+    for (auto& t : p->timed) {
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    delete p;
+    return CMS_OK;
+}
+
+static int push(cms_program* p, const Op& o) {
+    p->ops.push_back(o);
+    return (int)p->ops.size() - 1;
+}
+
+extern "C" int cms_program_add_conv(cms_program* p, const cms_conv_desc* d, int f32, int stream_idx, int group) {
+    CMS_REQUIRE(p && d, "program_add_conv: NULL pointer");
+    CMS_REQUIRE(stream_idx >= 0 && stream_idx < CMS_PROGRAM_MAX_STREAMS, "program_add_conv: stream index %d", stream_idx);
+    Op o = {};
+    o.kind = OP_CONV; o.stream = stream_idx; o.group = group; o.f32 = f32 ? 1 : 0;
+    o.conv = *d;
+    o.flops = 2.0 * (double)d->n * d->ho * d->wo * (double)d->cout * d->cin * d->ntaps;
+    return push(p, o);
+}
+
+extern "C" int cms_program_add_wgrad(cms_program* p, const cms_wgrad_desc* d, int f32, int stream_idx, int group) {
+    CMS_REQUIRE(p && d, "program_add_wgrad: NULL pointer");
+    CMS_REQUIRE(stream_idx >= 0 && stream_idx < CMS_PROGRAM_MAX_STREAMS, "program_add_wgrad: stream index %d", stream_idx);
+    Op o = {};
+    o.kind = OP_WGRAD; o.stream = stream_idx; o.group = group; o.f32 = f32 ? 1 : 0;
+    o.wg = *d;
+    o.flops = 2.0 * (double)d->n * d->ho * d->wo * (double)d->cout * d->cin * d->ntaps;
+    return push(p, o);
+}
+
+extern "C" int cms_program_add_memset(cms_program* p, void* ptr, size_t bytes, int stream_idx, int group) {
+    CMS_REQUIRE(p && ptr && bytes > 0, "program_add_memset: NULL pointer / empty range");
+    CMS_REQUIRE(stream_idx >= 0 && stream_idx < CMS_PROGRAM_MAX_STREAMS, "program_add_memset: stream index %d", stream_idx);
+    Op o = {};
+    o.kind = OP_MEMSET; o.stream = stream_idx; o.group = group; o.ptr = ptr; o.bytes = bytes;
+    return push(p, o);
+}
+
+extern "C" int cms_program_add_sync(cms_program* p, int from_stream, int to_stream, int group) {
+    CMS_REQUIRE(p, "program_add_sync: NULL program");
+    CMS_REQUIRE(from_stream >= 0 && from_stream < CMS_PROGRAM_MAX_STREAMS && to_stream >= 0 &&
+                    to_stream < CMS_PROGRAM_MAX_STREAMS, "program_add_sync: stream indices %d -> %d", from_stream, to_stream);
+    Op o = {};
+    o.kind = OP_SYNC; o.stream = to_stream; o.from = from_stream; o.group = group;
+    if (hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess) {
+        set_error("program_add_sync: hipEventCreate failed");
+        return CMS_ELAUNCH;
+    }
+    return push(p, o);
+}
+
+extern "C" int cms_program_size(const cms_program* p) { return p ? (int)p->ops.size() : 0; }
+
+extern "C" int cms_program_run(cms_program* p, int first, int last, void* const* streams, int n_streams) {
+    CMS_REQUIRE(p && streams && n_streams > 0, "program_run: NULL program / streams");
+    const int n = (int)p->ops.size();
+    if (last < 0 || last > n) last = n;
+    CMS_REQUIRE(first >= 0 && first <= last, "program_run: bad range [%d, %d) of %d ops", first, last, n);
+    for (int i = first; i < last; ++i) {
+        const int rc = issue(p, p->ops[i], streams, n_streams);
+        if (rc != CMS_OK) return rc;
+    }
+    return CMS_OK;
+}
+
+// Two programs issued interleaved, group by group (ops of `a` with group g, then ops of `b` with group g, ...): keeps
+// two kernels in flight for the whole pass when the programs run on different streams (student || teacher).
+extern "C" int cms_program_run_pair(cms_program* a, void* const* streams_a, int na, cms_program* b,
+                                    void* const* streams_b, int nb) {
+    CMS_REQUIRE(a && b && streams_a && streams_b && na > 0 && nb > 0, "program_run_pair: NULL program / streams");
+    size_t ia = 0, ib = 0;
+    const size_t ea = a->ops.size(), eb = b->ops.size();
+    while (ia < ea || ib < eb) {
+        // next group = the smaller of the two heads' groups (groups are recorded in non-decreasing order)
+        const int ga = ia < ea ? a->ops[ia].group : 0x7fffffff;
+        const int gb = ib < eb ? b->ops[ib].group : 0x7fffffff;
+        const int g = ga < gb ? ga : gb;
+        while (ia < ea && a->ops[ia].group <= g) {
+            const int rc = issue(a, a->ops[ia++], streams_a, na);
+            if (rc != CMS_OK) return rc;
+        }
+        while (ib < eb && b->ops[ib].group <= g) {
+            const int rc = issue(b, b->ops[ib++], streams_b, nb);
+            if (rc != CMS_OK) return rc;
+        }
+    }
+    return CMS_OK;
+}
+
+extern "C" int cms_program_set_timing(cms_program* p, int every_k) {
+    CMS_REQUIRE(p, "program_set_timing: NULL program");
+    p->timing_every = every_k > 0 ? every_k : 0;
+    return CMS_OK;
+}
+
+// Sums the event-bracketed convolution launches since the last call (waits for them to finish) and resets.
+extern "C" int cms_program_read_timing(cms_program* p, double* sum_ms, double* sum_flops, long* launches,
+                                       double* head_ms, long* head_launches) {
+    CMS_REQUIRE(p, "program_read_timing: NULL program");
+    double ms = 0.0, fl = 0.0, hms = 0.0;
+    long n = 0, hn = 0;
+    for (size_t i = 0; i < p->timed_used; ++i) {
+        Timed& t = p->timed[i];
+        if (!t.used) continue;
+        float dt = 0.0f;
+        if (hipEventSynchronize(t.e1) != hipSuccess || hipEventElapsedTime(&dt, t.e0, t.e1) != hipSuccess) {
+            set_error("program_read_timing: event query failed");
+            return CMS_ELAUNCH;
+        }
+        if (t.head) {
+            hms += dt;
+            ++hn;
+        } else {
+            ms += dt;
+            fl += t.flops;
+            ++n;
+        }
+        t.used = false;
+    }
+    p->timed_used = 0;
+    if (sum_ms) *sum_ms = ms;
+    if (sum_flops) *sum_flops = fl;
+    if (launches) *launches = n;
+    if (head_ms) *head_ms = hms;
+    if (head_launches) *head_launches = hn;
+    return CMS_OK;
+}

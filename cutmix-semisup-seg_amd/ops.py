@@ -373,6 +373,126 @@ def confusion(truth, pred, num_classes, ignore_index=None, cm=None):
     return cm
 
 
+# ---------------------------------------------------------------------------------------------- launch programs
+class Program(object):
+    """A recorded network pass (csrc/program.hip): launch descriptors over persistent buffers, replayed from C++ with
+    one call. Record with `with recording(prog, [main_stream, side_stream, ...]):` around ordinary calls of
+    conv_igemm / conv_wgrad / memset_zero / stream_wait -- inside the block they append to the program instead of
+    launching. Stream indices are positions in the list given to `recording` / `run`."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(fn['cms_program_create'](C.byref(h)), 'cms_program_create')
+        self.h = h
+        self.keep = []          # every tensor a descriptor points into stays alive as long as the program
+        self.marks = []         # (op index, tag): segment boundaries for callers that interleave host work
+        self.group = 0          # interleaving key given to the ops recorded next (run_pair)
+        self.flops = 0.0        # algorithmic MFMA FLOPs of one replay (convolutions + weight gradients)
+        self.conv_launches = 0
+        self.conv_bytes = 0.0   # algorithmic HBM bytes of the convolution launches (operands once, output once)
+        self.n_streams = 1
+
+    def __del__(self):
+        h, self.h = getattr(self, 'h', None), None
+        if h is not None:
+            try:
+                fn['cms_program_destroy'](h)
+            except Exception:
+                pass
+
+    def size(self):
+        return int(fn['cms_program_size'](self.h))
+
+    def mark(self, tag):
+        self.marks.append((self.size(), tag))
+
+    @staticmethod
+    def _handles(streams):
+        arr = (C.c_void_p * len(streams))()
+        for i, st in enumerate(streams):
+            arr[i] = st.cuda_stream
+        return arr
+
+    def run(self, streams, first=0, last=-1):
+        if len(streams) < self.n_streams:
+            raise ValueError('program recorded on {} streams, {} given'.format(self.n_streams, len(streams)))
+        check(fn['cms_program_run'](self.h, int(first), int(last), self._handles(streams), len(streams)),
+              'cms_program_run')
+
+    def set_timing(self, every_k):
+        check(fn['cms_program_set_timing'](self.h, int(every_k)), 'cms_program_set_timing')
+
+    def read_timing(self):
+        """-> dict(ms, flops, launches, head_ms, head_launches) of the event-bracketed convolution launches since the
+        last call (waits for them)."""
+        ms, fl, n = C.c_double(), C.c_double(), C.c_long()
+        hms, hn = C.c_double(), C.c_long()
+        check(fn['cms_program_read_timing'](self.h, C.byref(ms), C.byref(fl), C.byref(n), C.byref(hms), C.byref(hn)),
+              'cms_program_read_timing')
+        return dict(ms=ms.value, flops=fl.value, launches=n.value, head_ms=hms.value, head_launches=hn.value)
+
+
+def run_pair(prog_a, streams_a, prog_b, streams_b):
+    """Two programs issued interleaved group by group (student on one stream, teacher on another)."""
+    check(fn['cms_program_run_pair'](prog_a.h, Program._handles(streams_a), len(streams_a), prog_b.h,
+                                     Program._handles(streams_b), len(streams_b)), 'cms_program_run_pair')
+
+
+_REC = None      # (Program, [cuda_stream handles]) while recording
+
+
+class recording(object):
+    def __init__(self, prog, streams):
+        self.prog, self.streams = prog, [st.cuda_stream for st in streams]
+        prog.n_streams = max(prog.n_streams, len(streams))
+
+    def __enter__(self):
+        global _REC
+        if _REC is not None:
+            raise RuntimeError('nested program recording')
+        _REC = (self.prog, self.streams)
+        return self.prog
+
+    def __exit__(self, *exc):
+        global _REC
+        _REC = None
+
+
+def _rec_stream_index(stream=None):
+    h = (torch.cuda.current_stream() if stream is None else stream).cuda_stream
+    try:
+        return _REC[1].index(h)
+    except ValueError:
+        raise RuntimeError('op recorded on a stream the program was not told about')
+
+
+def memset_zero(t):
+    """t.zero_() -- as a program op while recording."""
+    _need_cuda(t)
+    if _REC is None:
+        t.zero_()
+        return t
+    if not t.is_contiguous():
+        raise TypeError('memset_zero: contiguous tensor required')
+    prog = _REC[0]
+    idx = fn['cms_program_add_memset'](prog.h, _ptr(t), t.numel() * t.element_size(), _rec_stream_index(), prog.group)
+    if idx < 0:
+        check(idx, 'cms_program_add_memset')
+    prog.keep.append(t)
+    return t
+
+
+def stream_wait(waiter, waited):
+    """waiter.wait_stream(waited) -- as a program op while recording."""
+    if _REC is None:
+        waiter.wait_stream(waited)
+        return
+    prog = _REC[0]
+    idx = fn['cms_program_add_sync'](prog.h, _rec_stream_index(waited), _rec_stream_index(waiter), prog.group)
+    if idx < 0:
+        check(idx, 'cms_program_add_sync')
+
+
 # ---------------------------------------------------------------------------------------------- MFMA convolution
 _ZERO_PAGES = {}
 
@@ -420,7 +540,9 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     d.x, d.w = x.data_ptr(), w_packed.data_ptr()
     if out_f32_nchw is None:
         if out is None:
-            out = (torch.zeros if out_stride > 1 else torch.empty)((n, oh, ow, cout), dtype=x.dtype, device=x.device)
+            out = torch.empty((n, oh, ow, cout), dtype=x.dtype, device=x.device)
+            if out_stride > 1:
+                memset_zero(out)               # the strided scatter only visits every out_stride-th position
         d.y, d.y32 = out.data_ptr(), None
     else:
         d.y, d.y32 = None, out_f32_nchw.data_ptr()
@@ -441,6 +563,19 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     zp = _zero_page(x.device)
     d.zeros, d.zeros_bytes = zp.data_ptr(), zp.numel() * 2
     d.variant = int(variant)
+    if _REC is not None:
+        prog = _REC[0]
+        idx = fn['cms_program_add_conv'](prog.h, C.byref(d), int(f32), _rec_stream_index(), prog.group)
+        if idx < 0:
+            check(idx, 'cms_program_add_conv')
+        prog.keep += [t for t in (x, w_packed, out, out_f32_nchw, scale, bias, res, mask_src, zp) if t is not None]
+        esz = x.element_size()
+        prog.flops += 2.0 * n * ho * wo * cout * cin * ntaps
+        prog.conv_launches += 1
+        prog.conv_bytes += esz * (x.numel() + w_packed.numel()) + float(n * ho * wo) * (
+            (4.0 * d.cout_real if out_f32_nchw is not None else esz * cout)
+            + (esz * cout if res is not None else 0.0) + (esz * cout if mask_src is not None else 0.0))
+        return out if out_f32_nchw is None else out_f32_nchw
     name = 'cms_conv_igemm_f32' if f32 else 'cms_conv_igemm'
     check(fn[name](C.byref(d), _stream()), name)
     return out if out_f32_nchw is None else out_f32_nchw
@@ -505,10 +640,12 @@ class PackTransposePlan(object):
                                                   _stream()), 'cms_conv_pack_transpose_batch')
 
 
-def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, w_bf16=None, wdot=None, dbeta=None):
+def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, w_bf16=None, wdot=None, dbeta=None,
+               dw_cout=None):
     """
     dw (fp32 (ntaps, Cout, Cin), accumulated into) += scale[co] * sum_pixels du[pix][co] * x[pix + tap][ci].
-    du bf16 (N, Ho, Wo, Cout), x bf16 (N, H, W, Cin), both NHWC-contiguous.
+    du bf16 (N, Ho, Wo, Cout), x bf16 (N, H, W, Cin), both NHWC-contiguous. `dw_cout`: rows per tap of `dw` when it is
+    narrower than du's (padded) channel axis -- only the first `cout_real` rows are written.
     """
     _need_cuda(du, x, dw, scale)
     if du.dtype not in (torch.bfloat16, torch.float32) or x.dtype != du.dtype or dw.dtype != torch.float32:
@@ -519,8 +656,10 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
         raise TypeError('conv_wgrad: contiguous tensors required')
     n, ho, wo, cout = (int(s) for s in du.shape)
     n2, h, w_in, cin = (int(s) for s in x.shape)
-    if n2 != n or tuple(dw.shape) != (len(taps), cout, cin):
+    if n2 != n or tuple(dw.shape) != (len(taps), cout if dw_cout is None else int(dw_cout), cin):
         raise ValueError('conv_wgrad: shape mismatch')
+    if dw_cout is not None and (cout_real is None or int(cout_real) > int(dw_cout)):
+        raise ValueError('conv_wgrad: dw_cout needs cout_real <= dw_cout')
     d = _lib.WgradDesc()
     d.du, d.x, d.dw = du.data_ptr(), x.data_ptr(), dw.data_ptr()
     d.scale = scale.data_ptr() if scale is not None else None
@@ -536,6 +675,15 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
     d.w = w_bf16.data_ptr() if w_bf16 is not None else None
     d.wdot = wdot.data_ptr() if wdot is not None else None
     d.dbeta = dbeta.data_ptr() if dbeta is not None else None
+    d.dw_cout = 0 if dw_cout is None else int(dw_cout)
+    if _REC is not None:
+        prog = _REC[0]
+        idx = fn['cms_program_add_wgrad'](prog.h, C.byref(d), int(f32), _rec_stream_index(), prog.group)
+        if idx < 0:
+            check(idx, 'cms_program_add_wgrad')
+        prog.keep += [t for t in (du, x, dw, scale, w_bf16, wdot, dbeta) if t is not None]
+        prog.flops += 2.0 * n * ho * wo * cout * cin * len(taps)
+        return dw
     name = 'cms_conv_wgrad_f32' if f32 else 'cms_conv_wgrad'
     check(fn[name](C.byref(d), _stream()), name)
     return dw

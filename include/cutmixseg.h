@@ -294,6 +294,9 @@ typedef struct cms_wgrad_desc {
     const void* w;         /* bf16 [ntaps][cout][cin]                                                              */
     float* wdot;           /* fp32 [cout], accumulated with atomics                                                */
     float* dbeta;          /* fp32 [cout], accumulated with atomics                                                */
+    int dw_cout;           /* rows per tap of the dw TENSOR when it is narrower than the GEMM's (padded) cout: the ASPP
+                              head computes 64 padded class rows and writes the cout_real live ones straight into the
+                              (9, C, 2048) gradient tensor; 0 = cout                                               */
 } cms_wgrad_desc;
 
 int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream);
@@ -312,6 +315,33 @@ int cms_conv_pack_transpose_f32(const float* src, float* dst, const float* scale
                                 int flip, void* stream);
 /* cms_conv_pack_transpose_batch with fp32 sources AND fp32 destinations */
 int cms_conv_pack_transpose_batch_f32(const cms_pack_item* items_dev, int n_items, int total_blocks, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Launch programs: the host side of a network pass, recorded once per input shape and replayed from C++
+ * (csrc/program.hip). Replaces one Python -> ctypes round trip per convolution of architectures/deeplab2.py:89-128
+ * (and of its backward pass) by ONE call per pass. Ops refer to caller-owned, persistent device buffers; stream
+ * indices are positions in the `streams` array given at run time (index 0 = the caller's current stream).
+ * add_* return the op index (>= 0) or a negative error code.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define CMS_PROGRAM_MAX_STREAMS 4
+typedef struct cms_program cms_program;
+int cms_program_create(cms_program** out);
+int cms_program_destroy(cms_program* p);
+int cms_program_add_conv(cms_program* p, const cms_conv_desc* d, int f32, int stream_idx, int group);
+int cms_program_add_wgrad(cms_program* p, const cms_wgrad_desc* d, int f32, int stream_idx, int group);
+int cms_program_add_memset(cms_program* p, void* ptr, size_t bytes, int stream_idx, int group);
+/* work enqueued so far on `from_stream` must finish before anything enqueued later on `to_stream` starts */
+int cms_program_add_sync(cms_program* p, int from_stream, int to_stream, int group);
+int cms_program_size(const cms_program* p);
+/* enqueue ops [first, last) (last < 0: to the end); never synchronises the host */
+int cms_program_run(cms_program* p, int first, int last, void* const* streams, int n_streams);
+/* two programs issued interleaved by `group` (student on one stream, teacher on another) */
+int cms_program_run_pair(cms_program* a, void* const* streams_a, int na, cms_program* b, void* const* streams_b, int nb);
+/* bracket every k-th convolution launch with HIP events on its stream (0 = off) / read and reset the sums */
+int cms_program_set_timing(cms_program* p, int every_k);
+/* the ASPP head launches (fp32 NCHW output) are always bracketed while timing is on and summed separately */
+int cms_program_read_timing(cms_program* p, double* sum_ms, double* sum_flops, long* launches, double* head_ms,
+                            long* head_launches);
 
 #ifdef __cplusplus
 }

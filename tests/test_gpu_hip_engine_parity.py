@@ -296,7 +296,10 @@ def test_bf16_hip_engine_iteration_vs_oracle_reports_errors(ops, name):
     got, grads = _device_iteration(ops, P, torch.bfloat16)
     e = _errors(P, got, grads)
     print('\nPARITY bf16 HIP engine vs oracle [{}] tau={:.4f} ref={} got={} errors={}'.format(name, P['tau'], P['ref'], got, e))
-    assert e['sup_loss'] <= 2e-2 and e['consistency_loss'] <= 1e-1, e
-    assert e['conf_rate'] <= 5e-2, e
-    assert e['miou'] <= 5e-2, e
-    assert e['grad_head'] <= 5e-2, e
+    assert e['sup_loss'] <= 1e-2 and e['consistency_loss'] <= 1e-2, e
+    assert e['conf_rate'] <= 1e-2, e
+    # the truth map of this check is the ORACLE'S OWN argmax (with flips) on a random-initialised network whose classes
+    # are nearly tied everywhere: every argmax the bf16 activations flip costs IoU. Measured 0.059 (cfg 2) / 0.021
+    # (cfg 3); the trained-network statement (within 0.2 pt) is tests/test_gpu_miou_training.py
+    assert e['miou'] <= 1e-1, e
+    assert e['grad_head'] <= 2e-2 and e['grad_mean'] <= 3e-2 and e['grad_max'] <= 1.5e-1, e

@@ -451,6 +451,8 @@ def test_deeplab2_fp32_vs_golden(tag, shapes):
         key = '{}__in{}'.format(tag, ii)
         x = cu(_cf_input(n, h, w, 0.3 + ii))
         net.zero_grad()
+        gerr = {}
+        assert net._use_hip_body()
         lo = net.forward_lowres(x)
         np.testing.assert_allclose(lo.detach().cpu().numpy(), g[key + '__lowres'], rtol=2e-3, atol=2e-4)
         y = net(x)
@@ -462,10 +464,15 @@ def test_deeplab2_fp32_vs_golden(tag, shapes):
                   'layer5.conv2d_list.0.weight', 'layer5.conv2d_list.1.bias']:
             want = g['{}__grad__{}'.format(key, k)]
             got = named[k].grad.cpu().numpy().reshape(-1)[:4096]
-            # the backbone convolutions of this engine are library (MIOpen) fp32 kernels; their wgrad/dgrad split-K
-            # accumulation order differs from ATen-CPU by up to ~1e-2 of the gradient scale on the deepest layers
+            # fp32 compute = the PARITY configuration: the body runs on the f32-input MFMA kernels (csrc/conv_f32.hip);
+            # only the stem still goes through the library
             np.testing.assert_allclose(got, want, rtol=5e-2, atol=1.5e-2 * (np.abs(want).max() + 1e-12))
-        assert named['layer5.conv2d_list.2.weight'].grad is None and named['layer5.conv2d_list.3.bias'].grad is None
+            gerr[k] = float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+        # ASPP d18 / d24 never receive a gradient: None on the library engine, an untouched all-zero view of
+        # the gradient arena on the hand-written engine (the fused optimizer skips them either way, k_updates == 0)
+        for k in ('layer5.conv2d_list.2.weight', 'layer5.conv2d_list.3.bias'):
+            assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0
+        print('fp32 HIP engine vs golden [{}]: max gradient error / gradient scale per tensor: {}'.format(key, gerr))
 
 
 def test_deeplab2_bf16_close_to_fp32_oracle():
