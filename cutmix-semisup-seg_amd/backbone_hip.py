@@ -102,6 +102,15 @@ class DeepLabHipExecutor(object):
         self.tile_rules = {}       # output channels -> tile code (per-layer choice against the workgroup-count staircase)
         self._wT_version = -1
         self.version = 0          # bumped whenever the weights change (optimizer step / load_state_dict)
+        # Launch programs (ops.Program, csrc/program.hip): the host side of a pass is recorded once per input shape over
+        # persistent buffers and replayed from C++ with one call -- False runs every launch eagerly from Python
+        # (tools that probe single layers, the DeepLab v3+ executor below)
+        self.use_programs = True
+        self._programs = {}       # key -> forward program
+        self._generation = 0      # forward passes issued; a backward pass checks that its activations are still there
+        # what was enqueued through programs so far (bench.py): algorithmic MFMA FLOPs, body-convolution launches
+        # and their algorithmic bytes, ASPP-head launches and bytes
+        self.issued = dict(flops=0.0, conv_launches=0, conv_bytes=0.0, head_launches=0, head_bytes=0.0)
         net.register_load_state_dict_post_hook(lambda module, incompatible: self.invalidate())
 
     def _add_blocks(self, prefix, layers):
@@ -258,18 +267,83 @@ class DeepLabHipExecutor(object):
         n, h, w, _ = cur.shape
         # 18 taps x 2048 channels = a K of 36864 against only ~260 pixel tiles: split the taps over 6x more workgroups
         # and accumulate the (tiny) fp32 logits with atomics
-        logits = torch.zeros((n, self.num_classes, h, w), dtype=torch.float32, device=cur.device)
+        logits = torch.empty((n, self.num_classes, h, w), dtype=torch.float32, device=cur.device)
+        ops.memset_zero(logits)
         ops.conv_igemm(cur, self.aspp_w32, self.aspp_taps, bias=self.aspp_bias, out_f32_nchw=logits,
                        cout_real=self.num_classes, ksplit=6)
         if saved is not None:
             saved.append(cur)
         return logits, saved
 
+    def _prepare_forward(self):
+        """Operand tables a forward pass reads (torch ops on the current stream, only when stale)."""
+        if not self._affine_ready:
+            self._refresh_affine()
+        self._refresh_aspp_fwd()
+
+    def _tile_key(self):
+        return (self.conv_tile, tuple(sorted(self.tile_rules.items())))
+
+    def forward_program(self, shape, save):
+        """The recorded forward pass for an input of `shape` (N, h, w, 64) -- recorded on first use, on the CURRENT
+        stream (its stream 0). Attributes: x_in (persistent input buffer), logits, saved."""
+        key = ('fwd', tuple(int(v) for v in shape), bool(save), self._tile_key())
+        prog = self._programs.get(key)
+        if prog is None:
+            if len(self._programs) >= 8:          # shapes come and go (evaluation crops): drop the oldest recording
+                torch.cuda.synchronize()
+                self._programs.pop(next(iter(self._programs)))
+            self._prepare_forward()
+            prog = ops.Program()
+            x_in = torch.empty(tuple(shape), dtype=self.dtype, device=self.arena.device)
+            with ops.recording(prog, [torch.cuda.current_stream()]):
+                st = self.fwd_begin(x_in, save)
+                for bi in range(len(self.blocks)):
+                    prog.group = bi
+                    self.fwd_block(st, bi)
+                prog.group = len(self.blocks)
+                logits, saved = self.fwd_end(st)
+            prog.x_in, prog.logits, prog.saved = x_in, logits, saved
+            prog.bwd = {}
+            prog.generation = -1
+            self._programs[key] = prog
+        return prog
+
+    def programs(self):
+        """Every recorded program of this executor (forward passes and their backward passes)."""
+        out = []
+        for p in self._programs.values():
+            out.append(p)
+            out += list(p.bwd.values())
+        return out
+
+    def _stamp(self, prog):
+        self._generation += 1
+        prog.generation = self._generation
+        self._account(prog)
+
+    def _account(self, prog):
+        i = self.issued
+        i['flops'] += prog.flops
+        i['conv_launches'] += prog.conv_launches
+        i['conv_bytes'] += prog.conv_bytes
+        i['head_launches'] += prog.head_launches
+        i['head_bytes'] += prog.head_bytes
+
     def forward(self, x, save):
-        st = self.fwd_begin(x, save)
-        for bi in range(len(self.blocks)):
-            self.fwd_block(st, bi)
-        return self.fwd_end(st)
+        """-> (logits fp32 NCHW, token for `backward`)."""
+        if not self.use_programs:
+            st = self.fwd_begin(x, save)
+            for bi in range(len(self.blocks)):
+                self.fwd_block(st, bi)
+            return self.fwd_end(st)
+        prog = self.forward_program(x.shape, save)
+        self._prepare_forward()
+        prog.x_in.copy_(x)
+        prog.run([torch.cuda.current_stream()])
+        self._stamp(prog)
+        # the logits buffer belongs to the program (the next pass of this shape overwrites it): hand out a copy
+        return prog.logits.clone(), ((prog, prog.generation) if save else None)
 
     # ------------------------------------------------------------------------------------------ backward
     def _wgrad(self, du, x, c):
@@ -287,32 +361,41 @@ class DeepLabHipExecutor(object):
         return ops.conv_igemm(du, c.wT, c.neg_taps, res=res, mode=1, mask_src=mask, out_hw=(ho, wo),
                               out_stride=c.stride, out_full_hw=in_hw, tile=self._tile(c.cin))
 
-    def backward(self, saved, dlogits):
-        """dlogits fp32 (N,C,h,w). Accumulates weight gradients into the arena; returns d loss / d x (bf16 NHWC)."""
+    def _want_w(self):
+        data_only = self.data_grad_only or getattr(self.net, '_data_grad_only', False)
+        return self.trainable and not data_only and self.arena.grad is not None
+
+    def _refresh_for_backward(self):
         if self._wT_version != self.version or self.blocks[0].c1.wT is None:
             self._refresh_backward_weights()
             self._wT_version = self.version
+
+    def _fill_dl(self, dl, dlogits, want_w):
+        """Head inputs of the backward pass that are plain element-wise work (torch ops on the current stream): the
+        logit gradient as a channel-padded NHWC operand, and the bias gradients of the two live ASPP branches."""
+        C = self.num_classes
+        dl[..., :C] = dlogits.permute(0, 2, 3, 1)
+        if want_w:
+            db = dlogits.sum(dim=(0, 2, 3))
+            for k in self.aspp_keys:
+                self.arena.view(k + '.bias', self.arena.grad).add_(db)
+
+    def _backward_chain(self, saved, dl, want_w, side, hook):
+        """The launches of the backward pass (recordable): ASPP head weight + data gradients, then the bottlenecks
+        from the last to the first. `hook(bi)` is called on the weight-gradient stream right after the weight
+        gradients of bottleneck `bi` were issued."""
         a = self.arena
         C = self.num_classes
         x4 = saved[-1]
-        n, _, h, w = dlogits.shape
-        dl = torch.zeros((n, h, w, 64), dtype=self.dtype, device=dlogits.device)
-        dl[..., :C] = dlogits.permute(0, 2, 3, 1)
-        data_only = self.data_grad_only or getattr(self.net, '_data_grad_only', False)
-        want_w = self.trainable and not data_only and a.grad is not None
-        # ASPP head: weight / bias gradients of the two live branches, then the data gradient
-        for i, k in enumerate(self.aspp_keys if want_w else []):
-            gw = a.packed(k + '.weight', a.grad)                     # fp32 (9, C, 2048)
-            tmp = torch.zeros((9, 64, 2048), dtype=torch.float32, device=dl.device)
-            ops.conv_wgrad(dl, x4, self.aspp_taps[9 * i:9 * i + 9], tmp, cout_real=C)
-            gw.add_(tmp[:, :C])
-            a.view(k + '.bias', a.grad).add_(dlogits.sum(dim=(0, 2, 3)))
-        dC = ops.conv_igemm(dl, self.aspp_wT, self.aspp_neg_taps, mode=1, mask_src=x4)
-        capture = getattr(self, 'debug_capture', None)
         # Weight gradients only feed the optimizer, the data-gradient chain never waits for them: they run on a second
         # HIP stream, one bottleneck behind the chain, and fill the tail / memory-wait gaps of the dgrad launches.
         main = torch.cuda.current_stream()
-        side = self._side_stream() if (self.overlap_wgrad and want_w) else None
+        for i, k in enumerate(self.aspp_keys if want_w else []):
+            # 64 padded class rows computed, the C live ones written straight into the (9, C, 2048) gradient tensor
+            ops.conv_wgrad(dl, x4, self.aspp_taps[9 * i:9 * i + 9], a.packed(k + '.weight', a.grad), cout_real=C,
+                           dw_cout=C)
+        dC = ops.conv_igemm(dl, self.aspp_wT, self.aspp_neg_taps, mode=1, mask_src=x4)
+        capture = getattr(self, 'debug_capture', None)
         keep = []                 # tensors read on the side stream must outlive the python scope that made them
         for bi in range(len(self.blocks) - 1, -1, -1):
             if capture is not None:
@@ -325,22 +408,66 @@ class DeepLabHipExecutor(object):
             if not want_w:
                 pass
             elif side is not None:
-                side.wait_stream(main)
+                ops.stream_wait(side, main)
                 keep.append((dC, dU2, dU1))
                 with torch.cuda.stream(side):
                     self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
-                    if self.grad_hook is not None:
-                        self.grad_hook(bi)
+                    hook(bi)
             else:
                 self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
-                if self.grad_hook is not None:
-                    self.grad_hook(bi)
+                hook(bi)
             dres = dC if b.cd is None else self._dgrad(dC, b.cd, in_hw=in_hw)
             dC = self._dgrad(dU1, b.c1, res=dres, mask=None if bi == 0 else xin, in_hw=in_hw)
         if side is not None:
-            main.wait_stream(side)
+            ops.stream_wait(main, side)
         del keep
         return dC
+
+    def backward(self, token, dlogits):
+        """dlogits fp32 (N,C,h,w); `token` from `forward(.., save=True)`. Accumulates weight gradients into the arena;
+        returns d loss / d x (NHWC, the executor's dtype)."""
+        self._refresh_for_backward()
+        want_w = self._want_w()
+        n, _, h, w = dlogits.shape
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if (self.overlap_wgrad and want_w) else None
+        if not self.use_programs:
+            dl = torch.zeros((n, h, w, 64), dtype=self.dtype, device=dlogits.device)
+            self._fill_dl(dl, dlogits, want_w)
+            hook = self.grad_hook if self.grad_hook is not None else (lambda bi: None)
+            return self._backward_chain(token, dl, want_w, side, hook)
+        fprog, gen = token
+        if fprog.generation != gen:
+            raise RuntimeError('the activations of this forward pass were overwritten by a later forward pass of the '
+                               'same shape through the same executor (programs keep ONE set of buffers per shape): '
+                               'run backward before the next forward, or set executor.use_programs = False')
+        key = (want_w, side is not None)
+        prog = fprog.bwd.get(key)
+        if prog is None:
+            prog = ops.Program()
+            dl = torch.zeros((n, h, w, 64), dtype=self.dtype, device=dlogits.device)      # channels >= C stay zero
+            streams = [main] + ([side] if side is not None else [])
+            with ops.recording(prog, streams):
+                dx = self._backward_chain(fprog.saved, dl, want_w, side, prog.mark)
+            prog.dl, prog.dx = dl, dx
+            fprog.bwd[key] = prog
+        self._fill_dl(prog.dl, dlogits, want_w)
+        streams = [main] + ([side] if side is not None else [])
+        if self.grad_hook is None or not want_w:
+            prog.run(streams)
+        else:
+            # segments between the recorded block marks: the hook (bucketed all-reduce) is host work that must see the
+            # weight-gradient stream as its current stream, right after the weight gradients of its block
+            first = 0
+            hook_stream = side if side is not None else main
+            for idx, bi in prog.marks:
+                prog.run(streams, first, idx)
+                first = idx
+                with torch.cuda.stream(hook_stream):
+                    self.grad_hook(bi)
+            prog.run(streams, first, -1)
+        self._account(prog)
+        return prog.dx.clone()
 
     def _block_wgrads(self, b, dC, dU2, dU1, xin, a1, a2):
         self._wgrad(dC, a2, b.c3)
@@ -373,6 +500,7 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
 
     def __init__(self, wrapper):
         self._init_common(wrapper)
+        self.use_programs = False          # (this executor's passes are issued launch by launch)
         bb = wrapper.deeplab.backbone
         self._add_blocks('deeplab.backbone.', [bb['layer{}'.format(li)] for li in range(1, 5)])
         self.tap_low = self._layer_first[1] - 1          # last bottleneck of layer1
@@ -574,9 +702,9 @@ class _BodyFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_nhwc, executor, need_grad):
-        logits, saved = executor.forward(x_nhwc, save=need_grad)
+        logits, token = executor.forward(x_nhwc, save=need_grad)
         ctx.executor = executor
-        ctx.saved_acts = saved
+        ctx.saved_acts = token
         return logits
 
     @staticmethod
@@ -594,16 +722,34 @@ class _BodyPairFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_stu, x_tea, ex_stu, ex_tea, side, need_grad):
-        st_s = ex_stu.fwd_begin(x_stu, need_grad)
-        with torch.cuda.stream(side):
-            st_t = ex_tea.fwd_begin(x_tea, False)
-        for bi in range(len(ex_stu.blocks)):
-            ex_stu.fwd_block(st_s, bi)
+        if ex_stu.use_programs and ex_tea.use_programs:
+            # both passes are recorded programs: ONE native call issues them interleaved, bottleneck by bottleneck
+            main = torch.cuda.current_stream()
+            ps = ex_stu.forward_program(x_stu.shape, need_grad)
+            ex_stu._prepare_forward()
+            ps.x_in.copy_(x_stu)
             with torch.cuda.stream(side):
-                ex_tea.fwd_block(st_t, bi)
-        logits_s, saved = ex_stu.fwd_end(st_s)
-        with torch.cuda.stream(side):
-            logits_t, _ = ex_tea.fwd_end(st_t)
+                pt = ex_tea.forward_program(x_tea.shape, False)
+                ex_tea._prepare_forward()
+                pt.x_in.copy_(x_tea)
+            ops.run_pair(ps, [main], pt, [side])
+            ex_stu._stamp(ps)
+            ex_tea._stamp(pt)
+            logits_s = ps.logits.clone()
+            with torch.cuda.stream(side):
+                logits_t = pt.logits.clone()
+            saved = (ps, ps.generation) if need_grad else None
+        else:
+            st_s = ex_stu.fwd_begin(x_stu, need_grad)
+            with torch.cuda.stream(side):
+                st_t = ex_tea.fwd_begin(x_tea, False)
+            for bi in range(len(ex_stu.blocks)):
+                ex_stu.fwd_block(st_s, bi)
+                with torch.cuda.stream(side):
+                    ex_tea.fwd_block(st_t, bi)
+            logits_s, saved = ex_stu.fwd_end(st_s)
+            with torch.cuda.stream(side):
+                logits_t, _ = ex_tea.fwd_end(st_t)
         ctx.executor = ex_stu
         ctx.saved_acts = saved
         ctx.mark_non_differentiable(logits_t)

@@ -93,9 +93,19 @@ struct RowInfo {            // one per pixel row of the workgroup tile, computed
 // registers, no ds_write); the XOR swizzle is applied on the SOURCE side (the LDS image of a wave instruction is
 // lane-linear), out-of-range rows read a zero page. One LDS buffer per workgroup, up to 4 workgroups per CU: the
 // load latency of a workgroup is covered by the MFMA phases of its neighbours.
-template <int WN, int WM, int TN, int TM, bool GLDS, int NS, int BK = CONV_BK>
-__global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4) ? ((NS == 1 || BK == 32) ? 4 : 2)
-                                            : ((WN * WM == 4 && TN * TM == 8) ? 2 : 1)) void conv_igemm_kernel(ConvArgs a) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_lds() {
+    // this wave's direct-to-LDS loads except the N youngest have landed; LDS reads of the previous phase are done
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+// OCC = workgroups per CU the register budget is declared for (0: the round-1 defaults). PF = the fragment reads of
+// K sub-step kk+1 are issued BEFORE the MFMAs of sub-step kk (register double buffer): without it every sub-step is
+// "4 ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 4 MFMAs", i.e. the LDS latency of each sub-step is exposed to the wave.
+template <int WN, int WM, int TN, int TM, bool GLDS, int NS, int BK = CONV_BK, bool PF = false, int OCC = 0>
+__global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
+                                           : ((GLDS && WN * WM == 4 && TN * TM == 4) ? ((NS == 1 || BK == 32) ? 4 : 2)
+                                              : ((WN * WM == 4 && TN * TM == 8) ? 2 : 1))) void conv_igemm_kernel(ConvArgs a) {
     // NS = LDS stages of the direct-to-LDS loader. 1: load -> barrier -> MFMA -> barrier; memory and MFMA phases only
     // overlap ACROSS the (up to 4) workgroups of a CU. 2: the loads of K-step k+1 are in flight during the MFMAs of
     // step k inside one workgroup -- what the DeepLab shapes need, whose grids are only ~2 workgroups per CU.
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int EPI_BYTES = BM * BN * 2;                // epilogue tile (bf16 output / staged residual or mask)
-    static_assert(NS == 1 || (NS == 2 && GLDS), "two stages only with the direct-to-LDS loader");
+    static_assert(NS == 1 || (NS >= 2 && NS <= 4 && GLDS), "stage rings only with the direct-to-LDS loader");
     constexpr int UNION_BYTES = NS * STAGE_BYTES > EPI_BYTES ? NS * STAGE_BYTES : EPI_BYTES;
     unsigned char* lds_x = smem;                          // [NS][BM][128 B]   (stage s at + s * STAGE_BYTES)
     unsigned char* lds_w = smem + BM * ROWB;              // [NS][BN][128 B]
@@ -295,6 +305,33 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     const unsigned char* fx_base = lds_x + wm * TM * 32 * ROWB;
 
     auto mfma_phase = [&](int buf) {
+        if constexpr (PF) {
+            // register double buffer over the K sub-steps: reads of kk+1 in flight during the MFMAs of kk
+            constexpr int KK = BK / 16;
+            u32x4 fw[2][TN], fx[2][TM];
+            auto frag_read = [&](int kk, u32x4* w_, u32x4* x_) {
+                const uint32_t fo = (lane_frag ^ (uint32_t)(kk * 32)) + (uint32_t)(buf * STAGE_BYTES);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) w_[i] = *reinterpret_cast<const u32x4*>(fw_base + fo + i * 32 * ROWB);
+#pragma unroll
+                for (int j = 0; j < TM; ++j) x_[j] = *reinterpret_cast<const u32x4*>(fx_base + fo + j * 32 * ROWB);
+            };
+            frag_read(0, fw[0], fx[0]);
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                if (kk + 1 < KK) frag_read(kk + 1, fw[(kk + 1) & 1], fx[(kk + 1) & 1]);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[kk & 1][i]),
+                                                                            __builtin_bit_cast(bf16x8, fx[kk & 1][j]),
+                                                                            acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             u32x4 fw[TN], fx[TM];     // (arrays of __bf16 vectors are not promoted to registers by the compiler)
@@ -319,7 +356,38 @@ __global__ __launch_bounds__(64 * WN * WM, (GLDS && WN * WM == 4 && TN * TM == 4
     } else {
         if (ks_begin < ksteps) load_tile(ks_begin, 0);
     }
-    if constexpr (GLDS && NS == 2) {
+    if constexpr (GLDS && NS >= 3) {
+        // Ring of NS stages, NS-1 of them in flight: counted s_waitcnt vmcnt (never 0 in the steady state) + a raw
+        // s_barrier, ONE barrier per K step. At the barrier of step k every wave has (a) waited for its own loads of
+        // stage k and (b) finished the fragment reads of step k-1, so the buffer refilled right after the barrier
+        // (stage k+NS-1 -> buffer (k-1) % NS) is free and the one the MFMAs read (k % NS) is complete.
+        constexpr int LPS = PA + PB;                           // direct-to-LDS instructions per wave per stage
+        static_assert(LPS * (NS - 2) <= 63, "vmcnt field");
+        const int total = ksteps - ks_begin;
+        for (int s = 1; s < NS - 1; ++s)
+            if (s < total) {
+                advance();
+                issue_loads(s);
+            }
+        int buf = 0;
+        for (int ks = ks_begin; ks < ksteps; ++ks) {
+            const int behind = ksteps - 1 - ks;                 // stages issued after stage ks that may stay in flight
+            if (behind >= NS - 2) wait_vmcnt_lds<LPS * (NS - 2)>();
+            else if (NS == 4 && behind == 1) wait_vmcnt_lds<LPS>();
+            else wait_vmcnt_lds<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (ks + NS - 1 < ksteps) {
+                advance();
+                int nb = buf + NS - 1;
+                if (nb >= NS) nb -= NS;
+                issue_loads(nb);
+            }
+            mfma_phase(buf);
+            if (++buf == NS) buf = 0;
+        }
+        __syncthreads();                                        // the epilogue reuses the staging area
+    } else if constexpr (GLDS && NS == 2) {
         int buf = 0;
         for (int ks = ks_begin; ks < ksteps; ++ks, buf ^= 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of stage `buf` has landed in LDS
@@ -595,6 +663,23 @@ static int conv_check(const cms_conv_desc* d) {
     return CMS_OK;
 }
 
+// Pipelined variants of the direct-to-LDS kernel (cms_conv_desc.variant 10..14): NS ring stages of BK K-elements,
+// fragment double buffer, register budget declared for OCC workgroups per CU.
+template <int WN, int WM, int TN, int TM, int NS, int BK, int OCC>
+static void conv_launch_ring(const ConvArgs& a, hipStream_t s) {
+    constexpr int BN = WN * TN * 32, BM = WM * TM * 32, NT = 64 * WN * WM;
+    const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM) * a.ksplit;
+    const size_t stage = (size_t)(BN + BM) * BK * 2 * NS, epi = (size_t)BM * BN * 2;
+    const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16;
+    auto kern = conv_igemm_kernel<WN, WM, TN, TM, true, NS, BK, true, OCC>;
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, a);
+}
+
 template <int WN, int WM, int TN, int TM>
 static void conv_launch(const ConvArgs& a, hipStream_t s, int loader) {      // loader: 0 registers, 1 / 2 = glds stages,
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;                       //         3 = two glds stages of BK = 32
@@ -655,6 +740,31 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
     const int glds = (d->zeros == nullptr || d->variant == 1) ? 0
                      : ((d->variant == 4 || d->variant == 6 || d->variant == 7) ? 2 : (d->variant == 5 ? 3 : 1));
     const int tile = d->tile;   // 0 = auto
+    if (d->variant >= 10 && d->variant <= 14) {
+        // pipelined kernels (ring of LDS stages with counted vmcnt, fragment double buffer), 128 x 128 tile on 4 waves or
+        // 128 (co) x 256 (pixels) on 8 waves:  10: 1 stage of 64   11: 2 x 64   12: 3 x 32   13: 4 x 32   14: 3 x 64
+        CMS_REQUIRE(d->zeros != nullptr, "conv: variants 10..14 need the zero run (direct-to-LDS loader)");
+        CMS_REQUIRE(d->cout % 128 == 0 && (tile == 0 || tile == 128 || tile == 256),
+                    "conv: variants 10..14 exist for the 128-channel tiles (tile 0 / 128 / 256)");
+        if (tile == 256) {
+            switch (d->variant) {
+            case 10: conv_launch_ring<2, 4, 2, 2, 1, 64, 2>(a, s); break;
+            case 11: conv_launch_ring<2, 4, 2, 2, 2, 64, 1>(a, s); break;
+            case 12: conv_launch_ring<2, 4, 2, 2, 3, 32, 2>(a, s); break;
+            case 13: conv_launch_ring<2, 4, 2, 2, 4, 32, 1>(a, s); break;
+            default: conv_launch_ring<2, 4, 2, 2, 3, 64, 1>(a, s); break;
+            }
+        } else {
+            switch (d->variant) {
+            case 10: conv_launch_ring<2, 2, 2, 2, 1, 64, 4>(a, s); break;
+            case 11: conv_launch_ring<2, 2, 2, 2, 2, 64, 2>(a, s); break;
+            case 12: conv_launch_ring<2, 2, 2, 2, 3, 32, 3>(a, s); break;
+            case 13: conv_launch_ring<2, 2, 2, 2, 4, 32, 2>(a, s); break;
+            default: conv_launch_ring<2, 2, 2, 2, 3, 64, 1>(a, s); break;
+            }
+        }
+        return launch_status("cms_conv_igemm");
+    }
     if (tile == 256) {                         // 8 waves: 128 co x 256 pixels (more reuse of the weight tile)
         CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 256 needs Cout %% 128 == 0");
         conv_launch<2, 4, 2, 2>(a, s, glds);

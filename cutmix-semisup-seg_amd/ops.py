@@ -390,6 +390,8 @@ class Program(object):
         self.flops = 0.0        # algorithmic MFMA FLOPs of one replay (convolutions + weight gradients)
         self.conv_launches = 0
         self.conv_bytes = 0.0   # algorithmic HBM bytes of the convolution launches (operands once, output once)
+        self.head_bytes = 0.0   # ... of the ASPP head launches among them (fp32 NCHW logits)
+        self.head_launches = 0
         self.n_streams = 1
 
     def __del__(self):
@@ -571,10 +573,15 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
         prog.keep += [t for t in (x, w_packed, out, out_f32_nchw, scale, bias, res, mask_src, zp) if t is not None]
         esz = x.element_size()
         prog.flops += 2.0 * n * ho * wo * cout * cin * ntaps
-        prog.conv_launches += 1
-        prog.conv_bytes += esz * (x.numel() + w_packed.numel()) + float(n * ho * wo) * (
+        nbytes = esz * (x.numel() + w_packed.numel()) + float(n * ho * wo) * (
             (4.0 * d.cout_real if out_f32_nchw is not None else esz * cout)
             + (esz * cout if res is not None else 0.0) + (esz * cout if mask_src is not None else 0.0))
+        if out_f32_nchw is not None:
+            prog.head_launches += 1
+            prog.head_bytes += nbytes
+        else:
+            prog.conv_launches += 1
+            prog.conv_bytes += nbytes
         return out if out_f32_nchw is None else out_f32_nchw
     name = 'cms_conv_igemm_f32' if f32 else 'cms_conv_igemm'
     check(fn[name](C.byref(d), _stream()), name)
