@@ -123,12 +123,29 @@ PROTOTYPES = {
     'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'cms_conv_pack_transpose_batch': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    'cms_aspp_gather_fwd': (c_int, [c_void_p, c_void_p, c_void_p, _P(c_int), _P(c_int), c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_void_p]),
+    'cms_aspp_spread_bwd': (c_int, [c_void_p, c_void_p, c_int, _P(c_int), _P(c_int), c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_void_p]),
+    'cms_stem_pack_weights': (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    'cms_stem_out_hw': (c_int, [c_int, c_int, _P(c_int), _P(c_int), _P(c_int), _P(c_int)]),
+    'cms_stem_fwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                             c_void_p]),
+    'cms_maxpool3x3s2_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'cms_maxpool3x3s2_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p]),
+    'cms_stem_wgrad': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'cms_stem_dgrad': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'cms_program_create': (c_int, [_P(c_void_p)]),
     'cms_program_destroy': (c_int, [c_void_p]),
     'cms_program_add_conv': (c_int, [c_void_p, _P(ConvDesc), c_int, c_int, c_int]),
     'cms_program_add_wgrad': (c_int, [c_void_p, _P(WgradDesc), c_int, c_int, c_int]),
     'cms_program_add_memset': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int]),
     'cms_program_add_sync': (c_int, [c_void_p, c_int, c_int, c_int]),
+    'cms_program_add_aspp_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _P(c_int), _P(c_int), c_int, c_int,
+                                            c_int, c_int, c_int, c_int, c_int, c_int]),
+    'cms_program_add_aspp_spread': (c_int, [c_void_p, c_void_p, c_void_p, c_int, _P(c_int), _P(c_int), c_int, c_int, c_int,
+                                            c_int, c_int, c_int, c_int, c_int]),
     'cms_program_size': (c_int, [c_void_p]),
     'cms_program_run': (c_int, [c_void_p, c_int, c_int, _P(c_void_p), c_int]),
     'cms_program_run_pair': (c_int, [c_void_p, _P(c_void_p), c_int, c_void_p, _P(c_void_p), c_int]),

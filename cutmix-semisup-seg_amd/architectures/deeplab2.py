@@ -171,6 +171,7 @@ class ResNetDeepLab(nn.Module):
         # 'auto': hand-written MFMA executor (backbone_hip.py) whenever BatchNorm is frozen (bf16 = throughput
         # configuration, fp32 = parity configuration), library engine otherwise; 'torch' / 'hip' force one
         self.engine_kind = 'auto'
+        self.stem_kind = 'hip'          # 'torch': stem through the library engine (comparison runs)
         self._hip_executor = None       # the executor used last
         self._hip_executors = {}        # compute dtype -> executor
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
@@ -234,7 +235,9 @@ class ResNetDeepLab(nn.Module):
         return ex
 
     def stem_nhwc(self, x):
-        """conv1 + bn1 + ReLU + max-pool (:183-186) -> bf16 NHWC, the input of the MFMA executor."""
+        """conv1 + bn1 + ReLU + max-pool (:183-186) -> NHWC, the input of the MFMA executor."""
+        if self.stem_kind == 'hip' and self._use_hip_body():
+            return self.hip_executor().stem(x)                 # csrc/stem.hip, no library convolution in the pass
         eng = self._engine(x)
         x = eng.prepare_input(x)
         x = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True)

@@ -102,6 +102,20 @@ class ParamArena(object):
         if self.grad is not None:
             self.grad.zero_()
 
+    def ensure_grads_attached(self):
+        """`module.zero_grad()` (set_to_none) drops the parameters' `.grad` views of the gradient arena. The kernels
+        accumulate into the arena regardless; before they do, give the views back -- and since "None" means "zero" to
+        the caller, clear what the arena still holds for those parameters."""
+        if self.grad is None:
+            return
+        params = dict(self.module.named_parameters())
+        for s in self.segments:
+            if s.requires_grad:
+                p = params[s.key]
+                if p.grad is None:
+                    self.grad[s.offset:s.offset + s.count].zero_()
+                    p.grad = _logical_view(self.grad[s.offset:s.offset + s.count], s.shape)
+
     def keys(self):
         return [s.key for s in self.segments]
 

@@ -63,6 +63,10 @@ class DeepLabHipExecutor(object):
         self._init_common(net, dtype)
         self.num_classes = net.num_classes
         self._add_blocks('', [getattr(net, 'layer{}'.format(li)) for li in range(1, 5)])
+        # the stem (7x7/2 convolution + frozen BatchNorm + ReLU + ceil-mode max-pool) on csrc/stem.hip
+        self.stem_wkey, self.stem_bn = 'conv1.weight', 'bn1'
+        self.stem_w147 = None
+        self._stem_version = -1
         head = net.layer5.conv2d_list
         self.aspp_keys = ['layer5.conv2d_list.0', 'layer5.conv2d_list.1']
         self.aspp_taps = []
@@ -73,11 +77,13 @@ class DeepLabHipExecutor(object):
         C = self.num_classes
         if C > 32:
             raise NotImplementedError('ASPP head kernel is specialised for <= 32 classes')
-        self.aspp_w = torch.zeros(18, 64, 2048, dtype=self.dtype, device=dev)     # class axis padded to 64 (dgrad K)
-        self.aspp_w32 = torch.zeros(18, 32, 2048, dtype=self.dtype, device=dev)   # forward operand (padded to 32)
-        self.aspp_wT = torch.zeros(18, 2048, 64, dtype=self.dtype, device=dev)
+        # the head as ONE pass over the 2048-channel activation (csrc/aspp.hip): rows of Wall = tap * C + class over the
+        # 18 taps of the two live dilations, padded to a multiple of 128 rows
+        self.aspp_zc = (18 * C + 127) // 128 * 128
+        self.aspp_wall = torch.zeros(1, self.aspp_zc, 2048, dtype=self.dtype, device=dev)     # forward / wgrad layout
+        self.aspp_wallT = torch.zeros(1, 2048, self.aspp_zc, dtype=self.dtype, device=dev)    # dgrad operand
         self._aspp_version = -1
-        self.aspp_bias = torch.zeros(32, dtype=torch.float32, device=dev)
+        self.aspp_bias = torch.zeros(C, dtype=torch.float32, device=dev)
 
     def _init_common(self, net, dtype=torch.bfloat16):
         if dtype not in (torch.bfloat16, torch.float32):
@@ -169,12 +175,21 @@ class DeepLabHipExecutor(object):
                 idx[k].append(torch.arange(s.offset, s.offset + s.count, dtype=torch.int64))
             spans.append((c, off, off + c.cout))
             off += c.cout
+        stem_span = None
+        if getattr(self, 'stem_bn', None) is not None:
+            for k in idx:
+                s = a.by_key[self.stem_bn + '.' + k]
+                idx[k].append(torch.arange(s.offset, s.offset + s.count, dtype=torch.int64))
+            stem_span = (off, off + a.by_key[self.stem_bn + '.weight'].count)
+            off = stem_span[1]
         dev = a.device
         self._bn_idx = {k: torch.cat(v).to(dev) for k, v in idx.items()}
         self._scale_all = torch.zeros(off, dtype=torch.float32, device=dev)
         self._bias_all = torch.zeros(off, dtype=torch.float32, device=dev)
         for c, lo, hi in spans:
             c.scale, c.bias = self._scale_all[lo:hi], self._bias_all[lo:hi]
+        if stem_span is not None:
+            self.stem_scale, self.stem_bias = self._scale_all[stem_span[0]:stem_span[1]], self._bias_all[stem_span[0]:stem_span[1]]
         if self.bn_trainable and self.trainable:
             self._wdot_all = torch.zeros(off, dtype=torch.float32, device=dev)
             self._dbeta_all = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -206,10 +221,9 @@ class DeepLabHipExecutor(object):
         C = self.num_classes
         a = self.arena
         for i, k in enumerate(self.aspp_keys):
-            wk = a.packed(k + '.weight', self._wbuf())
-            self.aspp_w[9 * i:9 * i + 9, :C].copy_(wk)
-            self.aspp_w32[9 * i:9 * i + 9, :C].copy_(wk)
-        self.aspp_bias[:C] = a.view(self.aspp_keys[0] + '.bias') + a.view(self.aspp_keys[1] + '.bias')
+            wk = a.packed(k + '.weight', self._wbuf())                       # (9, C, 2048): rows tap * C + class
+            self.aspp_wall[0, 9 * C * i:9 * C * (i + 1)].copy_(wk.reshape(9 * C, 2048))
+        torch.add(a.view(self.aspp_keys[0] + '.bias'), a.view(self.aspp_keys[1] + '.bias'), out=self.aspp_bias)
         self._aspp_version = self.version
 
     def _refresh_backward_weights(self):
@@ -222,8 +236,8 @@ class DeepLabHipExecutor(object):
                 w = self._w(c)
                 c.wT = torch.empty((w.shape[0], w.shape[2], w.shape[1]), dtype=self.dtype, device=w.device)
                 triples.append((w, c.wT, c.scale))
-            if hasattr(self, 'aspp_w'):
-                triples.append((self.aspp_w, self.aspp_wT, None))
+            if hasattr(self, 'aspp_wall'):
+                triples.append((self.aspp_wall, self.aspp_wallT, None))
             self._pack_plan = ops.PackTransposePlan(triples)
         self._pack_plan.run()
 
@@ -265,15 +279,28 @@ class DeepLabHipExecutor(object):
         cur, saved = st['cur'], st['saved']
         self._refresh_aspp_fwd()
         n, h, w, _ = cur.shape
-        # 18 taps x 2048 channels = a K of 36864 against only ~260 pixel tiles: split the taps over 6x more workgroups
-        # and accumulate the (tiny) fp32 logits with atomics
-        logits = torch.empty((n, self.num_classes, h, w), dtype=torch.float32, device=cur.device)
-        ops.memset_zero(logits)
-        ops.conv_igemm(cur, self.aspp_w32, self.aspp_taps, bias=self.aspp_bias, out_f32_nchw=logits,
-                       cout_real=self.num_classes, ksplit=6)
+        # Z[n][tap*C + c] = <W[tap][c], x> as ONE 1x1 GEMM (the activation is read once, not once per tap), then the 18
+        # shifted planes of every class are summed (csrc/aspp.hip)
+        z = torch.empty((n, self.aspp_zc, h, w), dtype=torch.float32, device=cur.device)
+        ops.conv_igemm(cur, self.aspp_wall, [(0, 0)], out_f32_nchw=z, cout_real=self.aspp_zc)
+        logits = ops.aspp_gather_fwd(z, self.aspp_bias, self.aspp_taps, self.num_classes)
         if saved is not None:
             saved.append(cur)
         return logits, saved
+
+    # ------------------------------------------------------------------------------------------ stem
+    def _stem_prepare(self):
+        if not self._affine_ready:
+            self._refresh_affine()
+        if self._stem_version != self.version:
+            self.stem_w147 = ops.stem_pack_weights(self.arena.packed(self.stem_wkey, self._wbuf()), out=self.stem_w147)
+            self._stem_version = self.version
+
+    def stem(self, x):
+        """(N, 3, H, W) image batch -> NHWC (N, hp, wp, 64) input of the body: 7x7/2 convolution + frozen BatchNorm +
+        ReLU + max-pool (deeplab2.py:183-186) on csrc/stem.hip, with its own backward pass (weight gradient into the
+        arena; image gradient only when the input asks for one: VAT)."""
+        return _StemFn.apply(x.contiguous(), dict(self.net.named_parameters())[self.stem_wkey], self)
 
     def _prepare_forward(self):
         """Operand tables a forward pass reads (torch ops on the current stream, only when stale)."""
@@ -361,6 +388,11 @@ class DeepLabHipExecutor(object):
         return ops.conv_igemm(du, c.wT, c.neg_taps, res=res, mode=1, mask_src=mask, out_hw=(ho, wo),
                               out_stride=c.stride, out_full_hw=in_hw, tile=self._tile(c.cin))
 
+    def _grad_sentinel(self):
+        if getattr(self, '_sentinel', None) is None:
+            self._sentinel = dict(self.net.named_parameters())[self.blocks[-1].c3.wkey]
+        return self._sentinel
+
     def _want_w(self):
         data_only = self.data_grad_only or getattr(self.net, '_data_grad_only', False)
         return self.trainable and not data_only and self.arena.grad is not None
@@ -370,31 +402,38 @@ class DeepLabHipExecutor(object):
             self._refresh_backward_weights()
             self._wT_version = self.version
 
-    def _fill_dl(self, dl, dlogits, want_w):
-        """Head inputs of the backward pass that are plain element-wise work (torch ops on the current stream): the
-        logit gradient as a channel-padded NHWC operand, and the bias gradients of the two live ASPP branches."""
-        C = self.num_classes
-        dl[..., :C] = dlogits.permute(0, 2, 3, 1)
+    def _head_bias_grads(self, dlogits, want_w):
+        """Bias gradients of the two live ASPP branches (plain reduction: torch ops on the current stream)."""
         if want_w:
             db = dlogits.sum(dim=(0, 2, 3))
             for k in self.aspp_keys:
                 self.arena.view(k + '.bias', self.arena.grad).add_(db)
 
-    def _backward_chain(self, saved, dl, want_w, side, hook):
-        """The launches of the backward pass (recordable): ASPP head weight + data gradients, then the bottlenecks
-        from the last to the first. `hook(bi)` is called on the weight-gradient stream right after the weight
-        gradients of bottleneck `bi` were issued."""
-        a = self.arena
+    def _head_weight_grads(self, dwall):
+        """dWall rows (tap*C + class) -> the (9, C, 2048) gradient tensors of the two branches."""
         C = self.num_classes
+        a = self.arena
+        for i, k in enumerate(self.aspp_keys):
+            a.packed(k + '.weight', a.grad).add_(dwall[0, 9 * C * i:9 * C * (i + 1)].view(9, C, 2048))
+
+    def _backward_chain(self, saved, dlg, want_w, side, hook, box=None):
+        """The launches of the backward pass (recordable): ASPP head weight + data gradients, then the bottlenecks
+        from the last to the first. `dlg`: fp32 (N, C, h, w) logit gradient. `hook(bi)` is called on the weight-gradient
+        stream right after the weight gradients of bottleneck `bi` were issued. -> (dx, dwall or None)"""
         x4 = saved[-1]
         # Weight gradients only feed the optimizer, the data-gradient chain never waits for them: they run on a second
         # HIP stream, one bottleneck behind the chain, and fill the tail / memory-wait gaps of the dgrad launches.
         main = torch.cuda.current_stream()
-        for i, k in enumerate(self.aspp_keys if want_w else []):
-            # 64 padded class rows computed, the C live ones written straight into the (9, C, 2048) gradient tensor
-            ops.conv_wgrad(dl, x4, self.aspp_taps[9 * i:9 * i + 9], a.packed(k + '.weight', a.grad), cout_real=C,
-                           dw_cout=C)
-        dC = ops.conv_igemm(dl, self.aspp_wT, self.aspp_neg_taps, mode=1, mask_src=x4)
+        # head: D[n][y][x][tap*C + c] = dlogits[n][c][y - dy][x - dx]; dX = D . Wall, dWall = D^T . X (csrc/aspp.hip)
+        d = ops.aspp_spread_bwd(dlg, self.aspp_taps, self.aspp_zc, self.dtype)
+        dwall = None
+        if want_w:
+            dwall = torch.empty((1, self.aspp_zc, 2048), dtype=torch.float32, device=d.device)
+            ops.memset_zero(dwall)
+            ops.conv_wgrad(d, x4, [(0, 0)], dwall)
+            if box is not None:
+                box['dwall'] = dwall
+        dC = ops.conv_igemm(d, self.aspp_wallT, [(0, 0)], mode=1, mask_src=x4)
         capture = getattr(self, 'debug_capture', None)
         keep = []                 # tensors read on the side stream must outlive the python scope that made them
         for bi in range(len(self.blocks) - 1, -1, -1):
@@ -421,21 +460,35 @@ class DeepLabHipExecutor(object):
         if side is not None:
             ops.stream_wait(main, side)
         del keep
-        return dC
+        return dC, dwall
 
     def backward(self, token, dlogits):
         """dlogits fp32 (N,C,h,w); `token` from `forward(.., save=True)`. Accumulates weight gradients into the arena;
         returns d loss / d x (NHWC, the executor's dtype)."""
         self._refresh_for_backward()
         want_w = self._want_w()
+        if want_w and self._grad_sentinel().grad is None:        # somebody called module.zero_grad(): re-home the views
+            self.arena.ensure_grads_attached()
         n, _, h, w = dlogits.shape
         main = torch.cuda.current_stream()
         side = self._side_stream() if (self.overlap_wgrad and want_w) else None
         if not self.use_programs:
-            dl = torch.zeros((n, h, w, 64), dtype=self.dtype, device=dlogits.device)
-            self._fill_dl(dl, dlogits, want_w)
-            hook = self.grad_hook if self.grad_hook is not None else (lambda bi: None)
-            return self._backward_chain(token, dl, want_w, side, hook)
+            self._head_bias_grads(dlogits, want_w)
+            box = {}
+
+            def hook(bi):
+                # first call (last bottleneck, on the weight-gradient stream, which has waited for the head's launches):
+                # the head's weight gradients go into the arena BEFORE any bucket of it is all-reduced
+                if 'done' not in box and box.get('dwall') is not None:
+                    self._head_weight_grads(box['dwall'])
+                    box['done'] = True
+                if self.grad_hook is not None:
+                    self.grad_hook(bi)
+            # the chain creates dwall before its first hook call: hand it over through the box
+            dx, dwall = self._backward_chain(token, dlogits, want_w, side, hook, box)
+            if dwall is not None and 'done' not in box:
+                self._head_weight_grads(dwall)
+            return dx
         fprog, gen = token
         if fprog.generation != gen:
             raise RuntimeError('the activations of this forward pass were overwritten by a later forward pass of the '
@@ -445,27 +498,38 @@ class DeepLabHipExecutor(object):
         prog = fprog.bwd.get(key)
         if prog is None:
             prog = ops.Program()
-            dl = torch.zeros((n, h, w, 64), dtype=self.dtype, device=dlogits.device)      # channels >= C stay zero
+            dlg = torch.empty(tuple(dlogits.shape), dtype=torch.float32, device=dlogits.device)   # persistent input
             streams = [main] + ([side] if side is not None else [])
             with ops.recording(prog, streams):
-                dx = self._backward_chain(fprog.saved, dl, want_w, side, prog.mark)
-            prog.dl, prog.dx = dl, dx
+                dx, dwall = self._backward_chain(fprog.saved, dlg, want_w, side, prog.mark)
+            prog.dlg, prog.dx, prog.dwall = dlg, dx, dwall
             fprog.bwd[key] = prog
-        self._fill_dl(prog.dl, dlogits, want_w)
+        prog.dlg.copy_(dlogits)
+        self._head_bias_grads(dlogits, want_w)
         streams = [main] + ([side] if side is not None else [])
         if self.grad_hook is None or not want_w:
             prog.run(streams)
+            if prog.dwall is not None:
+                self._head_weight_grads(prog.dwall)      # (after the program's final join of the weight-gradient stream)
         else:
             # segments between the recorded block marks: the hook (bucketed all-reduce) is host work that must see the
             # weight-gradient stream as its current stream, right after the weight gradients of its block
             first = 0
             hook_stream = side if side is not None else main
+            head_done = False
             for idx, bi in prog.marks:
                 prog.run(streams, first, idx)
                 first = idx
                 with torch.cuda.stream(hook_stream):
+                    if not head_done and prog.dwall is not None:
+                        # the head's weight gradients reach the arena BEFORE any bucket of it is all-reduced (the
+                        # weight-gradient stream has waited for the head's launches at this point)
+                        self._head_weight_grads(prog.dwall)
+                        head_done = True
                     self.grad_hook(bi)
             prog.run(streams, first, -1)
+            if prog.dwall is not None and not head_done:
+                self._head_weight_grads(prog.dwall)
         self._account(prog)
         return prog.dx.clone()
 
@@ -695,6 +759,32 @@ def hip_conv2d_eligible(x, conv):
             and conv.padding == (conv.dilation[0] * (kh - 1) // 2,) * 2 and conv.dilation[0] == conv.dilation[1]
             and (conv.in_channels % 64 == 0 or conv.in_channels >= 128) and conv.out_channels % 64 == 0
             and x.shape[2] * x.shape[3] >= 64)
+
+
+class _StemFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, executor):
+        executor._stem_prepare()
+        s = ops.stem_forward(x, executor.stem_w147, executor.stem_scale, executor.stem_bias, executor.dtype)
+        p, idx = ops.maxpool3x3s2_forward(s)
+        ctx.executor = executor
+        ctx.x_shape = tuple(x.shape)
+        ctx.x_dtype = x.dtype
+        ctx.w_grad = weight.requires_grad
+        ctx.save_for_backward(x, s, idx)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, s, idx = ctx.saved_tensors
+        ex = ctx.executor
+        ds = ops.maxpool3x3s2_relu_backward(dp.to(s.dtype), idx, s)
+        if ctx.w_grad and ex._want_w():
+            ops.stem_wgrad(x, ds, ex.arena.packed(ex.stem_wkey, ex.arena.grad), ex.stem_scale)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.stem_dgrad(ds, ex.stem_w147, ex.stem_scale, ctx.x_shape).to(ctx.x_dtype)
+        return dx, None, None
 
 
 class _BodyFn(torch.autograd.Function):

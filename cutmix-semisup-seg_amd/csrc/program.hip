@@ -17,7 +17,16 @@
 
 namespace cms {
 
-enum OpKind { OP_CONV = 0, OP_WGRAD = 1, OP_MEMSET = 2, OP_SYNC = 3 };
+enum OpKind { OP_CONV = 0, OP_WGRAD = 1, OP_MEMSET = 2, OP_SYNC = 3, OP_ASPP_GATHER = 4, OP_ASPP_SPREAD = 5 };
+
+struct AsppOp {            // arguments of cms_aspp_gather_fwd / cms_aspp_spread_bwd
+    const float* src;      // z / dlogits
+    const float* bias;
+    void* dst;             // logits / D
+    int d_dtype;
+    int tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
+    int n_taps, n, c, zc, h, w;
+};
 
 struct Op {
     int kind;
@@ -27,6 +36,7 @@ struct Op {
     int f32;
     cms_conv_desc conv;
     cms_wgrad_desc wg;
+    AsppOp aspp;
     void* ptr;
     size_t bytes;
     hipEvent_t ev;     // OP_SYNC
@@ -50,6 +60,8 @@ struct cms_program {
     size_t timed_used = 0;
     double acc_ms = 0.0, acc_flops = 0.0;
     long acc_launches = 0;
+    long last_head = -1;       // index into `timed` of the head GEMM bracket the next gather op extends
+    int last_head_stream = -1;
 };
 
 using namespace cms;
@@ -82,7 +94,22 @@ static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
         }
         const int rc = o.f32 ? cms_conv_igemm_f32(&o.conv, s) : cms_conv_igemm(&o.conv, s);
         if (t) (void)hipEventRecord(t->e1, s);
+        p->last_head = (t && head) ? (long)(t - &p->timed[0]) : -1;
+        p->last_head_stream = o.stream;
         return rc;
+    }
+    case OP_ASPP_GATHER: {
+        const AsppOp& g = o.aspp;
+        const int rc = cms_aspp_gather_fwd(g.src, g.bias, (float*)g.dst, g.tap_dy, g.tap_dx, g.n_taps, g.n, g.c, g.zc, g.h,
+                                           g.w, s);
+        // the head = GEMM + gather: move the closing event of the GEMM's bracket behind the gather
+        if (p->last_head >= 0 && p->last_head_stream == o.stream) (void)hipEventRecord(p->timed[p->last_head].e1, s);
+        p->last_head = -1;
+        return rc;
+    }
+    case OP_ASPP_SPREAD: {
+        const AsppOp& g = o.aspp;
+        return cms_aspp_spread_bwd(g.src, g.dst, g.d_dtype, g.tap_dy, g.tap_dx, g.n_taps, g.n, g.c, g.zc, g.h, g.w, s);
     }
     case OP_WGRAD:
         return o.f32 ? cms_conv_wgrad_f32(&o.wg, s) : cms_conv_wgrad(&o.wg, s);
@@ -171,6 +198,32 @@ extern "C" int cms_program_add_sync(cms_program* p, int from_stream, int to_stre
         return CMS_ELAUNCH;
     }
     return push(p, o);
+}
+
+static int add_aspp(cms_program* p, int kind, const float* src, const float* bias, void* dst, int d_dtype, const int* dy,
+                    const int* dx, int n_taps, int n, int c, int zc, int h, int w, int stream_idx, int group) {
+    CMS_REQUIRE(p && src && dst && dy && dx, "program_add_aspp: NULL pointer");
+    CMS_REQUIRE(n_taps > 0 && n_taps <= CMS_CONV_MAX_TAPS, "program_add_aspp: 1..%d taps", CMS_CONV_MAX_TAPS);
+    CMS_REQUIRE(stream_idx >= 0 && stream_idx < CMS_PROGRAM_MAX_STREAMS, "program_add_aspp: stream index %d", stream_idx);
+    Op o = {};
+    o.kind = kind; o.stream = stream_idx; o.group = group;
+    o.aspp.src = src; o.aspp.bias = bias; o.aspp.dst = dst; o.aspp.d_dtype = d_dtype;
+    for (int i = 0; i < n_taps; ++i) { o.aspp.tap_dy[i] = dy[i]; o.aspp.tap_dx[i] = dx[i]; }
+    o.aspp.n_taps = n_taps; o.aspp.n = n; o.aspp.c = c; o.aspp.zc = zc; o.aspp.h = h; o.aspp.w = w;
+    return push(p, o);
+}
+
+extern "C" int cms_program_add_aspp_gather(cms_program* p, const float* z, const float* bias, float* logits, const int* tap_dy,
+                                           const int* tap_dx, int n_taps, int n, int c, int zc, int h, int w, int stream_idx,
+                                           int group) {
+    return add_aspp(p, OP_ASPP_GATHER, z, bias, logits, CMS_F32, tap_dy, tap_dx, n_taps, n, c, zc, h, w, stream_idx, group);
+}
+
+extern "C" int cms_program_add_aspp_spread(cms_program* p, const float* dlogits, void* d_nhwc, int d_dtype, const int* tap_dy,
+                                           const int* tap_dx, int n_taps, int n, int c, int zc, int h, int w, int stream_idx,
+                                           int group) {
+    return add_aspp(p, OP_ASPP_SPREAD, dlogits, nullptr, d_nhwc, d_dtype, tap_dy, tap_dx, n_taps, n, c, zc, h, w, stream_idx,
+                    group);
 }
 
 extern "C" int cms_program_size(const cms_program* p) { return p ? (int)p->ops.size() : 0; }

@@ -1,0 +1,399 @@
+// The network stem on hand-written kernels: 7x7 / stride 2 / pad 3 convolution (3 -> 64 channels) + frozen BatchNorm +
+// ReLU, the 3x3 / stride 2 / pad 1 ceil-mode max-pool, and their backward passes
+// (architectures/deeplab2.py:140-146 construction, :183-186 forward; the reference runs them through cuDNN).
+//
+// 0.3 % of the network's FLOPs with Cin = 3: not GEMM-shaped (K = 147), so this is VALU work with fp32 accumulation:
+//   stem_fwd      thread = one output pixel x all 64 channels; the 37 x 37 x 3 input patch of a 16 x 16 pixel tile is
+//                 staged through LDS (converted to fp32 once), the weights -- wave-uniform -- come in through the SCALAR
+//                 cache ([tap][co] packed copy, s_load + v_fmac with an SGPR operand: no LDS / VGPR traffic for them);
+//                 epilogue scale / bias / ReLU, one NHWC row of 64 channels per thread (full cache lines).
+//   maxpool_fwd   thread = one output pixel x 8 channels (16-byte vectors), first-maximum-wins like ATen
+//                 (`val > max || isnan(val)`, scan order ky, kx), argmax position kept in one byte per element.
+//   maxpool_bwd   gather form (no atomics): thread = one stem-output pixel x 8 channels, looks at the <= 4 windows that
+//                 contain it, takes their gradient where the stored argmax is this pixel; fused with the ReLU mask.
+//   stem_wgrad    dW[co][c][ky][kx] += scale[co] * sum_pixels dS[pix][co] * x[c][2*oy-3+ky][2*ox-3+kx]; thread = one
+//                 output channel x 5-6 (c, ky) rows x 7 kx; dS tile and input patch in LDS, patch reads are broadcasts;
+//                 persistent blocks, one round of fp32 atomics per block at the end.
+//   stem_dgrad    gradient wrt the image (VAT direction pass only): thread = one input pixel x 3 channels.
+// Input images are NCHW (the reference's batch layout, A0), activations NHWC.
+#include "common.hpp"
+
+namespace cms {
+
+constexpr int STEM_K = 7, STEM_TAPS = 147, STEM_CO = 64;
+
+template <class T>
+__device__ __forceinline__ float ld_f32(const T* p);
+template <>
+__device__ __forceinline__ float ld_f32<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld_f32<uint16_t>(const uint16_t* p) { return bf16_to_f32(*p); }
+
+template <class T>
+__device__ __forceinline__ void st_f32(T* p, float v);
+template <>
+__device__ __forceinline__ void st_f32<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void st_f32<uint16_t>(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+
+// w_packed[(c*7 + ky)*7 + kx][co] = w[ky][kx][co][c]   (source: the arena's physical [kh][kw][Cout][Cin] layout)
+template <class T>
+__global__ __launch_bounds__(256) void stem_pack_kernel(const T* __restrict__ w, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= STEM_TAPS * STEM_CO) return;
+    const int co = i % STEM_CO, q = i / STEM_CO;
+    const int c = q / 49, ky = (q % 49) / 7, kx = q % 7;
+    out[i] = ld_f32(w + ((size_t)(ky * 7 + kx) * STEM_CO + co) * 3 + c);
+}
+
+constexpr int SF_T = 16;                       // output tile edge
+constexpr int SF_P = (SF_T - 1) * 2 + STEM_K;  // 37: input patch edge
+constexpr int SF_PW = SF_P + 1;                // row pitch
+
+template <class TX, class TY>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const TX* __restrict__ x, TY* __restrict__ y,
+                                                       const float* __restrict__ wp, const float* __restrict__ scale,
+                                                       const float* __restrict__ bias, int N, int H, int W, int Ho,
+                                                       int Wo) {
+    __shared__ float patch[3][SF_P][SF_PW];
+    const int n = blockIdx.z, ty0 = blockIdx.y * SF_T, tx0 = blockIdx.x * SF_T;
+    const int tid = threadIdx.x;
+    const int iy0 = ty0 * 2 - 3, ix0 = tx0 * 2 - 3;
+    for (int i = tid; i < 3 * SF_P * SF_P; i += 256) {
+        const int px = i % SF_P, r = i / SF_P, py = r % SF_P, c = r / SF_P;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v = 0.0f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld_f32(x + (((size_t)n * 3 + c) * H + iy) * W + ix);
+        patch[c][py][px] = v;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    const int oy = ty0 + ty, ox = tx0 + tx;
+    float acc[STEM_CO];
+#pragma unroll
+    for (int co = 0; co < STEM_CO; ++co) acc[co] = 0.0f;
+    for (int r = 0; r < 21; ++r) {                      // (c, ky) rows; kx unrolled
+        const int c = r / 7, ky = r % 7;
+        const float* prow = &patch[c][ty * 2 + ky][tx * 2];
+        const float* wrow = wp + (size_t)r * 7 * STEM_CO;    // wave-uniform -> scalar loads
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const float xv = prow[kx];
+#pragma unroll
+            for (int co = 0; co < STEM_CO; ++co) acc[co] = fmaf(xv, wrow[kx * STEM_CO + co], acc[co]);
+        }
+    }
+    if (oy < Ho && ox < Wo) {
+        TY* dst = y + (((size_t)n * Ho + oy) * Wo + ox) * STEM_CO;
+#pragma unroll
+        for (int co = 0; co < STEM_CO; ++co) {
+            float v = acc[co] * scale[co] + bias[co];
+            st_f32(dst + co, fmaxf(v, 0.0f));
+        }
+    }
+}
+
+// ---- max-pool 3x3 / 2 / pad 1, NHWC, C % 8 == 0
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ s, T* __restrict__ p,
+                                                          uint8_t* __restrict__ idx, int N, int Hs, int Ws, int Hp,
+                                                          int Wp, int C) {
+    const int cv = C / 8;
+    const size_t total = (size_t)N * Hp * Wp * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cv);
+        size_t t = i / cv;
+        const int px = (int)(t % Wp); t /= Wp;
+        const int py = (int)(t % Hp);
+        const int n = (int)(t / Hp);
+        float best[8];
+        uint8_t bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = py * 2 - 1 + ky;
+            if (yy < 0 || yy >= Hs) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = px * 2 - 1 + kx;
+                if (xx < 0 || xx >= Ws) continue;
+                const T* src = s + (((size_t)n * Hs + yy) * Ws + xx) * C + c8 * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = ld_f32(src + e);
+                    if (v > best[e] || v != v) { best[e] = v; bi[e] = (uint8_t)(ky * 3 + kx); }
+                }
+            }
+        }
+        T* dst = p + (((size_t)n * Hp + py) * Wp + px) * C + c8 * 8;
+        uint8_t* di = idx + (((size_t)n * Hp + py) * Wp + px) * C + c8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { st_f32(dst + e, best[e]); di[e] = bi[e]; }
+    }
+}
+
+// dS[n,y,x,c] = [s > 0] * sum over windows (py,px) containing (y,x) with argmax == (y,x) of dP[n,py,px,c]
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dp, const uint8_t* __restrict__ idx,
+                                                          const T* __restrict__ s, T* __restrict__ ds, int N, int Hs,
+                                                          int Ws, int Hp, int Wp, int C) {
+    const int cv = C / 8;
+    const size_t total = (size_t)N * Hs * Ws * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cv);
+        size_t t = i / cv;
+        const int x = (int)(t % Ws); t /= Ws;
+        const int y = (int)(t % Hs);
+        const int n = (int)(t / Hs);
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = 0.0f;
+        // windows: py*2-1 <= y <= py*2+1
+        const int py_lo = max(0, (y) / 2), py_hi = min(Hp - 1, (y + 1) / 2);
+        const int px_lo = max(0, (x) / 2), px_hi = min(Wp - 1, (x + 1) / 2);
+        for (int py = py_lo; py <= py_hi; ++py) {
+            const int ky = y - (py * 2 - 1);
+            if (ky < 0 || ky > 2) continue;
+            for (int px = px_lo; px <= px_hi; ++px) {
+                const int kx = x - (px * 2 - 1);
+                if (kx < 0 || kx > 2) continue;
+                const size_t o = (((size_t)n * Hp + py) * Wp + px) * C + c8 * 8;
+                const uint8_t want = (uint8_t)(ky * 3 + kx);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (idx[o + e] == want) g[e] += ld_f32(dp + o + e);
+            }
+        }
+        const size_t so = (((size_t)n * Hs + y) * Ws + x) * C + c8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st_f32(ds + so + e, ld_f32(s + so + e) > 0.0f ? g[e] : 0.0f);
+    }
+}
+
+// ---- weight gradient of the stem convolution
+constexpr int SW_TH = 8, SW_TW = 16;                       // output tile (rows x cols) = 128 pixels
+constexpr int SW_PH = (SW_TH - 1) * 2 + STEM_K;            // 21
+constexpr int SW_PW = (SW_TW - 1) * 2 + STEM_K;            // 37
+
+template <class TX, class TS>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const TX* __restrict__ x, const TS* __restrict__ ds,
+                                                         float* __restrict__ dw, const float* __restrict__ scale, int N,
+                                                         int H, int W, int Ho, int Wo) {
+    __shared__ float dst[SW_TH * SW_TW][STEM_CO];          // 32 KB
+    __shared__ float patch[3][SW_PH][SW_PW + 1];
+    const int tid = threadIdx.x, co = tid & 63, g = tid >> 6;     // g = wave index: wave-uniform
+    const int r0 = g * 5, nr = g == 3 ? 6 : 5;                    // (c, ky) rows of this wave: 5 + 5 + 5 + 6 = 21
+    float acc[6][7];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[i][k] = 0.0f;
+    const int tiles_x = (Wo + SW_TW - 1) / SW_TW, tiles_y = (Ho + SW_TH - 1) / SW_TH;
+    const int ntiles = N * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int txi = t % tiles_x, tyi = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const int oy0 = tyi * SW_TH, ox0 = txi * SW_TW;
+        __syncthreads();                                    // the previous tile's reads are done
+        for (int i = tid; i < SW_TH * SW_TW * STEM_CO; i += 256) {
+            const int c = i & 63, p = i >> 6;
+            const int oy = oy0 + p / SW_TW, ox = ox0 + p % SW_TW;
+            float v = 0.0f;
+            if (oy < Ho && ox < Wo) v = ld_f32(ds + (((size_t)n * Ho + oy) * Wo + ox) * STEM_CO + c);
+            dst[p][c] = v;
+        }
+        const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+        for (int i = tid; i < 3 * SW_PH * SW_PW; i += 256) {
+            const int px = i % SW_PW, r = i / SW_PW, py = r % SW_PH, c = r / SW_PH;
+            const int iy = iy0 + py, ix = ix0 + px;
+            float v = 0.0f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld_f32(x + (((size_t)n * 3 + c) * H + iy) * W + ix);
+            patch[c][py][px] = v;
+        }
+        __syncthreads();
+        for (int p = 0; p < SW_TH * SW_TW; ++p) {
+            const float dy = dst[p][co];
+            const int py = (p / SW_TW) * 2, px = (p % SW_TW) * 2;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                if (i < nr) {
+                    const int r = r0 + i;
+                    const float* prow = &patch[r / 7][py + r % 7][px];       // uniform address: LDS broadcast
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) acc[i][k] = fmaf(dy, prow[k], acc[i][k]);
+                }
+            }
+        }
+    }
+    const float sc = scale ? scale[co] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        if (i < nr) {
+            const int r = r0 + i, c = r / 7, ky = r % 7;
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                atomicAdd(dw + ((size_t)(ky * 7 + k) * STEM_CO + co) * 3 + c, acc[i][k] * sc);
+        }
+    }
+}
+
+// ---- gradient wrt the image: dx[n,c,iy,ix] = sum_{ky,kx,co} dS[n,(iy+3-ky)/2,(ix+3-kx)/2,co] * scale[co]-folded w
+// wp2[(ky*7+kx)*3 + c][co] = w[ky][kx][co][c] * scale[co]
+template <class TS>
+__global__ __launch_bounds__(256) void stem_dgrad_kernel(const TS* __restrict__ ds, const float* __restrict__ wp,
+                                                         const float* __restrict__ scale, float* __restrict__ dx, int N,
+                                                         int H, int W, int Ho, int Wo) {
+    const size_t total = (size_t)N * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % W);
+        size_t t = i / W;
+        const int iy = (int)(t % H);
+        const int n = (int)(t / H);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+        for (int ky = (iy + 3) & 1; ky < 7; ky += 2) {
+            const int oy = (iy + 3 - ky) >> 1;
+            if (oy < 0 || oy >= Ho) continue;
+            for (int kx = (ix + 3) & 1; kx < 7; kx += 2) {
+                const int ox = (ix + 3 - kx) >> 1;
+                if (ox < 0 || ox >= Wo) continue;
+                const TS* row = ds + (((size_t)n * Ho + oy) * Wo + ox) * STEM_CO;
+                const float* w0 = wp + (size_t)((0 * 7 + ky) * 7 + kx) * STEM_CO;
+                const float* w1 = wp + (size_t)((1 * 7 + ky) * 7 + kx) * STEM_CO;
+                const float* w2 = wp + (size_t)((2 * 7 + ky) * 7 + kx) * STEM_CO;
+#pragma unroll 8
+                for (int co = 0; co < STEM_CO; ++co) {
+                    const float d = ld_f32(row + co) * scale[co];
+                    a0 = fmaf(d, w0[co], a0);
+                    a1 = fmaf(d, w1[co], a1);
+                    a2 = fmaf(d, w2[co], a2);
+                }
+            }
+        }
+        dx[(((size_t)n * 3 + 0) * H + iy) * W + ix] = a0;
+        dx[(((size_t)n * 3 + 1) * H + iy) * W + ix] = a1;
+        dx[(((size_t)n * 3 + 2) * H + iy) * W + ix] = a2;
+    }
+}
+
+}  // namespace cms
+
+using namespace cms;
+
+static bool dt_ok(int d) { return d == CMS_F32 || d == CMS_BF16; }
+
+extern "C" int cms_stem_pack_weights(const void* w_khkwcoci, int w_dtype, float* w_packed, void* stream) {
+    CMS_REQUIRE(w_khkwcoci && w_packed && dt_ok(w_dtype), "stem_pack_weights: NULL pointer / bad dtype");
+    const int n = STEM_TAPS * STEM_CO;
+    hipStream_t s = (hipStream_t)stream;
+    if (w_dtype == CMS_F32)
+        hipLaunchKernelGGL(stem_pack_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)w_khkwcoci, w_packed);
+    else
+        hipLaunchKernelGGL(stem_pack_kernel<uint16_t>, dim3((n + 255) / 256), dim3(256), 0, s, (const uint16_t*)w_khkwcoci,
+                           w_packed);
+    return launch_status("cms_stem_pack_weights");
+}
+
+extern "C" int cms_stem_out_hw(int h, int w, int* ho, int* wo, int* hp, int* wp) {
+    CMS_REQUIRE(h > 0 && w > 0, "stem_out_hw: bad size");
+    const int Ho = (h + 6 - 7) / 2 + 1, Wo = (w + 6 - 7) / 2 + 1;
+    auto pool = [](int s) {                                  // ceil_mode, kernel 3, stride 2, pad 1 (ATen's rule)
+        int o = (s + 2 - 3 + 1) / 2 + 1;
+        if ((o - 1) * 2 >= s + 1) --o;
+        return o;
+    };
+    if (ho) *ho = Ho;
+    if (wo) *wo = Wo;
+    if (hp) *hp = pool(Ho);
+    if (wp) *wp = pool(Wo);
+    return CMS_OK;
+}
+
+extern "C" int cms_stem_fwd(const void* x_nchw, int x_dtype, void* y_nhwc, int y_dtype, const float* w_packed,
+                            const float* scale, const float* bias, int n, int h, int w, void* stream) {
+    CMS_REQUIRE(x_nchw && y_nhwc && w_packed && scale && bias, "stem_fwd: NULL pointer");
+    CMS_REQUIRE(dt_ok(x_dtype) && dt_ok(y_dtype), "stem_fwd: bad dtype");
+    CMS_REQUIRE(n > 0 && h > 0 && w > 0 && n <= 65535, "stem_fwd: bad geometry");
+    int Ho, Wo;
+    cms_stem_out_hw(h, w, &Ho, &Wo, nullptr, nullptr);
+    const dim3 grid((Wo + SF_T - 1) / SF_T, (Ho + SF_T - 1) / SF_T, n);
+    hipStream_t s = (hipStream_t)stream;
+#define CMS_STEM_FWD(TX, TY) \
+    hipLaunchKernelGGL((stem_fwd_kernel<TX, TY>), grid, dim3(256), 0, s, (const TX*)x_nchw, (TY*)y_nhwc, w_packed, scale, bias, n, h, w, Ho, Wo)
+    if (x_dtype == CMS_F32 && y_dtype == CMS_F32) CMS_STEM_FWD(float, float);
+    else if (x_dtype == CMS_F32) CMS_STEM_FWD(float, uint16_t);
+    else if (y_dtype == CMS_F32) CMS_STEM_FWD(uint16_t, float);
+    else CMS_STEM_FWD(uint16_t, uint16_t);
+#undef CMS_STEM_FWD
+    return launch_status("cms_stem_fwd");
+}
+
+extern "C" int cms_maxpool3x3s2_fwd(const void* s_nhwc, void* p_nhwc, uint8_t* argmax, int dtype, int n, int hs, int ws,
+                                    int c, void* stream) {
+    CMS_REQUIRE(s_nhwc && p_nhwc && argmax && dt_ok(dtype), "maxpool_fwd: NULL pointer / bad dtype");
+    CMS_REQUIRE(n > 0 && hs > 0 && ws > 0 && c > 0 && c % 8 == 0, "maxpool_fwd: bad geometry (C %% 8 == 0)");
+    auto pool = [](int s) { int o = (s + 2 - 3 + 1) / 2 + 1; if ((o - 1) * 2 >= s + 1) --o; return o; };
+    const int hp = pool(hs), wp = pool(ws);
+    const size_t total = (size_t)n * hp * wp * (c / 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CMS_F32)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, st, (const float*)s_nhwc,
+                           (float*)p_nhwc, argmax, n, hs, ws, hp, wp, c);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel<uint16_t>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, st,
+                           (const uint16_t*)s_nhwc, (uint16_t*)p_nhwc, argmax, n, hs, ws, hp, wp, c);
+    return launch_status("cms_maxpool3x3s2_fwd");
+}
+
+extern "C" int cms_maxpool3x3s2_relu_bwd(const void* dp_nhwc, const uint8_t* argmax, const void* s_nhwc, void* ds_nhwc,
+                                         int dtype, int n, int hs, int ws, int c, void* stream) {
+    CMS_REQUIRE(dp_nhwc && argmax && s_nhwc && ds_nhwc && dt_ok(dtype), "maxpool_bwd: NULL pointer / bad dtype");
+    CMS_REQUIRE(n > 0 && hs > 0 && ws > 0 && c > 0 && c % 8 == 0, "maxpool_bwd: bad geometry (C %% 8 == 0)");
+    auto pool = [](int s) { int o = (s + 2 - 3 + 1) / 2 + 1; if ((o - 1) * 2 >= s + 1) --o; return o; };
+    const int hp = pool(hs), wp = pool(ws);
+    const size_t total = (size_t)n * hs * ws * (c / 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CMS_F32)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, st, (const float*)dp_nhwc,
+                           argmax, (const float*)s_nhwc, (float*)ds_nhwc, n, hs, ws, hp, wp, c);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<uint16_t>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, st,
+                           (const uint16_t*)dp_nhwc, argmax, (const uint16_t*)s_nhwc, (uint16_t*)ds_nhwc, n, hs, ws, hp, wp, c);
+    return launch_status("cms_maxpool3x3s2_relu_bwd");
+}
+
+extern "C" int cms_stem_wgrad(const void* x_nchw, int x_dtype, const void* ds_nhwc, int ds_dtype, float* dw_khkwcoci,
+                              const float* scale, int n, int h, int w, void* stream) {
+    CMS_REQUIRE(x_nchw && ds_nhwc && dw_khkwcoci, "stem_wgrad: NULL pointer");
+    CMS_REQUIRE(dt_ok(x_dtype) && dt_ok(ds_dtype), "stem_wgrad: bad dtype");
+    CMS_REQUIRE(n > 0 && h > 0 && w > 0, "stem_wgrad: bad geometry");
+    int Ho, Wo;
+    cms_stem_out_hw(h, w, &Ho, &Wo, nullptr, nullptr);
+    const int ntiles = n * ((Ho + SW_TH - 1) / SW_TH) * ((Wo + SW_TW - 1) / SW_TW);
+    const dim3 grid(ntiles < 768 ? ntiles : 768);            // 3 blocks per CU (41 KB of LDS each), persistent over the tiles
+    hipStream_t s = (hipStream_t)stream;
+#define CMS_STEM_WG(TX, TS) \
+    hipLaunchKernelGGL((stem_wgrad_kernel<TX, TS>), grid, dim3(256), 0, s, (const TX*)x_nchw, (const TS*)ds_nhwc, dw_khkwcoci, scale, n, h, w, Ho, Wo)
+    if (x_dtype == CMS_F32 && ds_dtype == CMS_F32) CMS_STEM_WG(float, float);
+    else if (x_dtype == CMS_F32) CMS_STEM_WG(float, uint16_t);
+    else if (ds_dtype == CMS_F32) CMS_STEM_WG(uint16_t, float);
+    else CMS_STEM_WG(uint16_t, uint16_t);
+#undef CMS_STEM_WG
+    return launch_status("cms_stem_wgrad");
+}
+
+extern "C" int cms_stem_dgrad(const void* ds_nhwc, int ds_dtype, const float* w_packed, const float* scale, float* dx_nchw,
+                              int n, int h, int w, void* stream) {
+    CMS_REQUIRE(ds_nhwc && w_packed && scale && dx_nchw && dt_ok(ds_dtype), "stem_dgrad: NULL pointer / bad dtype");
+    CMS_REQUIRE(n > 0 && h > 0 && w > 0, "stem_dgrad: bad geometry");
+    int Ho, Wo;
+    cms_stem_out_hw(h, w, &Ho, &Wo, nullptr, nullptr);
+    const size_t total = (size_t)n * h * w;
+    hipStream_t s = (hipStream_t)stream;
+    if (ds_dtype == CMS_F32)
+        hipLaunchKernelGGL(stem_dgrad_kernel<float>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, (const float*)ds_nhwc,
+                           w_packed, scale, dx_nchw, n, h, w, Ho, Wo);
+    else
+        hipLaunchKernelGGL(stem_dgrad_kernel<uint16_t>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s,
+                           (const uint16_t*)ds_nhwc, w_packed, scale, dx_nchw, n, h, w, Ho, Wo);
+    return launch_status("cms_stem_dgrad");
+}

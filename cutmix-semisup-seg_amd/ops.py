@@ -373,6 +373,87 @@ def confusion(truth, pred, num_classes, ignore_index=None, cm=None):
     return cm
 
 
+# ---------------------------------------------------------------------------------------------- stem
+def stem_out_hw(h, w):
+    """-> (ho, wo, hp, wp): sizes after the 7x7/2 convolution and after the ceil-mode 3x3/2 max-pool."""
+    v = [C.c_int() for _ in range(4)]
+    check(fn['cms_stem_out_hw'](int(h), int(w), *[C.byref(t) for t in v]), 'cms_stem_out_hw')
+    return tuple(t.value for t in v)
+
+
+def stem_pack_weights(w_packed_khkwcoci, out=None):
+    """(49, 64, 3) fp32 / bf16 view of conv1.weight in the arena's physical layout -> fp32 (147, 64) [c,ky,kx][co]."""
+    _need_cuda(w_packed_khkwcoci, out)
+    if tuple(w_packed_khkwcoci.shape) != (49, 64, 3) or not w_packed_khkwcoci.is_contiguous():
+        raise ValueError('stem_pack_weights: contiguous (49, 64, 3) weight view required')
+    if out is None:
+        out = torch.empty((147, 64), dtype=torch.float32, device=w_packed_khkwcoci.device)
+    check(fn['cms_stem_pack_weights'](_ptr(w_packed_khkwcoci), _dtype_code(w_packed_khkwcoci), _ptr(out), _stream()),
+          'cms_stem_pack_weights')
+    return out
+
+
+def stem_forward(x, w147, scale, bias, out_dtype):
+    """relu(bn(conv7x7/2(x))) -> (N, ho, wo, 64) NHWC; x (N, 3, H, W) NCHW-contiguous fp32 / bf16."""
+    _need_cuda(x, w147, scale, bias)
+    if x.dim() != 4 or x.shape[1] != 3 or not x.is_contiguous():
+        raise ValueError('stem_forward: contiguous (N, 3, H, W) input required')
+    n, _, h, w = (int(v) for v in x.shape)
+    ho, wo, _, _ = stem_out_hw(h, w)
+    y = torch.empty((n, ho, wo, 64), dtype=out_dtype, device=x.device)
+    check(fn['cms_stem_fwd'](_ptr(x), _dtype_code(x), _ptr(y), _dtype_code(y), _ptr(w147), _ptr(scale), _ptr(bias), n, h, w,
+                             _stream()), 'cms_stem_fwd')
+    return y
+
+
+def maxpool3x3s2_forward(s):
+    """ceil-mode 3x3 / 2 / pad 1 max-pool of an NHWC tensor -> (pooled, argmax uint8)."""
+    _need_cuda(s)
+    n, hs, ws, c = (int(v) for v in s.shape)
+
+    def o(v):                       # ATen's ceil-mode output size for kernel 3, stride 2, padding 1
+        r = (v + 2 - 3 + 1) // 2 + 1
+        return r - 1 if (r - 1) * 2 >= v + 1 else r
+    hp, wp = o(hs), o(ws)
+    p = torch.empty((n, hp, wp, c), dtype=s.dtype, device=s.device)
+    idx = torch.empty((n, hp, wp, c), dtype=torch.uint8, device=s.device)
+    check(fn['cms_maxpool3x3s2_fwd'](_ptr(s), _ptr(p), _ptr(idx), _dtype_code(s), n, hs, ws, c, _stream()),
+          'cms_maxpool3x3s2_fwd')
+    return p, idx
+
+
+def maxpool3x3s2_relu_backward(dp, idx, s):
+    """gradient wrt the PRE-ReLU stem output: [s > 0] * max-pool backward."""
+    _need_cuda(dp, idx, s)
+    dp = dp.contiguous()
+    if dp.dtype != s.dtype or dp.shape != idx.shape:
+        raise ValueError('maxpool backward: dtype / shape mismatch')
+    n, hs, ws, c = (int(v) for v in s.shape)
+    ds = torch.empty_like(s)
+    check(fn['cms_maxpool3x3s2_relu_bwd'](_ptr(dp), _ptr(idx), _ptr(s), _ptr(ds), _dtype_code(s), n, hs, ws, c, _stream()),
+          'cms_maxpool3x3s2_relu_bwd')
+    return ds
+
+
+def stem_wgrad(x, ds, dw_khkwcoci, scale):
+    """dw (49, 64, 3) fp32 view of conv1.weight's gradient in the arena, accumulated into."""
+    _need_cuda(x, ds, dw_khkwcoci, scale)
+    if tuple(dw_khkwcoci.shape) != (49, 64, 3) or dw_khkwcoci.dtype != torch.float32 or not dw_khkwcoci.is_contiguous():
+        raise ValueError('stem_wgrad: contiguous fp32 (49, 64, 3) gradient view required')
+    n, _, h, w = (int(v) for v in x.shape)
+    check(fn['cms_stem_wgrad'](_ptr(x), _dtype_code(x), _ptr(ds), _dtype_code(ds), _ptr(dw_khkwcoci), _ptr(scale), n, h, w,
+                               _stream()), 'cms_stem_wgrad')
+
+
+def stem_dgrad(ds, w147, scale, x_shape):
+    _need_cuda(ds, w147, scale)
+    n, _, h, w = (int(v) for v in x_shape)
+    dx = torch.empty((n, 3, h, w), dtype=torch.float32, device=ds.device)
+    check(fn['cms_stem_dgrad'](_ptr(ds), _dtype_code(ds), _ptr(w147), _ptr(scale), _ptr(dx), n, h, w, _stream()),
+          'cms_stem_dgrad')
+    return dx
+
+
 # ---------------------------------------------------------------------------------------------- launch programs
 class Program(object):
     """A recorded network pass (csrc/program.hip): launch descriptors over persistent buffers, replayed from C++ with
@@ -493,6 +574,59 @@ def stream_wait(waiter, waited):
     idx = fn['cms_program_add_sync'](prog.h, _rec_stream_index(waited), _rec_stream_index(waiter), prog.group)
     if idx < 0:
         check(idx, 'cms_program_add_sync')
+
+
+# ---------------------------------------------------------------------------------------------- ASPP head
+def _tap_arrays(taps):
+    n = len(taps)
+    dy = (C.c_int * n)(*[int(t[0]) for t in taps])
+    dx = (C.c_int * n)(*[int(t[1]) for t in taps])
+    return dy, dx, n
+
+
+def aspp_gather_fwd(z, bias, taps, num_classes, out=None):
+    """logits[n][c][y][x] = bias[c] + sum_t z[n][t*C + c][y + dy_t][x + dx_t]; z fp32 (N, ZC, h, w) (csrc/aspp.hip)."""
+    _need_cuda(z, bias, out)
+    if z.dtype != torch.float32 or not z.is_contiguous():
+        raise TypeError('aspp_gather_fwd: contiguous fp32 (N, ZC, h, w) input required')
+    n, zc, h, w = (int(v) for v in z.shape)
+    if out is None:
+        out = torch.empty((n, int(num_classes), h, w), dtype=torch.float32, device=z.device)
+    dy, dx, nt = _tap_arrays(taps)
+    if _REC is not None:
+        prog = _REC[0]
+        idx = fn['cms_program_add_aspp_gather'](prog.h, _ptr(z), _ptr(bias), _ptr(out), dy, dx, nt, n, int(num_classes), zc,
+                                                h, w, _rec_stream_index(), prog.group)
+        if idx < 0:
+            check(idx, 'cms_program_add_aspp_gather')
+        prog.keep += [t for t in (z, bias, out) if t is not None]
+        prog.head_bytes += 4.0 * nt * int(num_classes) * n * h * w + 4.0 * out.numel()
+        return out
+    check(fn['cms_aspp_gather_fwd'](_ptr(z), _ptr(bias), _ptr(out), dy, dx, nt, n, int(num_classes), zc, h, w, _stream()),
+          'cms_aspp_gather_fwd')
+    return out
+
+
+def aspp_spread_bwd(dlogits, taps, zc, dtype, out=None):
+    """D[n][y][x][t*C + c] = dlogits[n][c][y - dy_t][x - dx_t] -> NHWC (N, h, w, zc) operand of the head's backward GEMMs."""
+    _need_cuda(dlogits, out)
+    if dlogits.dtype != torch.float32 or not dlogits.is_contiguous():
+        raise TypeError('aspp_spread_bwd: contiguous fp32 (N, C, h, w) gradient required')
+    n, c, h, w = (int(v) for v in dlogits.shape)
+    if out is None:
+        out = torch.empty((n, h, w, int(zc)), dtype=dtype, device=dlogits.device)
+    dy, dx, nt = _tap_arrays(taps)
+    if _REC is not None:
+        prog = _REC[0]
+        idx = fn['cms_program_add_aspp_spread'](prog.h, _ptr(dlogits), _ptr(out), _dtype_code(out), dy, dx, nt, n, c,
+                                                int(zc), h, w, _rec_stream_index(), prog.group)
+        if idx < 0:
+            check(idx, 'cms_program_add_aspp_spread')
+        prog.keep += [dlogits, out]
+        return out
+    check(fn['cms_aspp_spread_bwd'](_ptr(dlogits), _ptr(out), _dtype_code(out), dy, dx, nt, n, c, int(zc), h, w, _stream()),
+          'cms_aspp_spread_bwd')
+    return out
 
 
 # ---------------------------------------------------------------------------------------------- MFMA convolution

@@ -317,6 +317,44 @@ int cms_conv_pack_transpose_f32(const float* src, float* dst, const float* scale
 int cms_conv_pack_transpose_batch_f32(const cms_pack_item* items_dev, int n_items, int total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * ASPP head (architectures/deeplab2.py:112-128) with the 2048-channel activation read ONCE (csrc/aspp.hip):
+ *   forward   Z = X . Wall^T as a 1x1 cms_conv_igemm (rows of Wall: tap*C + class, fp32 NCHW output), then
+ *             logits[n][c][y][x] = bias[c] + sum_t Z[n][t*C + c][y + dy_t][x + dx_t]            (cms_aspp_gather_fwd)
+ *   backward  D[n][y][x][t*C + c] = dlogits[n][c][y - dy_t][x - dx_t]                             (cms_aspp_spread_bwd),
+ *             then dX = D . Wall (1x1 cms_conv_igemm) and dWall = D^T . X (one cms_conv_wgrad).
+ * zc = channel count of Z / D (taps * classes padded to what the GEMMs need); columns >= taps * classes are zero.
+ * ------------------------------------------------------------------------------------------------------------ */
+int cms_aspp_gather_fwd(const float* z, const float* bias, float* logits, const int* tap_dy, const int* tap_dx, int n_taps,
+                        int n, int c, int zc, int h, int w, void* stream);
+int cms_aspp_spread_bwd(const float* dlogits, void* d_nhwc, int d_dtype, const int* tap_dy, const int* tap_dx, int n_taps,
+                        int n, int c, int zc, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Network stem: 7x7 / stride 2 / pad 3 convolution 3 -> 64 + frozen BatchNorm + ReLU, 3x3 / stride 2 / pad 1 ceil-mode
+ * max-pool, and their backward passes (architectures/deeplab2.py:140-146, 183-186; csrc/stem.hip).
+ * Images NCHW (the reference's batch layout), activations NHWC; dtypes CMS_F32 / CMS_BF16 per tensor.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* w_packed[(c*7 + ky)*7 + kx][co] (fp32, 147 x 64) from the convolution weight in its [kh][kw][Cout][Cin] layout */
+int cms_stem_pack_weights(const void* w_khkwcoci, int w_dtype, float* w_packed, void* stream);
+/* sizes of the stem convolution output (ho, wo) and of the max-pool output (hp, wp) for an h x w image */
+int cms_stem_out_hw(int h, int w, int* ho, int* wo, int* hp, int* wp);
+/* y[n][oy][ox][co] = relu(conv(x)[co] * scale[co] + bias[co]) */
+int cms_stem_fwd(const void* x_nchw, int x_dtype, void* y_nhwc, int y_dtype, const float* w_packed, const float* scale,
+                 const float* bias, int n, int h, int w, void* stream);
+/* p = maxpool(s); argmax[n][py][px][c] = ky*3+kx of the FIRST maximum of the window (ATen's rule) */
+int cms_maxpool3x3s2_fwd(const void* s_nhwc, void* p_nhwc, uint8_t* argmax, int dtype, int n, int hs, int ws, int c,
+                         void* stream);
+/* ds = [s > 0] * scatter(dp through argmax): max-pool backward fused with the ReLU backward of its input */
+int cms_maxpool3x3s2_relu_bwd(const void* dp_nhwc, const uint8_t* argmax, const void* s_nhwc, void* ds_nhwc, int dtype,
+                              int n, int hs, int ws, int c, void* stream);
+/* dw[ky][kx][co][c] (fp32, accumulated with atomics) += scale[co] * sum_pixels ds[pix][co] * x[c][2oy-3+ky][2ox-3+kx] */
+int cms_stem_wgrad(const void* x_nchw, int x_dtype, const void* ds_nhwc, int ds_dtype, float* dw_khkwcoci,
+                   const float* scale, int n, int h, int w, void* stream);
+/* dx (fp32 NCHW) = gradient wrt the image (VAT direction pass, train_seg_semisup_vat_mt.py:244-268) */
+int cms_stem_dgrad(const void* ds_nhwc, int ds_dtype, const float* w_packed, const float* scale, float* dx_nchw, int n,
+                   int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Launch programs: the host side of a network pass, recorded once per input shape and replayed from C++
  * (csrc/program.hip). Replaces one Python -> ctypes round trip per convolution of architectures/deeplab2.py:89-128
  * (and of its backward pass) by ONE call per pass. Ops refer to caller-owned, persistent device buffers; stream
@@ -330,6 +368,10 @@ int cms_program_destroy(cms_program* p);
 int cms_program_add_conv(cms_program* p, const cms_conv_desc* d, int f32, int stream_idx, int group);
 int cms_program_add_wgrad(cms_program* p, const cms_wgrad_desc* d, int f32, int stream_idx, int group);
 int cms_program_add_memset(cms_program* p, void* ptr, size_t bytes, int stream_idx, int group);
+int cms_program_add_aspp_gather(cms_program* p, const float* z, const float* bias, float* logits, const int* tap_dy,
+                                const int* tap_dx, int n_taps, int n, int c, int zc, int h, int w, int stream_idx, int group);
+int cms_program_add_aspp_spread(cms_program* p, const float* dlogits, void* d_nhwc, int d_dtype, const int* tap_dy,
+                                const int* tap_dx, int n_taps, int n, int c, int zc, int h, int w, int stream_idx, int group);
 /* work enqueued so far on `from_stream` must finish before anything enqueued later on `to_stream` starts */
 int cms_program_add_sync(cms_program* p, int from_stream, int to_stream, int group);
 int cms_program_size(const cms_program* p);

@@ -303,3 +303,39 @@ def test_bf16_hip_engine_iteration_vs_oracle_reports_errors(ops, name):
     # (cfg 3); the trained-network statement (within 0.2 pt) is tests/test_gpu_miou_training.py
     assert e['miou'] <= 1e-1, e
     assert e['grad_head'] <= 2e-2 and e['grad_mean'] <= 3e-2 and e['grad_max'] <= 1.5e-1, e
+
+
+def test_aspp_single_pass_formulation_vs_fp64(ops):
+    """csrc/aspp.hip: Z = X . Wall^T (1x1 GEMM) + shifted-plane gather == conv_d6(x) + conv_d12(x) + biases; the
+    spread / GEMM backward == autograd of the same (architectures/deeplab2.py:124-128)."""
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C = 2, 15, 17, 21
+    ZC = (18 * C + 127) // 128 * 128
+    x = torch.randn(N, H, W, 2048, generator=g)
+    ws = [torch.randn(C, 2048, 3, 3, generator=g) * 0.01 for _ in range(2)]
+    bs = [torch.randn(C, generator=g) * 0.1 for _ in range(2)]
+    wall = torch.zeros(1, ZC, 2048)
+    taps = []
+    for i, d in enumerate((6, 12)):
+        wall[0, 9 * C * i:9 * C * (i + 1)] = _pack(ws[i]).reshape(9 * C, 2048)
+        taps += ops.conv_taps(3, 3, d, d)
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wd = [w.double().requires_grad_(True) for w in ws]
+    ref = sum(F.conv2d(xd, wd[i], bs[i].double(), 1, d, d) for i, d in enumerate((6, 12)))
+    dl = torch.randn(ref.shape, generator=g)
+    ref.backward(dl.double())
+    xg = x.to(DEV)
+    z = torch.empty(N, ZC, H, W, device=DEV)
+    ops.conv_igemm(xg, wall.to(DEV), [(0, 0)], out_f32_nchw=z, cout_real=ZC)
+    logits = ops.aspp_gather_fwd(z, (bs[0] + bs[1]).to(DEV), taps, C)
+    assert _rel(logits, ref) <= 5e-6
+    d = ops.aspp_spread_bwd(dl.to(DEV), taps, ZC, torch.float32)
+    wallT = ops.conv_pack_transpose(wall.to(DEV), flip=False, out_dtype=torch.float32)
+    dx = ops.conv_igemm(d, wallT, [(0, 0)], mode=1)
+    assert _rel(dx.permute(0, 3, 1, 2), xd.grad) <= 5e-6
+    dwall = torch.zeros(1, ZC, 2048, device=DEV)
+    ops.conv_wgrad(d, xg, [(0, 0)], dwall)
+    for i in range(2):
+        got = dwall[0, 9 * C * i:9 * C * (i + 1)].view(9, C, 2048)
+        assert _rel(got, _pack(wd[i].grad.float())) <= 5e-6
+    assert float(dwall[0, 18 * C:].abs().max()) == 0.0
