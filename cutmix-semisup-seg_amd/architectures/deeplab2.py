@@ -166,14 +166,7 @@ class ResNetDeepLab(nn.Module):
         self.inplanes = 64
         super(ResNetDeepLab, self).__init__()
         self.num_classes = num_classes
-        self.compute_dtype = torch.bfloat16
-        self.engine = None          # set to an engine object to override the default executor
-        # 'auto': hand-written MFMA executor (backbone_hip.py) whenever BatchNorm is frozen (bf16 = throughput
-        # configuration, fp32 = parity configuration), library engine otherwise; 'torch' / 'hip' force one
-        self.engine_kind = 'auto'
-        self.stem_kind = 'hip'          # 'torch': stem through the library engine (comparison runs)
-        self._hip_executor = None       # the executor used last
-        self._hip_executors = {}        # compute dtype -> executor
+        self._init_runtime()
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = _frozen_bn(64)
         self.relu = nn.ReLU(inplace=True)
@@ -189,6 +182,25 @@ class ResNetDeepLab(nn.Module):
             elif isinstance(m, nn.BatchNorm2d):
                 m.weight.data.fill_(1)
                 m.bias.data.zero_()
+
+    def _init_runtime(self):
+        """Execution state of this build (not part of the reference's module): set at construction and again after
+        unpickling a whole-module checkpoint (reference-made pickles do not carry it, checkpoint.py)."""
+        d = self.__dict__
+        d.setdefault('compute_dtype', torch.bfloat16)
+        d.setdefault('engine', None)          # set to an engine object to override the default executor
+        # 'auto': hand-written MFMA executor (backbone_hip.py) whenever BatchNorm is frozen (bf16 = throughput
+        # configuration, fp32 = parity configuration), library engine otherwise; 'torch' / 'hip' force one
+        d.setdefault('engine_kind', 'auto')
+        d.setdefault('stem_kind', 'hip')      # 'torch': stem through the library engine (comparison runs)
+        d.setdefault('_hip_executor', None)   # the executor used last
+        d.setdefault('_hip_executors', {})    # compute dtype -> executor
+        if 'num_classes' not in d:            # a reference-made pickle: read it off the head
+            d['num_classes'] = self.layer5.conv2d_list[0].out_channels
+
+    def __setstate__(self, state):
+        super(ResNetDeepLab, self).__setstate__(state)
+        self._init_runtime()
 
     def _make_layer(self, block, planes, blocks, stride=1, dilation=1):
         downsample = None
@@ -294,6 +306,12 @@ class ResNetDeepLab(nn.Module):
 
     def freeze_batchnorm(self):
         self.apply(freeze_bn_module)
+
+
+# whole-module pickles name the classes by module path: the reference's path, so that checkpoints written here load with
+# the reference's code and vice versa (the root-level `architectures/deeplab2.py` re-exports these very objects)
+for _cls in (Bottleneck, Classifier_Module, ResNetDeepLab):
+    _cls.__module__ = 'architectures.deeplab2'
 
 
 def _hung_mean_std():

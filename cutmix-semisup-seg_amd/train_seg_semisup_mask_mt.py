@@ -232,8 +232,11 @@ def train_seg_semisup_mask_mt(submit_config, dataset, model, arch, freeze_bn,
                                                       's' if world > 1 else ''))
 
     if save_model and rank == 0 and submit_config.run_dir is not None:
+        # the reference pickles the whole module (:533-535): a clean replica without this build's runtime state, under
+        # the reference's class paths (checkpoint.py)
+        from . import checkpoint
         model_path = os.path.join(submit_config.run_dir, 'model.pth')
-        torch.save(eval_net.state_dict(), model_path)
+        checkpoint.save_model(eval_net, model_path)
 
 
 _OPTIONS = [

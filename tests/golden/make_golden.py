@@ -605,7 +605,61 @@ def gen_cli_vat():
     print('wrote cli_options_vat.json ({} options)'.format(len(opts)))
 
 
+def gen_checkpoint():
+    """A whole-module pickle written by the REFERENCE's classes the way its trainer does (`torch.save(eval_net, path)`,
+    train_seg_semisup_mask_mt.py:533-535), plus the outcome of the reference's `_load_state_into_model`
+    (architectures/deeplab2.py:310-322) on a state dict with a missing key, a wrong-shaped entry and a foreign key.
+    To keep the fixture small every tensor of the pickled module is a stride-0 expansion of ONE element (value = a
+    closed form of its key), so the file holds the object graph, class paths, shapes and dtypes -- not 36 MB of weights."""
+    import io
+    odl = _load_oracle('deeplab2')
+    C, layers = 5, [1, 1, 1, 1]
+    net = ref_deeplab2.ResNetDeepLab(ref_deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
+    net.eval()
+    tag = {}
+    with torch.no_grad():
+        for m in net.modules():
+            for name, p in list(m._parameters.items()):
+                if p is not None:
+                    m._parameters[name] = nn.Parameter(torch.zeros(1).expand(p.shape), requires_grad=p.requires_grad)
+            for name, b in list(m._buffers.items()):
+                if b is not None and b.dtype == torch.float32:
+                    m._buffers[name] = torch.zeros(1).expand(b.shape)
+        for k, v in net.state_dict().items():
+            if v.dtype == torch.float32:
+                val = ((odl._key_seed(k) % 1000) - 500) / 1000.0
+                v.untyped_storage().copy_(torch.tensor([val]).untyped_storage())
+                tag[k] = val
+    path = os.path.join(HERE, 'ref_module_checkpoint.pth')
+    torch.save(net, path)
+    print('wrote {} ({:.1f} KB)'.format(path, os.path.getsize(path) / 1024))
+    # _load_state_into_model semantics
+    net2 = ref_deeplab2.ResNetDeepLab(ref_deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
+    torch.manual_seed(0)
+    before = {k: v.clone() for k, v in net2.state_dict().items()}
+    sd = odl.closed_form_state(C, layers)
+    sd = {k: v for k, v in sd.items()}
+    del sd['layer2.0.conv2.weight']                                   # missing -> keeps its initialisation
+    sd['layer5.conv2d_list.0.weight'] = torch.ones(C + 1, 2048, 3, 3)  # wrong shape -> keeps its initialisation
+    sd['not.a.key'] = torch.ones(3)                                   # foreign key -> ignored
+    buf = io.StringIO()
+    old = sys.stdout
+    sys.stdout = buf
+    try:
+        ref_deeplab2._load_state_into_model(net2, sd, verbose=True)
+    finally:
+        sys.stdout = old
+    after = net2.state_dict()
+    kept = sorted(k for k in after if torch.equal(after[k], before[k]) and k in ('layer2.0.conv2.weight', 'layer5.conv2d_list.0.weight'))
+    loaded = sorted(k for k in after if k in sd and after[k].shape == sd[k].shape and torch.equal(after[k], sd[k]))
+    with open(os.path.join(HERE, 'checkpoint_meta.json'), 'w') as f:
+        json.dump(dict(tag=tag, num_classes=C, layers=layers, kept_init=kept, n_loaded=len(loaded), n_keys=len(after),
+                       verbose_lines=buf.getvalue().strip().splitlines()), f, indent=0)
+    print('wrote checkpoint_meta.json (loaded {} of {} keys, kept {})'.format(len(loaded), len(after), kept))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['boxmask', 'ema', 'evaluation', 'lr', 'losses', 'deeplab2', 'optim', 'step', 'cli', 'cli_vat']
+    which = sys.argv[1:] or ['boxmask', 'ema', 'evaluation', 'lr', 'losses', 'deeplab2', 'optim', 'step', 'cli', 'cli_vat',
+                             'checkpoint']
     for w in which:
         globals()['gen_' + w]()

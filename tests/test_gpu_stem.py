@@ -37,7 +37,7 @@ def test_stem_forward_pool_and_backward(ops, shape, dtype):
     ho, wo, hp, wp = ops.stem_out_hw(H, W)
     assert (ho, wo, hp, wp) == (s_ref.shape[2], s_ref.shape[3], p_ref.shape[2], p_ref.shape[3])
     dp = torch.randn(p_ref.shape, generator=g)
-    p_ref.backward(dp.double())
+    p_ref.backward(dp.double(), retain_graph=True)
     cu = lambda t: t.to(DEV)
     w147 = ops.stem_pack_weights(cu(_pack49(w).to(dtype)))
     s = ops.stem_forward(cu(x.to(dtype)), w147, cu(scale), cu(bias), dtype)
