@@ -123,6 +123,13 @@ PROTOTYPES = {
     'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'cms_conv_pack_transpose_batch': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    'cms_bn_reduce': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
+                              c_void_p]),
+    'cms_bn_finalize': (c_int, [c_void_p, C.c_double, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'cms_bn_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_size_t, c_int, c_void_p]),
+    'cms_bn_bwd_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, C.c_double, c_size_t, c_int, c_void_p]),
     'cms_aspp_gather_fwd': (c_int, [c_void_p, c_void_p, c_void_p, _P(c_int), _P(c_int), c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_void_p]),
     'cms_aspp_spread_bwd': (c_int, [c_void_p, c_void_p, c_int, _P(c_int), _P(c_int), c_int, c_int, c_int, c_int, c_int,

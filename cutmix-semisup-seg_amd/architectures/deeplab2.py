@@ -117,7 +117,21 @@ class TorchEngine(object):
         y = self.conv2d(x, conv)
         if bn is not None:
             if bn.training:
-                # batch-statistics BN in fp32 (the library's bf16 channels-last training kernel faults on gfx950)
+                yh = y.permute(0, 2, 3, 1)                 # NHWC view of the channels-last tensor
+                if y.is_cuda and yh.is_contiguous() and y.shape[1] % 8 == 0 and bn.momentum is not None \
+                        and bn.running_mean is not None:
+                    # batch-statistics BatchNorm (+ residual + ReLU) on csrc/bn.hip; under torch.distributed its
+                    # statistics are all-reduced (SyncBN)
+                    rh = None
+                    if residual is not None:
+                        rh = residual.permute(0, 2, 3, 1)
+                        rh = rh if rh.is_contiguous() else rh.contiguous()
+                    out = ops.batch_norm_act(yh, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                             relu=relu, res=rh)
+                    if bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked += 1
+                    return out.permute(0, 3, 1, 2)
+                # (odd channel counts / non-channels-last inputs: the library, in fp32)
                 y = F.batch_norm(y.float(), bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum,
                                  bn.eps).to(y.dtype)
                 if bn.num_batches_tracked is not None:

@@ -1,0 +1,307 @@
+// Batch-statistics BatchNorm (+ ReLU, + residual) for NHWC activations: forward, backward, and the hooks a synchronised
+// (data-parallel) BatchNorm needs.
+//
+// The reference's networks run nn.BatchNorm2d in TRAINING mode wherever `--freeze_bn` does not reach: every BatchNorm of
+// DeepLab v2 without the flag (architectures/deeplab2.py:72-84 freeze the affine parameters only), the DeepLab v3+ head
+// always (architectures/deeplab3plus.py:40-64, 120-121), the U-Nets. Round 1 left those layers to the library.
+//
+//   forward    sums[c] = (sum_p x, sum_p x^2)             bn_reduce_kernel<.., 0>   (per-thread fp32, block tree in LDS,
+//                                                                                    fp64 atomics across blocks)
+//              [data parallel: all-reduce sums and the pixel count -- SURVEY.md 8(e), "BN statistics"]
+//              mean, var -> scale = gamma * rstd, shift = beta - mean * scale; running statistics   bn_finalize_kernel
+//              y = relu(x * scale + shift (+ residual))                                             bn_apply_kernel
+//   backward   dy' = dy * [y > 0];  sums[c] = (sum_p dy', sum_p dy' * xhat)                         bn_reduce_kernel<.., 1>
+//              [data parallel: all-reduce]
+//              dx = gamma * rstd * (dy' - mean(dy') - xhat * mean(dy' * xhat));  dgamma, dbeta      bn_bwd_apply_kernel
+//
+// HBM-bound: forward reads x twice and writes y once (2 passes, statistics are a global dependency), backward reads
+// (dy, x, y) twice and writes dx once. Threads own 8 consecutive channels of a pixel (16-byte bf16 / 32-byte fp32
+// vectors, coalesced along the channel axis); the per-channel reduction over pixels is per-thread accumulation, then a
+// cross-lane tree (__shfl_xor over the lanes of a wave that hold the same channel group) and LDS across waves.
+#include "common.hpp"
+
+namespace cms {
+
+template <class T>
+struct Vec8 {
+    float v[8];
+};
+
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const uint16_t* p, float (&v)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = float4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<float4*>(p + 4) = float4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void store8(uint16_t* p, const float (&v)[8]) {
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = o;
+}
+
+// MODE 0: (sum x, sum x^2).  MODE 1: (sum dy', sum dy' * xhat) with dy' = dy * [y > 0] (y == nullptr: no ReLU)
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                        const T* __restrict__ y, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, double* __restrict__ sums,
+                                                        size_t P, int C) {
+    extern __shared__ float red[];                    // [slots][CG][16]
+    const int CG = C / 8;
+    const int slots = CG >= 256 ? 1 : 256 / CG;       // pixels handled side by side by one block
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, slot = tid / CG;
+    const bool active = slot < slots && (CG <= 256);
+    float a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.0f;
+    if (CG <= 256) {
+        float mu[8], rs[8];
+        if (MODE == 1 && active) {
+            load8(mean + cg * 8, mu);
+            load8(rstd + cg * 8, rs);
+        }
+        if (active) {
+            for (size_t p = (size_t)blockIdx.x * slots + slot; p < P; p += (size_t)gridDim.x * slots) {
+                const size_t o = p * C + (size_t)cg * 8;
+                float xv[8];
+                load8(x + o, xv);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] = fmaf(xv[e], xv[e], a1[e]); }
+                } else {
+                    float dv[8], yv[8];
+                    load8(dy + o, dv);
+                    if (y) load8(y + o, yv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = (y == nullptr || yv[e] > 0.0f) ? dv[e] : 0.0f;
+                        a0[e] += d;
+                        a1[e] = fmaf(d, (xv[e] - mu[e]) * rs[e], a1[e]);
+                    }
+                }
+            }
+        }
+        // lanes of a wave that hold the same channel group: CG divides 64 -> tree over the lane bits above log2(CG)
+        if (CG < 64 && (64 % CG) == 0) {
+            for (int off = 32; off >= CG; off >>= 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    a0[e] += __shfl_xor(a0[e], off, 64);
+                    a1[e] += __shfl_xor(a1[e], off, 64);
+                }
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(slot * CG + cg) * 16 + e] = a0[e];
+                red[(slot * CG + cg) * 16 + 8 + e] = a1[e];
+            }
+        }
+        __syncthreads();
+        // one thread per (channel group, value): sum the slots that are distinct after the wave tree
+        const int step = (CG < 64 && (64 % CG) == 0) ? 64 / CG : 1;       // slots inside one wave hold the same sum
+        for (int i = tid; i < CG * 16; i += 256) {
+            const int g = i / 16, e = i % 16;
+            float s = 0.0f;
+            for (int sl = 0; sl < slots; sl += step) s += red[(sl * CG + g) * 16 + e];
+            const int c = g * 8 + (e & 7);
+            atomicAdd(sums + (size_t)(e >> 3) * C + c, (double)s);
+        }
+    } else {
+        // more than 2048 channels: a block walks the channel groups in turn (not used by the networks of this build)
+        for (int g = tid; g < CG; g += 256) {
+            float mu[8], rs[8];
+            if (MODE == 1) { load8(mean + g * 8, mu); load8(rstd + g * 8, rs); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.0f;
+            for (size_t p = blockIdx.x; p < P; p += gridDim.x) {
+                const size_t o = p * C + (size_t)g * 8;
+                float xv[8];
+                load8(x + o, xv);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] = fmaf(xv[e], xv[e], a1[e]); }
+                } else {
+                    float dv[8], yv[8];
+                    load8(dy + o, dv);
+                    if (y) load8(y + o, yv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = (y == nullptr || yv[e] > 0.0f) ? dv[e] : 0.0f;
+                        a0[e] += d;
+                        a1[e] = fmaf(d, (xv[e] - mu[e]) * rs[e], a1[e]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                atomicAdd(sums + g * 8 + e, (double)a0[e]);
+                atomicAdd(sums + (size_t)C + g * 8 + e, (double)a1[e]);
+            }
+        }
+    }
+}
+
+// sums (sum x, sum x^2) over `count` pixels -> mean, rstd, scale, shift; running statistics like nn.BatchNorm2d (momentum,
+// unbiased variance)
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ mean,
+                                   float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / count;
+    double var = sums[C + c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    rstd[c] = r;
+    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    scale[c] = g * r;
+    shift[c] = b - (float)m * g * r;
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)m;
+    if (running_var) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int relu, size_t P, int C) {
+    const int CG = C / 8;
+    const size_t total = P * CG;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const size_t o = i * 8;
+        float xv[8], sc[8], sh[8], rv[8];
+        load8(x + o, xv);
+        load8(scale + cg * 8, sc);
+        load8(shift + cg * 8, sh);
+        if (res) load8(res + o, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = fmaf(xv[e], sc[e], sh[e]);
+            if (res) v += rv[e];
+            xv[e] = relu ? fmaxf(v, 0.0f) : v;
+        }
+        store8(y + o, xv);
+    }
+}
+
+// dx = gamma * rstd * (dy' - sum_dy / n - xhat * sum_dyxhat / n); dres = dy' (gradient of the residual branch, optional)
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           const T* __restrict__ y, T* __restrict__ dx, T* __restrict__ dres,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                           double count, size_t P, int C) {
+    const int CG = C / 8;
+    const size_t total = P * CG;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const size_t o = i * 8;
+        float xv[8], dv[8], yv[8], mu[8], rs[8], out[8], dr[8];
+        load8(x + o, xv);
+        load8(dy + o, dv);
+        if (y) load8(y + o, yv);
+        load8(mean + cg * 8, mu);
+        load8(rstd + cg * 8, rs);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cg * 8 + e;
+            const float d = (y == nullptr || yv[e] > 0.0f) ? dv[e] : 0.0f;
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            const float m1 = (float)(sums[c] / count), m2 = (float)(sums[C + c] / count);
+            const float g = gamma ? gamma[c] : 1.0f;
+            out[e] = g * rs[e] * (d - m1 - xh * m2);
+            dr[e] = d;
+        }
+        store8(dx + o, out);
+        if (dres) store8(dres + o, dr);
+    }
+}
+
+}  // namespace cms
+
+using namespace cms;
+
+static int bn_geo_ok(size_t p, int c) { return p > 0 && c > 0 && c % 8 == 0; }
+
+extern "C" int cms_bn_reduce(const void* x, const void* dy, const void* y, int dtype, const float* mean, const float* rstd,
+                             double* sums, size_t n_pixels, int c, int mode, void* stream) {
+    CMS_REQUIRE(x && sums, "bn_reduce: NULL pointer");
+    CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_reduce: bad dtype");
+    CMS_REQUIRE(bn_geo_ok(n_pixels, c), "bn_reduce: bad geometry (channels %% 8 == 0)");
+    CMS_REQUIRE(mode == 0 || (mode == 1 && dy && mean && rstd), "bn_reduce: mode 1 needs dy, mean, rstd");
+    const int CG = c / 8;
+    const int slots = CG >= 256 ? 1 : 256 / CG;
+    size_t want = (n_pixels + slots - 1) / slots;
+    if (want > 1024) want = 1024;
+    const dim3 grid((unsigned)want);
+    const size_t lds = CG <= 256 ? (size_t)slots * CG * 16 * sizeof(float) : 0;
+    hipStream_t s = (hipStream_t)stream;
+#define CMS_BN_RED(T, M) hipLaunchKernelGGL((bn_reduce_kernel<T, M>), grid, dim3(256), lds, s, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, sums, n_pixels, c)
+    if (dtype == CMS_F32) { if (mode == 0) CMS_BN_RED(float, 0); else CMS_BN_RED(float, 1); }
+    else { if (mode == 0) CMS_BN_RED(uint16_t, 0); else CMS_BN_RED(uint16_t, 1); }
+#undef CMS_BN_RED
+    return launch_status("cms_bn_reduce");
+}
+
+extern "C" int cms_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
+                               float momentum, float* mean, float* rstd, float* scale, float* shift, float* running_mean,
+                               float* running_var, int c, void* stream) {
+    CMS_REQUIRE(sums && mean && rstd && scale && shift && c > 0 && count > 0, "bn_finalize: NULL pointer / bad geometry");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, gamma, beta,
+                       eps, momentum, mean, rstd, scale, shift, running_mean, running_var, c);
+    return launch_status("cms_bn_finalize");
+}
+
+extern "C" int cms_bn_apply(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
+                            size_t n_pixels, int c, void* stream) {
+    CMS_REQUIRE(x && y && scale && shift, "bn_apply: NULL pointer");
+    CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_apply: bad dtype");
+    CMS_REQUIRE(bn_geo_ok(n_pixels, c), "bn_apply: bad geometry (channels %% 8 == 0)");
+    const size_t total = n_pixels * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CMS_F32)
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, (const float*)x,
+                           (const float*)res, (float*)y, scale, shift, relu, n_pixels, c);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<uint16_t>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, (const uint16_t*)x,
+                           (const uint16_t*)res, (uint16_t*)y, scale, shift, relu, n_pixels, c);
+    return launch_status("cms_bn_apply");
+}
+
+extern "C" int cms_bn_bwd_apply(const void* x, const void* dy, const void* y, void* dx, void* dres, int dtype, const float* mean,
+                                const float* rstd, const float* gamma, const double* sums, double count, size_t n_pixels, int c,
+                                void* stream) {
+    CMS_REQUIRE(x && dy && dx && mean && rstd && sums, "bn_bwd_apply: NULL pointer");
+    CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_bwd_apply: bad dtype");
+    CMS_REQUIRE(bn_geo_ok(n_pixels, c) && count > 0, "bn_bwd_apply: bad geometry (channels %% 8 == 0)");
+    const size_t total = n_pixels * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CMS_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, (const float*)x,
+                           (const float*)dy, (const float*)y, (float*)dx, (float*)dres, mean, rstd, gamma, sums, count,
+                           n_pixels, c);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<uint16_t>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s,
+                           (const uint16_t*)x, (const uint16_t*)dy, (const uint16_t*)y, (uint16_t*)dx, (uint16_t*)dres, mean,
+                           rstd, gamma, sums, count, n_pixels, c);
+    return launch_status("cms_bn_bwd_apply");
+}

@@ -373,6 +373,80 @@ def confusion(truth, pred, num_classes, ignore_index=None, cm=None):
     return cm
 
 
+# ---------------------------------------------------------------------------------------------- BatchNorm (batch stats)
+def _world(group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
+class _BatchNormActFn(torch.autograd.Function):
+    """relu(batch_norm(x) (+ res)) on NHWC tensors with batch statistics (csrc/bn.hip); under torch.distributed the
+    statistics are all-reduced between the two passes of either direction (SyncBN)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, running_mean, running_var, momentum, eps, relu, group):
+        n_pix = x.numel() // x.shape[-1]
+        c = int(x.shape[-1])
+        dev = x.device
+        stats = torch.zeros(2 * c + 1, dtype=torch.float64, device=dev)
+        stats[2 * c] = n_pix
+        check(fn['cms_bn_reduce'](_ptr(x), None, None, _dtype_code(x), None, None, _ptr(stats), n_pix, c, 0, _stream()),
+              'cms_bn_reduce')
+        world = _world(group)
+        if world > 1:
+            _allreduce_sum(stats, group)
+            count = float(n_pix) * world       # (equal shards: the per-GPU batch is fixed under weak scaling)
+        else:
+            count = float(n_pix)
+        mean, rstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+        check(fn['cms_bn_finalize'](_ptr(stats), count, _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(mean),
+                                    _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var), c,
+                                    _stream()), 'cms_bn_finalize')
+        y = torch.empty_like(x)
+        check(fn['cms_bn_apply'](_ptr(x), _ptr(res), _ptr(y), _dtype_code(x), _ptr(scale), _ptr(shift), int(bool(relu)), n_pix,
+                                 c, _stream()), 'cms_bn_apply')
+        ctx.save_for_backward(x, y if relu else None, mean, rstd, gamma)
+        ctx.meta = (n_pix, c, count, group, res is not None, gamma is not None and gamma.requires_grad,
+                    beta is not None and beta.requires_grad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd, gamma = ctx.saved_tensors
+        n_pix, c, count, group, has_res, want_g, want_b = ctx.meta
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        sums = torch.zeros(2 * c, dtype=torch.float64, device=x.device)
+        check(fn['cms_bn_reduce'](_ptr(x), _ptr(dy), _ptr(y), _dtype_code(x), _ptr(mean), _ptr(rstd), _ptr(sums), n_pix, c, 1,
+                                  _stream()), 'cms_bn_reduce')
+        local = sums
+        if _world(group) > 1:
+            local = sums.clone()                 # parameter gradients stay local (the arena all-reduce sums them)
+            _allreduce_sum(sums, group)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        check(fn['cms_bn_bwd_apply'](_ptr(x), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dres), _dtype_code(x), _ptr(mean), _ptr(rstd),
+                                     _ptr(gamma), _ptr(sums), count, n_pix, c, _stream()), 'cms_bn_bwd_apply')
+        dgamma = local[c:2 * c].float() if want_g else None
+        dbeta = local[0:c].float() if want_b else None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+def batch_norm_act(x_nhwc, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=False, res=None,
+                   group=None):
+    """nn.BatchNorm2d in training mode (+ residual add, + ReLU) on a contiguous NHWC tensor (channels %% 8 == 0).
+    Updates the running statistics in place like the module does."""
+    _need_cuda(x_nhwc, gamma, beta, running_mean, running_var, res)
+    if not x_nhwc.is_contiguous() or x_nhwc.shape[-1] % 8 != 0 or x_nhwc.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError('batch_norm_act: contiguous NHWC bf16 / fp32 tensor with channels % 8 == 0 required')
+    if res is not None and (res.shape != x_nhwc.shape or res.dtype != x_nhwc.dtype or not res.is_contiguous()):
+        raise ValueError('batch_norm_act: residual must match the input')
+    return _BatchNormActFn.apply(x_nhwc, gamma, beta, res, running_mean, running_var, momentum, eps, relu, group)
+
+
 # ---------------------------------------------------------------------------------------------- stem
 def stem_out_hw(h, w):
     """-> (ho, wo, hp, wp): sizes after the 7x7/2 convolution and after the ceil-mode 3x3/2 max-pool."""

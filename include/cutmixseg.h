@@ -317,6 +317,28 @@ int cms_conv_pack_transpose_f32(const float* src, float* dst, const float* scale
 int cms_conv_pack_transpose_batch_f32(const cms_pack_item* items_dev, int n_items, int total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Batch-statistics BatchNorm (+ ReLU, + residual) on NHWC activations (csrc/bn.hip): nn.BatchNorm2d in training mode,
+ * architectures/deeplab2.py:72-84 without --freeze_bn, architectures/deeplab3plus.py:40-64 (head, always).
+ * Statistics are a two-pass protocol so that a data-parallel caller can all-reduce `sums` (and the pixel count) between
+ * the passes: SyncBN, SURVEY.md 8(e). `sums` = double[2*C], zero-filled by the caller, accumulated with atomics.
+ *   forward : cms_bn_reduce(mode 0) -> sums = (sum x, sum x^2);  cms_bn_finalize -> mean, rstd, scale, shift and the
+ *             running statistics (momentum, unbiased variance);  cms_bn_apply: y = relu(x*scale + shift (+ res))
+ *   backward: cms_bn_reduce(mode 1) -> sums = (sum dy', sum dy'*xhat), dy' = dy * [y > 0] (y NULL: no ReLU);
+ *             cms_bn_bwd_apply: dx = gamma*rstd*(dy' - sums0/count - xhat*sums1/count), optional dres = dy'.
+ *             dgamma = sums1, dbeta = sums0 (of the LOCAL pass).
+ * ------------------------------------------------------------------------------------------------------------ */
+int cms_bn_reduce(const void* x, const void* dy, const void* y, int dtype, const float* mean, const float* rstd, double* sums,
+                  size_t n_pixels, int c, int mode, void* stream);
+int cms_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
+                    float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var, int c,
+                    void* stream);
+int cms_bn_apply(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
+                 size_t n_pixels, int c, void* stream);
+int cms_bn_bwd_apply(const void* x, const void* dy, const void* y, void* dx, void* dres, int dtype, const float* mean,
+                     const float* rstd, const float* gamma, const double* sums, double count, size_t n_pixels, int c,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * ASPP head (architectures/deeplab2.py:112-128) with the 2048-channel activation read ONCE (csrc/aspp.hip):
  *   forward   Z = X . Wall^T as a 1x1 cms_conv_igemm (rows of Wall: tap*C + class, fp32 NCHW output), then
  *             logits[n][c][y][x] = bias[c] + sum_t Z[n][t*C + c][y + dy_t][x + dx_t]            (cms_aspp_gather_fwd)

@@ -1,0 +1,152 @@
+"""
+GPU: batch-statistics BatchNorm (+ residual, + ReLU) on csrc/bn.hip against nn.BatchNorm2d semantics in fp64 on the host
+(forward, running statistics, every gradient), the library engine's training-mode layers routed through it, and the
+synchronised variant (two ranks over gloo on one GPU: statistics all-reduced between the passes -- SURVEY.md 8(e)).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _reference(x, gamma, beta, res, relu, rm, rv, momentum, eps, dy):
+    """fp64 host reference: x (N,H,W,C) -> y, new running stats, grads (dx, dgamma, dbeta, dres)."""
+    xd = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rd = None if res is None else res.double().permute(0, 3, 1, 2).requires_grad_(True)
+    rm2, rv2 = rm.double().clone(), rv.double().clone()
+    y = F.batch_norm(xd, rm2, rv2, gd, bd, True, momentum, eps)
+    if rd is not None:
+        y = y + rd
+    if relu:
+        y = F.relu(y)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    nhwc = lambda t: t.permute(0, 2, 3, 1)
+    return (nhwc(y.detach()), rm2, rv2, nhwc(xd.grad), gd.grad, bd.grad, None if rd is None else nhwc(rd.grad))
+
+
+@pytest.mark.parametrize('C', [48, 64, 256, 2048])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+@pytest.mark.parametrize('relu,with_res', [(True, True), (False, False), (True, False)])
+def test_batch_norm_act_vs_fp64(C, dtype, relu, with_res):
+    from cutmix_semisup_seg_amd import ops
+    g = torch.Generator().manual_seed(C + int(relu))
+    N, H, W = 3, 13, 11
+    x = (torch.randn(N, H, W, C, generator=g) * 1.7 + 0.3).to(dtype).float()
+    res = torch.randn(N, H, W, C, generator=g).to(dtype).float() if with_res else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    dy = torch.randn(N, H, W, C, generator=g).to(dtype).float()
+    want = _reference(x, gamma, beta, res, relu, rm, rv, 0.1, 1e-5, dy)
+    cu = lambda t: None if t is None else t.to(DEV)
+    xg = cu(x.to(dtype)).requires_grad_(True)
+    gg, bg = cu(gamma).requires_grad_(True), cu(beta).requires_grad_(True)
+    rg = None if res is None else cu(res.to(dtype)).requires_grad_(True)
+    rmg, rvg = cu(rm.clone()), cu(rv.clone())
+    y = ops.batch_norm_act(xg, gg, bg, rmg, rvg, 0.1, 1e-5, relu=relu, res=rg)
+    y.backward(cu(dy.to(dtype)))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(y.detach().float().cpu(), want[0].float(), rtol=tol, atol=tol)
+    torch.testing.assert_close(rmg.cpu(), want[1].float(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rvg.cpu(), want[2].float(), rtol=1e-5, atol=1e-6)
+    if dtype == torch.bfloat16 and relu:
+        return          # (a bf16-rounded output can flip a ReLU mask bit relative to the fp64 reference)
+    gtol = 5e-4 if dtype == torch.float32 else 5e-2
+    torch.testing.assert_close(xg.grad.float().cpu(), want[3].float(), rtol=gtol, atol=gtol * float(want[3].abs().max()))
+    torch.testing.assert_close(gg.grad.cpu(), want[4].float(), rtol=gtol, atol=gtol * float(want[4].abs().max()))
+    torch.testing.assert_close(bg.grad.cpu(), want[5].float(), rtol=gtol, atol=gtol * float(want[5].abs().max()))
+    if with_res:
+        torch.testing.assert_close(rg.grad.float().cpu(), want[6].float(), rtol=gtol, atol=gtol)
+
+
+def test_library_engine_training_mode_layers_use_the_hip_batchnorm():
+    """DeepLab v2 WITHOUT --freeze_bn (BatchNorm on batch statistics, affine parameters frozen, deeplab2.py:72-84):
+    forward, running statistics and gradients vs the oracle."""
+    from architectures import deeplab2
+    from oracle import deeplab2 as odl
+    C, layers = 5, [1, 1, 1, 1]
+    st = odl.closed_form_state(C, layers)
+    net = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
+    net.load_state_dict(st)
+    net = net.to(DEV)
+    net.compute_dtype = torch.float32
+    net.train()                                            # no freeze_batchnorm()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 3, 65, 65, generator=g)
+    lo = net.forward_lowres(x.to(DEV))
+    new_stats = {}
+    want = odl.forward_lowres(x, st, layers, frozen=False, new_stats=new_stats)
+    torch.testing.assert_close(lo.detach().cpu(), want, rtol=2e-3, atol=2e-4)
+    sd = net.state_dict()
+    for k in ('bn1.running_mean', 'layer2.0.bn2.running_var', 'layer4.0.downsample.1.running_mean'):
+        torch.testing.assert_close(sd[k].cpu(), new_stats[k], rtol=1e-3, atol=1e-5)
+    assert int(sd['layer3.0.bn1.num_batches_tracked']) == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _sync_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from cutmix_semisup_seg_amd import ops
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(dev)
+        g = torch.Generator().manual_seed(5)
+        C = 64
+        x = torch.randn(4, 9, 7, C, generator=g)              # the WHOLE batch, identical on both ranks
+        dy = torch.randn(4, 9, 7, C, generator=g)
+        gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+        sl = slice(2 * rank, 2 * rank + 2)                    # this rank's shard
+        xs = x[sl].contiguous().to(dev).requires_grad_(True)
+        gg, bg = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        y = ops.batch_norm_act(xs, gg, bg, rm, rv, 0.1, 1e-5, relu=True)
+        y.backward(dy[sl].contiguous().to(dev))
+        q.put((rank, y.detach().cpu().numpy(), xs.grad.cpu().numpy(), gg.grad.cpu().numpy(), rm.cpu().numpy(),
+               rv.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_equals_single_process_on_the_whole_batch():
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(5)
+    C = 64
+    x = torch.randn(4, 9, 7, C, generator=g)
+    dy = torch.randn(4, 9, 7, C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    want = _reference(x, gamma, beta, None, True, torch.zeros(C), torch.ones(C), 0.1, 1e-5, dy)
+    y = np.concatenate([res[0][1], res[1][1]], 0)
+    dx = np.concatenate([res[0][2], res[1][2]], 0)
+    np.testing.assert_allclose(y, want[0].float().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(dx, want[3].float().numpy(), rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(res[0][3] + res[1][3], want[4].float().numpy(), rtol=5e-4, atol=5e-5)   # local dgamma's add up
+    for r in res:                                                       # every rank holds the GLOBAL running statistics
+        np.testing.assert_allclose(r[4], want[1].float().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r[5], want[2].float().numpy(), rtol=1e-5, atol=1e-6)

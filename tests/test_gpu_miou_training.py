@@ -1,0 +1,120 @@
+"""
+GPU (north star: "mIoU within 0.2 pt of reference"): a short CutMix mean-teacher TRAINING RUN on a learnable synthetic
+segmentation task, from identical initial weights and an identical data / mask sequence, on the device step and on the
+CPU oracle (oracle/step.py = train_seg_semisup_mask_mt.py:287-467), followed by the reference's evaluation
+(:484-517: teacher network in eval mode, EvaluatorIoU over a validation set). Asserted: |mIoU(device) - mIoU(oracle)|
+<= 0.2 pt for the fp32 parity configuration; the bf16 throughput configuration is reported and bounded at 2 pt
+(its trajectory separates from the fp32 one through Adam's sign-like first updates, not through a systematic bias).
+
+Task: images made of a background and two rectangles, every region filled with its class's mean colour + noise;
+5 classes, 2 % ignore labels. Small enough for the CPU oracle (tiny DeepLab v2, 65 x 65), learnable within ~100 iterations.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+C, LAYERS, N, H, W = 5, [1, 1, 1, 1], 4, 65, 65
+ITERS, LR, ALPHA, TAU = 100, 3e-4, 0.9, 0.6
+MEANS = torch.tensor([[1.2, -0.8, 0.1], [-1.0, 1.1, 0.3], [0.2, 0.1, -1.3], [-0.4, -1.2, 1.0], [1.0, 1.0, 1.0]])
+
+
+def _batch(g, n, with_labels=True):
+    y = torch.zeros(n, H, W, dtype=torch.int64)
+    for i in range(n):
+        y[i] = int(torch.randint(0, C, (1,), generator=g))
+        for _ in range(2):
+            y0, x0 = int(torch.randint(0, H - 16, (1,), generator=g)), int(torch.randint(0, W - 16, (1,), generator=g))
+            hh, ww = int(torch.randint(12, 40, (1,), generator=g)), int(torch.randint(12, 40, (1,), generator=g))
+            y[i, y0:y0 + hh, x0:x0 + ww] = int(torch.randint(0, C, (1,), generator=g))
+    x = MEANS[y].permute(0, 3, 1, 2) + 0.35 * torch.randn(n, 3, H, W, generator=g)
+    x = x.bfloat16().float()                     # identical (bf16-representable) inputs for every configuration
+    if with_labels:
+        y = y.clone()
+        y[torch.rand(n, H, W, generator=g) < 0.02] = 255
+    return x, y.unsqueeze(1)
+
+
+def _data():
+    import mask_gen
+    g = torch.Generator().manual_seed(2024)
+    rng = np.random.RandomState(7)
+    gen = mask_gen.BoxMaskGenerator(0.5, invert=True)
+    train = []
+    for _ in range(ITERS):
+        x, y = _batch(g, N)
+        u0, _ = _batch(g, N, False)
+        u1, _ = _batch(g, N, False)
+        train.append((x, y, u0, u1, gen.generate_ranges(N, (H, W), rng=rng)))
+    val = [_batch(g, N) for _ in range(6)]
+    return train, val
+
+
+def _oracle_run(train, val):
+    from oracle import deeplab2 as odl, step as ostep, boxmask as obox, evaluation as oev
+    st = odl.closed_form_state(C, LAYERS)
+    S = ostep.StepState(st, C, LAYERS, opt='adam', lr=LR, teacher_alpha=ALPHA)
+    ones = torch.ones(N, 1, H, W)
+    log = []
+    for x, y, u0, u1, ranges in train:
+        m = torch.tensor(obox.rasterise(ranges, (H, W), True).astype(np.float32))
+        log.append(ostep.train_iteration(S, x, y, u0, u1, ones, ones, m, conf_thresh=TAU)['sup_loss'])
+    acc = oev.IoUAccumulator(C)
+    with torch.no_grad():
+        for x, y in val:
+            pred = odl.forward(x, S.teacher, LAYERS, frozen=True).argmax(dim=1)
+            for i in range(N):
+                acc.sample(y[i, 0].numpy(), pred[i].numpy(), ignore_value=255)
+    return float(acc.score().mean()), log
+
+
+def _device_run(train, val, dtype):
+    from architectures import deeplab2
+    from oracle import deeplab2 as odl
+    import evaluation
+    import optim_weight_ema
+    from cutmix_semisup_seg_amd import ops, optim as fo
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
+    mk = lambda: deeplab2.ResNetDeepLab(deeplab2.Bottleneck, LAYERS, C, np.zeros(3), np.ones(3))
+    stu, tea = mk(), mk()
+    stu.load_state_dict(odl.closed_form_state(C, LAYERS))
+    stu, tea = stu.to(DEV), tea.to(DEV)
+    stu.compute_dtype = tea.compute_dtype = dtype
+    stu.engine_kind = tea.engine_kind = 'hip'
+    opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=LR * 0.1),
+                             dict(params=list(stu.new_parameters()), lr=LR)])
+    for p in tea.parameters():
+        p.requires_grad = False
+    ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, ALPHA)
+    ema.fuse_into(opt)
+    stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()
+    step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=TAU, compute_dtype=dtype))
+    cu = lambda t: t.to(DEV).to(dtype)
+    log = []
+    for x, y, u0, u1, ranges in train:
+        r = step(cu(x), y.to(torch.uint8).to(DEV), [UnsupBatch(cu(u0), ops.ranges_to_device(ranges, DEV), x1_tea=cu(u1))])
+        log.append(r['sup_loss'])
+    log = [float(v) for v in log]
+    tea.eval()
+    ev = evaluation.EvaluatorIoU(C)
+    with torch.no_grad():
+        for x, y in val:
+            ev.sample_logits(tea.forward_lowres(cu(x)), y.to(torch.uint8).to(DEV), (H, W), ignore_value=255,
+                             align_corners=True)
+    return float(ev.score().mean()), log
+
+
+def test_trained_miou_matches_the_oracle_within_0p2_points():
+    train, val = _data()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    miou_ref, log_ref = _oracle_run(train, val)
+    miou_32, log_32 = _device_run(train, val, torch.float32)
+    miou_16, log_16 = _device_run(train, val, torch.bfloat16)
+    print('\nN1 mIoU after {} iterations: oracle {:.4f}  device fp32 {:.4f}  device bf16 {:.4f}; first/last sup loss: oracle '
+          '{:.4f}/{:.4f}, fp32 {:.4f}/{:.4f}, bf16 {:.4f}/{:.4f}'.format(ITERS, miou_ref, miou_32, miou_16, log_ref[0],
+                                                                      log_ref[-1], log_32[0], log_32[-1], log_16[0],
+                                                                      log_16[-1]))
+    assert log_ref[-1] < 0.6 * log_ref[0] and miou_ref > 0.3          # the task really was learnt
+    assert abs(miou_32 - miou_ref) <= 0.002, (miou_32, miou_ref)      # 0.2 pt: the parity configuration
+    assert abs(miou_16 - miou_ref) <= 0.02, (miou_16, miou_ref)       # throughput configuration: reported, bounded at 2 pt
