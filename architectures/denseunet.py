@@ -1,0 +1,5 @@
+"""Drop-in module name of the reference (`architectures/denseunet.py`); implementation in
+cutmix-semisup-seg_amd/architectures/denseunet.py."""
+from cutmix_semisup_seg_amd.architectures import denseunet as _impl
+
+globals().update({_k: _v for _k, _v in vars(_impl).items() if not _k.startswith('__')})

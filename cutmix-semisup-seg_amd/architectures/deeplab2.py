@@ -114,7 +114,10 @@ class TorchEngine(object):
         return F.conv2d(x, self._weight(conv), None, conv.stride, conv.padding, conv.dilation)
 
     def conv_bn_act(self, x, conv, bn, relu, residual=None):
-        y = self.conv2d(x, conv)
+        return self.bn_act(self.conv2d(x, conv), bn, relu, residual)
+
+    def bn_act(self, y, bn, relu, residual=None):
+        """relu(bn(y) (+ residual)): batch statistics (training mode) on csrc/bn.hip, frozen statistics as an affine."""
         if bn is not None:
             if bn.training:
                 yh = y.permute(0, 2, 3, 1)                 # NHWC view of the channels-last tensor

@@ -205,6 +205,38 @@ class HipConvEngine(TorchEngine):
         return super(HipConvEngine, self).conv2d(x, conv)
 
 
+class EngineNetMixin(object):
+    """Execution plumbing shared by the networks that run layer by layer through an engine object (the U-Nets):
+    compute dtype, engine selection, runtime attributes that survive whole-module pickles (checkpoint.py)."""
+
+    def _init_runtime(self):
+        d = self.__dict__
+        d.setdefault('compute_dtype', torch.bfloat16)
+        d.setdefault('engine', None)            # set to an engine object to override the default
+        d.setdefault('engine_kind', 'auto')     # 'torch': library convolutions only
+        d.setdefault('_hip_engine', None)
+
+    def __setstate__(self, state):
+        super(EngineNetMixin, self).__setstate__(state)
+        self._init_runtime()
+
+    def _engine(self, x):
+        if self.engine is not None:
+            return self.engine
+        if not x.is_cuda:
+            raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
+                               'fallback'.format(x.device))
+        if self.engine_kind != 'torch' and self.compute_dtype == torch.bfloat16:
+            if self._hip_engine is None:
+                self._hip_engine = HipConvEngine(self.compute_dtype, self)
+                self.register_load_state_dict_post_hook(lambda module, incompatible: self._hip_engine.arena.refresh_bf16())
+            return self._hip_engine
+        key = ('torch', self.compute_dtype)
+        if key not in _ENGINES:
+            _ENGINES[key] = TorchEngine(self.compute_dtype)
+        return _ENGINES[key]
+
+
 class DeepLabv3Wrapper(nn.Module):
     BLOCK_SIZE = (1, 1)
     MEAN = np.array([0.485, 0.456, 0.406])

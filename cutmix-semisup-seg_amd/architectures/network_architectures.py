@@ -3,8 +3,8 @@ Mirror of the reference's architectures/network_architectures.py: the `seg` arch
 (network_architectures.py:15-41), the factory names registered on it (:44-112), `robust_binary_crossentropy`
 (:115-118) and `sigmoid_rampup` (:122-130).
 
-Factories whose backbones are outside the CutMix mean-teacher hot path (U-Nets, plain DeepLab v3 from torchvision,
-PSPNet from mit_semseg) stay registered under the reference's names and raise NotImplementedError when called, which is
+Factories whose backbones are outside the CutMix mean-teacher hot path (plain DeepLab v3 from torchvision, PSPNet from
+mit_semseg) stay registered under the reference's names and raise NotImplementedError when called, which is
 what the reference itself does when their dependencies are missing (:77-79, mit_csail_semseg.py:24-25).
 """
 import sys
@@ -14,6 +14,8 @@ import torch
 
 from . import deeplab2
 from . import deeplab3plus
+from . import resunet
+from . import denseunet
 
 
 class ArchRegistry(object):
@@ -51,11 +53,28 @@ def _outside_hot_path(name, needs):
     return factory
 
 
-for _name, _needs in (('resnet50unet_imagenet', 'torchvision ResNet-50 U-Net'),
-                      ('resnet101unet_imagenet', 'torchvision ResNet-101 U-Net'),
-                      ('densenet161unet', 'torchvision DenseNet-161 U-Net'),
-                      ('densenet161unet_imagenet', 'torchvision DenseNet-161 U-Net'),
-                      ('resnet101_deeplabv3_coco', 'torchvision DeepLab v3'),
+@seg.register('resnet50unet_imagenet')
+def resnet50unet_imagenet(num_classes, pretrained=True):
+    return resunet.resnet50unet(num_classes, pretrained=pretrained)
+
+
+@seg.register('resnet101unet_imagenet')
+def resnet101unet_imagenet(num_classes, pretrained=True):
+    return resunet.resnet101unet(num_classes, pretrained=pretrained)
+
+
+@seg.register('densenet161unet')
+def densenet161unet(num_classes, pretrained=False):
+    # (the reference's factory takes no `pretrained`; accepted and ignored so that the trainers can pass it uniformly)
+    return denseunet.densenet161unet(num_classes)
+
+
+@seg.register('densenet161unet_imagenet')
+def densenet161unet_imagenet(num_classes, pretrained=True):
+    return denseunet.densenet161unet_imagenet(num_classes, pretrained=pretrained)
+
+
+for _name, _needs in (('resnet101_deeplabv3_coco', 'torchvision DeepLab v3'),
                       ('resnet101_deeplabv3_imagenet', 'torchvision DeepLab v3'),
                       ('resnet101_pspnet_imagenet', 'the mit_semseg package')):
     seg.register(_name)(_outside_hot_path(_name, _needs))

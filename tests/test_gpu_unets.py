@@ -1,0 +1,125 @@
+"""
+GPU: the reference's U-Nets (BASELINE configs[0] resunet, configs[4] denseunet) on this build's engine -- batch-statistics
+BatchNorm on csrc/bn.hip, MFMA convolutions where a layer fits them -- against the independent CPU restatement
+oracle/unets.py (PARITY UNPINNED: torchvision encoders, see the oracle's header): logits, gradients, and one whole
+training iteration of each configuration (supervised-only step for configs[0], VAT mean-teacher step for configs[4]).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _rel(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _randomise(net, seed):
+    """BatchNorm affine / running statistics away from (1, 0, 0, 1) so that the comparison sees them."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(0.6 + 0.8 * torch.rand(m.weight.shape, generator=g))
+                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+
+
+@pytest.mark.parametrize('arch,shape', [('resnet50unet_imagenet', (4, 3, 64, 96)), ('densenet161unet', (2, 3, 64, 64))])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+def test_unet_forward_backward_vs_oracle(arch, shape, dtype):
+    from architectures import network_architectures
+    from oracle import unets
+    torch.manual_seed(3)
+    net = network_architectures.seg.get(arch)(2, pretrained=False)
+    _randomise(net, 4)
+    st = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    net.compute_dtype = dtype
+    net.train()
+    net.final_dec_drop.eval()                                  # dropout off for the comparison
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g).bfloat16().float()
+    gr = torch.randn(shape[0], 2, shape[2], shape[3], generator=g)
+    lo = net.forward_lowres(x.to(DEV).to(dtype))
+    assert lo.dtype == torch.float32 and tuple(lo.shape) == tuple(gr.shape)
+    lo.backward(gr.to(DEV))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.dtype == torch.float32 and 'running' not in k}
+    st2 = dict(st)
+    st2.update(leaves)
+    if 'resnet' in arch:
+        want = unets.resunet_forward(x, st2, [3, 4, 6, 3], train=True)
+    else:
+        want = unets.denseunet_forward(x, st2, train=True)
+    want.backward(gr)
+    e = _rel(lo.detach(), want.detach())
+    named = dict(net.named_parameters())
+    keys = ['final_clf.weight', 'final_dec_conv.weight', 'line0_conv.weight', 'final_dec_bn.weight']
+    keys += ['base_model.conv1.weight', 'base_model.layer3.0.conv2.weight', 'decoder2.conv.weight'] if 'resnet' in arch else \
+        ['base_model.features.conv0.weight', 'base_model.features.denseblock3.denselayer5.conv2.weight',
+         'decoder_blocks.2.conv.weight']
+    ge = {k: _rel(named[k].grad, leaves[k].grad) for k in keys}
+    print('\n{} {}: logits rel err {:.2e}; gradient rel errs {}'.format(arch, dtype, e, {k: round(v, 5) for k, v in ge.items()}))
+    if dtype == torch.float32:
+        assert e <= 2e-3 and max(ge.values()) <= 2e-2, (e, ge)
+    else:
+        assert e <= 8e-2 and ge['final_clf.weight'] <= 8e-2, (e, ge)
+    # running statistics moved like nn.BatchNorm2d's (momentum 0.1)
+    rm = net.state_dict()['final_dec_bn.running_mean'].cpu()
+    assert float((rm - st['final_dec_bn.running_mean']).abs().max()) > 0
+
+
+def test_config0_supervised_only_step_resunet():
+    """BASELINE configs[0]: resunet on 4 x 256 x 256 two-class images, supervised-only (cons_weight = 0) -- the training
+    step runs, the loss falls over a few iterations of SGD."""
+    from architectures import network_architectures
+    from cutmix_semisup_seg_amd import optim as fo
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig
+    import optim_weight_ema
+    torch.manual_seed(0)
+    Net = network_architectures.seg.get('resnet50unet_imagenet')
+    stu, tea = Net(2, pretrained=False).to(DEV), Net(2, pretrained=False).to(DEV)
+    opt = fo.FusedSGD(stu, [dict(params=list(stu.new_parameters()), lr=0.05)], momentum=0.9, weight_decay=5e-4)
+    for p in tea.parameters():
+        p.requires_grad = False
+    ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
+    ema.fuse_into(opt)
+    stu.train(); tea.train()
+    step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(cons_weight=0.0, fuse_batches=False))
+    g = torch.Generator(device=DEV).manual_seed(1)
+    y = (torch.rand(4, 1, 256, 256, generator=g, device=DEV) < 0.4).to(torch.uint8)
+    x = (torch.randn(4, 3, 256, 256, generator=g, device=DEV) + 1.5 * y.float()).bfloat16()
+    losses = [float(step(x, y, [])['sup_loss']) for _ in range(6)]
+    print('\nconfigs[0] resunet supervised-only losses:', [round(v, 4) for v in losses])
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_config4_vat_step_denseunet():
+    """BASELINE configs[4]: DenseNet-161 U-Net, 2 classes, VAT mean-teacher iteration (train_seg_semisup_vat_mt.py)."""
+    from architectures import network_architectures
+    from cutmix_semisup_seg_amd import optim as fo
+    from cutmix_semisup_seg_amd.vat import VATMeanTeacherStep, VATConfig, VATUnsupBatch
+    import optim_weight_ema
+    torch.manual_seed(0)
+    Net = network_architectures.seg.get('densenet161unet')
+    stu, tea = Net(2).to(DEV), Net(2).to(DEV)
+    opt = fo.FusedSGD(stu, [dict(params=list(stu.new_parameters()), lr=0.01)], momentum=0.9, nesterov=True, weight_decay=5e-4)
+    for p in tea.parameters():
+        p.requires_grad = False
+    ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
+    ema.fuse_into(opt)
+    stu.train(); tea.train()
+    step = VATMeanTeacherStep(stu, tea, opt, ema, VATConfig(vat_radius=0.5, cons_loss_fn='kld', cons_weight=0.001, conf_thresh=0.0),
+                              generator=torch.Generator(device=DEV).manual_seed(2))
+    g = torch.Generator(device=DEV).manual_seed(1)
+    H = W = 224
+    y = (torch.rand(4, 1, H, W, generator=g, device=DEV) < 0.4).to(torch.uint8)
+    x = (torch.randn(4, 3, H, W, generator=g, device=DEV) + 1.5 * y.float()).bfloat16()
+    u = torch.randn(4, 3, H, W, generator=g, device=DEV).bfloat16()
+    out = [step(x, y, [VATUnsupBatch(u)]) for _ in range(3)]
+    vals = [{k: float(v) for k, v in r.items()} for r in out]
+    print('\nconfigs[4] denseunet VAT iterations:', vals)
+    assert all(np.isfinite(v['sup_loss']) and np.isfinite(v['consistency_loss']) for v in vals)
+    assert vals[-1]['sup_loss'] < vals[0]['sup_loss']

@@ -102,13 +102,43 @@ def test_registry_names_and_unavailable_architectures():
     with pytest.raises(NotImplementedError):
         network_architectures.seg.get('resnet101_pspnet_imagenet')(21)
     with pytest.raises(NotImplementedError):
-        network_architectures.seg.get('resnet50unet_imagenet')(2, pretrained=False)
+        network_architectures.seg.get('resnet101_deeplabv3_coco')(21)
+    with pytest.raises(NotImplementedError, match='cannot be downloaded'):
+        network_architectures.seg.get('resnet50unet_imagenet')(2)            # pretrained=True needs the network
     reg = network_architectures.ArchRegistry()
 
     @reg.register('x')
     def x():
         return 1
     assert reg.get('x') is x and list(reg.names()) == ['x']
+
+
+def test_unet_encoders_have_torchvisions_published_parameter_counts_and_keys():
+    """The U-Net encoders are restated from torchvision 0.5.0's published structure (PARITY UNPINNED, oracle/unets.py):
+    what pins them is structural -- parameter counts of resnet50 / resnet101 / densenet161 and torchvision's key names."""
+    from architectures import resunet, denseunet
+    r50 = resunet.resnet50unet(2, pretrained=False)
+    r101 = resunet.resnet101unet(2, pretrained=False)
+    d161 = denseunet.densenet161unet(2)
+    count = lambda m: sum(p.numel() for p in m.parameters())
+    assert count(r50.base_model) == 25557032 and count(r101.base_model) == 44549160 and count(d161.base_model) == 28681000
+    ks = list(r50.state_dict().keys())
+    assert ks[0] == 'base_model.conv1.weight' and 'base_model.layer4.2.bn3.running_var' in ks and 'base_model.fc.bias' in ks
+    assert {'line0_conv.weight', 'line0_conv.bias', 'decoder3.conv.weight', 'decoder0.conv_bn.weight', 'final_dec_conv.weight',
+            'final_dec_bn.bias', 'final_clf.bias'} <= set(ks)
+    kd = list(d161.state_dict().keys())
+    assert kd[0] == 'base_model.features.conv0.weight' and 'base_model.classifier.weight' in kd
+    assert 'base_model.features.denseblock3.denselayer36.conv2.weight' in kd and 'base_model.features.transition3.conv.weight' in kd
+    assert [(b.x_chn_in, b.chn_out) for b in d161.decoder_blocks] == [(96, 96), (384, 96), (768, 384), (2208, 768)]
+    assert d161.line0_conv.in_channels == 2112 and d161.line0_conv.out_channels == 2208
+    assert r50.BLOCK_SIZE == (32, 32) and d161.BLOCK_SIZE == (32, 32)
+    # parameter groups (resunet.py:97-108, denseunet.py:134-143)
+    assert r50.pretrained_parameters() == [] and len(r50.new_parameters()) == len(list(r50.parameters()))
+    dimg = denseunet.densenet161unet_imagenet(2, pretrained=False)
+    assert len(dimg.pretrained_parameters()) == len(list(dimg.base_model.features.parameters()))
+    assert len(dimg.new_parameters()) + len(dimg.pretrained_parameters()) == len(list(dimg.parameters()))
+    with pytest.raises(ValueError, match='x_chn_in != skip_chn_in'):
+        resunet.DecoderBlock(64, 32, 16)
 
 
 def test_robust_bce_formula():

@@ -1,6 +1,9 @@
 #!/usr/bin/env python
-"""VAT mean-teacher iteration throughput at BASELINE configs[1] geometry (DeepLab v2 / ResNet-101, 10 x 3 x 321 x 321):
-the iteration in bf16 on the MFMA executor, the direction pass in fp32 on the library engine (vat.py)."""
+"""VAT mean-teacher iteration throughput (train_seg_semisup_vat_mt.py iteration):
+    python tools/vat_bench.py deeplab     DeepLab v2 / ResNet-101 at BASELINE configs[1] geometry (10 x 3 x 321 x 321): bf16
+                                          iteration on the MFMA executor, direction pass on the fp32 MFMA executor
+    python tools/vat_bench.py denseunet   BASELINE configs[4]: DenseNet-161 U-Net, 10 x 3 x 224 x 224, 2 classes, SGD
+                                          (run_isic2017_experiments.sh:14-18), batch-statistics BatchNorm on csrc/bn.hip"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,19 +11,31 @@ from cutmix_semisup_seg_amd import optim as fo, vat
 from architectures import network_architectures
 import optim_weight_ema
 
+which = sys.argv[1] if len(sys.argv) > 1 else 'deeplab'
 dev = torch.device('cuda:0')
-B, H, W, C = 10, 321, 321, 21
 torch.manual_seed(0)
-Net = network_architectures.seg.get('resnet101_deeplab_imagenet')
-stu, tea = Net(C, pretrained=False).to(dev), Net(C, pretrained=False).to(dev)
-opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=3e-6), dict(params=list(stu.new_parameters()), lr=3e-5)])
+if which == 'denseunet':
+    B, H, W, C = 10, 224, 224, 2
+    Net = network_architectures.seg.get('densenet161unet_imagenet')
+    stu, tea = Net(C, pretrained=False).to(dev), Net(C, pretrained=False).to(dev)
+    opt = fo.FusedSGD(stu, [dict(params=list(stu.pretrained_parameters()), lr=0.01), dict(params=list(stu.new_parameters()), lr=0.1)],
+                      momentum=0.9, nesterov=True, weight_decay=5e-4)
+    cfg = vat.VATConfig(vat_radius=1.0, adaptive_vat_radius=True, cons_loss_fn='kld', cons_weight=0.001, conf_thresh=0.97)
+else:
+    B, H, W, C = 10, 321, 321, 21
+    Net = network_architectures.seg.get('resnet101_deeplab_imagenet')
+    stu, tea = Net(C, pretrained=False).to(dev), Net(C, pretrained=False).to(dev)
+    opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=3e-6), dict(params=list(stu.new_parameters()), lr=3e-5)])
+    cfg = vat.VATConfig(cons_loss_fn='kld', conf_thresh=0.97)
 for p in tea.parameters():
     p.requires_grad = False
 ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
 ema.fuse_into(opt)
-stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()
+stu.train(); tea.train()
+if which != 'denseunet':
+    stu.freeze_batchnorm(); tea.freeze_batchnorm()
 g = torch.Generator(device=dev).manual_seed(1)
-step = vat.VATMeanTeacherStep(stu, tea, opt, ema, vat.VATConfig(cons_loss_fn='kld', conf_thresh=0.97), generator=g)
+step = vat.VATMeanTeacherStep(stu, tea, opt, ema, cfg, generator=g)
 im = lambda: torch.randn(B, 3, H, W, generator=g, device=dev).bfloat16()
 y = torch.randint(0, C, (B, 1, H, W), generator=g, device=dev).to(torch.uint8)
 x, xt = im(), im()
@@ -33,4 +48,5 @@ for _ in range(K):
     r = step(x, y, [vat.VATUnsupBatch(xt)])
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print('VAT step: {:.1f} ms, {:.1f} img/s (sup loss {:.3f})'.format(dt * 1e3, B / dt, float(r['sup_loss'])))
+print('VAT step [{}]: {:.1f} ms, {:.1f} img/s (sup loss {:.3f}, cons loss {:.5f})'.format(
+    which, dt * 1e3, B / dt, float(r['sup_loss']), float(r['consistency_loss'])))
