@@ -14,8 +14,11 @@ What runs where:
     as in the CutMix step (step.py);
   * the VAT DIRECTION is one step of power iteration: the gradient, wrt a perturbation of norm 1e-6*H*W/1000, of the
     distance between net(x_hat + eps) and net(x) (:244-268). That perturbation is ~2e-7 per pixel -- below bf16
-    resolution of the input (and barely above fp32's); the pass therefore runs the network in fp32 on the library
-    engine, whatever `compute_dtype` the iteration uses. The distance and its gradient wrt the low-resolution logits come
+    resolution of the input (and barely above fp32's); the pass therefore runs the network in fp32, whatever
+    `compute_dtype` the iteration uses: for the DeepLab networks on the fp32 configuration of the hand-written engine
+    (f32-input MFMA convolutions csrc/conv_f32.hip, stem incl. its image gradient csrc/stem.hip -- no library
+    convolution in the pass), for the U-Nets on the library's fp32 convolutions with csrc/bn.hip BatchNorm. The
+    distance and its gradient wrt the low-resolution logits come
     from the fused consistency kernels (the reference SUMS where the kernel averages; the direction is normalised, so a
     positive factor is immaterial), the gradient wrt the image from the network's backward pass with the weight
     gradients switched off (`torch.autograd.grad` wrt eps only, like the reference);
