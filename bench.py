@@ -167,6 +167,8 @@ def run_workload(key, args, world, rank, dev):
     has_ex = hasattr(stu, 'hip_executor')
     if args.no_overlap and has_ex:
         stu.hip_executor().overlap_wgrad = False
+    if args.wgrad_streams and has_ex:
+        stu.hip_executor().wgrad_streams = args.wgrad_streams
     if args.conv_tile and has_ex:
         stu.hip_executor().conv_tile = tea.hip_executor().conv_tile = args.conv_tile
     if args.tile_rule and has_ex:
@@ -520,6 +522,7 @@ def main():
     ap.add_argument('--conv_tile', type=int, default=0, help='experiment: force a conv tile code (256, 1128, 128)')
     ap.add_argument('--tile_rule', default='', help='experiment: cout:tile[,cout:tile...] per-layer tile codes')
     ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')
+    ap.add_argument('--wgrad_streams', type=int, default=0, help='experiment: streams the weight gradients are spread over')
     ap.add_argument('--no_roofline_events', action='store_true', help='skip the per-launch event brackets')
     ap.add_argument('--roofline_sample', type=int, default=5,
                     help='bracket every k-th launch of the conv kernel with events (1 = all; the brackets cost ~3 %% '

@@ -104,6 +104,10 @@ class DeepLabHipExecutor(object):
         self.grad_hook = None      # callable(block_index): weight gradients of that bottleneck are enqueued
         self.data_grad_only = False   # backward computes d/d input only (VAT direction: torch.autograd.grad wrt eps)
         self.overlap_wgrad = True
+        # weight gradients of a bottleneck are independent launches of only ~1.5 workgroups per CU each: spread over
+        # this many extra streams they run side by side (and beside the data-gradient chain on the main stream)
+        self.wgrad_streams = 2
+        self._sides = []
         self.conv_tile = 0         # experiment knob: force a tile shape on the 128-multiple layers (tools, bench)
         self.tile_rules = {}       # output channels -> tile code (per-layer choice against the workgroup-count staircase)
         self._wT_version = -1
@@ -416,7 +420,13 @@ class DeepLabHipExecutor(object):
         for i, k in enumerate(self.aspp_keys):
             a.packed(k + '.weight', a.grad).add_(dwall[0, 9 * C * i:9 * C * (i + 1)].view(9, C, 2048))
 
-    def _backward_chain(self, saved, dlg, want_w, side, hook, box=None):
+    def bucket_starts(self):
+        """Bottleneck indices at which a gradient bucket of the data-parallel all-reduce closes (step.GradBuckets):
+        [layer4 + head], the two halves of layer3, [layer1 - layer2]; the stem's slice follows the autograd backward."""
+        l3, l4 = self._layer_first[2], self._layer_first[3]
+        return sorted(set([0, l3, (l3 + l4 + 1) // 2, l4]))
+
+    def _backward_chain(self, saved, dlg, want_w, sides, hook, box=None):
         """The launches of the backward pass (recordable): ASPP head weight + data gradients, then the bottlenecks
         from the last to the first. `dlg`: fp32 (N, C, h, w) logit gradient. `hook(bi)` is called on the weight-gradient
         stream right after the weight gradients of bottleneck `bi` were issued. -> (dx, dwall or None)"""
@@ -436,6 +446,7 @@ class DeepLabHipExecutor(object):
         dC = ops.conv_igemm(d, self.aspp_wallT, [(0, 0)], mode=1, mask_src=x4)
         capture = getattr(self, 'debug_capture', None)
         keep = []                 # tensors read on the side stream must outlive the python scope that made them
+        closes = set(self.bucket_starts())
         for bi in range(len(self.blocks) - 1, -1, -1):
             if capture is not None:
                 capture[bi] = dC
@@ -446,19 +457,26 @@ class DeepLabHipExecutor(object):
             dU1 = self._dgrad(dU2, b.c2, mask=a1)
             if not want_w:
                 pass
-            elif side is not None:
-                ops.stream_wait(side, main)
+            elif sides:
+                for sd in sides:
+                    ops.stream_wait(sd, main)
                 keep.append((dC, dU2, dU1))
-                with torch.cuda.stream(side):
-                    self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
+                jobs = [(dC, a2, b.c3), (dU2, a1, b.c2)] + ([(dC, xin, b.cd)] if b.cd is not None else []) + [(dU1, xin, b.c1)]
+                for ji, (du_, x_, c_) in enumerate(jobs):
+                    with torch.cuda.stream(sides[ji % len(sides)]):
+                        self._wgrad(du_, x_, c_)
+                if len(sides) > 1 and bi in closes:
+                    for sd in sides[1:]:                      # a bucket closes here: stream 0 must have seen every stream
+                        ops.stream_wait(sides[0], sd)
+                with torch.cuda.stream(sides[0]):
                     hook(bi)
             else:
                 self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
                 hook(bi)
             dres = dC if b.cd is None else self._dgrad(dC, b.cd, in_hw=in_hw)
             dC = self._dgrad(dU1, b.c1, res=dres, mask=None if bi == 0 else xin, in_hw=in_hw)
-        if side is not None:
-            ops.stream_wait(main, side)
+        for sd in sides:
+            ops.stream_wait(main, sd)
         del keep
         return dC, dwall
 
@@ -471,7 +489,7 @@ class DeepLabHipExecutor(object):
             self.arena.ensure_grads_attached()
         n, _, h, w = dlogits.shape
         main = torch.cuda.current_stream()
-        side = self._side_stream() if (self.overlap_wgrad and want_w) else None
+        sides = self._side_streams(self.wgrad_streams) if (self.overlap_wgrad and want_w) else []
         if not self.use_programs:
             self._head_bias_grads(dlogits, want_w)
             box = {}
@@ -485,7 +503,7 @@ class DeepLabHipExecutor(object):
                 if self.grad_hook is not None:
                     self.grad_hook(bi)
             # the chain creates dwall before its first hook call: hand it over through the box
-            dx, dwall = self._backward_chain(token, dlogits, want_w, side, hook, box)
+            dx, dwall = self._backward_chain(token, dlogits, want_w, sides, hook, box)
             if dwall is not None and 'done' not in box:
                 self._head_weight_grads(dwall)
             return dx
@@ -494,19 +512,19 @@ class DeepLabHipExecutor(object):
             raise RuntimeError('the activations of this forward pass were overwritten by a later forward pass of the '
                                'same shape through the same executor (programs keep ONE set of buffers per shape): '
                                'run backward before the next forward, or set executor.use_programs = False')
-        key = (want_w, side is not None)
+        key = (want_w, len(sides))
         prog = fprog.bwd.get(key)
         if prog is None:
             prog = ops.Program()
             dlg = torch.empty(tuple(dlogits.shape), dtype=torch.float32, device=dlogits.device)   # persistent input
-            streams = [main] + ([side] if side is not None else [])
+            streams = [main] + sides
             with ops.recording(prog, streams):
-                dx, dwall = self._backward_chain(fprog.saved, dlg, want_w, side, prog.mark)
+                dx, dwall = self._backward_chain(fprog.saved, dlg, want_w, sides, prog.mark)
             prog.dlg, prog.dx, prog.dwall = dlg, dx, dwall
             fprog.bwd[key] = prog
         prog.dlg.copy_(dlogits)
         self._head_bias_grads(dlogits, want_w)
-        streams = [main] + ([side] if side is not None else [])
+        streams = [main] + sides
         if self.grad_hook is None or not want_w:
             prog.run(streams)
             if prog.dwall is not None:
@@ -515,7 +533,7 @@ class DeepLabHipExecutor(object):
             # segments between the recorded block marks: the hook (bucketed all-reduce) is host work that must see the
             # weight-gradient stream as its current stream, right after the weight gradients of its block
             first = 0
-            hook_stream = side if side is not None else main
+            hook_stream = sides[0] if sides else main
             head_done = False
             for idx, bi in prog.marks:
                 prog.run(streams, first, idx)
@@ -539,6 +557,12 @@ class DeepLabHipExecutor(object):
         if b.cd is not None:
             self._wgrad(dC, xin, b.cd)
         self._wgrad(dU1, xin, b.c1)
+
+    def _side_streams(self, k):
+        k = max(1, min(int(k), 3))
+        while len(self._sides) < k:
+            self._sides.append(torch.cuda.Stream(device=self.arena.device))
+        return self._sides[:k]
 
     def _side_stream(self):
         if self._side is None:

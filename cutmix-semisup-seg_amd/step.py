@@ -144,10 +144,9 @@ class CutMixMeanTeacherStep(object):
         ex = self.student.hip_executor()
         if self._bucket_obj is None:
             offs = ex.block_grad_offsets()
-            firsts = ex.layer_first_blocks()                 # block index of layerK.0 for K = 1..4
-            l3, l4 = firsts[2], firsts[3]
-            starts = sorted(set([0, l3, (l3 + l4 + 1) // 2, l4]))
-            self._bucket_obj = GradBuckets(self.student_optim.arena.grad, offs, starts, group=self.group)
+            # [layer4 + head], the two halves of layer3, [layer1 - layer2]: the executor orders its weight-gradient
+            # streams at exactly these bottlenecks (backbone_hip.bucket_starts)
+            self._bucket_obj = GradBuckets(self.student_optim.arena.grad, offs, ex.bucket_starts(), group=self.group)
         self._buckets = self._bucket_obj
         self._buckets.begin()
         ex.grad_hook = self._buckets.on_block
