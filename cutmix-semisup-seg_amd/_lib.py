@@ -138,9 +138,9 @@ PROTOTYPES = {
     'cms_stem_out_hw': (c_int, [c_int, c_int, _P(c_int), _P(c_int), _P(c_int), _P(c_int)]),
     'cms_stem_fwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_void_p]),
-    'cms_maxpool3x3s2_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'cms_maxpool3x3s2_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'cms_maxpool3x3s2_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                          c_void_p]),
+                                          c_int, c_void_p]),
     'cms_stem_wgrad': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'cms_stem_dgrad': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'cms_program_create': (c_int, [_P(c_void_p)]),

@@ -104,9 +104,10 @@ class DeepLabHipExecutor(object):
         self.grad_hook = None      # callable(block_index): weight gradients of that bottleneck are enqueued
         self.data_grad_only = False   # backward computes d/d input only (VAT direction: torch.autograd.grad wrt eps)
         self.overlap_wgrad = True
-        # weight gradients of a bottleneck are independent launches of only ~1.5 workgroups per CU each: spread over
-        # this many extra streams they run side by side (and beside the data-gradient chain on the main stream)
-        self.wgrad_streams = 2
+        # number of extra streams the weight gradients of a bottleneck are spread over (they are independent launches
+        # of ~1.5 workgroups per CU each). Measured on cfg 2 (profiles/r02f_wgrad_streams.txt): 1 -> 443-445 img/s,
+        # 2 -> 433, 3 -> 443: one stream beside the data-gradient chain already keeps the machine busy
+        self.wgrad_streams = 1
         self._sides = []
         self.conv_tile = 0         # experiment knob: force a tile shape on the 128-multiple layers (tools, bench)
         self.tile_rules = {}       # output channels -> tile code (per-layer choice against the workgroup-count staircase)
@@ -607,15 +608,28 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
         return low, st['cur']
 
     def _dgrad_strided(self, du, c, mask, in_hw):
-        """Data gradient of a strided k x k convolution (+ ReLU mask of its input) through the library."""
+        """Data gradient of the stride-2 3x3 convolution (torchvision v1.5 `layer2.0.conv2`; + ReLU mask of its input):
+        a transposed convolution, computed as its four PHASES on the MFMA kernel. With y[o] = sum_k W[k] x[2o + k - 1],
+        an input pixel 2a + p (p = its parity) receives from the taps k = p + 1 (mod 2): p = 0 -> k = 1 (dy[a]);
+        p = 1 -> k = 0 (dy[a + 1]) and k = 2 (dy[a]). Each (py, px) phase is therefore a stride-1 convolution over the dy
+        grid with 1, 2, 2 or 4 taps whose outputs land on every second pixel of dx starting at (py, px)."""
+        if not (c.stride == 2 and c.ksize == 3 and c.pad == 1 and c.dil == 1):
+            raise NotImplementedError('phase decomposition is written for the 3x3 / stride 2 / pad 1 convolution')
         n = du.shape[0]
-        w = (self.arena.view(c.wkey) * c.scale.view(-1, 1, 1, 1)).to(torch.bfloat16)
-        g = torch.nn.grad.conv2d_input((n, c.cin, in_hw[0], in_hw[1]), w, du.permute(0, 3, 1, 2), stride=c.stride,
-                                       padding=c.pad, dilation=c.dil)
-        g = g.permute(0, 2, 3, 1)
-        if mask is not None:
-            g = g * (mask > 0)
-        return g.contiguous()
+        H, W = int(in_hw[0]), int(in_hw[1])
+        dx = torch.empty((n, H, W, c.cin), dtype=du.dtype, device=du.device)
+        sel = {0: [1], 1: [0, 2]}
+        for py in (0, 1):
+            for px in (0, 1):
+                ha, wb = (H - py + 1) // 2, (W - px + 1) // 2
+                if ha <= 0 or wb <= 0:
+                    continue
+                ks = [(ky, kx) for ky in sel[py] for kx in sel[px]]
+                wsub = c.wT[[ky * 3 + kx for ky, kx in ks]].contiguous()          # (taps, Cin, Cout), BN scale folded
+                taps = [((py + 1 - ky) // 2, (px + 1 - kx) // 2) for ky, kx in ks]
+                ops.conv_igemm(du, wsub, taps, mode=1, mask_src=mask, out=dx, out_hw=(ha, wb), out_stride=2,
+                               out_full_hw=(H, W), out_pixel_offset=py * W + px)
+        return dx
 
     def backward_taps(self, saved, d_low, d_out):
         """Gradients wrt the two taps (bf16 NHWC or None) -> gradient wrt the stem output; weight and BatchNorm-affine

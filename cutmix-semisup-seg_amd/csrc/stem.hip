@@ -293,18 +293,20 @@ extern "C" int cms_stem_pack_weights(const void* w_khkwcoci, int w_dtype, float*
     return launch_status("cms_stem_pack_weights");
 }
 
+static int pool_out(int s, int ceil_mode) {        // kernel 3, stride 2, padding 1 (ATen's rule for ceil_mode)
+    if (!ceil_mode) return (s + 2 - 3) / 2 + 1;
+    int o = (s + 2 - 3 + 1) / 2 + 1;
+    if ((o - 1) * 2 >= s + 1) --o;
+    return o;
+}
+
 extern "C" int cms_stem_out_hw(int h, int w, int* ho, int* wo, int* hp, int* wp) {
     CMS_REQUIRE(h > 0 && w > 0, "stem_out_hw: bad size");
     const int Ho = (h + 6 - 7) / 2 + 1, Wo = (w + 6 - 7) / 2 + 1;
-    auto pool = [](int s) {                                  // ceil_mode, kernel 3, stride 2, pad 1 (ATen's rule)
-        int o = (s + 2 - 3 + 1) / 2 + 1;
-        if ((o - 1) * 2 >= s + 1) --o;
-        return o;
-    };
     if (ho) *ho = Ho;
     if (wo) *wo = Wo;
-    if (hp) *hp = pool(Ho);
-    if (wp) *wp = pool(Wo);
+    if (hp) *hp = pool_out(Ho, 1);            // (DeepLab v2's ceil-mode pool, deeplab2.py:146)
+    if (wp) *wp = pool_out(Wo, 1);
     return CMS_OK;
 }
 
@@ -328,11 +330,10 @@ extern "C" int cms_stem_fwd(const void* x_nchw, int x_dtype, void* y_nhwc, int y
 }
 
 extern "C" int cms_maxpool3x3s2_fwd(const void* s_nhwc, void* p_nhwc, uint8_t* argmax, int dtype, int n, int hs, int ws,
-                                    int c, void* stream) {
+                                    int c, int ceil_mode, void* stream) {
     CMS_REQUIRE(s_nhwc && p_nhwc && argmax && dt_ok(dtype), "maxpool_fwd: NULL pointer / bad dtype");
     CMS_REQUIRE(n > 0 && hs > 0 && ws > 0 && c > 0 && c % 8 == 0, "maxpool_fwd: bad geometry (C %% 8 == 0)");
-    auto pool = [](int s) { int o = (s + 2 - 3 + 1) / 2 + 1; if ((o - 1) * 2 >= s + 1) --o; return o; };
-    const int hp = pool(hs), wp = pool(ws);
+    const int hp = pool_out(hs, ceil_mode), wp = pool_out(ws, ceil_mode);
     const size_t total = (size_t)n * hp * wp * (c / 8);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CMS_F32)
@@ -345,11 +346,10 @@ extern "C" int cms_maxpool3x3s2_fwd(const void* s_nhwc, void* p_nhwc, uint8_t* a
 }
 
 extern "C" int cms_maxpool3x3s2_relu_bwd(const void* dp_nhwc, const uint8_t* argmax, const void* s_nhwc, void* ds_nhwc,
-                                         int dtype, int n, int hs, int ws, int c, void* stream) {
+                                         int dtype, int n, int hs, int ws, int c, int ceil_mode, void* stream) {
     CMS_REQUIRE(dp_nhwc && argmax && s_nhwc && ds_nhwc && dt_ok(dtype), "maxpool_bwd: NULL pointer / bad dtype");
     CMS_REQUIRE(n > 0 && hs > 0 && ws > 0 && c > 0 && c % 8 == 0, "maxpool_bwd: bad geometry (C %% 8 == 0)");
-    auto pool = [](int s) { int o = (s + 2 - 3 + 1) / 2 + 1; if ((o - 1) * 2 >= s + 1) --o; return o; };
-    const int hp = pool(hs), wp = pool(ws);
+    const int hp = pool_out(hs, ceil_mode), wp = pool_out(ws, ceil_mode);
     const size_t total = (size_t)n * hs * ws * (c / 8);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CMS_F32)

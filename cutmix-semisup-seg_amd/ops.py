@@ -480,23 +480,26 @@ def stem_forward(x, w147, scale, bias, out_dtype):
     return y
 
 
-def maxpool3x3s2_forward(s):
-    """ceil-mode 3x3 / 2 / pad 1 max-pool of an NHWC tensor -> (pooled, argmax uint8)."""
+def _pool_out(v, ceil_mode):
+    if not ceil_mode:
+        return (v + 2 - 3) // 2 + 1
+    r = (v + 2 - 3 + 1) // 2 + 1            # ATen's ceil-mode output size for kernel 3, stride 2, padding 1
+    return r - 1 if (r - 1) * 2 >= v + 1 else r
+
+
+def maxpool3x3s2_forward(s, ceil_mode=True):
+    """3x3 / 2 / pad 1 max-pool of an NHWC tensor -> (pooled, argmax uint8)."""
     _need_cuda(s)
     n, hs, ws, c = (int(v) for v in s.shape)
-
-    def o(v):                       # ATen's ceil-mode output size for kernel 3, stride 2, padding 1
-        r = (v + 2 - 3 + 1) // 2 + 1
-        return r - 1 if (r - 1) * 2 >= v + 1 else r
-    hp, wp = o(hs), o(ws)
+    hp, wp = _pool_out(hs, ceil_mode), _pool_out(ws, ceil_mode)
     p = torch.empty((n, hp, wp, c), dtype=s.dtype, device=s.device)
     idx = torch.empty((n, hp, wp, c), dtype=torch.uint8, device=s.device)
-    check(fn['cms_maxpool3x3s2_fwd'](_ptr(s), _ptr(p), _ptr(idx), _dtype_code(s), n, hs, ws, c, _stream()),
-          'cms_maxpool3x3s2_fwd')
+    check(fn['cms_maxpool3x3s2_fwd'](_ptr(s), _ptr(p), _ptr(idx), _dtype_code(s), n, hs, ws, c, int(bool(ceil_mode)),
+                                     _stream()), 'cms_maxpool3x3s2_fwd')
     return p, idx
 
 
-def maxpool3x3s2_relu_backward(dp, idx, s):
+def maxpool3x3s2_relu_backward(dp, idx, s, ceil_mode=True):
     """gradient wrt the PRE-ReLU stem output: [s > 0] * max-pool backward."""
     _need_cuda(dp, idx, s)
     dp = dp.contiguous()
@@ -504,8 +507,8 @@ def maxpool3x3s2_relu_backward(dp, idx, s):
         raise ValueError('maxpool backward: dtype / shape mismatch')
     n, hs, ws, c = (int(v) for v in s.shape)
     ds = torch.empty_like(s)
-    check(fn['cms_maxpool3x3s2_relu_bwd'](_ptr(dp), _ptr(idx), _ptr(s), _ptr(ds), _dtype_code(s), n, hs, ws, c, _stream()),
-          'cms_maxpool3x3s2_relu_bwd')
+    check(fn['cms_maxpool3x3s2_relu_bwd'](_ptr(dp), _ptr(idx), _ptr(s), _ptr(ds), _dtype_code(s), n, hs, ws, c,
+                                          int(bool(ceil_mode)), _stream()), 'cms_maxpool3x3s2_relu_bwd')
     return ds
 
 
@@ -724,13 +727,15 @@ def conv_taps(kh, kw, dilation, padding):
 
 def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, res=None, relu=False, mode=0,
                mask_src=None, out=None, out_f32_nchw=None, cout_real=None, out_stride=1, out_full_hw=None, tile=0,
-               ksplit=1, variant=0):
+               ksplit=1, variant=0, out_pixel_offset=0):
     """
     Implicit-GEMM convolution on the MFMA units (csrc/conv.hip).
       x         bf16 NHWC-contiguous tensor of logical shape (N, H, W, Cin)
       w_packed  bf16 (ntaps, Cout, Cin)
       taps      list of (dy, dx) input offsets per tap
     Returns the bf16 (N, out_h, out_w, Cout) output (or the fp32 NCHW tensor given in `out_f32_nchw`).
+    `out_pixel_offset` (with `out`, `out_stride` > 1): the strided scatter starts at that pixel of the output tensor
+    instead of pixel 0 -- residual / mask are read at the same shifted positions (the phases of a transposed convolution).
     """
     _need_cuda(x, w_packed, scale, bias, res, mask_src, out, out_f32_nchw)
     if x.dtype not in (torch.bfloat16, torch.float32) or w_packed.dtype != x.dtype or not x.is_contiguous() \
@@ -753,13 +758,17 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
             out = torch.empty((n, oh, ow, cout), dtype=x.dtype, device=x.device)
             if out_stride > 1:
                 memset_zero(out)               # the strided scatter only visits every out_stride-th position
-        d.y, d.y32 = out.data_ptr(), None
+        shift = int(out_pixel_offset) * cout * x.element_size()
+        if shift and (out_stride <= 1 or out is None):
+            raise ValueError('conv_igemm: out_pixel_offset needs a caller-owned `out` and out_stride > 1')
+        d.y, d.y32 = out.data_ptr() + shift, None
     else:
         d.y, d.y32 = None, out_f32_nchw.data_ptr()
     d.scale = scale.data_ptr() if scale is not None else None
     d.bias = bias.data_ptr() if bias is not None else None
-    d.res = res.data_ptr() if res is not None else None
-    d.mask_src = mask_src.data_ptr() if mask_src is not None else None
+    shift = int(out_pixel_offset) * cout * x.element_size() if out_f32_nchw is None else 0
+    d.res = res.data_ptr() + shift if res is not None else None
+    d.mask_src = mask_src.data_ptr() + shift if mask_src is not None else None
     d.n, d.h, d.w_in, d.cin = n, h, w_in, cin
     d.ho, d.wo, d.cout = ho, wo, cout
     d.cout_real = cout if cout_real is None else int(cout_real)

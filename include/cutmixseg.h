@@ -363,12 +363,13 @@ int cms_stem_out_hw(int h, int w, int* ho, int* wo, int* hp, int* wp);
 /* y[n][oy][ox][co] = relu(conv(x)[co] * scale[co] + bias[co]) */
 int cms_stem_fwd(const void* x_nchw, int x_dtype, void* y_nhwc, int y_dtype, const float* w_packed, const float* scale,
                  const float* bias, int n, int h, int w, void* stream);
-/* p = maxpool(s); argmax[n][py][px][c] = ky*3+kx of the FIRST maximum of the window (ATen's rule) */
+/* ceil_mode 1: DeepLab v2 (deeplab2.py:146); 0: torchvision's ResNet stem (DeepLab v3+ backbone).
+ * p = maxpool(s); argmax[n][py][px][c] = ky*3+kx of the FIRST maximum of the window (ATen's rule) */
 int cms_maxpool3x3s2_fwd(const void* s_nhwc, void* p_nhwc, uint8_t* argmax, int dtype, int n, int hs, int ws, int c,
-                         void* stream);
+                         int ceil_mode, void* stream);
 /* ds = [s > 0] * scatter(dp through argmax): max-pool backward fused with the ReLU backward of its input */
 int cms_maxpool3x3s2_relu_bwd(const void* dp_nhwc, const uint8_t* argmax, const void* s_nhwc, void* ds_nhwc, int dtype,
-                              int n, int hs, int ws, int c, void* stream);
+                              int n, int hs, int ws, int c, int ceil_mode, void* stream);
 /* dw[ky][kx][co][c] (fp32, accumulated with atomics) += scale[co] * sum_pixels ds[pix][co] * x[c][2oy-3+ky][2ox-3+kx] */
 int cms_stem_wgrad(const void* x_nchw, int x_dtype, const void* ds_nhwc, int ds_dtype, float* dw_khkwcoci,
                    const float* scale, int n, int h, int w, void* stream);

@@ -284,3 +284,27 @@ def test_conv_wgrad_batchnorm_affine_side_outputs(ops, case):
     assert float((dbeta - ref_beta).abs().max()) <= 2e-3 * float(ref_beta.abs().max()) + 1e-3
     ref_dw = (G * scale.view(-1, 1, 1, 1)).permute(2, 3, 0, 1).reshape(k * k, Cout, Cin)
     assert float((dw - ref_dw).abs().max()) <= 2e-3 * float(ref_dw.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize('hw', [(41, 41), (32, 48), (17, 18)])
+def test_strided_3x3_dgrad_as_four_phases(ops, hw):
+    """Data gradient of the stride-2 3x3 convolution (DeepLab v3+ backbone, layer2.0.conv2) as the four phases of a
+    transposed convolution on the MFMA kernel (backbone_hip._dgrad_strided) vs autograd of the same convolution."""
+    import types
+    from cutmix_semisup_seg_amd.backbone_hip import DeepLabV3PlusBackboneExecutor
+    H, W = hw
+    N, Cin, Cout = 2, 128, 128
+    g = torch.Generator(device=DEV).manual_seed(H)
+    w = _mk((Cout, Cin, 3, 3), g, 0.05)
+    scale = torch.rand(Cout, generator=g, device=DEV) + 0.5
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    du = _mk((N, Ho, Wo, Cout), g)
+    mask = _mk((N, H, W, Cin), g)
+    wT = ops.conv_pack_transpose(_pack(w), scale=scale, flip=False)
+    c = types.SimpleNamespace(stride=2, ksize=3, pad=1, dil=1, cin=Cin, wT=wT)
+    dx = DeepLabV3PlusBackboneExecutor._dgrad_strided(None, du, c, mask, (H, W))
+    xr = torch.zeros(N, Cin, H, W, device=DEV, requires_grad=True)
+    y = F.conv2d(xr, w.float(), None, 2, 1) * scale.view(1, -1, 1, 1)
+    y.backward(du.float().permute(0, 3, 1, 2))
+    ref = xr.grad.permute(0, 2, 3, 1) * (mask.float() > 0)
+    assert float((dx.float() - ref).abs().max()) <= 1.5e-2 * float(ref.abs().max()) + 1e-3
