@@ -162,6 +162,9 @@ class DeepLabHeadV3Plus(nn.Module):
         y = eng.conv_bn_act(y, self.classifier[0], self.classifier[1], relu=True)
         y = eng.conv_bn_act(y, self.classifier[3], self.classifier[4], relu=True)
         last = self.classifier[6]
+        clf = getattr(eng, 'classifier', None)
+        if clf is not None and y.is_cuda and y.dtype == torch.bfloat16 and last.out_channels <= 64 and last.in_channels % 64 == 0:
+            return clf(y, last)                                 # MFMA kernel, fp32 NCHW logits from the epilogue
         y = F.conv2d(y, last.weight.to(y.dtype), None)
         return y.float() + last.bias.view(1, -1, 1, 1)
 
@@ -203,6 +206,12 @@ class HipConvEngine(TorchEngine):
         if key is not None and hip_conv2d_eligible(x, conv):
             return hip_conv2d(x, conv, self.arena, key)
         return super(HipConvEngine, self).conv2d(x, conv)
+
+    def classifier(self, x, conv):
+        """1x1 convolution with bias to <= 64 classes -> fp32 NCHW logits (csrc/conv.hip epilogue)."""
+        from ..backbone_hip import hip_classifier
+        key = self.keys[id(conv)]
+        return hip_classifier(x, conv, self.arena, key, key[:-len('weight')] + 'bias')
 
 
 class EngineNetMixin(object):
@@ -292,11 +301,9 @@ class DeepLabv3Wrapper(nn.Module):
         final interpolate, deeplab3plus.py:76)."""
         eng = self._engine(x)
         if x.is_cuda and self._use_hip_backbone():
-            bb = self.deeplab.backbone
-            y = eng.conv_bn_act(eng.prepare_input(x), bb['conv1'], bb['bn1'], relu=True)
-            y = F.max_pool2d(y, kernel_size=3, stride=2, padding=1)
             from ..backbone_hip import run_v3_body
-            low, out = run_v3_body(self.hip_executor(), y.permute(0, 2, 3, 1).contiguous())
+            ex = self.hip_executor()
+            low, out = run_v3_body(ex, ex.stem(x))              # stem on csrc/stem.hip (floor-mode pool, trainable BN affine)
             feats = {'low_level': low.permute(0, 3, 1, 2), 'out': out.permute(0, 3, 1, 2)}    # channels-last views
         else:
             feats = self.deeplab.backbone(eng.prepare_input(x), eng)

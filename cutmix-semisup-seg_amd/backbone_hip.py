@@ -64,7 +64,7 @@ class DeepLabHipExecutor(object):
         self.num_classes = net.num_classes
         self._add_blocks('', [getattr(net, 'layer{}'.format(li)) for li in range(1, 5)])
         # the stem (7x7/2 convolution + frozen BatchNorm + ReLU + ceil-mode max-pool) on csrc/stem.hip
-        self.stem_wkey, self.stem_bn = 'conv1.weight', 'bn1'
+        self.stem_wkey, self.stem_bn, self.stem_ceil = 'conv1.weight', 'bn1', True
         self.stem_w147 = None
         self._stem_version = -1
         head = net.layer5.conv2d_list
@@ -590,6 +590,10 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
     def __init__(self, wrapper):
         self._init_common(wrapper)
         self.use_programs = False          # (this executor's passes are issued launch by launch)
+        # torchvision's stem: same 7x7/2 convolution, max-pool WITHOUT ceil_mode, trainable BatchNorm affine
+        self.stem_wkey, self.stem_bn, self.stem_ceil = 'deeplab.backbone.conv1.weight', 'deeplab.backbone.bn1', False
+        self.stem_w147 = None
+        self._stem_version = -1
         bb = wrapper.deeplab.backbone
         self._add_blocks('deeplab.backbone.', [bb['layer{}'.format(li)] for li in range(1, 5)])
         self.tap_low = self._layer_first[1] - 1          # last bottleneck of layer1
@@ -744,47 +748,102 @@ class _HipConv2dFn(torch.autograd.Function):
 
 
 class _HipConv2dPaddedFn(torch.autograd.Function):
-    """The same for an input-channel count that is not a multiple of 64 (the 48 + 256 = 304-channel concat convolution
-    of the DeepLab v3+ head): activations and the bf16 weight operand are zero-padded along Cin to the next multiple of
-    64 for the call; the weight gradient comes back through a padded fp32 scratch."""
+    """The same for channel counts that are not multiples of 64 (DeepLab v3+ head: the 48 + 256 = 304-channel concat
+    convolution, the 256 -> 48 low-level projection): activations, gradients and the bf16 weight operand are
+    zero-padded along Cin / Cout to the next multiple of 64 for the call; the weight gradient comes back through a
+    padded fp32 scratch."""
 
     @staticmethod
     def forward(ctx, x, weight, arena, key, taps):
         n, cin, h, w = x.shape
-        cpad = (cin + 63) // 64 * 64
-        xh = torch.zeros((n, h, w, cpad), dtype=torch.bfloat16, device=x.device)
-        xh[..., :cin] = x.permute(0, 2, 3, 1)
         wp = arena.packed(key, arena.bf16)                            # (taps, Cout, Cin)
-        wpad = torch.zeros((wp.shape[0], wp.shape[1], cpad), dtype=torch.bfloat16, device=x.device)
-        wpad[..., :cin] = wp
+        cout = int(wp.shape[1])
+        cpad, opad = (cin + 63) // 64 * 64, (cout + 63) // 64 * 64
+        if cpad != cin:
+            xh = torch.zeros((n, h, w, cpad), dtype=torch.bfloat16, device=x.device)
+            xh[..., :cin] = x.permute(0, 2, 3, 1)
+        else:
+            xh = x.permute(0, 2, 3, 1).contiguous()
+        wpad = torch.zeros((wp.shape[0], opad, cpad), dtype=torch.bfloat16, device=x.device)
+        wpad[:, :cout, :cin] = wp
         y = ops.conv_igemm(xh, wpad, taps)
-        ctx.arena, ctx.key, ctx.taps, ctx.cin = arena, key, taps, cin
+        ctx.arena, ctx.key, ctx.taps, ctx.cin, ctx.cout = arena, key, taps, cin, cout
         ctx.need_w = weight.requires_grad and arena.grad is not None
         ctx.save_for_backward(xh, wpad)
+        if opad != cout:
+            y = y[..., :cout].contiguous()
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dy):
         xh, wpad = ctx.saved_tensors
-        a, cin = ctx.arena, ctx.cin
-        dyh = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+        a, cin, cout = ctx.arena, ctx.cin, ctx.cout
+        opad = int(wpad.shape[1])
+        if opad != cout:
+            dyh = torch.zeros(tuple(xh.shape[:3]) + (opad,), dtype=torch.bfloat16, device=dy.device)
+            dyh[..., :cout] = dy.permute(0, 2, 3, 1)
+        else:
+            dyh = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
         dx = None
         if ctx.needs_input_grad[0]:
             wT = ops.conv_pack_transpose(wpad, flip=False)
             dxp = ops.conv_igemm(dyh, wT, [(-dy_, -dx_) for dy_, dx_ in ctx.taps], mode=1)
-            dx = dxp[..., :cin].permute(0, 3, 1, 2)
+            dx = (dxp[..., :cin] if dxp.shape[-1] != cin else dxp).permute(0, 3, 1, 2)
         if ctx.need_w:
             tmp = torch.zeros(wpad.shape, dtype=torch.float32, device=dyh.device)
             ops.conv_wgrad(dyh, xh, ctx.taps, tmp)
-            a.packed(ctx.key, a.grad).add_(tmp[..., :cin])
+            a.packed(ctx.key, a.grad).add_(tmp[:, :cout, :cin])
         return dx, None, None, None, None
+
+
+class _HipClassifierFn(torch.autograd.Function):
+    """The final 1x1 classifier with bias (DeepLab v3+ head, deeplab3plus.py:47: 256 -> num_classes): class axis padded
+    to 64 for the MFMA kernels, fp32 NCHW logits straight out of the convolution epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, arena, wkey, bkey):
+        n, cin, h, w = x.shape
+        xh = x.permute(0, 2, 3, 1).contiguous()
+        wp = arena.packed(wkey, arena.bf16)                            # (1, C, Cin)
+        c = int(wp.shape[1])
+        wpad = torch.zeros((1, 64, cin), dtype=torch.bfloat16, device=x.device)
+        wpad[:, :c] = wp
+        bpad = torch.zeros(64, dtype=torch.float32, device=x.device)
+        bpad[:c] = arena.view(bkey)
+        logits = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        ops.conv_igemm(xh, wpad, [(0, 0)], bias=bpad, out_f32_nchw=logits, cout_real=c)
+        ctx.arena, ctx.wkey, ctx.bkey, ctx.c = arena, wkey, bkey, c
+        ctx.need_w = weight.requires_grad and arena.grad is not None
+        ctx.save_for_backward(xh, wpad)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        xh, wpad = ctx.saved_tensors
+        a, c = ctx.arena, ctx.c
+        dlh = torch.zeros(tuple(xh.shape[:3]) + (64,), dtype=torch.bfloat16, device=dl.device)
+        dlh[..., :c] = dl.permute(0, 2, 3, 1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv_igemm(dlh, ops.conv_pack_transpose(wpad, flip=False), [(0, 0)], mode=1).permute(0, 3, 1, 2)
+        if ctx.need_w:
+            tmp = torch.zeros(wpad.shape, dtype=torch.float32, device=dl.device)
+            ops.conv_wgrad(dlh, xh, [(0, 0)], tmp)
+            a.packed(ctx.wkey, a.grad).add_(tmp[:, :c])
+            a.view(ctx.bkey, a.grad).add_(dl.float().sum(dim=(0, 2, 3)))
+        return dx, None, None, None, None, None
+
+
+def hip_classifier(x, conv, arena, wkey, bkey):
+    """`conv(x)` for a 1x1 nn.Conv2d WITH bias and <= 64 output channels -> fp32 NCHW."""
+    return _HipClassifierFn.apply(x, conv.weight, conv.bias, arena, wkey, bkey)
 
 
 def hip_conv2d(x, conv, arena, key):
     """`conv(x)` for a stride-1, 'same'-padded, bias-free nn.Conv2d whose weight lives in `arena` under `key`."""
     kh, kw = conv.kernel_size
     taps = ops.conv_taps(kh, kw, conv.dilation[0], conv.padding[0])
-    fn = _HipConv2dFn if conv.in_channels % 64 == 0 else _HipConv2dPaddedFn
+    fn = _HipConv2dFn if (conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0) else _HipConv2dPaddedFn
     return fn.apply(x, conv.weight, arena, key, taps)
 
 
@@ -795,7 +854,8 @@ def hip_conv2d_eligible(x, conv):
     return (x.is_cuda and x.dtype == torch.bfloat16 and conv.bias is None and conv.groups == 1
             and conv.stride == (1, 1) and kh == kw and kh * kw <= 18
             and conv.padding == (conv.dilation[0] * (kh - 1) // 2,) * 2 and conv.dilation[0] == conv.dilation[1]
-            and (conv.in_channels % 64 == 0 or conv.in_channels >= 128) and conv.out_channels % 64 == 0
+            and (conv.in_channels % 64 == 0 or conv.in_channels >= 128)
+            and (conv.out_channels % 64 == 0 or conv.out_channels >= 32)
             and x.shape[2] * x.shape[3] >= 64)
 
 
@@ -804,7 +864,7 @@ class _StemFn(torch.autograd.Function):
     def forward(ctx, x, weight, executor):
         executor._stem_prepare()
         s = ops.stem_forward(x, executor.stem_w147, executor.stem_scale, executor.stem_bias, executor.dtype)
-        p, idx = ops.maxpool3x3s2_forward(s)
+        p, idx = ops.maxpool3x3s2_forward(s, ceil_mode=executor.stem_ceil)
         ctx.executor = executor
         ctx.x_shape = tuple(x.shape)
         ctx.x_dtype = x.dtype
@@ -816,9 +876,22 @@ class _StemFn(torch.autograd.Function):
     def backward(ctx, dp):
         x, s, idx = ctx.saved_tensors
         ex = ctx.executor
-        ds = ops.maxpool3x3s2_relu_backward(dp.to(s.dtype), idx, s)
+        ds = ops.maxpool3x3s2_relu_backward(dp.to(s.dtype), idx, s, ceil_mode=ex.stem_ceil)
         if ctx.w_grad and ex._want_w():
-            ops.stem_wgrad(x, ds, ex.arena.packed(ex.stem_wkey, ex.arena.grad), ex.stem_scale)
+            if ex.bn_trainable:
+                # frozen statistics, TRAINABLE affine (torchvision-style stem): with G the unscaled weight gradient,
+                # d(beta) = sum_p dS and d(gamma) = (<W, G> - mean * d(beta)) / sqrt(var + eps), like the body's convolutions
+                a = ex.arena
+                g = torch.zeros((49, 64, 3), dtype=torch.float32, device=ds.device)
+                ops.stem_wgrad(x, ds, g, None)
+                a.packed(ex.stem_wkey, a.grad).add_(g * ex.stem_scale.view(1, -1, 1))
+                wdot = (g * a.packed(ex.stem_wkey, ex._wbuf()).float()).sum(dim=(0, 2))
+                dbeta = ds.float().sum(dim=(0, 1, 2))
+                mean, var = a.view(ex.stem_bn + '.running_mean'), a.view(ex.stem_bn + '.running_var')
+                a.view(ex.stem_bn + '.weight', a.grad).add_((wdot - mean * dbeta) * torch.rsqrt(var + 1e-5))
+                a.view(ex.stem_bn + '.bias', a.grad).add_(dbeta)
+            else:
+                ops.stem_wgrad(x, ds, ex.arena.packed(ex.stem_wkey, ex.arena.grad), ex.stem_scale)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.stem_dgrad(ds, ex.stem_w147, ex.stem_scale, ctx.x_shape).to(ctx.x_dtype)

@@ -289,7 +289,7 @@ def test_which_convolutions_of_the_v3plus_head_are_routed_to_the_mfma_kernels():
     assert hip_conv2d_eligible(FakeCuda((10, 304, 129, 129)), head.classifier[0])            # padded to 320 channels
     assert hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.classifier[3])
     assert not hip_conv2d_eligible(FakeCuda((10, 2048, 1, 1)), head.aspp.convs[4][1])        # pooled branch: 1 pixel
-    assert not hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.project[0])           # 48 output channels
+    assert hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.project[0])               # 48 outputs, padded to 64
     assert not hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.classifier[6])        # bias, 21 outputs
     assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), torch.float32), head.aspp.convs[1][0])
     assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), cuda=False), head.aspp.convs[1][0])
