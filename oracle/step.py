@@ -79,12 +79,15 @@ def _sgd_k(p, g, buf, lr, k, momentum, nesterov, wd):
 
 
 def train_iteration(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode='mix', loss_fn='var', conf_thresh=0.97,
-                    conf_per_pixel=False, ramp_val=1.0, rampup=-1, cons_weight=1.0, frozen_bn=True, grads_out=None):
+                    conf_per_pixel=False, ramp_val=1.0, rampup=-1, cons_weight=1.0, frozen_bn=True, grads_out=None,
+                    pi_model=False):
     """
     One iteration. `sup_y` int64 (N,1,H,W) with 255 = ignore; `masks` float (N,1,H,W) in {0,1}.
     In cut mode ux1/um1 are ignored. Returns dict(sup_loss, consistency_loss, conf_rate).
     `grads_out` (dict, optional) receives the autograd gradient of every trainable tensor (what the optimizer consumed)
     -- the yardstick the tests hold the device backward pass to.
+    `pi_model`: `--model pi` (train_seg_semisup_mask_mt.py:110-113): the teacher IS the student network (its forward
+    passes run under no_grad with the student's current weights) and there is no EMA step.
     """
     if not frozen_bn:
         raise NotImplementedError('oracle step covers the --freeze_bn configuration (cfg 2/3)')
@@ -99,9 +102,10 @@ def train_iteration(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode='mix', loss
     closs = None
     rate = None
     if cons_weight > 0.0:
+        tea = S.student if pi_model else S.teacher
         with torch.no_grad():
-            l0 = dl.forward(ux0, S.teacher, S.layers, frozen=True)
-            l1 = dl.forward(ux1, S.teacher, S.layers, frozen=True) if mode == 'mix' else None
+            l0 = dl.forward(ux0, tea, S.layers, frozen=True)
+            l1 = dl.forward(ux1, tea, S.layers, frozen=True) if mode == 'mix' else None
         kw = dict(loss_fn=loss_fn, conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, ramp_val=ramp_val,
                   rampup=rampup, cons_weight=cons_weight)
         if mode == 'mix':
@@ -129,7 +133,7 @@ def train_iteration(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode='mix', loss
                 mom, nest, wd = S.sgd
                 S.buf[k] = _sgd_k(S.student[k], g, S.buf[k], lr, mult, mom, nest, wd)
         a = S.teacher_alpha
-        for k, t in S.teacher.items():
+        for k, t in ([] if pi_model else S.teacher.items()):
             if t.dtype == torch.float32:
                 t.mul_(a)
                 t.add_(S.student[k] * (1.0 - a))

@@ -606,3 +606,44 @@ def test_pi_model_step_teacher_is_the_student(ops, fuse):
     assert res[0] == pytest.approx(res[1], rel=1e-4, abs=1e-6)
     for k in weights[0]:
         torch.testing.assert_close(weights[0][k], weights[1][k], rtol=1e-3, atol=2e-5)     # (library conv run-to-run noise through the first Adam update: lr * g / (|g| + eps))
+
+
+@pytest.mark.parametrize('fuse', [True, False])
+def test_pi_model_step_vs_oracle(ops, fuse):
+    """`--model pi` against the CPU oracle (oracle/step.py, pi_model=True): two iterations, losses, confidence rate and the
+    updated student (fp32 parity configuration of the hand-written engine)."""
+    from architectures import deeplab2
+    from oracle import deeplab2 as odl, step as ostep, boxmask as obox
+    import mask_gen
+    from cutmix_semisup_seg_amd import optim as fo
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
+    C, layers, N, H, W, lr = 5, [1, 1, 1, 1], 2, 33, 33, 1e-3
+    st = odl.closed_form_state(C, layers)
+    stu = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
+    stu.load_state_dict(st)
+    stu = stu.to(DEV)
+    stu.compute_dtype = torch.float32
+    stu.engine_kind = 'hip'
+    opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=lr * 0.1),
+                             dict(params=list(stu.new_parameters()), lr=lr)])
+    stu.train(); stu.freeze_batchnorm()
+    step = CutMixMeanTeacherStep(stu, stu, opt, None, StepConfig(conf_thresh=0.3, fuse_batches=fuse, compute_dtype=torch.float32))
+    S = ostep.StepState(st, C, layers, opt='adam', lr=lr)
+    gen_m = mask_gen.BoxMaskGenerator(0.5, invert=True)
+    rng = np.random.RandomState(11)
+    ones = torch.ones(N, 1, H, W)
+    for it in range(2):
+        g = torch.Generator().manual_seed(300 + it)
+        x = torch.randn(N, 3, H, W, generator=g)
+        y = torch.randint(0, C, (N, 1, H, W), generator=g)
+        y[torch.rand(N, 1, H, W, generator=g) < 0.05] = 255
+        ux0, ux1 = torch.randn(N, 3, H, W, generator=g), torch.randn(N, 3, H, W, generator=g)
+        rn = gen_m.generate_ranges(N, (H, W), rng=rng)
+        r = step(cu(x), cu(y).to(torch.uint8), [UnsupBatch(cu(ux0), ops.ranges_to_device(rn, DEV), x1_tea=cu(ux1))])
+        m = torch.tensor(obox.rasterise(rn, (H, W), True).astype(np.float32))
+        want = ostep.train_iteration(S, x, y, ux0, ux1, ones, ones, m, conf_thresh=0.3, pi_model=True)
+        assert float(r['sup_loss']) == pytest.approx(want['sup_loss'], rel=2e-4)
+        assert float(r['consistency_loss']) == pytest.approx(want['consistency_loss'], rel=2e-3, abs=1e-9)
+        assert float(r['conf_rate']) == pytest.approx(want['conf_rate'], abs=2e-3)
+    for k in ('conv1.weight', 'layer3.0.conv2.weight', 'layer5.conv2d_list.1.weight'):
+        torch.testing.assert_close(stu.state_dict()[k].cpu(), S.student[k], rtol=5e-3, atol=5e-5)
