@@ -25,6 +25,7 @@ LABEL_U8, LABEL_I64 = 0, 1
 LOSS_IDS = {'var': 0, 'logits_var': 1, 'logits_smoothl1': 2, 'bce': 3, 'kld': 4}
 MODE_MIX, MODE_CUT = 0, 1
 OPT_CHUNK = 2048
+AUG_PARAMS = 16
 
 c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -75,6 +76,13 @@ class WgradDesc(C.Structure):
                 ('dw_cout', c_int)]
 
 
+class AugmentDesc(C.Structure):
+    _fields_ = [('src', c_void_p), ('src_labels', c_void_p), ('out0', c_void_p), ('out1', c_void_p),
+                ('out_labels', c_void_p), ('out_mask', c_void_p), ('params', c_void_p),
+                ('mean', c_float * 3), ('std_', c_float * 3),
+                ('n', c_int), ('hs', c_int), ('ws', c_int), ('h', c_int), ('w', c_int), ('out_dtype', c_int)]
+
+
 class PackItem(C.Structure):
     _fields_ = [('src', c_void_p), ('dst', c_void_p), ('scale', c_void_p),
                 ('ntaps', c_int), ('cout', c_int), ('cin', c_int), ('first_block', c_int)]
@@ -123,6 +131,8 @@ PROTOTYPES = {
     'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'cms_conv_pack_transpose_batch': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    'cms_augment_batch': (c_int, [_P(AugmentDesc), c_void_p]),
+    'cms_augment_luma': (c_int, [_P(AugmentDesc), c_void_p, c_void_p]),
     'cms_bn_reduce': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
                               c_void_p]),
     'cms_bn_finalize': (c_int, [c_void_p, C.c_double, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,

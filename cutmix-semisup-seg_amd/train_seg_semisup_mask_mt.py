@@ -35,7 +35,7 @@ def train_seg_semisup_mask_mt(submit_config, dataset, model, arch, freeze_bn,
                               n_sup, n_unsup, n_val, split_seed, split_path, val_seed, save_preds, save_model,
                               num_workers,
                               synthetic=False, synthetic_n_classes=21, synthetic_val_batches=2, compute_dtype='bf16',
-                              no_fuse_batches=False):
+                              no_fuse_batches=False, synthetic_source_size=''):
     settings = locals().copy()
     del settings['submit_config']
 
@@ -151,6 +151,32 @@ def train_seg_semisup_mask_mt(submit_config, dataset, model, arch, freeze_bn,
         y[torch.rand(batch_size, 1, H, W, generator=gen, device=torch_device) < 0.05] = 255
         return y.to(torch.uint8)
 
+    # `--synthetic_source_size h,w`: the synthetic samples are uint8 SOURCE images of that size resident in HBM and every
+    # batch goes through the device-side input staging (device_pipeline.py: crop / Hung scale / flips / colour
+    # augmentation / standardisation -- the reference's loader-worker transforms, :150-183, with the --aug_* options)
+    augment = None
+    if synthetic_source_size:
+        from .device_pipeline import DeviceAugmenter
+        hs, ws = [int(v.strip()) for v in synthetic_source_size.split(',')]
+        augment = DeviceAugmenter((H, W), student_net.MEAN, student_net.STD, scale_hung=aug_scale_hung,
+                                  scale_non_uniform=aug_scale_non_uniform, hflip=aug_hflip, vflip=aug_vflip,
+                                  hvflip=aug_hvflip, strong_colour=aug_strong_colour, brightness=aug_colour_brightness,
+                                  contrast=aug_colour_contrast, saturation=aug_colour_saturation, hue=aug_colour_hue,
+                                  colour_prob=aug_colour_prob, greyscale_prob=aug_colour_greyscale_prob, out_dtype=dtype,
+                                  rng=np.random.RandomState(54321 + rank), colour_rng=np.random.RandomState(99 + rank))
+        if aug_max_scale != 1.0 or aug_rot_mag != 0.0:
+            raise NotImplementedError('the device-side staging covers crop / Hung scale / flips / colour; rotation and '
+                                      'free scaling (--aug_max_scale, --aug_rot_mag) are not built')
+        src_pool = torch.randint(0, 256, (4 * batch_size, hs, ws, 3), generator=gen, device=torch_device, dtype=torch.uint8)
+        lab_pool = torch.randint(0, n_classes, (4 * batch_size, hs, ws), generator=gen, device=torch_device).to(torch.uint8)
+        pool_pos = [0]
+
+        def staged(with_labels):
+            i = pool_pos[0] % 4
+            pool_pos[0] += 1
+            sl = slice(i * batch_size, (i + 1) * batch_size)
+            return augment(src_pool[sl], lab_pool[sl] if with_labels else None)
+
     print('Settings:')
     print(', '.join(['{}={}'.format(key, settings[key]) for key in sorted(list(settings.keys()))]))
     print('Dataset:')
@@ -181,12 +207,24 @@ def train_seg_semisup_mask_mt(submit_config, dataset, model, arch, freeze_bn,
             if step.nan_detected():
                 print('NaN detected; network dead, bailing.')
                 return
-            batch_x, batch_y = synth_images(), synth_labels()
+            if augment is not None:
+                sb = staged(True)
+                batch_x, batch_y = sb['image'], sb['labels']
+            else:
+                batch_x, batch_y = synth_images(), synth_labels()
             unsup = []
             if cons_weight > 0.0:
                 for _r in range(unsup_batch_ratio):
                     rng_np = mask_generator.generate_ranges(batch_size, (H, W), rng=mask_rng)
                     ranges = ops.ranges_to_device(rng_np, torch_device)
+                    if augment is not None:
+                        u0 = staged(False)
+                        u1 = staged(False) if step_cfg.mix else None
+                        unsup.append(UnsupBatch(u0['image'], ranges, um0=u0['mask'],
+                                                x1_tea=None if u1 is None else u1['image'],
+                                                um1=None if u1 is None else u1['mask'], x0_stu=u0.get('image_stu'),
+                                                x1_stu=None if u1 is None else u1.get('image_stu')))
+                        continue
                     x0 = synth_images()
                     x1 = synth_images() if step_cfg.mix else None
                     x0s = synth_images() if aug_strong_colour else None
@@ -295,6 +333,7 @@ _OPTIONS = [
     click.option('--split_seed', type=int, default=12345),
     click.option('--split_path', type=click.Path(readable=True, exists=True)),
     click.option('--val_seed', type=int, default=131),
+    click.option('--synthetic_source_size', type=str, default=''),
     click.option('--save_preds', is_flag=True, default=False),
     click.option('--save_model', is_flag=True, default=False),
     click.option('--num_workers', type=int, default=4),

@@ -317,6 +317,35 @@ int cms_conv_pack_transpose_f32(const float* src, float* dst, const float* scale
 int cms_conv_pack_transpose_batch_f32(const cms_pack_item* items_dev, int n_items, int total_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Device-side input staging (csrc/augment.hip): crop with random scale, flips, ColorJitter / RandomGrayscale,
+ * standardisation and NCHW conversion of uint8 source images resident in HBM -- the loader-worker transforms of
+ * datapipe/seg_transforms_cv.py:29-133, 169-231, 452-497, 541-623 as wired at train_seg_semisup_mask_mt.py:150-183.
+ * params[n][CMS_AUG_PARAMS] (DEVICE, float), drawn on the host in the reference's order:
+ *   0 y0, 1 x0   window origin in (unpadded) source pixels, may be negative (padding: image 0 after standardisation,
+ *                label 255, mask 0)         2 sc_h, 3 sc_w   window size (== h, w without random scale)
+ *   4 flip_x, 5 flip_y, 6 transpose (0/1)   7 brightness, 8 contrast, 9 saturation factors, 10 hue shift (turns)
+ *   11 greyscale (0/1)   12 colour jitter applied (0/1)   13 order of the four jitter ops, base-4 digits
+ *   14 contrast pivot (mean luminance; fill with cms_augment_luma x brightness when brightness comes first)   15 reserved
+ * out0 = geometric transform only (teacher view), out1 = + colour augmentation (student view); either may be NULL.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define CMS_AUG_PARAMS 16
+typedef struct cms_augment_desc {
+    const uint8_t* src;         /* uint8 [N][hs][ws][3]                                  */
+    const uint8_t* src_labels;  /* uint8 [N][hs][ws] or NULL                             */
+    void* out0;                 /* (N,3,h,w) NCHW, out_dtype, or NULL                    */
+    void* out1;                 /* (N,3,h,w) NCHW, out_dtype, or NULL                    */
+    uint8_t* out_labels;        /* (N,h,w) uint8 or NULL (255 outside the source image)  */
+    float* out_mask;            /* (N,1,h,w) fp32 validity mask or NULL                  */
+    const float* params;        /* DEVICE [N][CMS_AUG_PARAMS]                            */
+    float mean[3], std_[3];     /* standardisation (seg_transforms_cv.py:600-612)        */
+    int n, hs, ws, h, w;
+    int out_dtype;
+} cms_augment_desc;
+int cms_augment_batch(const cms_augment_desc* d, void* stream);
+/* luma[n] = mean luminance in [0,1] of sample n after its geometric transform (ColorJitter's contrast pivot) */
+int cms_augment_luma(const cms_augment_desc* d, float* luma, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Batch-statistics BatchNorm (+ ReLU, + residual) on NHWC activations (csrc/bn.hip): nn.BatchNorm2d in training mode,
  * architectures/deeplab2.py:72-84 without --freeze_bn, architectures/deeplab3plus.py:40-64 (head, always).
  * Statistics are a two-pass protocol so that a data-parallel caller can all-reduce `sums` (and the pixel count) between

@@ -1,0 +1,81 @@
+"""
+GPU: device-side input staging (csrc/augment.hip, device_pipeline.py) against the numpy restatement of the reference's
+per-sample transforms (oracle/augment.py; PARITY UNPINNED -- cv2 / PIL / torchvision absent, see its header): identity
+parameters are an exact standardisation + NCHW transpose; crops with random scale, padding, flips and colour
+augmentation agree with the oracle for the same parameter rows; both views of the paired layout share their geometry.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+MEAN, STD = np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225])
+
+
+def test_identity_parameters_are_standardisation_and_transpose():
+    from cutmix_semisup_seg_amd.device_pipeline import DeviceAugmenter
+    g = torch.Generator().manual_seed(0)
+    src = torch.randint(0, 256, (3, 40, 56, 3), generator=g, dtype=torch.uint8)
+    lab = torch.randint(0, 21, (3, 40, 56), generator=g).to(torch.uint8)
+    aug = DeviceAugmenter((40, 56), MEAN, STD, out_dtype=torch.float32, rng=np.random.RandomState(0))
+    out = aug(src.to(DEV), lab.to(DEV))
+    want = (src.double() / 255.0 - torch.tensor(MEAN)) / torch.tensor(STD)
+    torch.testing.assert_close(out['image'].cpu().double(), want.permute(0, 3, 1, 2), rtol=1e-5, atol=1e-5)
+    assert torch.equal(out['labels'].cpu()[:, 0], lab) and float(out['mask'].min()) == 1.0
+    assert 'image_stu' not in out
+
+
+@pytest.mark.parametrize('cfg', [dict(scale_hung=True, hflip=True, vflip=True), dict(scale_hung=True, scale_non_uniform=True),
+                                 dict(hflip=True, vflip=True, hvflip=True, square=True), dict(strong_colour=True, scale_hung=True, hflip=True)],
+                         ids=['hung_flips', 'hung_nonuniform', 'all_flips_square', 'colour'])
+def test_device_staging_vs_numpy_oracle(cfg):
+    from cutmix_semisup_seg_amd.device_pipeline import DeviceAugmenter
+    from oracle import augment as oaug
+    cfg = dict(cfg)
+    crop = (48, 48) if cfg.pop('square', False) else (48, 64)
+    g = torch.Generator().manual_seed(3)
+    N, Hs, Ws = 6, 60, 70                        # Hung scale 0.5 asks for a 96 x 128 window: padding on both axes
+    src = torch.randint(0, 256, (N, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    lab = torch.randint(0, 5, (N, Hs, Ws), generator=g).to(torch.uint8)
+    aug = DeviceAugmenter(crop, MEAN, STD, out_dtype=torch.float32, rng=np.random.RandomState(11),
+                          colour_rng=np.random.RandomState(12), **cfg)
+    params = aug.draw_params(N, (Hs, Ws))
+    out = aug(src.to(DEV), lab.to(DEV), params=params)
+    if cfg.get('strong_colour'):
+        assert 'image_stu' in out
+    for i in range(N):
+        pivot = None
+        if cfg.get('strong_colour') and params[i, 12]:
+            img0, _, _, _ = oaug.augment_sample(src[i].numpy(), None, params[i] * np.array([1] * 7 + [1, 1, 1, 0, 0, 0, 0, 0, 0]),
+                                                crop, np.zeros(3), np.ones(3))
+            luma = float((img0.transpose(1, 2, 0) @ oaug.GREY).mean())
+            order = int(params[i, 13])
+            ops_ = [(order >> s) & 3 for s in (6, 4, 2, 0)]
+            pivot = luma * (params[i, 7] if ops_.index(0) < ops_.index(1) else 1.0)
+        i0, i1, lb, al = oaug.augment_sample(src[i].numpy(), lab[i].numpy(), params[i], crop, MEAN, STD, pivot=pivot)
+        torch.testing.assert_close(out['image'][i].cpu().double(), torch.from_numpy(i0), rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(out['mask'][i, 0].cpu().double(), torch.from_numpy(np.ascontiguousarray(al)), rtol=1e-5, atol=1e-5)
+        assert np.array_equal(out['labels'][i, 0].cpu().numpy(), lb)
+        if cfg.get('strong_colour'):
+            # (nearest-tap luminance pre-pass on the device vs the bilinear mean here: the pivot differs in the 3rd digit)
+            torch.testing.assert_close(out['image_stu'][i].cpu().double(), torch.from_numpy(i1), rtol=2e-2, atol=2e-2)
+    if cfg.get('strong_colour'):
+        same = [i for i in range(N) if not params[i, 12] and not params[i, 11]]
+        for i in same:                                           # jitter not drawn: the student view IS the teacher view
+            assert torch.equal(out['image'][i], out['image_stu'][i])
+        assert any(params[:, 12] != 0)
+
+
+def test_trainer_cli_with_device_side_staging(tmp_path, monkeypatch):
+    """The reference's augmentation options on the command line, served by the device-side staging."""
+    from click.testing import CliRunner
+    import train_seg_semisup_mask_mt as trainer
+    monkeypatch.chdir(tmp_path)
+    args = ['--job_desc', 'aug', '--synthetic', '--synthetic_source_size', '90,120', '--arch', 'resnet101_deeplab_imagenet',
+            '--freeze_bn', '--batch_size', '2', '--crop_size', '65,65', '--aug_scale_hung', '--aug_hflip', '--aug_strong_colour',
+            '--num_epochs', '1', '--iters_per_epoch', '2', '--synthetic_val_batches', '1']
+    res = CliRunner().invoke(trainer.experiment, args, catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    log = open(tmp_path / 'results' / 'train_seg_semisup_mask_mt' / 'log_aug.txt').read()
+    assert 'Epoch 1' in log

@@ -141,6 +141,34 @@ def test_unet_encoders_have_torchvisions_published_parameter_counts_and_keys():
         resunet.DecoderBlock(64, 32, 16)
 
 
+def test_device_augmenter_draws_parameters_in_the_references_order():
+    """device_pipeline.DeviceAugmenter.draw_params against the reference's formulas re-evaluated on the same RandomState
+    stream (seg_transforms_cv.py:193-204 Hung scale + position, :122-123 plain crop, :479-480 flips)."""
+    from cutmix_semisup_seg_amd.device_pipeline import DeviceAugmenter
+    crop, src = (64, 96), (50, 200)              # source shorter than the window in y: padding; wider in x
+    aug = DeviceAugmenter(crop, None, None, scale_hung=True, hflip=True, vflip=False, hvflip=False,
+                          rng=np.random.RandomState(7))
+    got = aug.draw_params(5, src)
+    rng = np.random.RandomState(7)
+    for i in range(5):
+        f = 0.5 + rng.randint(0, 11, size=(1,)) / 10.0
+        sc = np.round(np.array(crop) / f).astype(int)
+        pad = np.maximum(sc - np.array(src), 0)
+        pos = np.round((np.array(src) + pad - sc) * rng.uniform(0.0, 1.0, size=(2,))).astype(int)
+        fl = (rng.binomial(1, 0.5, size=(3,)) != 0) & np.array([True, False, False])
+        assert tuple(got[i, 2:4]) == tuple(sc) and tuple(got[i, 0:2]) == tuple(pos - pad // 2)
+        assert tuple(got[i, 4:7] != 0) == tuple(fl)
+        assert got[i, 12] == 0 and tuple(got[i, 7:10]) == (1.0, 1.0, 1.0)          # no colour augmentation asked for
+    col = DeviceAugmenter((32, 32), None, None, strong_colour=True, rng=np.random.RandomState(1),
+                          colour_rng=np.random.RandomState(2)).draw_params(200, (40, 40))
+    assert 0.6 < col[:, 12].mean() < 0.95 and 0.08 < col[:, 11].mean() < 0.35         # p = 0.8 / 0.2
+    assert col[:, 7:10].min() >= 0.6 - 1e-6 and col[:, 7:10].max() <= 1.4 + 1e-6 and np.abs(col[:, 10]).max() <= 0.1
+    for o in col[:, 13].astype(int):
+        assert sorted((o >> s) & 3 for s in (6, 4, 2, 0)) == [0, 1, 2, 3]
+    with pytest.raises(ValueError, match='square crop'):
+        DeviceAugmenter((32, 48), None, None, hvflip=True)
+
+
 def test_robust_bce_formula():
     p = torch.tensor([0.2, 0.9])
     t = torch.tensor([0.0, 1.0])
@@ -215,7 +243,8 @@ def test_cli_surface_matches_reference():
         if o['choices'] is not None:
             assert list(p.type.choices) == o['choices']
     extra = set(mine) - {o['name'] for o in ref}
-    assert extra == {'synthetic', 'synthetic_n_classes', 'synthetic_val_batches', 'compute_dtype', 'no_fuse_batches'}
+    assert extra == {'synthetic', 'synthetic_n_classes', 'synthetic_val_batches', 'compute_dtype', 'no_fuse_batches',
+                     'synthetic_source_size'}
 
 
 def test_job_helper_log_layout_and_skip(tmp_path, monkeypatch, capsys):
