@@ -128,6 +128,7 @@ PROTOTYPES = {
                                      c_int, c_void_p, c_void_p, c_void_p]),
     'cms_confusion': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
     'cms_conv_igemm': (c_int, [_P(ConvDesc), c_void_p]),
+    'cms_conv_set_trace': (c_int, [c_void_p, c_int]),
     'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'cms_conv_pack_transpose_batch': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -26,6 +26,7 @@
 //
 // Roofline: dilated 3x3 (layer3: K = 2304, AI ~ 680 FLOP/B) is MFMA-bound; 1x1 (AI ~ 180 FLOP/B) is HBM-bound on the
 // activation stream; DESIGN.md section 4 lists algorithmic FLOPs / bytes per layer shape.
+#include <type_traits>
 #include "common.hpp"
 
 namespace cms {
@@ -58,6 +59,10 @@ struct ConvArgs {
     int ksplit;                // > 1: the taps are split across workgroups, fp32 output accumulated with atomics
     int dbg;                   // profiling experiments only: 2 = skip the MFMA phase, 3 = skip the loads after the first
     short tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
+    uint32_t* trace;        // diagnostic (variant 30): per-workgroup s_memtime stamps, CONV_TRACE_DWORDS each, or NULL
+    int trace_wgs;          // workgroups the trace buffer holds
+    int stagger;            // != 0: co-resident workgroups of the first dispatch round start 1/4 K-step period apart (24 / 25)
+    int krot;               // != 0: workgroup (tile_m) starts its K loop krot * tile_m steps in and wraps (variant 20)
 };
 
 
@@ -81,6 +86,8 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     bf16x2 p = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(uint32_t, p);
 }
+
+constexpr int CONV_TRACE_DWORDS = 512;      // per workgroup: 16 header dwords + 6 stamps per K step (<= 82 steps)
 
 struct RowInfo {            // one per pixel row of the workgroup tile, computed once (2 integer divisions per row)
     uint32_t in_off;        // element offset of input pixel (oy*stride, ox*stride), channel 0
@@ -134,6 +141,17 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
     unsigned char* lds_w = smem + BM * ROWB;              // [NS][BN][128 B]
     short* lds_tap = reinterpret_cast<short*>(smem + UNION_BYTES);                       // [2][CMS_CONV_MAX_TAPS]
     RowInfo* lds_row = reinterpret_cast<RowInfo*>(smem + UNION_BYTES + 80);              // [BM]
+    float* lds_sb = reinterpret_cast<float*>(smem + UNION_BYTES + 80 + BM * 16);         // [2][BN]: BN scale, bias of the tile
+    uint32_t* lds_trace = reinterpret_cast<uint32_t*>(smem + UNION_BYTES + 80 + BM * 16 + 2 * BN * 4); // [CONV_TRACE_DWORDS], variant 30 only
+    const bool tracing = a.trace != nullptr && (int)blockIdx.x < a.trace_wgs;
+    const uint64_t t_start = tracing ? __builtin_amdgcn_s_memtime() : 0;
+    const uint64_t rt_start = tracing ? __builtin_amdgcn_s_memrealtime() : 0;
+    auto stamp = [&](int slot) {
+        if (tracing) {
+            const uint32_t t = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
+            if (threadIdx.x == 0 && slot < CONV_TRACE_DWORDS) lds_trace[slot] = t;
+        }
+    };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WN, wm = wave / WN;
@@ -180,6 +198,27 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
             ri.opix = 0xffffffffu;
         }
         lds_row[tid] = ri;
+    }
+    // BN affine of the tile's channels: fetched here, so that the epilogue has no global load of its own in front of
+    // its arithmetic (tools/conv_trace.py: the per-element float4 loads cost ~10k cycles per workgroup)
+    static_assert(BN <= NT && (BN == 32 || 2 * BN / 64 <= NW), "scale / bias staging");
+    const bool use_scale = a.scale && a.mode == 0, use_bias = a.bias && a.mode == 0 && split == 0;   // (1, 0) in the dgrad epilogue
+    if constexpr (GLDS && BN >= 64) {
+        // asynchronously (4-byte direct-to-LDS loads, 64 floats per wave instruction): they land with the first stage
+        if (wave < 2 * BN / 64) {                                    // wave-uniform
+            const int e = wave * 64 + lane;                          // element of [scale BN | bias BN]
+            const bool is_scale = e < BN;
+            if ((is_scale && use_scale) || (!is_scale && use_bias)) {
+                const float* src = is_scale ? a.scale + co0 + e : a.bias + co0 + (e - BN);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lds_sb + wave * 64), 4, 0, 0);
+            } else {
+                lds_sb[e] = is_scale ? 1.0f : 0.0f;
+            }
+        }
+    } else if (tid < BN) {
+        lds_sb[tid] = use_scale ? a.scale[co0 + tid] : 1.0f;
+        lds_sb[BN + tid] = use_bias ? a.bias[co0 + tid] : 0.0f;
     }
     __syncthreads();
 
@@ -250,12 +289,26 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);            // scalar: LDS destinations live in SGPRs / M0
     const uint16_t* xaddr[GLDS ? PA : 1];
     const uint16_t* wt = a.w;
+    if (a.stagger != 0) {
+        // the first 1024 workgroups start at the same instant, 4 per CU, and would run their load and MFMA phases in
+        // lockstep; dispatch is round-robin over 8 XCDs x 32 CUs, so blockIdx / 256 is the slot on the CU
+        const int slot = (blockIdx.x >> 8) & 3;
+        for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(27);
+    }
     int cur_tap = tap_begin, cur_kc = 0;
+    if (a.krot != 0 && ksteps > ks_begin) {
+        // K rotation: workgroups of different pixel tiles walk the (tap, chunk) sequence from different starting
+        // points, so at any instant they request DIFFERENT weight lines from L2 (fp32 accumulation: the sum only
+        // changes its order)
+        const int r = (int)(((unsigned)tile_m * (unsigned)a.krot) % (unsigned)(ksteps - ks_begin));
+        cur_tap = tap_begin + r / kc_per_tap;
+        cur_kc = r - (r / kc_per_tap) * kc_per_tap;
+    }
     auto setup_tap = [&]() {
         const int dy = __builtin_amdgcn_readfirstlane((int)lds_tap[cur_tap]);
         const int dx = __builtin_amdgcn_readfirstlane((int)lds_tap[CMS_CONV_MAX_TAPS + cur_tap]);
         const int delta = (dy * a.W + dx) * a.Cin;                     // scalar element offset of this tap
-        wt = a.w + ((size_t)cur_tap * a.Cout + co0) * a.Cin;           // scalar base
+        wt = a.w + ((size_t)cur_tap * a.Cout + co0) * a.Cin + cur_kc * BK;   // scalar base (cur_kc != 0 only when rotated)
 #pragma unroll
         for (int i = 0; i < (GLDS ? PA : 0); ++i) {
             const int row = (NW * i + wave) * LRPI + lane / CH;
@@ -264,7 +317,7 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
             const uint32_t iy = (ri.yx >> 16) + (uint32_t)dy, ix = (ri.yx & 0xffffu) + (uint32_t)dx;
             const bool ok = iy < (uint32_t)a.H && ix < (uint32_t)a.W;    // unsigned compare covers the negative side
             xaddr[i] = select_ptr(ok, a.x + (size_t)(ri.in_off + (uint32_t)(c * 8) + (uint32_t)delta),
-                                  a.zeros + (lane & 7) * 8);
+                                  a.zeros + (lane & 7) * 8) + cur_kc * BK;
         }
     };
     auto issue_loads = [&](int buf) {
@@ -285,7 +338,8 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
         for (int i = 0; i < (GLDS ? PA : 0); ++i) xaddr[i] += BK;
         if (++cur_kc == kc_per_tap) {
             cur_kc = 0;
-            if (++cur_tap < tap_end) setup_tap();
+            if (++cur_tap == tap_end) cur_tap = tap_begin;       // wraps only under K rotation (else this is past the last step)
+            setup_tap();
         }
     };
 
@@ -401,16 +455,25 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
         }
         __syncthreads();                                        // the epilogue reuses the staging area
     } else if constexpr (GLDS) {
+        stamp(4);                                               // prologue done (tables, first stage issued)
         for (int ks = ks_begin; ks < ksteps; ++ks) {
+            const int tb = 16 + (ks - ks_begin) * 6;
+            stamp(tb);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the stage has landed in LDS
+            stamp(tb + 1);
             __syncthreads();                                    // ... and everybody else's
+            stamp(tb + 2);
             if (a.dbg != 2) mfma_phase(0);
+            stamp(tb + 3);
             __syncthreads();                                    // all fragment reads done: the buffer may be refilled
+            stamp(tb + 4);
             if (ks + 1 < ksteps && a.dbg != 3) {
                 advance();
                 issue_loads(0);
             }
+            stamp(tb + 5);
         }
+        stamp(5);                                               // K loop done
     } else {
         for (int ks = ks_begin; ks < ksteps; ++ks) {
             __syncthreads();            // previous stage's fragment reads are done
@@ -421,6 +484,10 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
         }
     }
 
+    if (ks_begin >= ksteps) {                       // empty K range (a tap split past the last tap): nothing waited yet
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     // ---- epilogue. The accumulator layout gives every lane runs of 4 consecutive channels of one pixel (8 bytes of
     // NHWC). BN affine, residual / gradient add, ReLU or ReLU-mask are applied in registers (one rounding to bf16).
     // Global traffic of the epilogue is row-contiguous on BOTH sides: the bf16 output tile is transposed through LDS
@@ -477,81 +544,170 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
         }
         if (staged && (a.res || a.mask_src)) stage_tile(a.res ? a.res : a.mask_src);
     }
+    // value of this lane's 4 consecutive channels (i, q) of pixel row j: BN affine, residual / gradient add, ReLU or
+    // ReLU mask. Reads the staged operand from `cell` when there is one (so it must run before the cell is overwritten).
+    auto element = [&](int i, int j, int q, bool valid, size_t obase, const unsigned char* cell, float (&v)[4]) {
+        const int co_l = (wn * TN + i) * 32 + 8 * q + 4 * fhalf;
+        const int co = co0 + co_l;
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int prow_l = (wm * TM + j) * 32 + frow;
-        const RowInfo ri = lds_row[prow_l];
-        const bool valid = ri.opix != 0xffffffffu;
-        const size_t obase = (size_t)ri.opix * a.Cout;
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+        if (a.mode == 0) {
+            const float4 sc = *reinterpret_cast<const float4*>(lds_sb + co_l);
+            const float4 b = *reinterpret_cast<const float4*>(lds_sb + BN + co_l);
+            v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (a.res && (staged || valid)) {
+            const uint2 rr = staged ? *reinterpret_cast<const uint2*>(cell)
+                                    : *reinterpret_cast<const uint2*>(a.res + obase + co);
+            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+        }
+        if (a.mode == 0) {
+            if (a.relu) {
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+            }
+        } else if (both) {
+            const int bit = ((i * TM + j) * 4 + q) * 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co_l = (wn * TN + i) * 32 + 8 * q + 4 * fhalf;
-                const int co = co0 + co_l;
-                unsigned char* cell = smem + slot(prow_l, co_l);
-                float v[4];
+            for (int e = 0; e < 4; ++e) v[e] = ((mbits[bit >> 6] >> ((bit & 63) + e)) & 1u) ? v[e] : 0.0f;
+        } else if (a.mask_src && (staged || valid)) {
+            const uint2 mk = staged ? *reinterpret_cast<const uint2*>(cell)
+                                    : *reinterpret_cast<const uint2*>(a.mask_src + obase + co);
+            // bf16 > 0  <=>  as a signed 16-bit integer it is > 0 (NaNs with the sign bit clear count as > 0,
+            // like the float comparison the reference's ReLU backward makes on NaN-free activations)
+            v[0] = (int16_t)(mk.x & 0xffffu) > 0 ? v[0] : 0.0f;
+            v[1] = (int16_t)(mk.x >> 16) > 0 ? v[1] : 0.0f;
+            v[2] = (int16_t)(mk.y & 0xffffu) > 0 ? v[2] : 0.0f;
+            v[3] = (int16_t)(mk.y >> 16) > 0 ? v[3] : 0.0f;
+        }
+    };
+    // Two loop nests instead of one with both outputs in its body: the fp32 NCHW output (ASPP head / classifier
+    // logits; divisions, per-element stores or atomics, per-lane branches) kept the compiler from scheduling the bf16
+    // path -- every (i, j, q) iteration became its own load / wait / branch island.
+    if (a.y32) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                if (a.mode == 0) {
-                    if (a.scale) {
-                        const float4 sc = *reinterpret_cast<const float4*>(a.scale + co);
-                        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
-                    }
-                    if (a.bias && split == 0) {
-                        const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
-                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                    }
-                }
-                if (a.res && (staged || valid)) {
-                    const uint2 rr = staged ? *reinterpret_cast<const uint2*>(cell)
-                                            : *reinterpret_cast<const uint2*>(a.res + obase + co);
-                    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-                }
-                if (a.mode == 0) {
-                    if (a.relu) {
+        for (int j = 0; j < TM; ++j) {
+            const int prow_l = (wm * TM + j) * 32 + frow;
+            const RowInfo ri = lds_row[prow_l];
+            const bool valid = ri.opix != 0xffffffffu;
+            const size_t obase = (size_t)ri.opix * a.Cout;
+            const int m = (int)ri.m;
+            const int ox = m % a.Wo;
+            const int t = m / a.Wo;
+            const int oy = t % a.Ho;
+            const int n = t / a.Ho;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-                    }
-                } else if (both) {
-                    const int bit = ((i * TM + j) * 4 + q) * 4;
+            for (int i = 0; i < TN; ++i) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ((mbits[bit >> 6] >> ((bit & 63) + e)) & 1u) ? v[e] : 0.0f;
-                } else if (a.mask_src && (staged || valid)) {
-                    const uint2 mk = staged ? *reinterpret_cast<const uint2*>(cell)
-                                            : *reinterpret_cast<const uint2*>(a.mask_src + obase + co);
-                    // bf16 > 0  <=>  as a signed 16-bit integer it is > 0 (NaNs with the sign bit clear count as > 0,
-                    // like the float comparison the reference's ReLU backward makes on NaN-free activations)
-                    v[0] = (int16_t)(mk.x & 0xffffu) > 0 ? v[0] : 0.0f;
-                    v[1] = (int16_t)(mk.x >> 16) > 0 ? v[1] : 0.0f;
-                    v[2] = (int16_t)(mk.y & 0xffffu) > 0 ? v[2] : 0.0f;
-                    v[3] = (int16_t)(mk.y >> 16) > 0 ? v[3] : 0.0f;
-                }
-                if (to_lds) {
-                    uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(cell) = o;
-                }
-                if (a.y32 && valid) {
-                    const int m = (int)ri.m;
-                    const int ox = m % a.Wo;
-                    const int t = m / a.Wo;
-                    const int oy = t % a.Ho;
-                    const int n = t / a.Ho;
+                for (int q = 0; q < 4; ++q) {
+                    const int co_l = (wn * TN + i) * 32 + 8 * q + 4 * fhalf;
+                    const int co = co0 + co_l;
+                    float v[4];
+                    element(i, j, q, valid, obase, smem + slot(prow_l, co_l), v);
+                    if (valid) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (co + e < a.cout_real) {
-                            float* dst = a.y32 + (((size_t)n * a.cout_real + co + e) * a.Ho + oy) * a.Wo + ox;
-                            if (a.ksplit > 1) atomicAdd(dst, v[e]);
-                            else *dst = v[e];
+                        for (int e = 0; e < 4; ++e) {
+                            if (co + e < a.cout_real) {
+                                float* dst = a.y32 + (((size_t)n * a.cout_real + co + e) * a.Ho + oy) * a.Wo + ox;
+                                if (a.ksplit > 1) atomicAdd(dst, v[e]);
+                                else *dst = v[e];
+                            }
                         }
                     }
                 }
             }
         }
     }
+    // bf16 output, operands (if any) staged in LDS: one straight-line nest per epilogue kind, chosen once per
+    // workgroup (wave-uniform), so that the compiler sees 32 independent LDS read -> arithmetic -> LDS write chains
+    auto nest = [&](auto RES_, auto MSK_, auto RELU_) {
+        constexpr int RES = decltype(RES_)::value;      // 1: residual / gradient add from the staged tile
+        constexpr int MSK = decltype(MSK_)::value;      // 1: ReLU mask bits (both operands), 2: mask from the staged tile
+        constexpr int RELU = decltype(RELU_)::value;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co_l = (wn * TN + i) * 32 + 8 * q + 4 * fhalf;
+                const float4 sc = *reinterpret_cast<const float4*>(lds_sb + co_l);
+                const float4 b = *reinterpret_cast<const float4*>(lds_sb + BN + co_l);
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int prow_l = (wm * TM + j) * 32 + frow;
+                    unsigned char* cell = smem + slot(prow_l, co_l);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                    v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    if constexpr (RES == 1 || MSK == 2) {
+                        const uint2 rr = *reinterpret_cast<const uint2*>(cell);
+                        if constexpr (RES == 1) {
+                            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                        } else {
+                            v[0] = (int16_t)(rr.x & 0xffffu) > 0 ? v[0] : 0.0f;
+                            v[1] = (int16_t)(rr.x >> 16) > 0 ? v[1] : 0.0f;
+                            v[2] = (int16_t)(rr.y & 0xffffu) > 0 ? v[2] : 0.0f;
+                            v[3] = (int16_t)(rr.y >> 16) > 0 ? v[3] : 0.0f;
+                        }
+                    }
+                    if constexpr (RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                    }
+                    if constexpr (MSK == 1) {
+                        const int bit = ((i * TM + j) * 4 + q) * 4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ((mbits[bit >> 6] >> ((bit & 63) + e)) & 1u) ? v[e] : 0.0f;
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(cell) = o;
+                }
+            }
+        }
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    if (to_lds && (staged || (!a.res && !a.mask_src))) {
+        if (a.mode == 0) {
+            if (a.res) { if (a.relu) nest(K1{}, K0{}, K1{}); else nest(K1{}, K0{}, K0{}); }
+            else { if (a.relu) nest(K0{}, K0{}, K1{}); else nest(K0{}, K0{}, K0{}); }
+        } else {
+            if (both) nest(K1{}, K1{}, K0{});
+            else if (a.mask_src) nest(K0{}, K2{}, K0{});
+            else if (a.res) nest(K1{}, K0{}, K0{});
+            else nest(K0{}, K0{}, K0{});
+        }
+    } else if (to_lds) {            // register-staged loader: operands come from global memory in accumulator layout
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int prow_l = (wm * TM + j) * 32 + frow;
+            const uint32_t opix = lds_row[prow_l].opix;
+            const bool valid = opix != 0xffffffffu;
+            const size_t obase = (size_t)opix * a.Cout;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co_l = (wn * TN + i) * 32 + 8 * q + 4 * fhalf;
+                    unsigned char* cell = smem + slot(prow_l, co_l);
+                    float v[4];
+                    element(i, j, q, valid, obase, cell, v);
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(cell) = o;
+                }
+            }
+        }
+    }
+    stamp(6);                                       // operands staged, epilogue arithmetic done
     if (to_lds) {
         __syncthreads();
         constexpr int RPP = NT / CPR;               // rows per pass
@@ -565,6 +721,22 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
                 *reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + clog * 8) = val;
             }
         }
+    }
+    if (tracing) {                                  // diagnostic dump: header + stamps of thread 0 (tools/conv_trace.py)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(7);                                   // output stores acknowledged
+        __syncthreads();
+        uint32_t* out = a.trace + (size_t)blockIdx.x * CONV_TRACE_DWORDS;
+        if (tid == 0) {
+            out[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID: wave / simd / cu / sh / se
+            out[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+            out[2] = (uint32_t)rt_start; out[3] = (uint32_t)(rt_start >> 32);
+            out[8] = (uint32_t)(ksteps - ks_begin);
+            out[9] = (uint32_t)tile_m; out[10] = (uint32_t)tile_n;
+            out[11] = (uint32_t)t_start; out[12] = (uint32_t)(t_start >> 32);
+        }
+        for (int i = 4 + tid; i < CONV_TRACE_DWORDS; i += NT)
+            if (i < 8 || i >= 16) out[i] = lds_trace[i];
     }
 }
 
@@ -670,7 +842,7 @@ static void conv_launch_ring(const ConvArgs& a, hipStream_t s) {
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32, NT = 64 * WN * WM;
     const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM) * a.ksplit;
     const size_t stage = (size_t)(BN + BM) * BK * 2 * NS, epi = (size_t)BM * BN * 2;
-    const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16;
+    const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16 + 2 * BN * 4;
     auto kern = conv_igemm_kernel<WN, WM, TN, TM, true, NS, BK, true, OCC>;
     static bool raised = false;
     if (!raised) {
@@ -685,7 +857,7 @@ static void conv_launch(const ConvArgs& a, hipStream_t s, int loader) {      // 
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;                       //         3 = two glds stages of BK = 32
     const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM) * a.ksplit;
     const size_t stage = (size_t)(BN + BM) * CONV_ROW_BYTES * (loader == 2 ? 2 : 1), epi = (size_t)BM * BN * 2;
-    const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16;
+    const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16 + 2 * BN * 4 + (a.trace ? CONV_TRACE_DWORDS * 4 : 0);
     constexpr int NT = 64 * WN * WM;
     if (loader == 2) {
         // two stages of the 128 x 128 tile need 66 KB of dynamic LDS: above the 64 KB a kernel gets without asking
@@ -704,6 +876,15 @@ static void conv_launch(const ConvArgs& a, hipStream_t s, int loader) {      // 
     } else {
         hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, false, 1>), dim3(grid), dim3(NT), lds, s, a);
     }
+}
+
+static uint32_t* g_conv_trace = nullptr;
+static int g_conv_trace_wgs = 0;
+
+extern "C" int cms_conv_set_trace(void* buf, int workgroups) {
+    g_conv_trace = (uint32_t*)buf;
+    g_conv_trace_wgs = buf ? workgroups : 0;
+    return 0;
 }
 
 extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
@@ -730,6 +911,13 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
     a.zeros = (const uint16_t*)d->zeros;
     CMS_REQUIRE(d->zeros == nullptr || d->zeros_bytes >= 2 * d->cin + 128,
                 "conv: the zero run (%d bytes) must be at least 2 * Cin + 128 = %d bytes long", d->zeros_bytes, 2 * d->cin + 128);
+    // 20..23: the default kernel with K rotation (stride 1 / 3 / 5 / 11 K steps per pixel tile)
+    // 24: the default kernel with staggered starts of co-resident workgroups; 25: stagger + rotation by 3
+    a.krot = d->variant == 20 ? 1 : (d->variant == 21 ? 3 : (d->variant == 22 ? 5 : (d->variant == 23 ? 11 : (d->variant == 25 ? 3 : 0))));
+    a.stagger = (d->variant == 24 || d->variant == 25) ? 1 : 0;
+    // 30: the default kernel with per-workgroup cycle stamps into the buffer given to cms_conv_set_trace
+    a.trace = d->variant == 30 ? g_conv_trace : nullptr;
+    a.trace_wgs = g_conv_trace_wgs;
     a.dbg = (d->variant == 2 || d->variant == 3) ? d->variant : (d->variant == 6 ? 2 : (d->variant == 7 ? 3 : 0));
     // variant 0: direct-to-LDS, one stage, up to 4 workgroups per CU (default); 1: register-staged loader;
     // 4: direct-to-LDS, two stages, 2 workgroups per CU -- measured 10 % faster on grids of exactly <= 2 workgroups per
@@ -863,6 +1051,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_u = smem;                  // [64][256 B]  dU tile (only the first BCO channels are used)
     unsigned char* lds_x = smem + 64 * 256;       // [64][256 B]  X tile
+    float* lds_scale = reinterpret_cast<float*>(smem + 2 * 64 * 256);   // [BCO] per-row factor of the epilogue
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wco = wave & 1, wci = wave >> 1;
@@ -886,6 +1075,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int p_begin = ks * a.pix_per_split;
     const int p_end = min(a.M, p_begin + a.pix_per_split);
     if (p_begin >= p_end) return;      // empty slice (uniform for the whole workgroup)
+    // the epilogue's per-row factor, fetched up front (a global load per accumulator row in front of the atomics
+    // serialised 16 * TCO memory round trips; made visible by the first barrier of the pixel loop)
+    if (tid < BCO) lds_scale[tid] = a.scale ? a.scale[co0 + tid] : 1.0f;
 
     // loader: 64 pixels x 16 chunks of 16 B per operand; thread -> chunk (tid & 15), pixel rows (tid >> 4) + 16*i
     const int c16 = tid & 15, prow = tid >> 4;
@@ -1031,9 +1223,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < TCO; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+            const int co_l = (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+            const int co = co0 + co_l;
             if (co >= a.cout_real) continue;
-            const float s = a.scale ? a.scale[co] : 1.0f;
+            const float s = lds_scale[co_l];
             float dot = 0.0f;
 #pragma unroll
             for (int j = 0; j < TCI; ++j) {
@@ -1091,7 +1284,7 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     a.pix_per_split = per;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(tiles * ksplit);
-    const size_t lds = 2 * 64 * 256;
+    const size_t lds = 2 * 64 * 256 + 128 * 4;
     const bool beta = d->dbeta != nullptr;
     const bool plain = d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho &&
                        d->w_in == d->wo;

@@ -247,11 +247,20 @@ typedef struct cms_conv_desc {
                               it like a live pixel's channel run); NULL = register-staged loader                 */
     int variant;           /* 0 = auto (direct-to-LDS, 1 stage), 1 = register-staged loader, 4 = direct-to-LDS with
                               two stages, 5 = two stages of 32 K-elements; 2 / 3 = ablation switches (no MFMA / no
-                              loads) of variant 0, 6 / 7 = the same of variant 4 (tools/conv_ablate*.py)         */
+                              loads) of variant 0, 6 / 7 = the same of variant 4 (tools/conv_ablate*.py); 10..14 = stage
+                              rings, 20..25 = K rotation / staggered starts, 30 = cycle trace (all measured, none
+                              faster: DESIGN.md section 4.1)                                                     */
     int zeros_bytes;       /* length of the `zeros` run (checked against 2 * cin + 128)                          */
 } cms_conv_desc;
 
 int cms_conv_igemm(const cms_conv_desc* d, void* stream);
+
+/* Diagnostic (tools/conv_trace.py): launches with variant 30 stamp s_memtime at every phase of the K loop of wave 0
+ * (own loads landed / barrier / MFMAs issued / barrier / next stage issued) into `buf`: 512 dwords per workgroup for
+ * the first `workgroups` workgroups -- dwords 0..12 = HW_ID, XCC_ID, s_memrealtime at start (lo, hi), cycles since
+ * start at: prologue done, K loop done, epilogue arithmetic done, stores acknowledged; K steps; tile_m; tile_n;
+ * s_memtime at start (lo, hi); from dword 16 on six stamps per K step. NULL switches it off. Not part of the data path. */
+int cms_conv_set_trace(void* buf, int workgroups);
 
 /* dst[tap'][ci][co] = bf16(src[tap][co][ci] * scale[co]) with tap' = ntaps-1-tap when flip != 0: the operand of
  * the dgrad pass (which is cms_conv_igemm on the transposed, tap-flipped, BN-scale-folded weights). */

@@ -25,6 +25,8 @@ SHAPES = [
     ('c3 l4 3x3d4 512->512', 8, 65, 129, 512, 512, 3, 4, False),
 ]
 VARIANTS = [(0, 0)] + [(0, v) for v in (10, 11, 12, 13, 14)] + [(256, 0)] + [(256, v) for v in (10, 11, 12, 13, 14)]
+if os.environ.get('CMS_VARIANTS'):            # e.g. CMS_VARIANTS=0:0,0:20,0:21 (tile:variant)
+    VARIANTS = [tuple(int(v) for v in p.split(':')) for p in os.environ['CMS_VARIANTS'].split(',')]
 if len(sys.argv) > 1:
     SHAPES = [s for s in SHAPES if any(a in s[0] for a in sys.argv[1:])]
 
@@ -62,7 +64,10 @@ for name, N, H, W, Cin, Cout, k, dil, use_res in SHAPES:
         for _ in range(3):
             out.fill_(7.0)
             ops.conv_igemm(x, wp, taps, scale=scale, bias=bias, res=res, relu=True, out=out, tile=tile, variant=var)
-            if not torch.equal(out, ref):
+            if var >= 20:      # K rotation changes the summation order: one bf16 ulp of the output
+                if not torch.allclose(out.float(), ref.float(), rtol=2 ** -7, atol=2e-2):
+                    ok = False
+            elif not torch.equal(out, ref):
                 ok = False
         if not ok:
             bad.append((name, tile, var, float((out.float() - ref.float()).abs().max())))
