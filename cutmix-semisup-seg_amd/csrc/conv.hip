@@ -26,6 +26,7 @@
 //
 // Roofline: dilated 3x3 (layer3: K = 2304, AI ~ 680 FLOP/B) is MFMA-bound; 1x1 (AI ~ 180 FLOP/B) is HBM-bound on the
 // activation stream; DESIGN.md section 4 lists algorithmic FLOPs / bytes per layer shape.
+#include <cstdlib>
 #include <type_traits>
 #include "common.hpp"
 
@@ -100,6 +101,22 @@ struct RowInfo {            // one per pixel row of the workgroup tile, computed
 // registers, no ds_write); the XOR swizzle is applied on the SOURCE side (the LDS image of a wave instruction is
 // lane-linear), out-of-range rows read a zero page. One LDS buffer per workgroup, up to 4 workgroups per CU: the
 // load latency of a workgroup is covered by the MFMA phases of its neighbours.
+// Buffer-addressed direct-to-LDS load of 16 bytes per lane. The descriptor type and the builtins exist in the device
+// compilation only; the host pass (which still has to instantiate the kernel to emit its launch stub) sees dummies.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_buf_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, unsigned char* lds, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+#else
+struct buf_rsrc_t {};
+__device__ __forceinline__ buf_rsrc_t make_buf_rsrc(const void*, int) { return buf_rsrc_t{}; }
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, unsigned char*, uint32_t, uint32_t) {}
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_lds() {
     // this wave's direct-to-LDS loads except the N youngest have landed; LDS reads of the previous phase are done
@@ -109,7 +126,12 @@ __device__ __forceinline__ void wait_vmcnt_lds() {
 // OCC = workgroups per CU the register budget is declared for (0: the round-1 defaults). PF = the fragment reads of
 // K sub-step kk+1 are issued BEFORE the MFMAs of sub-step kk (register double buffer): without it every sub-step is
 // "4 ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 4 MFMAs", i.e. the LDS latency of each sub-step is exposed to the wave.
-template <int WN, int WM, int TN, int TM, bool GLDS, int NS, int BK = CONV_BK, bool PF = false, int OCC = 0>
+// BUFA = the direct-to-LDS loads use buffer addressing (buffer_load_dwordx4 ... offen lds): descriptor in SGPRs, one
+// 32-bit byte offset per lane and row piece (rewritten once per TAP), the K position in a scalar offset -- a K step then
+// issues its 8 pieces per wave with NO vector ALU instruction (the flat-address form spends ~5 per piece on 64-bit
+// pointer arithmetic, which tools/conv_trace.py shows as a 700..1450-cycle issue phase). Padding and rows past M are
+// out-of-range offsets: the hardware bounds check writes zeros, no zero page.
+template <int WN, int WM, int TN, int TM, bool GLDS, int NS, int BK = CONV_BK, bool PF = false, int OCC = 0, bool BUFA = false>
 __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
                                            : ((GLDS && WN * WM == 4 && TN * TM == 4) ? ((NS == 1 || BK == 32) ? 4 : 2)
                                               : ((WN * WM == 4 && TN * TM == 8) ? 2 : 1))) void conv_igemm_kernel(ConvArgs a) {
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
     for (int i = 0; i < PB; ++i) {
         const int row = GLDS ? (NW * i + wave) * LRPI + lane / CH : lrow + RSTEP * i;
         const int c = GLDS ? ((lane % CH) ^ ((row >> WSH) & (CH - 1))) : chunk;
-        woff[i] = (uint32_t)(row * a.Cin + c * 8);
+        woff[i] = (uint32_t)(row * a.Cin + c * 8) * (BUFA ? 2u : 1u);     // elements (bytes under buffer addressing)
     }
     const uint32_t st_off = swz(lrow, chunk);            // rows lrow + RSTEP*i share the swizzle term (RSTEP % 16 == 0)
 
@@ -287,8 +309,13 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
     // channel run, so dead rows advance like live ones). This took the load phase from ~125 to ~40 instructions per
     // stage and removed an LDS round trip from every stage's critical path.
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);            // scalar: LDS destinations live in SGPRs / M0
-    const uint16_t* xaddr[GLDS ? PA : 1];
+    const uint16_t* xaddr[(GLDS && !BUFA) ? PA : 1];
     const uint16_t* wt = a.w;
+    static_assert(!BUFA || GLDS, "buffer addressing belongs to the direct-to-LDS loader");
+    uint32_t xvoff[BUFA ? PA : 1];                   // BUFA: byte offset of this lane's 16 bytes of row piece i (tap applied)
+    uint32_t soff_x = 0, soff_w = 0;                 // BUFA: scalar byte offsets (K position; tap and channel tile of W)
+    const buf_rsrc_t rsrc_x = make_buf_rsrc(a.x, BUFA ? a.N * a.H * a.W * a.Cin * 2 : 0);
+    const buf_rsrc_t rsrc_w = make_buf_rsrc(a.w, BUFA ? a.ntaps * a.Cout * a.Cin * 2 : 0);
     if (a.stagger != 0) {
         // the first 1024 workgroups start at the same instant, 4 per CU, and would run their load and MFMA phases in
         // lockstep; dispatch is round-robin over 8 XCDs x 32 CUs, so blockIdx / 256 is the slot on the CU
@@ -308,9 +335,23 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
         const int dy = __builtin_amdgcn_readfirstlane((int)lds_tap[cur_tap]);
         const int dx = __builtin_amdgcn_readfirstlane((int)lds_tap[CMS_CONV_MAX_TAPS + cur_tap]);
         const int delta = (dy * a.W + dx) * a.Cin;                     // scalar element offset of this tap
+        if constexpr (BUFA) {
+            soff_x = (uint32_t)(cur_kc * BK * 2);
+            soff_w = (uint32_t)((((cur_tap * a.Cout + co0) * a.Cin) + cur_kc * BK) * 2);
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int row = (NW * i + wave) * LRPI + lane / CH;
+                const int c = (lane % CH) ^ ((row >> WSH) & (CH - 1));
+                const RowInfo ri = lds_row[row];
+                const uint32_t iy = (ri.yx >> 16) + (uint32_t)dy, ix = (ri.yx & 0xffffu) + (uint32_t)dx;
+                const bool ok = iy < (uint32_t)a.H && ix < (uint32_t)a.W;    // unsigned compare covers the negative side
+                xvoff[i] = ok ? (ri.in_off + (uint32_t)(c * 8) + (uint32_t)delta) * 2u : 0x80000000u;   // out of range: zeros
+            }
+            return;
+        }
         wt = a.w + ((size_t)cur_tap * a.Cout + co0) * a.Cin + cur_kc * BK;   // scalar base (cur_kc != 0 only when rotated)
 #pragma unroll
-        for (int i = 0; i < (GLDS ? PA : 0); ++i) {
+        for (int i = 0; i < ((GLDS && !BUFA) ? PA : 0); ++i) {
             const int row = (NW * i + wave) * LRPI + lane / CH;
             const int c = (lane % CH) ^ ((row >> WSH) & (CH - 1));
             const RowInfo ri = lds_row[row];
@@ -321,8 +362,17 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
         }
     };
     auto issue_loads = [&](int buf) {
+        if constexpr (BUFA) {
 #pragma unroll
-        for (int i = 0; i < (GLDS ? PA : 0); ++i)
+            for (int i = 0; i < PA; ++i)
+                buf_load_lds16(rsrc_x, lds_x + buf * STAGE_BYTES + (NW * i + wave_s) * 1024, xvoff[i], soff_x);
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                buf_load_lds16(rsrc_w, lds_w + buf * STAGE_BYTES + (NW * i + wave_s) * 1024, woff[i], soff_w);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < ((GLDS && !BUFA) ? PA : 0); ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xaddr[i],
                                              (__attribute__((address_space(3))) void*)(lds_x + buf * STAGE_BYTES + (NW * i + wave_s) * 1024),
                                              16, 0, 0);
@@ -333,9 +383,14 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
                                              16, 0, 0);
     };
     auto advance = [&]() {
-        wt += BK;
+        if constexpr (BUFA) {
+            soff_x += BK * 2;
+            soff_w += BK * 2;
+        } else {
+            wt += BK;
 #pragma unroll
-        for (int i = 0; i < (GLDS ? PA : 0); ++i) xaddr[i] += BK;
+            for (int i = 0; i < (GLDS ? PA : 0); ++i) xaddr[i] += BK;
+        }
         if (++cur_kc == kc_per_tap) {
             cur_kc = 0;
             if (++cur_tap == tap_end) cur_tap = tap_begin;       // wraps only under K rotation (else this is past the last step)
@@ -837,13 +892,13 @@ static int conv_check(const cms_conv_desc* d) {
 
 // Pipelined variants of the direct-to-LDS kernel (cms_conv_desc.variant 10..14): NS ring stages of BK K-elements,
 // fragment double buffer, register budget declared for OCC workgroups per CU.
-template <int WN, int WM, int TN, int TM, int NS, int BK, int OCC>
+template <int WN, int WM, int TN, int TM, int NS, int BK, int OCC, bool BUFA = false>
 static void conv_launch_ring(const ConvArgs& a, hipStream_t s) {
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32, NT = 64 * WN * WM;
     const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM) * a.ksplit;
     const size_t stage = (size_t)(BN + BM) * BK * 2 * NS, epi = (size_t)BM * BN * 2;
     const size_t lds = (stage > epi ? stage : epi) + 80 + BM * 16 + 2 * BN * 4;
-    auto kern = conv_igemm_kernel<WN, WM, TN, TM, true, NS, BK, true, OCC>;
+    auto kern = conv_igemm_kernel<WN, WM, TN, TM, true, NS, BK, true, OCC, BUFA>;
     static bool raised = false;
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -871,6 +926,8 @@ static void conv_launch(const ConvArgs& a, hipStream_t s, int loader) {      // 
     } else if (loader == 3 && BN % (16 * WN * WM) == 0 && BM % (16 * WN * WM) == 0) {
         if constexpr (BN % (16 * WN * WM) == 0 && BM % (16 * WN * WM) == 0)       // 64-byte rows: 16 rows per wave load
             hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 2, 32>), dim3(grid), dim3(NT), lds, s, a);
+    } else if (loader == 4) {                    // direct-to-LDS with buffer addressing
+        hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 1, CONV_BK, false, 0, true>), dim3(grid), dim3(NT), lds, s, a);
     } else if (loader == 1 || loader == 3) {
         hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 1>), dim3(grid), dim3(NT), lds, s, a);
     } else {
@@ -887,9 +944,32 @@ extern "C" int cms_conv_set_trace(void* buf, int workgroups) {
     return 0;
 }
 
-extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
-    int rc = conv_check(d);
+// A/B switch for whole-step measurements (bench.py under CMS_CONV_DEFAULT_VARIANT=43 etc.): the variant used by
+// descriptors that ask for 0 = auto. Diagnostic only; read once.
+static int conv_default_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CMS_CONV_DEFAULT_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
+    int rc = conv_check(d_in);
     if (rc) return rc;
+    cms_conv_desc d_copy;
+    const cms_conv_desc* d = d_in;
+    if (d_in->variant == 0 && conv_default_variant() != 0) {
+        const int v = conv_default_variant();
+        // ring variants exist for the 128-channel tile of the bf16 output only
+        const bool ring = (v >= 10 && v <= 14) || (v >= 50 && v <= 54);
+        if (!ring || (d_in->cout % 128 == 0 && (d_in->tile == 0 || d_in->tile == 128) && d_in->zeros != nullptr)) {
+            d_copy = *d_in;
+            d_copy.variant = v;
+            d = &d_copy;
+        }
+    }
     ConvArgs a;
     a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.y = (uint16_t*)d->y; a.y32 = d->y32;
     a.scale = d->scale; a.bias = d->bias; a.res = (const uint16_t*)d->res; a.mask_src = (const uint16_t*)d->mask_src;
@@ -916,7 +996,7 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
     a.krot = d->variant == 20 ? 1 : (d->variant == 21 ? 3 : (d->variant == 22 ? 5 : (d->variant == 23 ? 11 : (d->variant == 25 ? 3 : 0))));
     a.stagger = (d->variant == 24 || d->variant == 25) ? 1 : 0;
     // 30: the default kernel with per-workgroup cycle stamps into the buffer given to cms_conv_set_trace
-    a.trace = d->variant == 30 ? g_conv_trace : nullptr;
+    a.trace = (d->variant == 30 || d->variant == 41) ? g_conv_trace : nullptr;      // 41: trace of variant 40
     a.trace_wgs = g_conv_trace_wgs;
     a.dbg = (d->variant == 2 || d->variant == 3) ? d->variant : (d->variant == 6 ? 2 : (d->variant == 7 ? 3 : 0));
     // variant 0: direct-to-LDS, one stage, up to 4 workgroups per CU (default); 1: register-staged loader;
@@ -925,9 +1005,27 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d, void* stream) {
     // 2 / 3: ablation switches of the default kernel (no MFMA / no loads after the first stage)
     // 5: direct-to-LDS, two stages of 32 K-elements each (same LDS footprint and occupancy as the default)
     // 6 / 7: the ablation switches applied to the two-stage kernel (variant 4)
+    // default (and 40 / 41): direct-to-LDS with buffer addressing when both tensors are below 2 GB; 43 forces the flat
+    // 64-bit addresses of round 1 (A/B: profiles/r02o_*)
+    const bool small = (size_t)d->n * d->h * d->w_in * d->cin * 2 < (1ull << 31) &&
+                       (size_t)d->ntaps * d->cout * d->cin * 2 < (1ull << 31);
     const int glds = (d->zeros == nullptr || d->variant == 1) ? 0
-                     : ((d->variant == 4 || d->variant == 6 || d->variant == 7) ? 2 : (d->variant == 5 ? 3 : 1));
+                     : ((d->variant == 4 || d->variant == 6 || d->variant == 7) ? 2
+                        : (d->variant == 5 ? 3 : ((small && d->variant != 43) ? 4 : 1)));      // 43: flat addresses (round-1 loader)
     const int tile = d->tile;   // 0 = auto
+    if (d->variant >= 50 && d->variant <= 54) {
+        // 50..54: the stage rings 10..14 of the 128 x 128 tile with buffer addressing
+        CMS_REQUIRE(d->zeros != nullptr && small && d->cout % 128 == 0 && (tile == 0 || tile == 128),
+                    "conv: variants 50..54 need the zero run, tensors below 2 GB and the 128-channel tile");
+        switch (d->variant) {
+        case 50: conv_launch_ring<2, 2, 2, 2, 1, 64, 4, true>(a, s); break;
+        case 51: conv_launch_ring<2, 2, 2, 2, 2, 64, 2, true>(a, s); break;
+        case 52: conv_launch_ring<2, 2, 2, 2, 3, 32, 3, true>(a, s); break;
+        case 53: conv_launch_ring<2, 2, 2, 2, 4, 32, 2, true>(a, s); break;
+        default: conv_launch_ring<2, 2, 2, 2, 3, 64, 1, true>(a, s); break;
+        }
+        return launch_status("cms_conv_igemm");
+    }
     if (d->variant >= 10 && d->variant <= 14) {
         // pipelined kernels (ring of LDS stages with counted vmcnt, fragment double buffer), 128 x 128 tile on 4 waves or
         // 128 (co) x 256 (pixels) on 8 waves:  10: 1 stage of 64   11: 2 x 64   12: 3 x 32   13: 4 x 32   14: 3 x 64
@@ -1031,6 +1129,8 @@ struct WgradArgs {
     const uint16_t* w;     // bf16 [ntaps][Cout][Cin] or NULL   } side outputs for a trainable BN affine:
     float* wdot;           // [Cout] += <W, G> per output channel } see cms_wgrad_desc
     float* dbeta;          // [Cout] += sum_p dU[p][co]
+    uint32_t* trace;       // diagnostic: cycle stamps (cms_conv_set_trace), NULL in production
+    int trace_wgs;
     short tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
 };
 
@@ -1052,6 +1152,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     unsigned char* lds_u = smem;                  // [64][256 B]  dU tile (only the first BCO channels are used)
     unsigned char* lds_x = smem + 64 * 256;       // [64][256 B]  X tile
     float* lds_scale = reinterpret_cast<float*>(smem + 2 * 64 * 256);   // [BCO] per-row factor of the epilogue
+    uint32_t* lds_trace = reinterpret_cast<uint32_t*>(smem + 2 * 64 * 256 + 128 * 4);   // [CONV_TRACE_DWORDS] when tracing
+    const bool tracing = a.trace != nullptr && (int)blockIdx.x < a.trace_wgs;
+    const uint64_t t_start = tracing ? __builtin_amdgcn_s_memtime() : 0;
+    const uint64_t rt_start = tracing ? __builtin_amdgcn_s_memrealtime() : 0;
+    auto stamp = [&](int slot) {
+        if (tracing) {
+            const uint32_t t = (uint32_t)(__builtin_amdgcn_s_memtime() - t_start);
+            if (threadIdx.x == 0 && slot < CONV_TRACE_DWORDS) lds_trace[slot] = t;
+        }
+    };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wco = wave & 1, wci = wave >> 1;
@@ -1169,12 +1279,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int pix_in_blk = 8 * (g >> 1) + (li >> 2);        // pixel row this lane supplies (within a 16-pixel k-step)
 
     load_tile();
+    stamp(4);                                               // prologue done (first stage's loads issued)
     for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+        const int tb = 16 + ((p0 - p_begin) >> 6) * 6;
+        stamp(tb);
         __syncthreads();
-        store_tile();
+        stamp(tb + 1);
+        store_tile();                                       // (waits for the stage's global loads)
+        stamp(tb + 2);
         __syncthreads();
+        stamp(tb + 3);
         advance();
         load_tile();                                        // next stage (all-zero past the end of the slice)
+        stamp(tb + 4);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {                    // 16 pixels per MFMA
             u32x4 fu[TCO], fx[TCI];
@@ -1214,7 +1331,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 }
             }
         }
+        stamp(tb + 5);
     }
+    stamp(5);                                               // pixel loop done
 
     // epilogue: acc rows = co, columns = ci (lane&31) -> 128-byte contiguous atomics per row
     float* dwt = a.dw + (size_t)tap * a.dw_cout * a.Cin;
@@ -1244,6 +1363,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 if (do_beta && fcol == 0) atomicAdd(a.dbeta + co, accb[i][r]);
             }
         }
+    }
+    if (tracing) {
+        stamp(6);                                           // atomics issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(7);                                           // ... and acknowledged
+        __syncthreads();
+        uint32_t* out = a.trace + (size_t)blockIdx.x * CONV_TRACE_DWORDS;
+        if (tid == 0) {
+            out[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            out[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            out[2] = (uint32_t)rt_start; out[3] = (uint32_t)(rt_start >> 32);
+            out[8] = (uint32_t)((p_end - p_begin + 63) >> 6);
+            out[9] = (uint32_t)ks; out[10] = (uint32_t)(tap * 256 + tci * 16 + tco);
+        }
+        for (int i = 4 + tid; i < CONV_TRACE_DWORDS; i += 256)
+            if (i < 8 || i >= 16) out[i] = lds_trace[i];
     }
 }
 
@@ -1284,7 +1419,9 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     a.pix_per_split = per;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(tiles * ksplit);
-    const size_t lds = 2 * 64 * 256 + 128 * 4;
+    a.trace = g_conv_trace;                      // diagnostic (cms_conv_set_trace); NULL in production
+    a.trace_wgs = g_conv_trace_wgs;
+    const size_t lds = 2 * 64 * 256 + 128 * 4 + (a.trace ? CONV_TRACE_DWORDS * 4 : 0);
     const bool beta = d->dbeta != nullptr;
     const bool plain = d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho &&
                        d->w_in == d->wo;

@@ -259,7 +259,8 @@ int cms_conv_igemm(const cms_conv_desc* d, void* stream);
  * (own loads landed / barrier / MFMAs issued / barrier / next stage issued) into `buf`: 512 dwords per workgroup for
  * the first `workgroups` workgroups -- dwords 0..12 = HW_ID, XCC_ID, s_memrealtime at start (lo, hi), cycles since
  * start at: prologue done, K loop done, epilogue arithmetic done, stores acknowledged; K steps; tile_m; tile_n;
- * s_memtime at start (lo, hi); from dword 16 on six stamps per K step. NULL switches it off. Not part of the data path. */
+ * s_memtime at start (lo, hi); from dword 16 on six stamps per K step. While a buffer is set, cms_conv_wgrad launches
+ * stamp their stages the same way (tools/wgrad_trace.py). NULL switches it off. Not part of the data path. */
 int cms_conv_set_trace(void* buf, int workgroups);
 
 /* dst[tap'][ci][co] = bf16(src[tap][co][ci] * scale[co]) with tap' = ntaps-1-tap when flip != 0: the operand of

@@ -50,7 +50,8 @@ for name, N, H, W, Cin, Cout, k, dil, use_res in SHAPES:
     t_plain = e0.elapsed_time(e1) * 1e3
     lib.cms_conv_set_trace(buf.data_ptr(), nwg)
     e0.record()
-    ops.conv_igemm(x, wp, taps, scale=scale, bias=bias, res=res, relu=True, out=out, variant=30)
+    ops.conv_igemm(x, wp, taps, scale=scale, bias=bias, res=res, relu=True, out=out,
+                   variant=int(os.environ.get('CMS_TRACE_VARIANT', '30')))
     e1.record()
     torch.cuda.synchronize()
     t_traced = e0.elapsed_time(e1) * 1e3
