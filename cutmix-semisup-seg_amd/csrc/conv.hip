@@ -26,6 +26,7 @@
 //
 // Roofline: dilated 3x3 (layer3: K = 2304, AI ~ 680 FLOP/B) is MFMA-bound; 1x1 (AI ~ 180 FLOP/B) is HBM-bound on the
 // activation stream; DESIGN.md section 4 lists algorithmic FLOPs / bytes per layer shape.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include "common.hpp"
@@ -103,18 +104,65 @@ struct RowInfo {            // one per pixel row of the workgroup tile, computed
 // load latency of a workgroup is covered by the MFMA phases of its neighbours.
 // Buffer-addressed direct-to-LDS load of 16 bytes per lane. The descriptor type and the builtins exist in the device
 // compilation only; the host pass (which still has to instantiate the kernel to emit its launch stub) sees dummies.
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+//
+// The loads are issued from INLINE ASSEMBLY, on purpose: hipcc counts a direct-to-LDS load it knows about (the
+// __builtin_amdgcn_*_load_lds forms) as a pending LDS WRITE that any later ds_read may alias, and puts
+// `s_waitcnt vmcnt(0)` in front of the first LDS read that follows it in program order -- with more than one stage in
+// flight that drains the whole pipeline every K step (seen in the ISA of every stage-ring variant of rounds 1 and 2,
+// which is why none of them ever beat the single-stage kernel). Loads issued from asm are invisible to that
+// bookkeeping; completion is counted by the kernels' own `s_waitcnt vmcnt(N)` statements + barrier.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+struct buf_rsrc_t { i32x4_t w; };
 __device__ __forceinline__ buf_rsrc_t make_buf_rsrc(const void* p, int bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+    const uint64_t addr = (uint64_t)p;
+    buf_rsrc_t r;
+    r.w[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)addr);
+    r.w[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(addr >> 32) & 0xffffu));      // stride 0: raw buffer
+    r.w[2] = __builtin_amdgcn_readfirstlane(bytes);                                         // num_records (bytes)
+    r.w[3] = 0x00020000;
+    return r;
 }
-__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, unsigned char* lds, uint32_t voff, uint32_t soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+// one wave instruction: 16 bytes per lane from rsrc[voff + soff] to LDS bytes [lds, lds + 1024) lane-linearly
+__device__ __forceinline__ void buf_load_lds16(const buf_rsrc_t& r, const unsigned char* lds, uint32_t voff, uint32_t soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr_of(lds)), "v"(voff), "s"(r.w), "s"(soff)
+                 : "memory");
+}
+// four of them: LDS destinations lds + k * step (k = 0..3)
+__device__ __forceinline__ void buf_load_lds16_x4(const buf_rsrc_t& r, const unsigned char* lds, uint32_t step, uint32_t v0,
+                                                  uint32_t v1, uint32_t v2, uint32_t v3, uint32_t soff) {
+    unsigned keep;
+    const uint32_t l0 = lds_addr_of(lds);
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %9, %10 offen lds\n\t"
+                 "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %6, %9, %10 offen lds\n\t"
+                 "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %7, %9, %10 offen lds\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %8, %9, %10 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(l0), "s"(l0 + step), "s"(l0 + 2 * step), "s"(l0 + 3 * step), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(r.w),
+                   "s"(soff)
+                 : "memory");
+}
+// flat form, 4 bytes per lane (64 floats per wave instruction)
+__device__ __forceinline__ void glds4_asm(const void* gsrc, const void* lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr_of(lds))
+                 : "memory");
 }
 #else
-struct buf_rsrc_t {};
-__device__ __forceinline__ buf_rsrc_t make_buf_rsrc(const void*, int) { return buf_rsrc_t{}; }
-__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, unsigned char*, uint32_t, uint32_t) {}
+__device__ __forceinline__ void buf_load_lds16(const buf_rsrc_t&, const unsigned char*, uint32_t, uint32_t) {}
+__device__ __forceinline__ void buf_load_lds16_x4(const buf_rsrc_t&, const unsigned char*, uint32_t, uint32_t, uint32_t, uint32_t,
+                                                  uint32_t, uint32_t) {}
+__device__ __forceinline__ void glds4_asm(const void*, const void*) {}
 #endif
 
 template <int N>
@@ -227,13 +275,13 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
     const bool use_scale = a.scale && a.mode == 0, use_bias = a.bias && a.mode == 0 && split == 0;   // (1, 0) in the dgrad epilogue
     if constexpr (GLDS && BN >= 64) {
         // asynchronously (4-byte direct-to-LDS loads, 64 floats per wave instruction): they land with the first stage
-        if (wave < 2 * BN / 64) {                                    // wave-uniform
-            const int e = wave * 64 + lane;                          // element of [scale BN | bias BN]
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        if (wave_u < 2 * BN / 64) {                                  // wave-uniform
+            const int e = wave_u * 64 + lane;                        // element of [scale BN | bias BN]
             const bool is_scale = e < BN;
             if ((is_scale && use_scale) || (!is_scale && use_bias)) {
                 const float* src = is_scale ? a.scale + co0 + e : a.bias + co0 + (e - BN);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(lds_sb + wave * 64), 4, 0, 0);
+                glds4_asm(src, lds_sb + wave_u * 64);
             } else {
                 lds_sb[e] = is_scale ? 1.0f : 0.0f;
             }
@@ -429,6 +477,7 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 if (kk + 1 < KK) frag_read(kk + 1, fw[(kk + 1) & 1], fx[(kk + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);           // keep the reads of kk+1 in front of the MFMAs of kk
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
@@ -438,6 +487,7 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
                                                                             __builtin_bit_cast(bf16x8, fx[kk & 1][j]),
                                                                             acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             return;
         }
@@ -1145,14 +1195,22 @@ __device__ __forceinline__ uint32_t wg_off(int pix, int ch) {     // byte offset
 // no bounds test -- two thirds of the network's weight-gradient launches.
 // BETA = also accumulate sum_p dU[p][co] (cms_wgrad_desc.dbeta). A compile-time switch: as a run-time one its extra
 // accumulators sat in the main loop of EVERY launch (32 v_accvgpr moves per stage, +3-5 % on the DeepLab v2 step).
-template <int TCO, int TCI, bool PLAIN, bool BETA>      // 32x32 MFMA tiles per wave along co / ci; waves are 2 x 2
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+// DMA = both operands go global -> LDS with buffer-addressed direct-to-LDS loads (the swizzle applied on the source
+// side), no staging registers and no ds_write; one LDS stage, up to 4 workgroups per CU overlap each other's phases.
+// PLAIN launches then advance a SCALAR offset per stage (no vector ALU in the loader at all); rows past the slice are
+// out-of-range offsets (hardware zero fill). tools/wgrad_trace.py: the register loader spent 1450..1900 of a
+// 3700..4100-cycle stage issuing its 8 loads (64-bit address arithmetic) and 750 waiting for them + ds_write.
+template <int TCO, int TCI, bool PLAIN, bool BETA, bool DMA = false, int DNS = 1>   // 32x32 MFMA tiles per wave along co / ci; waves are 2 x 2
+__global__ __launch_bounds__(256, DMA ? ((BETA || !PLAIN) ? 3 : 4) : 1) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int BCO = 2 * TCO * 32, BCI = 2 * TCI * 32;       // <= 128 each
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WG_STAGE = 2 * 64 * 256;        // one stage: dU tile + X tile (32 KB)
+    constexpr int WG_NS = DMA ? DNS : 1;          // DMA, DNS = 2: the loads of stage k+1 fly during the MFMAs of stage k
+    static_assert(DNS == 1 || DNS == 2, "one or two stages");
     unsigned char* lds_u = smem;                  // [64][256 B]  dU tile (only the first BCO channels are used)
     unsigned char* lds_x = smem + 64 * 256;       // [64][256 B]  X tile
-    float* lds_scale = reinterpret_cast<float*>(smem + 2 * 64 * 256);   // [BCO] per-row factor of the epilogue
-    uint32_t* lds_trace = reinterpret_cast<uint32_t*>(smem + 2 * 64 * 256 + 128 * 4);   // [CONV_TRACE_DWORDS] when tracing
+    float* lds_scale = reinterpret_cast<float*>(smem + WG_NS * WG_STAGE);   // [BCO] per-row factor of the epilogue
+    uint32_t* lds_trace = reinterpret_cast<uint32_t*>(smem + WG_NS * WG_STAGE + 128 * 4);   // [CONV_TRACE_DWORDS] when tracing
     const bool tracing = a.trace != nullptr && (int)blockIdx.x < a.trace_wgs;
     const uint64_t t_start = tracing ? __builtin_amdgcn_s_memtime() : 0;
     const uint64_t rt_start = tracing ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -1255,6 +1313,68 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
     };
 
+    // ---- DMA loader: wave instruction (pass i, wave w) fills the 4 pixel rows of piece 4i + w (1 KB, lane-linear):
+    // lane -> row lane >> 4, PHYSICAL 16-byte chunk lane & 15, and fetches the LOGICAL chunk the swizzle puts there
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int drow = lane >> 4, dcp = lane & 15;
+    const int dchl = ((((dcp >> 2) ^ drow) & 3) << 5) + ((dcp & 3) << 3);       // logical channel of this lane's 16 bytes
+    constexpr uint32_t OOB = 0x80000000u;                                       // beyond any (< 2 GB) tensor: zero fill
+    uint32_t uvoff[DMA ? 4 : 1], xvoff[DMA ? 4 : 1];
+    uint32_t soff_u = 0, soff_x = 0;                                            // scalar: stage * 64 pixels (PLAIN: both)
+    const buf_rsrc_t rsrc_u = make_buf_rsrc(a.du, DMA ? a.M * a.Cout * 2 : 0);
+    const buf_rsrc_t rsrc_x = make_buf_rsrc(a.x, DMA ? a.N * a.H * a.W * a.Cin * 2 : 0);
+    int dn[(DMA && !PLAIN) ? 4 : 1], dyy[(DMA && !PLAIN) ? 4 : 1], dxx[(DMA && !PLAIN) ? 4 : 1];   // (n, oy, ox) cursors
+    auto dma_x_offsets = [&](int p0) {             // !PLAIN: X offsets of the stage starting at pixel p0 from the cursors
+        if constexpr (DMA && !PLAIN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = p0 + 4 * (4 * i + wave) + drow;
+                const uint32_t iy = (uint32_t)(dyy[i] * a.stride + dy), ix = (uint32_t)(dxx[i] * a.stride + dx);
+                const bool ok = m < p_end && dchl < BCI && iy < (uint32_t)a.H && ix < (uint32_t)a.W;
+                xvoff[i] = ok ? (uint32_t)((((dn[i] * a.H + (int)iy) * a.W + (int)ix) * a.Cin + ci0 + dchl) * 2) : OOB;
+            }
+        }
+    };
+    auto dma_tail_mask = [&](int p0) {             // last, partial stage of the slice: rows >= p_end read zeros
+        if constexpr (DMA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = p0 + 4 * (4 * i + wave) + drow;
+                if (m >= p_end) {
+                    uvoff[i] = OOB;
+                    xvoff[i] = OOB;
+                }
+            }
+        }
+    };
+    auto dma_issue = [&](int buf) {
+        if constexpr (DMA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                buf_load_lds16(rsrc_u, lds_u + buf * WG_STAGE + (4 * i + wave_s) * 1024, uvoff[i], soff_u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                buf_load_lds16(rsrc_x, lds_x + buf * WG_STAGE + (4 * i + wave_s) * 1024, xvoff[i], soff_x);
+        }
+    };
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = p_begin + 4 * (4 * i + wave) + drow;
+            uvoff[i] = dchl < BCO ? (uint32_t)((m * a.Cout + co0 + dchl) * 2) : OOB;
+            if constexpr (PLAIN) {
+                xvoff[i] = dchl < BCI ? (uint32_t)((m * a.Cin + ci0 + dchl) * 2) : OOB;
+            } else {
+                dxx[i] = m % a.Wo;
+                const int t = m / a.Wo;
+                dyy[i] = t % a.Ho;
+                dn[i] = t / a.Ho;
+            }
+        }
+        dma_x_offsets(p_begin);
+        if (p_begin + 64 > p_end) dma_tail_mask(p_begin);
+    }
+
     f32x16 acc[TCO][TCI];
 #pragma unroll
     for (int i = 0; i < TCO; ++i)
@@ -1278,31 +1398,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int ch_in_tile = 16 * (g & 1) + 4 * (li & 3);     // channel chunk this lane SUPPLIES (within a 32-wide tile)
     const int pix_in_blk = 8 * (g >> 1) + (li >> 2);        // pixel row this lane supplies (within a 16-pixel k-step)
 
-    load_tile();
-    stamp(4);                                               // prologue done (first stage's loads issued)
-    for (int p0 = p_begin; p0 < p_end; p0 += 64) {
-        const int tb = 16 + ((p0 - p_begin) >> 6) * 6;
-        stamp(tb);
-        __syncthreads();
-        stamp(tb + 1);
-        store_tile();                                       // (waits for the stage's global loads)
-        stamp(tb + 2);
-        __syncthreads();
-        stamp(tb + 3);
-        advance();
-        load_tile();                                        // next stage (all-zero past the end of the slice)
-        stamp(tb + 4);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {                    // 16 pixels per MFMA
-            u32x4 fu[TCO], fx[TCI];
+    auto mfma_phase = [&](int buf) {
+        unsigned char* su = smem + buf * WG_STAGE;                      // this stage's dU / X tiles
+        unsigned char* sx = smem + buf * WG_STAGE + 64 * 256;
+        auto frag_read = [&](int kk, u32x4* fu, u32x4* fx) {
             const int pr0 = kk * 16 + pix_in_blk;           // first read: pixels +0..3 of this lane group's 8
 #pragma unroll
             for (int i = 0; i < TCO; ++i) {
                 const int ch = (wco * TCO + i) * 32 + ch_in_tile;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(lds_u + wg_off(pr0, ch)));
+                    (__attribute__((address_space(3))) s16x4*)(su + wg_off(pr0, ch)));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(lds_u + wg_off(pr0 + 4, ch)));
+                    (__attribute__((address_space(3))) s16x4*)(su + wg_off(pr0 + 4, ch)));
                 uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
                 fu[i] = u32x4{l2.x, l2.y, h2.x, h2.y};
             }
@@ -1310,57 +1417,161 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             for (int j = 0; j < TCI; ++j) {
                 const int ch = (wci * TCI + j) * 32 + ch_in_tile;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(lds_x + wg_off(pr0, ch)));
+                    (__attribute__((address_space(3))) s16x4*)(sx + wg_off(pr0, ch)));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(lds_x + wg_off(pr0 + 4, ch)));
+                    (__attribute__((address_space(3))) s16x4*)(sx + wg_off(pr0 + 4, ch)));
                 uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
                 fx[j] = u32x4{l2.x, l2.y, h2.x, h2.y};
             }
+        };
+        // register double buffer over the four 16-pixel sub-steps: the transpose reads of sub-step kk+1 are in flight
+        // during the MFMAs of kk (a wgrad grid has 1..2 waves per SIMD: nobody else hides the LDS latency)
+        u32x4 fu[2][TCO], fx[2][TCI];
+        frag_read(0, fu[0], fx[0]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {                    // 16 pixels per MFMA
+            if (kk + 1 < 4) frag_read(kk + 1, fu[(kk + 1) & 1], fx[(kk + 1) & 1]);
+            // (without the fences hipcc sinks the reads of kk+1 below the MFMAs of kk and waits lgkmcnt(0) in front
+            // of every MFMA pair: the phase then takes ~1100 cycles instead of ~600)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TCO; ++i)
 #pragma unroll
                 for (int j = 0; j < TCI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fu[i]),
-                                                                        __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fu[kk & 1][i]),
+                                                                        __builtin_bit_cast(bf16x8, fx[kk & 1][j]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (BETA) {
                 if (do_beta) {                              // wave-uniform
 #pragma unroll
                     for (int i = 0; i < TCO; ++i)
-                        accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fu[i]),
+                        accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fu[kk & 1][i]),
                                                                           __builtin_bit_cast(bf16x8, ones), accb[i], 0, 0, 0);
                 }
             }
         }
-        stamp(tb + 5);
+    };
+    if constexpr (DMA) {
+        dma_issue(0);
+        stamp(4);                                           // prologue done (first stage's loads issued)
+        int buf = 0;
+        auto next_stage = [&](int p0, int nbuf) {
+            if (p0 + 64 < p_end) {
+                soff_u += 64 * a.Cout * 2;
+                if constexpr (PLAIN) {
+                    soff_x += 64 * a.Cin * 2;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        dxx[i] += 64;
+                        while (dxx[i] >= a.Wo) { dxx[i] -= a.Wo; dyy[i] += 1; }
+                        while (dyy[i] >= a.Ho) { dyy[i] -= a.Ho; dn[i] += 1; }
+                    }
+                    dma_x_offsets(p0 + 64);
+                }
+                if (p0 + 128 > p_end) dma_tail_mask(p0 + 64);
+                dma_issue(nbuf);
+            }
+        };
+        for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+            const int tb = 16 + ((p0 - p_begin) >> 6) * 6;
+            stamp(tb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of stage `buf` have landed in LDS
+            stamp(tb + 1);
+            __syncthreads();                                    // ... everybody else's too (two stages: and all fragment
+            stamp(tb + 2);                                      // reads of the previous stage, the other buffer, are done)
+            if constexpr (WG_NS == 2) next_stage(p0, buf ^ 1);  // in flight during the MFMAs below
+            stamp(tb + 3);
+            mfma_phase(buf);
+            stamp(tb + 4);
+            if constexpr (WG_NS == 1) {
+                __syncthreads();                                // all fragment reads done: the stage may be refilled
+                next_stage(p0, 0);
+            } else {
+                buf ^= 1;
+            }
+            stamp(tb + 5);
+        }
+    } else {
+        load_tile();
+        stamp(4);                                           // prologue done (first stage's loads issued)
+        for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+            const int tb = 16 + ((p0 - p_begin) >> 6) * 6;
+            stamp(tb);
+            __syncthreads();
+            stamp(tb + 1);
+            store_tile();                                   // (waits for the stage's global loads)
+            stamp(tb + 2);
+            __syncthreads();
+            stamp(tb + 3);
+            advance();
+            load_tile();                                    // next stage (all-zero past the end of the slice)
+            stamp(tb + 4);
+            mfma_phase(0);
+            stamp(tb + 5);
+        }
     }
     stamp(5);                                               // pixel loop done
 
-    // epilogue: acc rows = co, columns = ci (lane&31) -> 128-byte contiguous atomics per row
+    // epilogue. The side outputs (trainable-BN launches only) come straight from the accumulator registers. The
+    // gradient itself goes through LDS, every wave through its OWN 8 KB (32 rows x TCI*32 columns, no barrier inside):
+    // the split-K workgroups of one output tile finish at about the same time and would all start their atomics at
+    // row 0 of the same cache lines -- the memory-side atomic units serialise same-address updates (tools/wgrad_trace.py:
+    // 13.6k / 21.7k / 34k cycles of epilogue at 11 / 24 / 88 slices for the same 25 MB of atomics). From LDS the rows can
+    // be walked from a slice-dependent starting row, and one wave instruction covers 64 consecutive floats of a row.
     float* dwt = a.dw + (size_t)tap * a.dw_cout * a.Cin;
     const int fcol = lane & 31, fhalf = lane >> 5;
+    if (a.wdot || (BETA && do_beta)) {
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co_l = (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                const int co = co0 + co_l;
+                if (co >= a.cout_real) continue;
+                if (a.wdot) {
+                    float dot = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < TCI; ++j) {
+                        const int ci = ci0 + (wci * TCI + j) * 32 + fcol;
+                        dot += acc[i][j][r] * bf16_to_f32(a.w[((size_t)tap * a.Cout + co) * a.Cin + ci]);
+                    }
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);   // the 32 lanes of this row
+                    if (fcol == 0) atomicAdd(a.wdot + co, dot);
+                }
+                if constexpr (BETA) {
+                    if (do_beta && fcol == 0) atomicAdd(a.dbeta + co, accb[i][r]);
+                }
+            }
+        }
+    }
+    __syncthreads();                                        // every wave is done with the stage buffers
+    float* stg = reinterpret_cast<float*>(smem) + wave * (32 * TCI * 32);   // this wave's [32][TCI*32] floats
+    const int rot = (ks * 5 + tap * 3) & 31;
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co_l = (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-            const int co = co0 + co_l;
-            if (co >= a.cout_real) continue;
-            const float s = lds_scale[co_l];
-            float dot = 0.0f;
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int j = 0; j < TCI; ++j) {
-                const int ci = ci0 + (wci * TCI + j) * 32 + fcol;
-                const size_t e = (size_t)co * a.Cin + ci;
-                if (a.wdot) dot += acc[i][j][r] * bf16_to_f32(a.w[(size_t)tap * a.Cout * a.Cin + e]);
-                atomicAdd(dwt + e, acc[i][j][r] * s);
-            }
-            if (a.wdot) {                                    // row sum over the 32 lanes that share this row
-#pragma unroll
-                for (int off = 16; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);
-                if (fcol == 0) atomicAdd(a.wdot + co, dot);
-            }
-            if constexpr (BETA) {
-                if (do_beta && fcol == 0) atomicAdd(a.dbeta + co, accb[i][r]);
+            for (int j = 0; j < TCI; ++j)
+                stg[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * (TCI * 32) + j * 32 + fcol] = acc[i][j][r];
+        // (same wave writes and reads: LDS operations of one wave complete in order, no barrier)
+        for (int rr = 0; rr < 32; ++rr) {
+            const int row = (rr + rot) & 31;
+            if constexpr (TCI == 2) {
+                const int co_l = (wco * TCO + i) * 32 + row;
+                const int co = co0 + co_l;
+                if (co >= a.cout_real) continue;             // wave-uniform
+                atomicAdd(dwt + (size_t)co * a.Cin + ci0 + wci * 64 + lane, stg[row * 64 + lane] * lds_scale[co_l]);
+            } else {
+                // 32 columns per row: the two half-waves take two rows (row, row ^ 16) per instruction
+                if (rr >= 16) break;
+                const int row2 = (row + 16 * fhalf) & 31;
+                const int co2 = co0 + (wco * TCO + i) * 32 + row2;
+                if (co2 < a.cout_real)
+                    atomicAdd(dwt + (size_t)co2 * a.Cin + ci0 + wci * 32 + fcol,
+                              stg[row2 * 32 + fcol] * lds_scale[(wco * TCO + i) * 32 + row2]);
             }
         }
     }
@@ -1384,6 +1595,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
 
 }  // namespace cms
+
+template <int TCO, int TCI, bool PLAIN, bool BETA, bool DMA, int DNS>
+static void wgrad_launch(dim3 grid, size_t lds, hipStream_t s, const WgradArgs& a) {
+    auto kern = conv_wgrad_kernel<TCO, TCI, PLAIN, BETA, DMA, DNS>;
+    static bool raised = false;
+    if (DMA && !raised) {           // two stages = 64 KB + tables: above what a kernel gets without asking
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+}
 
 extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     CMS_REQUIRE(d && d->du && d->x && d->dw, "conv_wgrad: NULL pointer");
@@ -1411,7 +1633,36 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
                 "conv_wgrad: tensors must have < 2^31 elements");
     // split the pixel axis so that the grid has ~1.5 workgroups per CU (more slices only add atomic traffic and
     // per-workgroup prologue / epilogue); each slice is a multiple of 64 pixels
-    int ksplit = d->ksplit > 0 ? d->ksplit : (384 + tiles - 1) / tiles;
+    // direct-to-LDS loader (buffer addressing: both tensors below 2 GB); CMS_WGRAD_DMA=0 forces the register loader and
+    // CMS_WGRAD_TARGET the workgroup count the automatic split aims at (A/B switches, read once)
+    static int env_dma = -1, env_target = -1, env_stages = 1;
+    if (env_dma < 0) {
+        const char* e = getenv("CMS_WGRAD_DMA");
+        env_dma = e ? atoi(e) : 1;
+        const char* g = getenv("CMS_WGRAD_STAGES");
+        env_stages = g ? atoi(g) : 1;
+        const char* t = getenv("CMS_WGRAD_TARGET");
+        env_target = t ? atoi(t) : 0;
+    }
+    const bool dma = env_dma != 0 && (size_t)a.M * d->cout * 2 < (1ull << 31) &&
+                     (size_t)d->n * d->h * d->w_in * d->cin * 2 < (1ull << 31);
+    const int target = env_target > 0 ? env_target : 384;
+    // one stage by default: alone on the chip two stages are ~8 % faster (5.5 vs 6.0 ms over the DeepLab v2 layer
+    // list), inside the step -- where the weight gradients share the CUs with the data-gradient convolutions of the
+    // other stream -- the 64 KB of LDS per workgroup cost 3-4 % of the step (profiles/r02u_*)
+    const int stages = env_stages == 2 ? 2 : 1;
+    int ksplit = d->ksplit > 0 ? d->ksplit : (target + tiles - 1) / tiles;
+    const bool plain_shape = d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho &&
+                             d->w_in == d->wo;
+    if (d->ksplit <= 0 && dma && env_target <= 0) {
+        // the direct-to-LDS kernel runs 4 workgroups per CU: more slices pay as long as a slice keeps >= 32 stages
+        // of 64 pixels in front of its 64 KB of atomics (sweep: profiles/r02r_wgrad_bench.log)
+        const int nst = (a.M + 63) / 64;
+        // resident workgroups: 2 per CU with two stages (LDS), 3 where the register budget is 168 (taps / side outputs)
+        const int cap = stages == 2 ? 512 : ((plain_shape && d->dbeta == nullptr) ? 864 : 720);
+        const int hi = std::min(cap / tiles, nst / 32);
+        if (hi > ksplit) ksplit = hi;
+    }
     int per = ((a.M + ksplit - 1) / ksplit + 63) / 64 * 64;
     if (per < 64) per = 64;
     ksplit = (a.M + per - 1) / per;
@@ -1421,21 +1672,28 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     const dim3 grid(tiles * ksplit);
     a.trace = g_conv_trace;                      // diagnostic (cms_conv_set_trace); NULL in production
     a.trace_wgs = g_conv_trace_wgs;
-    const size_t lds = 2 * 64 * 256 + 128 * 4 + (a.trace ? CONV_TRACE_DWORDS * 4 : 0);
+    const size_t lds = (dma ? stages : 1) * 2 * 64 * 256 + 128 * 4 + (a.trace ? CONV_TRACE_DWORDS * 4 : 0);
     const bool beta = d->dbeta != nullptr;
     const bool plain = d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho &&
                        d->w_in == d->wo;
-#define CMS_WGRAD_LAUNCH(TCO, TCI)                                                                                   \
-    do {                                                                                                             \
-        if (plain && beta) hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, true, true>), grid, dim3(256), lds, s, a);  \
-        else if (plain) hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, true, false>), grid, dim3(256), lds, s, a);   \
-        else if (beta) hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, false, true>), grid, dim3(256), lds, s, a);    \
-        else hipLaunchKernelGGL((conv_wgrad_kernel<TCO, TCI, false, false>), grid, dim3(256), lds, s, a);             \
+#define CMS_WGRAD_LAUNCH2(TCO, TCI, DMA, DNS)                                                         \
+    do {                                                                                              \
+        if (plain && beta) wgrad_launch<TCO, TCI, true, true, DMA, DNS>(grid, lds, s, a);             \
+        else if (plain) wgrad_launch<TCO, TCI, true, false, DMA, DNS>(grid, lds, s, a);               \
+        else if (beta) wgrad_launch<TCO, TCI, false, true, DMA, DNS>(grid, lds, s, a);                \
+        else wgrad_launch<TCO, TCI, false, false, DMA, DNS>(grid, lds, s, a);                         \
+    } while (0)
+#define CMS_WGRAD_LAUNCH(TCO, TCI)                                                                    \
+    do {                                                                                              \
+        if (dma && stages == 2) CMS_WGRAD_LAUNCH2(TCO, TCI, true, 2);                                 \
+        else if (dma) CMS_WGRAD_LAUNCH2(TCO, TCI, true, 1);                                           \
+        else CMS_WGRAD_LAUNCH2(TCO, TCI, false, 1);                                                   \
     } while (0)
     if (bco == 128 && bci == 128) CMS_WGRAD_LAUNCH(2, 2);
     else if (bco == 128) CMS_WGRAD_LAUNCH(2, 1);
     else if (bci == 128) CMS_WGRAD_LAUNCH(1, 2);
     else CMS_WGRAD_LAUNCH(1, 1);
 #undef CMS_WGRAD_LAUNCH
+#undef CMS_WGRAD_LAUNCH2
     return launch_status("cms_conv_wgrad");
 }
