@@ -64,6 +64,7 @@ struct ConvArgs {
     uint32_t* trace;        // diagnostic (variant 30): per-workgroup s_memtime stamps, CONV_TRACE_DWORDS each, or NULL
     int trace_wgs;          // workgroups the trace buffer holds
     int stagger;            // != 0: co-resident workgroups of the first dispatch round start 1/4 K-step period apart (24 / 25)
+    int n_main, rem_tile_base;   // conv_igemm_mixed_kernel: workgroups of the main tile shape, first pixel tile of the rest
     int krot;               // != 0: workgroup (tile_m) starts its K loop krot * tile_m steps in and wraps (variant 20)
 };
 
@@ -179,10 +180,10 @@ __device__ __forceinline__ void wait_vmcnt_lds() {
 // issues its 8 pieces per wave with NO vector ALU instruction (the flat-address form spends ~5 per piece on 64-bit
 // pointer arithmetic, which tools/conv_trace.py shows as a 700..1450-cycle issue phase). Padding and rows past M are
 // out-of-range offsets: the hardware bounds check writes zeros, no zero page.
+// The kernel body is a device function of (logical block id, number of blocks, first pixel tile), so that ONE launch
+// can run two tile shapes (conv_igemm_mixed_kernel below).
 template <int WN, int WM, int TN, int TM, bool GLDS, int NS, int BK = CONV_BK, bool PF = false, int OCC = 0, bool BUFA = false>
-__global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
-                                           : ((GLDS && WN * WM == 4 && TN * TM == 4) ? ((NS == 1 || BK == 32) ? 4 : 2)
-                                              : ((WN * WM == 4 && TN * TM == 8) ? 2 : 1))) void conv_igemm_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, const int nblk_in, const int m_tile_base) {
     // NS = LDS stages of the direct-to-LDS loader. 1: load -> barrier -> MFMA -> barrier; memory and MFMA phases only
     // overlap ACROSS the (up to 4) workgroups of a CU. 2: the loads of K-step k+1 are in flight during the MFMAs of
     // step k inside one workgroup -- what the DeepLab shapes need, whose grids are only ~2 workgroups per CU.
@@ -228,8 +229,8 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
 
     // XCD-aware tile order: consecutive logical ids (same pixel tile, different co tiles) stay on one XCD's L2
     const int ntn = a.Cout / BN;
-    const int nblk = gridDim.x;
-    int bid = blockIdx.x;
+    const int nblk = nblk_in;
+    int bid = bid_raw;
     {
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
     const int ntiles = nblk / a.ksplit;
     const int split = bid / ntiles;
     bid -= split * ntiles;
-    const int tile_n = bid % ntn, tile_m = bid / ntn;
+    const int tile_n = bid % ntn, tile_m = bid / ntn + m_tile_base;
     const int co0 = tile_n * BN, m0 = tile_m * BM;
 
     // ---- one-time tables in LDS: tap offsets (a dynamically indexed by-value kernel argument would go to scratch)
@@ -845,6 +846,28 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
     }
 }
 
+template <int WN, int WM, int TN, int TM, bool GLDS, int NS, int BK = CONV_BK, bool PF = false, int OCC = 0, bool BUFA = false>
+__global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
+                                           : ((GLDS && WN * WM == 4 && TN * TM == 4) ? ((NS == 1 || BK == 32) ? 4 : 2)
+                                              : ((WN * WM == 4 && TN * TM == 8) ? 2 : 1))) void conv_igemm_kernel(ConvArgs a) {
+    conv_body<WN, WM, TN, TM, GLDS, NS, BK, PF, OCC, BUFA>(a, (int)blockIdx.x, (int)gridDim.x, 0);
+}
+
+// Two tile shapes in one launch. A layer of T = pixel tiles x channel tiles workgroups of the 128 x 128 tile leaves
+// T mod 256 of them for a last, nearly empty round of the 256 CUs (DeepLab v2 at 321 x 321: 526 = 2 * 256 + 14, the
+// CUs that get a third workgroup finish 26 % after the others; tools/conv_trace.py). Here the first n_main = a multiple
+// of 256 workgroups run the 128 x 128 tile over pixel tiles [0, rem_tile_base), and the pixel tiles behind them are cut
+// into 32-channel slices (128 pixels x 32 channels, a quarter of the work each): four times as many, four times
+// shorter, spread over four times as many CUs.
+template <bool BUFA>
+__global__ __launch_bounds__(256, 4) void conv_igemm_mixed_kernel(ConvArgs a) {
+    if ((int)blockIdx.x < a.n_main)
+        conv_body<2, 2, 2, 2, true, 1, CONV_BK, false, 0, BUFA>(a, (int)blockIdx.x, a.n_main, 0);
+    else
+        conv_body<1, 4, 1, 1, true, 1, CONV_BK, false, 0, BUFA>(a, (int)blockIdx.x - a.n_main, (int)gridDim.x - a.n_main,
+                                                               a.rem_tile_base);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // dgrad operand: wT[tap'][ci][co] = bf16( w[tap][co][ci] * scale[co] ), tap' = ntaps-1-tap when `flip`
 // (32x32 LDS tile transpose; coalesced on both sides). src may be fp32 or bf16.
@@ -1045,6 +1068,7 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
     // 24: the default kernel with staggered starts of co-resident workgroups; 25: stagger + rotation by 3
     a.krot = d->variant == 20 ? 1 : (d->variant == 21 ? 3 : (d->variant == 22 ? 5 : (d->variant == 23 ? 11 : (d->variant == 25 ? 3 : 0))));
     a.stagger = (d->variant == 24 || d->variant == 25) ? 1 : 0;
+    a.n_main = 0; a.rem_tile_base = 0;
     // 30: the default kernel with per-workgroup cycle stamps into the buffer given to cms_conv_set_trace
     a.trace = (d->variant == 30 || d->variant == 41) ? g_conv_trace : nullptr;      // 41: trace of variant 40
     a.trace_wgs = g_conv_trace_wgs;
@@ -1114,6 +1138,25 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
         // default: 128 co x 128 pixels, 4 waves of 64 x 64 (the 8-wave layouts above measured within +-5 % of it on
         // the DeepLab v2 layer shapes and no better end to end, tools/conv_ablate.py)
         CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 128 needs Cout %% 128 == 0");
+        // balanced launch (conv_igemm_mixed_kernel): when the 128 x 128 grid is a few workgroups more than a multiple of
+        // the 256 CUs, those few are cut into 32-channel slices. CMS_CONV_MIXED=0 switches it off (A/B).
+        static int env_mixed = -1;
+        if (env_mixed < 0) {
+            const char* e = getenv("CMS_CONV_MIXED");
+            env_mixed = e ? atoi(e) : 1;
+        }
+        const int ntn = d->cout / 128, mtiles = (a.M + 127) / 128, total = mtiles * ntn;
+        const int rounds = total / 256, rem = total % 256;
+        if (env_mixed != 0 && tile == 0 && d->variant == 0 && (glds == 4 || glds == 1) && a.ksplit == 1 && 256 % ntn == 0 &&
+            rounds >= 1 && rounds <= 9 && rem > 0 && rem <= 100) {
+            a.n_main = rounds * 256;
+            a.rem_tile_base = a.n_main / ntn;
+            const int n_rem = (mtiles - a.rem_tile_base) * (d->cout / 32);
+            const size_t lds = 32768 + 80 + 128 * 16 + 2 * 128 * 4 + (a.trace ? CONV_TRACE_DWORDS * 4 : 0);
+            if (glds == 4) hipLaunchKernelGGL(conv_igemm_mixed_kernel<true>, dim3(a.n_main + n_rem), dim3(256), lds, s, a);
+            else hipLaunchKernelGGL(conv_igemm_mixed_kernel<false>, dim3(a.n_main + n_rem), dim3(256), lds, s, a);
+            return launch_status("cms_conv_igemm");
+        }
         conv_launch<2, 2, 2, 2>(a, s, glds);
     } else if ((tile == 0 && d->cout % 64 == 0) || tile == 64) {
         CMS_REQUIRE(d->cout % 64 == 0, "conv: tile 64 needs Cout %% 64 == 0");

@@ -16,6 +16,7 @@
 //                 persistent blocks, one round of fp32 atomics per block at the end.
 //   stem_dgrad    gradient wrt the image (VAT direction pass only): thread = one input pixel x 3 channels.
 // Input images are NCHW (the reference's batch layout, A0), activations NHWC.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace cms {
@@ -89,6 +90,122 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const TX* __restrict__ x,
         for (int co = 0; co < STEM_CO; ++co) {
             float v = acc[co] * scale[co] + bias[co];
             st_f32(dst + co, fmaxf(v, 0.0f));
+        }
+    }
+}
+
+// ---- the same forward on the matrix cores (bf16 in, bf16 out) -----------------------------------------------------
+// K is ordered (c, ky) x kx with kx padded from 7 to 8: 21 rows of 8 = 168 -> 11 MFMA K steps of 16 (two rows each, the
+// 22nd row has zero weights). A row's 8 operands of pixel (ty, tx) are patch[c][2 ty + ky][2 tx .. 2 tx + 7]: 16
+// CONTIGUOUS bytes of the LDS patch, so the pixel operand of v_mfma_f32_32x32x16_bf16 is read with two ds_read2_b32 (4-byte
+// aligned) -- no im2col buffer. The weights keep fp32 precision as a bf16 pair hi + lo (two MFMAs per step): the step's
+// numerics stay those of the VALU kernel (fp32 weights x bf16 pixels, fp32 accumulation) to 2^-17 relative.
+// Workgroup = 16 x 16 output pixels x 64 channels; wave (wc, wp) = channel half wc x pixel half wp: its 11 x 2 weight
+// fragments (hi, lo) live in registers for the whole (persistent) workgroup, accumulators 4 x [32 co x 32 px].
+typedef uint32_t su32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+typedef float sf32x16 __attribute__((ext_vector_type(16)));
+constexpr int SM_ROWS = 22;                    // (c, ky) rows incl. the zero row
+constexpr int SM_PITCH = 40;                   // patch row pitch in elements (80 B: rows stay 4-byte aligned)
+
+template <class T>
+__global__ __launch_bounds__(256) void stem_pack_frag_kernel(const T* __restrict__ w, uint16_t* __restrict__ frag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= STEM_CO * SM_ROWS * 8) return;
+    const int kx = i & 7, r = (i >> 3) % SM_ROWS, co = i / (8 * SM_ROWS);
+    float v = 0.0f;
+    if (r < 21 && kx < 7) v = ld_f32(w + ((size_t)((r % 7) * 7 + kx) * STEM_CO + co) * 3 + r / 7);
+    const uint16_t hi = f32_to_bf16(v);
+    frag[i] = hi;
+    frag[STEM_CO * SM_ROWS * 8 + i] = f32_to_bf16(v - bf16_to_f32(hi));
+}
+
+__global__ __launch_bounds__(256, 2) void stem_fwd_mfma_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                               const uint16_t* __restrict__ frag,
+                                                               const float* __restrict__ scale, const float* __restrict__ bias,
+                                                               int N, int H, int W, int Ho, int Wo) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SF_P * SM_PITCH * 2 + 256 * STEM_CO * 2];
+    uint16_t* patch = reinterpret_cast<uint16_t*>(smem);                           // [3][37][40] bf16
+    unsigned char* stage = smem + 3 * SF_P * SM_PITCH * 2;                         // [256 px][128 B], 16-byte chunks swizzled
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wp = wave >> 1;
+    const int fcol = lane & 31, fhalf = lane >> 5;
+
+    // this wave's weight fragments: row 2s + fhalf of channel wc*32 + fcol, hi and lo
+    su32x4 whi[11], wlo[11];
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+        const size_t e = ((size_t)(wc * 32 + fcol) * SM_ROWS + 2 * s + fhalf) * 8;
+        whi[s] = *reinterpret_cast<const su32x4*>(frag + e);
+        wlo[s] = *reinterpret_cast<const su32x4*>(frag + STEM_CO * SM_ROWS * 8 + e);
+    }
+    // the pad columns 37..39 of the patch are read (times a zero weight): keep them finite
+    for (int i = tid; i < 3 * SF_P * 3; i += 256) patch[(i / 3) * SM_PITCH + SF_P + i % 3] = 0;
+
+    const int tiles_x = (Wo + SF_T - 1) / SF_T, tiles_y = (Ho + SF_T - 1) / SF_T;
+    const int ntiles = N * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int txi = t % tiles_x, tyi = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const int ty0 = tyi * SF_T, tx0 = txi * SF_T;
+        const int iy0 = ty0 * 2 - 3, ix0 = tx0 * 2 - 3;
+        __syncthreads();                                   // the previous tile's patch reads and stage reads are done
+        for (int i = tid; i < 3 * SF_P * SF_P; i += 256) {
+            const int px = i % SF_P, r = i / SF_P, py = r % SF_P, c = r / SF_P;
+            const int iy = iy0 + py, ix = ix0 + px;
+            uint16_t v = 0;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)n * 3 + c) * H + iy) * W + ix];
+            patch[(c * SF_P + py) * SM_PITCH + px] = v;
+        }
+        __syncthreads();
+
+        sf32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            const int r = min(2 * s + fhalf, 20);          // row 21 does not exist: re-read row 20 (its weights are zero)
+            const int c = r / 7, ky = r - c * 7;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = (4 * wp + q) * 32 + fcol;    // pixel of the tile: row p >> 4, column p & 15
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(
+                    patch + (c * SF_P + 2 * (p >> 4) + ky) * SM_PITCH + 2 * (p & 15));
+                const su32x4 b = su32x4{src[0], src[1], src[2], src[3]};
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sbf16x8, whi[s]),
+                                                                 __builtin_bit_cast(sbf16x8, b), acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sbf16x8, wlo[s]),
+                                                                 __builtin_bit_cast(sbf16x8, b), acc[q], 0, 0, 0);
+            }
+        }
+        // epilogue: lane holds, per accumulator, pixel column fcol and channels (r & 3) + 8 (r >> 2) + 4 fhalf of its
+        // half: BN affine + ReLU, 8-byte cells into the staging tile (16-byte chunks XOR-swizzled with the pixel)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = (4 * wp + q) * 32 + fcol;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = wc * 32 + 8 * g + 4 * fhalf;
+                const float4 sc = *reinterpret_cast<const float4*>(scale + co);
+                const float4 bi = *reinterpret_cast<const float4*>(bias + co);
+                const float v0 = fmaxf(acc[q][4 * g + 0] * sc.x + bi.x, 0.0f), v1 = fmaxf(acc[q][4 * g + 1] * sc.y + bi.y, 0.0f);
+                const float v2 = fmaxf(acc[q][4 * g + 2] * sc.z + bi.z, 0.0f), v3 = fmaxf(acc[q][4 * g + 3] * sc.w + bi.w, 0.0f);
+                uint2 o;
+                o.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+                o.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                *reinterpret_cast<uint2*>(stage + p * 128 + ((((co >> 3) ^ p) & 7) << 4) + ((co & 4) << 1)) = o;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                      // 256 pixels x 8 chunks of 16 bytes
+            const int idx = i * 256 + tid, p = idx >> 3, ch = idx & 7;
+            const int oy = ty0 + (p >> 4), ox = tx0 + (p & 15);
+            if (oy < Ho && ox < Wo) {
+                const su32x4 v = *reinterpret_cast<const su32x4*>(stage + p * 128 + (((ch ^ p) & 7) << 4));
+                *reinterpret_cast<su32x4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * STEM_CO + ch * 8) = v;
+            }
         }
     }
 }
@@ -290,6 +407,14 @@ extern "C" int cms_stem_pack_weights(const void* w_khkwcoci, int w_dtype, float*
     else
         hipLaunchKernelGGL(stem_pack_kernel<uint16_t>, dim3((n + 255) / 256), dim3(256), 0, s, (const uint16_t*)w_khkwcoci,
                            w_packed);
+    // bf16 (hi, lo) MFMA fragments behind the 147 x 64 floats (stem_fwd_mfma_kernel)
+    uint16_t* frag = reinterpret_cast<uint16_t*>(w_packed + n);
+    const int nf = STEM_CO * SM_ROWS * 8;
+    if (w_dtype == CMS_F32)
+        hipLaunchKernelGGL(stem_pack_frag_kernel<float>, dim3((nf + 255) / 256), dim3(256), 0, s, (const float*)w_khkwcoci, frag);
+    else
+        hipLaunchKernelGGL(stem_pack_frag_kernel<uint16_t>, dim3((nf + 255) / 256), dim3(256), 0, s, (const uint16_t*)w_khkwcoci,
+                           frag);
     return launch_status("cms_stem_pack_weights");
 }
 
@@ -319,6 +444,18 @@ extern "C" int cms_stem_fwd(const void* x_nchw, int x_dtype, void* y_nhwc, int y
     cms_stem_out_hw(h, w, &Ho, &Wo, nullptr, nullptr);
     const dim3 grid((Wo + SF_T - 1) / SF_T, (Ho + SF_T - 1) / SF_T, n);
     hipStream_t s = (hipStream_t)stream;
+    static int env_mfma = -1;                   // CMS_STEM_MFMA=0: the VALU kernel also for bf16 (A/B switch)
+    if (env_mfma < 0) {
+        const char* e = getenv("CMS_STEM_MFMA");
+        env_mfma = e ? atoi(e) : 1;
+    }
+    if (x_dtype == CMS_BF16 && y_dtype == CMS_BF16 && env_mfma != 0) {
+        const int ntiles = (int)(grid.x * grid.y * grid.z);
+        hipLaunchKernelGGL(stem_fwd_mfma_kernel, dim3(ntiles < 512 ? ntiles : 512), dim3(256), 0, s, (const uint16_t*)x_nchw,
+                           (uint16_t*)y_nhwc, reinterpret_cast<const uint16_t*>(w_packed + STEM_TAPS * STEM_CO), scale, bias, n,
+                           h, w, Ho, Wo);
+        return launch_status("cms_stem_fwd");
+    }
 #define CMS_STEM_FWD(TX, TY) \
     hipLaunchKernelGGL((stem_fwd_kernel<TX, TY>), grid, dim3(256), 0, s, (const TX*)x_nchw, (TY*)y_nhwc, w_packed, scale, bias, n, h, w, Ho, Wo)
     if (x_dtype == CMS_F32 && y_dtype == CMS_F32) CMS_STEM_FWD(float, float);

@@ -456,12 +456,17 @@ def stem_out_hw(h, w):
 
 
 def stem_pack_weights(w_packed_khkwcoci, out=None):
-    """(49, 64, 3) fp32 / bf16 view of conv1.weight in the arena's physical layout -> fp32 (147, 64) [c,ky,kx][co]."""
+    """(49, 64, 3) fp32 / bf16 view of conv1.weight in the arena's physical layout -> fp32 (147 + 176, 64): rows
+    0..146 = [c,ky,kx][co], the rest = the bf16 (hi, lo) MFMA fragments of the bf16 forward (csrc/stem.hip)."""
     _need_cuda(w_packed_khkwcoci, out)
     if tuple(w_packed_khkwcoci.shape) != (49, 64, 3) or not w_packed_khkwcoci.is_contiguous():
         raise ValueError('stem_pack_weights: contiguous (49, 64, 3) weight view required')
     if out is None:
-        out = torch.empty((147, 64), dtype=torch.float32, device=w_packed_khkwcoci.device)
+        # 147 x 64 floats ([tap][co], the VALU kernels and the image gradient) + 2 x 64 x 22 x 8 bf16 behind them: the
+        # (hi, lo) MFMA fragments of the bf16 forward = 176 more rows of 64 floats
+        out = torch.empty((147 + 176, 64), dtype=torch.float32, device=w_packed_khkwcoci.device)
+    if out.dtype != torch.float32 or out.numel() < (147 + 176) * 64 or not out.is_contiguous():
+        raise ValueError('stem_pack_weights: `out` must be a contiguous fp32 buffer of at least (147 + 176) x 64 elements')
     check(fn['cms_stem_pack_weights'](_ptr(w_packed_khkwcoci), _dtype_code(w_packed_khkwcoci), _ptr(out), _stream()),
           'cms_stem_pack_weights')
     return out

@@ -395,7 +395,8 @@ int cms_aspp_spread_bwd(const float* dlogits, void* d_nhwc, int d_dtype, const i
  * max-pool, and their backward passes (architectures/deeplab2.py:140-146, 183-186; csrc/stem.hip).
  * Images NCHW (the reference's batch layout), activations NHWC; dtypes CMS_F32 / CMS_BF16 per tensor.
  * ------------------------------------------------------------------------------------------------------------ */
-/* w_packed[(c*7 + ky)*7 + kx][co] (fp32, 147 x 64) from the convolution weight in its [kh][kw][Cout][Cin] layout */
+/* w_packed[(c*7 + ky)*7 + kx][co] (fp32, 147 x 64) from the convolution weight in its [kh][kw][Cout][Cin] layout,
+ * followed by the bf16 (hi, lo) MFMA fragments of the bf16 forward: the buffer holds (147 + 176) x 64 floats. */
 int cms_stem_pack_weights(const void* w_khkwcoci, int w_dtype, float* w_packed, void* stream);
 /* sizes of the stem convolution output (ho, wo) and of the max-pool output (hp, wp) for an h x w image */
 int cms_stem_out_hw(int h, int w, int* ho, int* wo, int* hp, int* wp);

@@ -308,3 +308,41 @@ def test_strided_3x3_dgrad_as_four_phases(ops, hw):
     y.backward(du.float().permute(0, 3, 1, 2))
     ref = xr.grad.permute(0, 2, 3, 1) * (mask.float() > 0)
     assert float((dx.float() - ref).abs().max()) <= 1.5e-2 * float(ref.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize('case', [('l3_1x1_1024_256', 20, 41, 41, 1024, 256, 1, 1, 'fwd'),
+                                  ('l3_3x3_d2', 20, 41, 41, 256, 256, 3, 2, 'fwd_res'),
+                                  ('l3_1x1_256_1024', 20, 41, 41, 256, 1024, 1, 1, 'fwd_res'),
+                                  ('dgrad_mask_res', 20, 41, 41, 256, 256, 3, 2, 'dgrad'),
+                                  ('c3_l3_1x1', 8, 65, 129, 512, 256, 1, 1, 'fwd')], ids=lambda c: c[0])
+def test_conv_balanced_launch_equals_plain_tiles(ops, case):
+    """Grids of a few workgroups more than a multiple of the 256 CUs run their last pixel tiles as 32-channel slices
+    (conv_igemm_mixed_kernel, the automatic choice of cms_conv_igemm at the BASELINE shapes: 526 / 1052 / 2104
+    workgroups). Same MFMA sequence per output element, so the result must equal the plain 128 x 128 launch
+    (tile = 128 asks for it explicitly) bit for bit -- and the fp32 reference within bf16 rounding."""
+    name, N, H, W, Cin, Cout, k, dil, kind = case
+    g = torch.Generator(device=DEV).manual_seed(11)
+    pad = dil * (k - 1) // 2
+    x = _mk((N, H, W, Cin), g)
+    w = _mk((Cout, Cin, k, k), g, (2.0 / (Cin * k * k)) ** 0.5)
+    taps = ops.conv_taps(k, k, dil, pad)
+    scale = torch.rand(Cout, generator=g, device=DEV) + 0.5
+    bias = torch.randn(Cout, generator=g, device=DEV) * 0.1
+    res = _mk((N, H, W, Cout), g) if kind != 'fwd' else None
+    if kind == 'dgrad':
+        act = _mk((N, H, W, Cout), g)
+        kw = dict(res=res, mask_src=act, mode=1)
+    else:
+        kw = dict(scale=scale, bias=bias, res=res, relu=True)
+    y_auto = ops.conv_igemm(x, _pack(w), taps, **kw)
+    y_plain = ops.conv_igemm(x, _pack(w), taps, tile=128, **kw)
+    assert torch.equal(y_auto, y_plain)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, 1, pad, dil).permute(0, 2, 3, 1)
+    if kind == 'dgrad':
+        ref = (ref + res.float()) * (act.float() > 0)
+    else:
+        ref = ref * scale + bias
+        if res is not None:
+            ref = ref + res.float()
+        ref = ref.relu()
+    torch.testing.assert_close(y_auto.float(), ref, rtol=2 ** -7, atol=2e-2)

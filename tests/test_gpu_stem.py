@@ -90,3 +90,25 @@ def test_network_runs_without_library_convolutions(ops):
         gw, ww = named[k].grad.cpu(), leaves[k].grad
         assert float((gw - ww).abs().max()) <= 1e-3 * float(ww.abs().max()) + 1e-7, k
     assert float((xd.grad.cpu() - xr.grad).abs().max()) <= 1e-3 * float(xr.grad.abs().max()) + 1e-8
+
+
+@pytest.mark.parametrize('shape', [(2, 321, 321), (1, 65, 97), (3, 33, 47)])
+def test_stem_forward_bf16_on_the_matrix_cores(ops, shape):
+    """bf16 forward = stem_fwd_mfma_kernel (K = (c, ky) x 8 kx, weights as a bf16 hi + lo pair, fp32 accumulation):
+    within one bf16 rounding of the fp64 reference on the same bf16 inputs and fp32 weights (the weights are NOT
+    rounded to bf16: the pair keeps 16 mantissa bits)."""
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(N, 3, H, W, generator=g).bfloat16()
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1                      # fp32 weights, not representable in bf16
+    scale, bias = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    ref = F.relu(F.conv2d(x.double(), w.double(), None, 2, 3) * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1))
+    cu = lambda t: t.to(DEV)
+    w147 = ops.stem_pack_weights(cu(_pack49(w)))
+    s = ops.stem_forward(cu(x), w147, cu(scale), cu(bias), torch.bfloat16)
+    got = s.float().cpu().permute(0, 3, 1, 2).double()
+    err = (got - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-4).all()), float((err - 2.0 ** -8 * ref.abs()).max())
+    # and the fp32 output of the same inputs (VALU kernel) agrees to fp32 accuracy with the reference
+    s32 = ops.stem_forward(cu(x.float()), w147, cu(scale), cu(bias), torch.float32)
+    torch.testing.assert_close(s32.cpu().permute(0, 3, 1, 2).double(), ref, rtol=1e-5, atol=1e-5)
