@@ -354,6 +354,121 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TX* __restrict__ 
     }
 }
 
+// ---- the same weight gradient on the matrix cores (bf16 image, bf16 dS): both operands are exact in bf16, so the
+// products are exact in fp32 and only the summation order differs from the VALU kernel.
+// GEMM dW[co][k] = sum_pixels dS[pixel][co] * P[pixel][k] with the forward's K order k = (c, ky) * 8 + kx (22 rows of 8,
+// 176 columns, padded to 6 MFMA column tiles of 32). Per stage of 64 pixels (4 rows of the 16 x 16 tile) the workgroup
+// builds the im2col tile P[64][176] in LDS -- one 16-byte copy per (pixel, row), the same contiguous 8-operand run the
+// forward reads -- and stages dS[64][64]; both are pixel-major = K-major, so the MFMA operands (8 consecutive PIXELS
+// per lane) come out of ds_read_b64_tr_b16 exactly as in conv_wgrad_kernel (csrc/conv.hip). Row pitches 144 / 400 B keep
+// the four pixel rows of a transpose read in different banks. Wave w: channel half w & 1, column tiles w>>1, +2, +4.
+// Persistent over the tiles, one round of fp32 atomics per workgroup at the end.
+typedef short ss16x4 __attribute__((ext_vector_type(4)));
+constexpr int SWM_DS_PITCH = 144;              // bytes per pixel row of the dS stage (64 channels + pad)
+constexpr int SWM_P_PITCH = 400;               // bytes per pixel row of the im2col stage (192 columns + pad)
+
+__global__ __launch_bounds__(256, 2) void stem_wgrad_mfma_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ ds,
+                                                                 float* __restrict__ dw, const float* __restrict__ scale, int N,
+                                                                 int H, int W, int Ho, int Wo) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SF_P * SM_PITCH * 2 + 64 * SWM_DS_PITCH + 64 * SWM_P_PITCH];
+    uint16_t* patch = reinterpret_cast<uint16_t*>(smem);                           // [3][37][40] bf16
+    unsigned char* lds_ds = smem + 3 * SF_P * SM_PITCH * 2;                        // [64 px][144 B]
+    unsigned char* lds_p = lds_ds + 64 * SWM_DS_PITCH;                             // [64 px][400 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave & 1, wk = wave >> 1;
+    const int g = lane >> 4, li = lane & 15;
+    const int ch_in_tile = 16 * (g & 1) + 4 * (li & 3);     // column chunk this lane SUPPLIES to the transpose read
+    const int pix_in_blk = 8 * (g >> 1) + (li >> 2);        // pixel row this lane supplies (within a 16-pixel K step)
+
+    sf32x16 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    // patch pad columns 37..39 and the im2col columns 176..191 are read (into outputs that are never written): finite
+    for (int i = tid; i < 3 * SF_P * 3; i += 256) patch[(i / 3) * SM_PITCH + SF_P + i % 3] = 0;
+    for (int i = tid; i < 64 * 4; i += 256)
+        *reinterpret_cast<uint2*>(lds_p + (i >> 2) * SWM_P_PITCH + 352 + (i & 3) * 8) = uint2{0u, 0u};
+
+    const int tiles_x = (Wo + SF_T - 1) / SF_T, tiles_y = (Ho + SF_T - 1) / SF_T;
+    const int ntiles = N * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int txi = t % tiles_x, tyi = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const int ty0 = tyi * SF_T, tx0 = txi * SF_T;
+        const int iy0 = ty0 * 2 - 3, ix0 = tx0 * 2 - 3;
+        __syncthreads();                                   // the previous tile's patch reads are done
+        for (int i = tid; i < 3 * SF_P * SF_P; i += 256) {
+            const int px = i % SF_P, r = i / SF_P, py = r % SF_P, c = r / SF_P;
+            const int iy = iy0 + py, ix = ix0 + px;
+            uint16_t v = 0;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)n * 3 + c) * H + iy) * W + ix];
+            patch[(c * SF_P + py) * SM_PITCH + px] = v;
+        }
+        for (int st = 0; st < 4; ++st) {                   // 4 stages of 64 pixels = tile rows 4 st .. 4 st + 3
+            __syncthreads();                               // patch complete (st = 0) / previous stage's reads done
+            // dS stage: 64 pixels x 8 chunks of 16 bytes (zero outside the image)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = i * 256 + tid, p = idx >> 3, ch = idx & 7;
+                const int oy = ty0 + 4 * st + (p >> 4), ox = tx0 + (p & 15);
+                su32x4 v = su32x4{0u, 0u, 0u, 0u};
+                if (oy < Ho && ox < Wo) v = *reinterpret_cast<const su32x4*>(ds + (((size_t)n * Ho + oy) * Wo + ox) * STEM_CO + ch * 8);
+                *reinterpret_cast<su32x4*>(lds_ds + p * SWM_DS_PITCH + ch * 16) = v;
+            }
+            // im2col stage: 64 pixels x 22 rows of 8 operands (row 21 = zeros)
+            for (int idx = tid; idx < 64 * SM_ROWS; idx += 256) {
+                const int p = idx / SM_ROWS, r = idx - p * SM_ROWS;
+                su32x4 v = su32x4{0u, 0u, 0u, 0u};
+                if (r < 21) {
+                    const int c = r / 7, ky = r - c * 7;
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(
+                        patch + (c * SF_P + 2 * (4 * st + (p >> 4)) + ky) * SM_PITCH + 2 * (p & 15));
+                    v = su32x4{src[0], src[1], src[2], src[3]};
+                }
+                *reinterpret_cast<su32x4*>(lds_p + p * SWM_P_PITCH + r * 16) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {               // 16 pixels per MFMA
+                const int pr0 = kk * 16 + pix_in_blk;
+                const int cha = wc * 32 + ch_in_tile;
+                const ss16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) ss16x4*)(lds_ds + pr0 * SWM_DS_PITCH + cha * 2));
+                const ss16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) ss16x4*)(lds_ds + (pr0 + 4) * SWM_DS_PITCH + cha * 2));
+                const uint2 al = __builtin_bit_cast(uint2, alo), ah = __builtin_bit_cast(uint2, ahi);
+                const su32x4 fa = su32x4{al.x, al.y, ah.x, ah.y};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int chb = (wk + 2 * q) * 32 + ch_in_tile;
+                    const ss16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) ss16x4*)(lds_p + pr0 * SWM_P_PITCH + chb * 2));
+                    const ss16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) ss16x4*)(lds_p + (pr0 + 4) * SWM_P_PITCH + chb * 2));
+                    const uint2 bl = __builtin_bit_cast(uint2, blo), bh = __builtin_bit_cast(uint2, bhi);
+                    const su32x4 fb = su32x4{bl.x, bl.y, bh.x, bh.y};
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sbf16x8, fa), __builtin_bit_cast(sbf16x8, fb),
+                                                                     acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // acc[q]: rows = channel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of half wc, column = lane & 31 of column tile wk + 2 q
+    const int fcol = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int k = (wk + 2 * q) * 32 + fcol, r = k >> 3, kx = k & 7;
+        if (r < 21 && kx < 7) {
+            const int c = r / 7, ky = r - c * 7;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = wc * 32 + (i & 3) + 8 * (i >> 2) + 4 * fhalf;
+                atomicAdd(dw + ((size_t)(ky * 7 + kx) * STEM_CO + co) * 3 + c, acc[q][i] * (scale ? scale[co] : 1.0f));
+            }
+        }
+    }
+}
+
 // ---- gradient wrt the image: dx[n,c,iy,ix] = sum_{ky,kx,co} dS[n,(iy+3-ky)/2,(ix+3-kx)/2,co] * scale[co]-folded w
 // wp2[(ky*7+kx)*3 + c][co] = w[ky][kx][co][c] * scale[co]
 template <class TS>
@@ -508,6 +623,17 @@ extern "C" int cms_stem_wgrad(const void* x_nchw, int x_dtype, const void* ds_nh
     const int ntiles = n * ((Ho + SW_TH - 1) / SW_TH) * ((Wo + SW_TW - 1) / SW_TW);
     const dim3 grid(ntiles < 768 ? ntiles : 768);            // 3 blocks per CU (41 KB of LDS each), persistent over the tiles
     hipStream_t s = (hipStream_t)stream;
+    static int env_mfma = -1;                   // CMS_STEM_MFMA=0: the VALU kernel also for bf16 (A/B switch)
+    if (env_mfma < 0) {
+        const char* e = getenv("CMS_STEM_MFMA");
+        env_mfma = e ? atoi(e) : 1;
+    }
+    if (x_dtype == CMS_BF16 && ds_dtype == CMS_BF16 && env_mfma != 0) {
+        const int nt = n * ((Ho + SF_T - 1) / SF_T) * ((Wo + SF_T - 1) / SF_T);
+        hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nt < 512 ? nt : 512), dim3(256), 0, s, (const uint16_t*)x_nchw,
+                           (const uint16_t*)ds_nhwc, dw_khkwcoci, scale, n, h, w, Ho, Wo);
+        return launch_status("cms_stem_wgrad");
+    }
 #define CMS_STEM_WG(TX, TS) \
     hipLaunchKernelGGL((stem_wgrad_kernel<TX, TS>), grid, dim3(256), 0, s, (const TX*)x_nchw, (const TS*)ds_nhwc, dw_khkwcoci, scale, n, h, w, Ho, Wo)
     if (x_dtype == CMS_F32 && ds_dtype == CMS_F32) CMS_STEM_WG(float, float);

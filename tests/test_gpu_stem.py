@@ -112,3 +112,25 @@ def test_stem_forward_bf16_on_the_matrix_cores(ops, shape):
     # and the fp32 output of the same inputs (VALU kernel) agrees to fp32 accuracy with the reference
     s32 = ops.stem_forward(cu(x.float()), w147, cu(scale), cu(bias), torch.float32)
     torch.testing.assert_close(s32.cpu().permute(0, 3, 1, 2).double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 321, 321), (1, 65, 97), (3, 33, 47)])
+def test_stem_wgrad_bf16_on_the_matrix_cores(ops, shape):
+    """bf16 image x bf16 dS = stem_wgrad_mfma_kernel (im2col tile built in LDS, transpose reads, fp32 accumulation):
+    both operands are exact in bf16, so the result equals the fp64 reference up to fp32 summation order; accumulates
+    into the gradient buffer like the VALU kernel."""
+    N, H, W = shape
+    g = torch.Generator().manual_seed(3 * H + W)
+    x = torch.randn(N, 3, H, W, generator=g).bfloat16()
+    ho, wo, _, _ = ops.stem_out_hw(H, W)
+    ds = (torch.randn(N, ho, wo, 64, generator=g) * (torch.rand(N, ho, wo, 64, generator=g) > 0.5)).bfloat16()
+    scale = torch.rand(64, generator=g) + 0.5
+    wd = torch.zeros(64, 3, 7, 7, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), wd, None, 2, 3)
+    y.backward(ds.double().permute(0, 3, 1, 2) * scale.double().view(1, -1, 1, 1))
+    want = _pack49(wd.grad.float()) + 0.25
+    cu = lambda t: t.to(DEV)
+    dw = torch.full((49, 64, 3), 0.25, device=DEV)
+    ops.stem_wgrad(cu(x), cu(ds), dw, cu(scale))
+    err = float((dw.cpu() - want).abs().max())
+    assert err <= 2e-5 * float(want.abs().max()) + 1e-5, err
