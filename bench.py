@@ -394,6 +394,18 @@ def run_workload(key, args, world, rank, dev):
             host_ms.append(1e3 * (time.perf_counter() - th))
         torch.cuda.synchronize()
         host_unblocked = float(np.median(host_ms))
+        if args.host_profile and rank == 0:          # where the host time of a step goes (stderr; not part of the line)
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            for i in range(3):
+                one_step(i)
+                torch.cuda.synchronize()
+            pr.disable()
+            st_ = pstats.Stats(pr, stream=sys.stderr)
+            st_.sort_stats('cumulative').print_stats(45)
+            st_.sort_stats('tottime').print_stats(30)
 
         # Outside the timed region: the same kernel with the GPU to itself (single stream, every launch bracketed). In
         # the timed region the teacher pass and the weight gradients run concurrently on other streams, so a launch's
@@ -536,6 +548,7 @@ def main():
     ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')
     ap.add_argument('--wgrad_streams', type=int, default=0, help='experiment: streams the weight gradients are spread over')
     ap.add_argument('--no_roofline_events', action='store_true', help='skip the per-launch event brackets')
+    ap.add_argument('--host_profile', action='store_true', help='cProfile of three steps after the timed region (stderr)')
     ap.add_argument('--roofline_sample', type=int, default=5,
                     help='bracket every k-th launch of the conv kernel with events (1 = all; the brackets cost ~3 %% '
                          'of the step when every launch carries them)')

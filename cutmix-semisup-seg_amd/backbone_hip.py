@@ -589,7 +589,7 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
 
     def __init__(self, wrapper):
         self._init_common(wrapper)
-        self.use_programs = False          # (this executor's passes are issued launch by launch)
+        self.use_programs = True           # passes recorded once per input shape and replayed (csrc/program.hip)
         # torchvision's stem: same 7x7/2 convolution, max-pool WITHOUT ceil_mode, trainable BatchNorm affine
         self.stem_wkey, self.stem_bn, self.stem_ceil = 'deeplab.backbone.conv1.weight', 'deeplab.backbone.bn1', False
         self.stem_w147 = None
@@ -597,26 +597,73 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
         bb = wrapper.deeplab.backbone
         self._add_blocks('deeplab.backbone.', [bb['layer{}'.format(li)] for li in range(1, 5)])
         self.tap_low = self._layer_first[1] - 1          # last bottleneck of layer1
+        self._phase_w = {}                               # (conv id, py, px) -> persistent sub-weight of the phase
 
-    def forward_taps(self, x, save=False):
-        """x: bf16 NHWC stem output -> (low_level (N,h/4,w/4,256), out (N,h/8,w/8,2048)) bf16 NHWC [, saved]."""
+    def _prepare_forward(self):
+        if not self._affine_ready:
+            self._refresh_affine()
+
+    def _taps_pass(self, x, save):
         st = self.fwd_begin(x, save)
         low = None
         for bi in range(len(self.blocks)):
+            if ops._REC is not None:
+                ops._REC[0].group = bi
             self.fwd_block(st, bi)
             if bi == self.tap_low:
                 low = st['cur']
         if save:
             st['saved'].append(st['cur'])
-            return low, st['cur'], st['saved']
-        return low, st['cur']
+        return low, st['cur'], st['saved']
+
+    def taps_program(self, shape, save):
+        """The recorded backbone pass for a stem output of `shape`: x_in (persistent input), low, out, saved."""
+        key = ('taps', tuple(int(v) for v in shape), bool(save), self._tile_key())
+        prog = self._programs.get(key)
+        if prog is None:
+            if len(self._programs) >= 8:
+                torch.cuda.synchronize()
+                self._programs.pop(next(iter(self._programs)))
+            self._prepare_forward()
+            prog = ops.Program()
+            x_in = torch.empty(tuple(shape), dtype=self.dtype, device=self.arena.device)
+            with ops.recording(prog, [torch.cuda.current_stream()]):
+                low, out, saved = self._taps_pass(x_in, save)
+            prog.x_in, prog.low, prog.out, prog.saved = x_in, low, out, saved
+            prog.bwd = {}
+            prog.generation = -1
+            self._programs[key] = prog
+        return prog
+
+    def forward_taps(self, x, save=False):
+        """x: bf16 NHWC stem output -> (low_level (N,h/4,w/4,256), out (N,h/8,w/8,2048)) bf16 NHWC [, saved].
+        With programs the two taps are the program's own buffers: valid until the next pass of the same shape through
+        this executor is ENQUEUED behind their consumers (stream order), which is how the head uses them."""
+        if not self.use_programs:
+            low, out, saved = self._taps_pass(x, save)
+            return (low, out, saved) if save else (low, out)
+        prog = self.taps_program(x.shape, save)
+        self._prepare_forward()
+        prog.x_in.copy_(x)
+        prog.run([torch.cuda.current_stream()])
+        self._stamp(prog)
+        # (fresh tensor objects over the program's buffers: an autograd node must not hand out the same object twice)
+        if save:
+            return prog.low.detach(), prog.out.detach(), (prog, prog.generation)
+        return prog.low.detach(), prog.out.detach()
+
+    def _refresh_backward_weights(self):
+        super()._refresh_backward_weights()
+        for (cid, py, px), (c, idx, buf) in self._phase_w.items():          # persistent phase sub-weights, in place
+            torch.index_select(c.wT, 0, idx, out=buf)
 
     def _dgrad_strided(self, du, c, mask, in_hw):
         """Data gradient of the stride-2 3x3 convolution (torchvision v1.5 `layer2.0.conv2`; + ReLU mask of its input):
         a transposed convolution, computed as its four PHASES on the MFMA kernel. With y[o] = sum_k W[k] x[2o + k - 1],
         an input pixel 2a + p (p = its parity) receives from the taps k = p + 1 (mod 2): p = 0 -> k = 1 (dy[a]);
         p = 1 -> k = 0 (dy[a + 1]) and k = 2 (dy[a]). Each (py, px) phase is therefore a stride-1 convolution over the dy
-        grid with 1, 2, 2 or 4 taps whose outputs land on every second pixel of dx starting at (py, px)."""
+        grid with 1, 2, 2 or 4 taps whose outputs land on every second pixel of dx starting at (py, px). The phases'
+        sub-weights live in persistent buffers (refreshed with the dgrad operands), so that a recorded pass stays valid."""
         if not (c.stride == 2 and c.ksize == 3 and c.pad == 1 and c.dil == 1):
             raise NotImplementedError('phase decomposition is written for the 3x3 / stride 2 / pad 1 convolution')
         n = du.shape[0]
@@ -629,30 +676,28 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
                 if ha <= 0 or wb <= 0:
                     continue
                 ks = [(ky, kx) for ky in sel[py] for kx in sel[px]]
-                wsub = c.wT[[ky * 3 + kx for ky, kx in ks]].contiguous()          # (taps, Cin, Cout), BN scale folded
+                ent = self._phase_w.get((id(c), py, px))
+                if ent is None:
+                    idx = torch.tensor([ky * 3 + kx for ky, kx in ks], dtype=torch.long, device=du.device)
+                    ent = (c, idx, c.wT[idx].contiguous())                   # (taps, Cin, Cout), BN scale folded
+                    self._phase_w[(id(c), py, px)] = ent
                 taps = [((py + 1 - ky) // 2, (px + 1 - kx) // 2) for ky, kx in ks]
-                ops.conv_igemm(du, wsub, taps, mode=1, mask_src=mask, out=dx, out_hw=(ha, wb), out_stride=2,
+                ops.conv_igemm(du, ent[2], taps, mode=1, mask_src=mask, out=dx, out_hw=(ha, wb), out_stride=2,
                                out_full_hw=(H, W), out_pixel_offset=py * W + px)
         return dx
 
-    def backward_taps(self, saved, d_low, d_out):
-        """Gradients wrt the two taps (bf16 NHWC or None) -> gradient wrt the stem output; weight and BatchNorm-affine
-        gradients are accumulated into the arena."""
-        if self._wT_version != self.version or self.blocks[0].c1.wT is None:
-            self._refresh_backward_weights()
-            self._wT_version = self.version
-        x4 = saved[-1]
-        track_bn = self.bn_trainable
-        if track_bn:
-            self._wdot_all.zero_()
-            self._dbeta_all.zero_()
-        if d_out is None:
-            d_out = torch.zeros_like(x4)
-        dC = (d_out * (x4 > 0)).contiguous()
+    def _taps_chain(self, saved, dC, d_low, track_bn, side, rec):
+        """The launches of the backward pass (recordable). `dC`: gradient wrt the layer4 output, already masked with its
+        ReLU. `d_low`: gradient wrt the layer1 tap or None; while recording it is added between two program segments
+        (`rec.dres` is the buffer it goes into, the segment boundary is marked 'dlow')."""
         main = torch.cuda.current_stream()
-        side = self._side_stream() if self.overlap_wgrad else None
+        if track_bn:
+            ops.memset_zero(self._wdot_all)
+            ops.memset_zero(self._dbeta_all)
         keep = []
         for bi in range(len(self.blocks) - 1, -1, -1):
+            if rec is not None:
+                rec.group = bi
             b = self.blocks[bi]
             xin, a1, a2 = saved[bi]
             in_hw = (xin.shape[1], xin.shape[2])
@@ -662,7 +707,7 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
             else:
                 dU1 = self._dgrad_strided(dU2, b.c2, a1, (a1.shape[1], a1.shape[2]))
             if side is not None:
-                side.wait_stream(main)
+                ops.stream_wait(side, main)
                 keep.append((dC, dU2, dU1))
                 with torch.cuda.stream(side):
                     self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
@@ -670,18 +715,76 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
                 self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
             dres = dC if b.cd is None else self._dgrad(dC, b.cd, in_hw=in_hw)
             if bi == self.tap_low + 1 and d_low is not None:
-                dres = dres + d_low            # second gradient into the layer1 output; masked with it just below
+                # second gradient into the layer1 output (masked with it just below). layer2.0 has a downsample
+                # convolution, so dres is that convolution's own output buffer: the in-place add races with nobody
+                if b.cd is None:
+                    raise RuntimeError('the layer1 tap must feed a bottleneck with a downsample branch')
+                if rec is not None:
+                    rec.mark('dlow')
+                    rec.dres = dres
+                else:
+                    dres.add_(d_low)
             dC = self._dgrad(dU1, b.c1, res=dres, mask=None if bi == 0 else xin, in_hw=in_hw)
         if side is not None:
-            main.wait_stream(side)
+            ops.stream_wait(main, side)
         del keep
+        return dC
+
+    def backward_taps(self, saved, d_low, d_out):
+        """Gradients wrt the two taps (bf16 NHWC or None) -> gradient wrt the stem output; weight and BatchNorm-affine
+        gradients are accumulated into the arena."""
+        if self._wT_version != self.version or self.blocks[0].c1.wT is None:
+            self._refresh_backward_weights()
+            self._wT_version = self.version
+        track_bn = self.bn_trainable
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_wgrad else None
+        recorded = isinstance(saved, tuple) and len(saved) == 2 and isinstance(saved[0], ops.Program)
+        if not recorded:
+            x4 = saved[-1]
+            if d_out is None:
+                d_out = torch.zeros_like(x4)
+            dC = (d_out * (x4 > 0)).contiguous()
+            dx = self._taps_chain(saved, dC, d_low, track_bn, side, None)
+        else:
+            fprog, gen = saved
+            if fprog.generation != gen:
+                raise RuntimeError('the activations of this forward pass were overwritten by a later forward pass of the '
+                                   'same shape through the same executor (programs keep ONE set of buffers per shape): '
+                                   'run backward before the next forward, or set executor.use_programs = False')
+            x4 = fprog.saved[-1]
+            key = (d_low is not None, track_bn, side is not None)
+            prog = fprog.bwd.get(key)
+            streams = [main] + ([side] if side is not None else [])
+            if prog is None:
+                prog = ops.Program()
+                prog.dC_in = torch.empty_like(x4)
+                prog.dlow_in = torch.empty_like(fprog.low) if d_low is not None else None
+                prog.dres = None
+                with ops.recording(prog, streams):
+                    prog.dx = self._taps_chain(fprog.saved, prog.dC_in, prog.dlow_in, track_bn, side, prog)
+                fprog.bwd[key] = prog
+            if d_out is None:
+                prog.dC_in.zero_()
+            else:
+                torch.mul(d_out, x4 > 0, out=prog.dC_in)
+            if d_low is not None:
+                prog.dlow_in.copy_(d_low)
+                cut = [i for i, tag in prog.marks if tag == 'dlow'][0]
+                prog.run(streams, 0, cut)
+                prog.dres.add_(prog.dlow_in)              # main stream, between the two segments
+                prog.run(streams, cut, -1)
+            else:
+                prog.run(streams)
+            self._account(prog)
+            dx = prog.dx.clone()
         if track_bn:
             a, ix = self.arena, self._bn_idx
             dgamma = (self._wdot_all - a.flat[ix['running_mean']] * self._dbeta_all) * \
                 torch.rsqrt(a.flat[ix['running_var']] + 1e-5)
             a.grad.index_add_(0, ix['weight'], dgamma)
             a.grad.index_add_(0, ix['bias'], self._dbeta_all)
-        return dC
+        return dx
 
     def backward(self, saved, dlogits):
         raise NotImplementedError('use backward_taps')

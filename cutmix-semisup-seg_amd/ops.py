@@ -391,7 +391,9 @@ class _BatchNormActFn(torch.autograd.Function):
         c = int(x.shape[-1])
         dev = x.device
         stats = torch.zeros(2 * c + 1, dtype=torch.float64, device=dev)
-        stats[2 * c] = n_pix
+        # (fill_, not `stats[2 * c] = n_pix`: the element assignment is a host-to-device copy of a pageable scalar, which
+        # on this runtime waits for the stream -- 1.7 ms per BatchNorm, 63 ms per DeepLab v3+ step)
+        stats[2 * c:].fill_(float(n_pix))
         check(fn['cms_bn_reduce'](_ptr(x), None, None, _dtype_code(x), None, None, _ptr(stats), n_pix, c, 0, _stream()),
               'cms_bn_reduce')
         world = _world(group)

@@ -285,3 +285,47 @@ def test_training_pass_on_the_executor_matches_the_library_gradients():
     for k in ('deeplab.backbone.layer2.0.bn2.weight', 'deeplab.backbone.layer3.1.bn3.bias',
               'deeplab.backbone.layer1.0.downsample.1.weight'):
         assert float(hip[k].abs().max()) > 0
+
+
+def test_recorded_backbone_passes_equal_the_launch_by_launch_passes():
+    """The executor records its forward and backward passes once per input shape (csrc/program.hip) and replays them:
+    same kernels, same order, persistent buffers -- outputs and every gradient must agree with the launch-by-launch
+    issue of the same executor (atomics in the weight gradients: 1e-5 relative), over two iterations with a weight
+    change in between (the replay must pick up the re-packed operands, incl. the four phase sub-weights of the strided
+    3x3 data gradient)."""
+    layers, C = (2, 2, 2, 2), 5
+    st = _he_state(C, layers)
+    g = torch.Generator().manual_seed(23)
+    xs = [torch.randn(3, 3, 97, 129, generator=g).to(DEV) for _ in range(2)]
+    tgt = torch.randn(3, C, 25, 33, generator=g).to(DEV)
+
+    def run(programs):
+        net = _net(C, layers, torch.bfloat16, st)
+        net.engine_kind = 'auto'
+        net.eval()
+        outs, grads = [], []
+        for it, x in enumerate(xs):
+            for p in net.parameters():
+                p.grad = None
+            ex = net.hip_executor()
+            ex.use_programs = programs
+            out = net.forward_lowres(x)
+            ((out - tgt) ** 2).mean().backward()
+            outs.append(out.detach().float().cpu())
+            grads.append({k: p.grad.float().cpu().clone() for k, p in net.named_parameters() if p.grad is not None})
+            with torch.no_grad():                       # a weight update between the iterations
+                for p in net.parameters():
+                    p.mul_(1.0 + 0.01 * (it + 1))
+            ex.invalidate()                             # fp32 weights edited by hand: refresh the bf16 arena / operands
+        return outs, grads, net.hip_executor()
+
+    o_rec, g_rec, ex = run(True)
+    o_eag, g_eag, _ = run(False)
+    assert ex.use_programs and len(ex.programs()) >= 2           # a forward and its backward were recorded
+    for a, b in zip(o_rec, o_eag):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+    for ga, gb in zip(g_rec, g_eag):
+        assert ga.keys() == gb.keys()
+        for k in ga:
+            denom = float(gb[k].norm()) + 1e-20
+            assert float((ga[k] - gb[k]).norm()) / denom <= 2e-5, k
