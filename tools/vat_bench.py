@@ -50,3 +50,20 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 print('VAT step [{}]: {:.1f} ms, {:.1f} img/s (sup loss {:.3f}, cons loss {:.5f})'.format(
     which, dt * 1e3, B / dt, float(r['sup_loss']), float(r['consistency_loss'])))
+if os.environ.get('CMS_HOST_PROFILE'):         # where the host time of an iteration goes
+    import cProfile, pstats
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(x, y, [vat.VATUnsupBatch(xt)])
+        ts.append(1e3 * (time.perf_counter() - t0))
+    torch.cuda.synchronize()
+    print('host ms per iteration on an empty queue:', ['%.1f' % t for t in ts])
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(2):
+        step(x, y, [vat.VATUnsupBatch(xt)])
+        torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr, stream=sys.stdout).sort_stats('tottime').print_stats(25)
