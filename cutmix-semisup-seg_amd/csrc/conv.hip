@@ -1224,8 +1224,33 @@ struct WgradArgs {
     float* dbeta;          // [Cout] += sum_p dU[p][co]
     uint32_t* trace;       // diagnostic: cycle stamps (cms_conv_set_trace), NULL in production
     int trace_wgs;
+    float* slab;           // split-K partial sums [ksplit][ntaps][Cout][Cin] (plain stores) or NULL (atomics into dw)
+    size_t slab_stride;    // floats per slice
     short tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
 };
+
+// dw[tap][co][ci] += sum over slices of slab[s][tap][co][ci], co < cout_real (4 floats per thread)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ksplit,
+                                                            size_t slab_stride, int ntaps, int Cout, int Cin, int cout_real,
+                                                            int dw_cout) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;          // float4 index over [ntaps][cout_real][Cin / 4]
+    const int c4 = Cin >> 2;
+    const size_t total = (size_t)ntaps * cout_real * c4;
+    if (q >= total) return;
+    const int ci = (int)(q % c4) * 4;
+    const size_t r = q / c4;
+    const int co = (int)(r % cout_real), tap = (int)(r / cout_real);
+    const float* src = slab + ((size_t)tap * Cout + co) * Cin + ci;
+    float4 acc = *reinterpret_cast<const float4*>(src);
+    for (int s = 1; s < ksplit; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)s * slab_stride);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(dw + ((size_t)tap * dw_cout + co) * Cin + ci);
+    float4 o = *dst;
+    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    *dst = o;
+}
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -1592,6 +1617,7 @@ __global__ __launch_bounds__(256, DMA ? ((BETA || !PLAIN) ? 3 : 4) : 1) void con
     __syncthreads();                                        // every wave is done with the stage buffers
     float* stg = reinterpret_cast<float*>(smem) + wave * (32 * TCI * 32);   // this wave's [32][TCI*32] floats
     const int rot = (ks * 5 + tap * 3) & 31;
+    float* slab_t = a.slab ? a.slab + (size_t)ks * a.slab_stride + (size_t)tap * a.Cout * a.Cin : nullptr;
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
 #pragma unroll
@@ -1600,6 +1626,24 @@ __global__ __launch_bounds__(256, DMA ? ((BETA || !PLAIN) ? 3 : 4) : 1) void con
             for (int j = 0; j < TCI; ++j)
                 stg[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * (TCI * 32) + j * 32 + fcol] = acc[i][j][r];
         // (same wave writes and reads: LDS operations of one wave complete in order, no barrier)
+        if (slab_t) {
+            // split-K partial sums as plain 16-byte stores: one wave instruction = 4 (TCI = 2) or 8 rows of the tile
+            constexpr int RW = TCI * 32, LPR = RW / 4, RPI = 64 / LPR;      // floats per row, lanes per row, rows / instr
+            const int c4 = (lane % LPR) * 4;
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int row = it * RPI + lane / LPR;
+                const int co_l = (wco * TCO + i) * 32 + row;
+                const int co = co0 + co_l;
+                if (co < a.cout_real) {
+                    const float sc = lds_scale[co_l];
+                    float4 v = *reinterpret_cast<const float4*>(stg + row * RW + c4);
+                    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                    *reinterpret_cast<float4*>(slab_t + (size_t)co * a.Cin + ci0 + wci * RW + c4) = v;
+                }
+            }
+            continue;
+        }
         for (int rr = 0; rr < 32; ++rr) {
             const int row = (rr + rot) & 31;
             if constexpr (TCI == 2) {
@@ -1713,6 +1757,21 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     a.pix_per_split = per;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(tiles * ksplit);
+    // split-K combine through slabs + a reduce launch (CMS_WGRAD_SLAB=1, needs the caller's workspace) instead of fp32
+    // atomics. Measured: alone the layer list is 6 % faster (5.71 vs 6.06 ms) and the sums become order-deterministic;
+    // inside the step it is 1.5 % SLOWER (488 vs 496 img/s, profiles/r02ah_*): the atomics are fire-and-forget work
+    // for the otherwise idle memory-side units while the other stream computes, the slabs cost HBM bandwidth and one
+    // more launch per layer. Default: atomics.
+    static int env_slab = -1;
+    if (env_slab < 0) {
+        const char* e = getenv("CMS_WGRAD_SLAB");
+        env_slab = e ? atoi(e) : 0;
+    }
+    const size_t slice_elems = (size_t)d->ntaps * d->cout * d->cin;
+    const bool use_slab = env_slab != 0 && d->workspace != nullptr && ksplit > 1 && d->cin % 4 == 0 &&
+                          (unsigned long long)d->workspace_bytes >= (unsigned long long)ksplit * slice_elems * sizeof(float);
+    a.slab = use_slab ? (float*)d->workspace : nullptr;
+    a.slab_stride = slice_elems;
     a.trace = g_conv_trace;                      // diagnostic (cms_conv_set_trace); NULL in production
     a.trace_wgs = g_conv_trace_wgs;
     const size_t lds = (dma ? stages : 1) * 2 * 64 * 256 + 128 * 4 + (a.trace ? CONV_TRACE_DWORDS * 4 : 0);
@@ -1738,5 +1797,10 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     else CMS_WGRAD_LAUNCH(1, 1);
 #undef CMS_WGRAD_LAUNCH
 #undef CMS_WGRAD_LAUNCH2
+    if (use_slab) {
+        const size_t total4 = (size_t)d->ntaps * a.cout_real * (d->cin / 4);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, a.slab, d->dw, ksplit,
+                           slice_elems, d->ntaps, d->cout, d->cin, a.cout_real, a.dw_cout);
+    }
     return launch_status("cms_conv_wgrad");
 }

@@ -871,6 +871,20 @@ class PackTransposePlan(object):
                                                   _stream()), 'cms_conv_pack_transpose_batch')
 
 
+_WGRAD_WS = {}            # (device index, stream handle) -> uint8 scratch for the split-K partial sums
+WGRAD_WORKSPACE_BYTES = 160 << 20
+
+
+def _wgrad_workspace(device, stream_handle):
+    """One scratch buffer per stream (launches on one stream are serialised; the recorded programs keep pointing into
+    it, so it is never reallocated). Largest need at the BASELINE shapes: 6 slices x 9 x 512 x 512 floats = 57 MB."""
+    key = (device.index, int(stream_handle))
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(WGRAD_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
 def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, w_bf16=None, wdot=None, dbeta=None,
                dw_cout=None):
     """
@@ -907,6 +921,10 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
     d.wdot = wdot.data_ptr() if wdot is not None else None
     d.dbeta = dbeta.data_ptr() if dbeta is not None else None
     d.dw_cout = 0 if dw_cout is None else int(dw_cout)
+    if not f32:
+        # (while recording, the current stream IS the stream the op is recorded for)
+        ws = _wgrad_workspace(du.device, torch.cuda.current_stream().cuda_stream)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     if _REC is not None:
         prog = _REC[0]
         idx = fn['cms_program_add_wgrad'](prog.h, C.byref(d), int(f32), _rec_stream_index(), prog.group)

@@ -307,6 +307,13 @@ typedef struct cms_wgrad_desc {
     int dw_cout;           /* rows per tap of the dw TENSOR when it is narrower than the GEMM's (padded) cout: the ASPP
                               head computes 64 padded class rows and writes the cout_real live ones straight into the
                               (9, C, 2048) gradient tensor; 0 = cout                                               */
+    void* workspace;       /* optional scratch for the split-K partial sums (bf16 entry point), used under
+                              CMS_WGRAD_SLAB=1 when it holds at least ksplit * ntaps * cout * cin floats: the pixel
+                              slices write their tiles there with plain stores and a second launch on the same stream
+                              adds their sum to dw (order-deterministic; 6 % faster alone, 1.5 % slower inside the
+                              two-stream step than the default fp32 atomics). NULL or too small: atomics. One workspace
+                              per stream (launches on one stream are serialised).                                      */
+    long long workspace_bytes;
 } cms_wgrad_desc;
 
 int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream);

@@ -302,7 +302,8 @@ def test_strided_3x3_dgrad_as_four_phases(ops, hw):
     mask = _mk((N, H, W, Cin), g)
     wT = ops.conv_pack_transpose(_pack(w), scale=scale, flip=False)
     c = types.SimpleNamespace(stride=2, ksize=3, pad=1, dil=1, cin=Cin, wT=wT)
-    dx = DeepLabV3PlusBackboneExecutor._dgrad_strided(None, du, c, mask, (H, W))
+    ex = types.SimpleNamespace(_phase_w={})          # (the executor keeps the phases' sub-weights in persistent buffers)
+    dx = DeepLabV3PlusBackboneExecutor._dgrad_strided(ex, du, c, mask, (H, W))
     xr = torch.zeros(N, Cin, H, W, device=DEV, requires_grad=True)
     y = F.conv2d(xr, w.float(), None, 2, 1) * scale.view(1, -1, 1, 1)
     y.backward(du.float().permute(0, 3, 1, 2))
