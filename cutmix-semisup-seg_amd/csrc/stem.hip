@@ -453,7 +453,13 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_mfma_kernel(const uint16_t*
             }
         }
     }
-    // acc[q]: rows = channel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of half wc, column = lane & 31 of column tile wk + 2 q
+    // acc[q]: rows = channel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of half wc, column = lane & 31 of column tile wk + 2 q.
+    // The gradient tensor is [ky][kx][co][c]: a lane's elements are 12 bytes apart there, and an fp32 atomic is a
+    // memory-side request per cache line touched (6.3 M requests per launch from 512 workgroups: 465 us, r02z kernel
+    // stats). So the workgroup first lays its 9408 results out in LDS in the tensor's order, then adds them with
+    // consecutive lanes on consecutive addresses (147 wave instructions of 256 bytes).
+    __syncthreads();                                       // the stage buffers are free
+    float* lds_out = reinterpret_cast<float*>(smem);       // [49][64][3] floats = 37.6 KB
     const int fcol = lane & 31, fhalf = lane >> 5;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -463,10 +469,12 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_mfma_kernel(const uint16_t*
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int co = wc * 32 + (i & 3) + 8 * (i >> 2) + 4 * fhalf;
-                atomicAdd(dw + ((size_t)(ky * 7 + kx) * STEM_CO + co) * 3 + c, acc[q][i] * (scale ? scale[co] : 1.0f));
+                lds_out[((ky * 7 + kx) * STEM_CO + co) * 3 + c] = acc[q][i] * (scale ? scale[co] : 1.0f);
             }
         }
     }
+    __syncthreads();
+    for (int i = tid; i < 49 * STEM_CO * 3; i += 256) atomicAdd(dw + i, lds_out[i]);
 }
 
 // ---- gradient wrt the image: dx[n,c,iy,ix] = sum_{ky,kx,co} dS[n,(iy+3-ky)/2,(ix+3-kx)/2,co] * scale[co]-folded w
@@ -630,7 +638,7 @@ extern "C" int cms_stem_wgrad(const void* x_nchw, int x_dtype, const void* ds_nh
     }
     if (x_dtype == CMS_BF16 && ds_dtype == CMS_BF16 && env_mfma != 0) {
         const int nt = n * ((Ho + SF_T - 1) / SF_T) * ((Wo + SF_T - 1) / SF_T);
-        hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nt < 512 ? nt : 512), dim3(256), 0, s, (const uint16_t*)x_nchw,
+        hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nt < 256 ? nt : 256), dim3(256), 0, s, (const uint16_t*)x_nchw,
                            (const uint16_t*)ds_nhwc, dw_khkwcoci, scale, n, h, w, Ho, Wo);
         return launch_status("cms_stem_wgrad");
     }
