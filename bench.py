@@ -394,6 +394,19 @@ def run_workload(key, args, world, rank, dev):
             host_ms.append(1e3 * (time.perf_counter() - th))
         torch.cuda.synchronize()
         host_unblocked = float(np.median(host_ms))
+        if args.copy_profile and rank == 0:          # which python lines issue device-to-device copies / fills (stderr)
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+                for i in range(2):
+                    one_step(i)
+                torch.cuda.synchronize()
+            rows = [e for e in prof.key_averages(group_by_stack_n=8)
+                    if ('copy_' in e.key or 'clone' in e.key or 'Memcpy' in e.key or 'fill_' in e.key or 'zero_' in e.key)]
+            rows.sort(key=lambda e: -e.count)
+            for e in rows[:40]:
+                sys.stderr.write('{:6d} x {:28s} cuda {:9.1f} us | {}\n'.format(
+                    e.count, e.key[:28], e.device_time_total if hasattr(e, 'device_time_total') else 0.0,
+                    ' <- '.join(str(f).split('/')[-1] for f in e.stack[:5])))
         if args.host_profile and rank == 0:          # where the host time of a step goes (stderr; not part of the line)
             import cProfile
             import pstats
@@ -548,6 +561,7 @@ def main():
     ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')
     ap.add_argument('--wgrad_streams', type=int, default=0, help='experiment: streams the weight gradients are spread over')
     ap.add_argument('--no_roofline_events', action='store_true', help='skip the per-launch event brackets')
+    ap.add_argument('--copy_profile', action='store_true', help='torch.profiler: python sources of the device copies / fills of two steps (stderr)')
     ap.add_argument('--host_profile', action='store_true', help='cProfile of three steps after the timed region (stderr)')
     ap.add_argument('--roofline_sample', type=int, default=5,
                     help='bracket every k-th launch of the conv kernel with events (1 = all; the brackets cost ~3 %% '

@@ -27,6 +27,7 @@
 // Roofline: dilated 3x3 (layer3: K = 2304, AI ~ 680 FLOP/B) is MFMA-bound; 1x1 (AI ~ 180 FLOP/B) is HBM-bound on the
 // activation stream; DESIGN.md section 4 lists algorithmic FLOPs / bytes per layer shape.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 #include "common.hpp"
@@ -1742,13 +1743,31 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     const bool plain_shape = d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho &&
                              d->w_in == d->wo;
     if (d->ksplit <= 0 && dma && env_target <= 0) {
-        // the direct-to-LDS kernel runs 4 workgroups per CU: more slices pay as long as a slice keeps >= 32 stages
-        // of 64 pixels in front of its 64 KB of atomics (sweep: profiles/r02r_wgrad_bench.log)
+        // Number of pixel slices from a two-term model (env CMS_WGRAD_MODEL=0: the sweep-tuned rule of profiles/r02r):
+        //   the slices' K loops run side by side (<= `cap` resident workgroups): nst / ks stages of t_stage each;
+        //   their atomics are served by the memory-side units at ~0.7 TB/s IN TOTAL (tools/atomic_probe.hip): ks * |dW|.
+        // The sum is smallest at ks = sqrt(nst * t_stage * 0.7e12 / |dW| bytes). It reproduces the tuned values at
+        // the 321 x 321 shapes (21 / 16 / 8 / 10 slices for the 1x1 1024->256, 3x3 256->256, 3x3 512->512, 1x1 2048->512
+        // layers) and follows M where the tuning did not go: DeepLab v3+ at 513 x 513 has 10 890 pixels per layer-3/4
+        // launch, where 24 slices of 7 stages each spent their time in the atomics.
+        static int env_model = -1;
+        if (env_model < 0) {
+            const char* e = getenv("CMS_WGRAD_MODEL");
+            env_model = e ? atoi(e) : 1;
+        }
         const int nst = (a.M + 63) / 64;
         // resident workgroups: 2 per CU with two stages (LDS), 3 where the register budget is 168 (taps / side outputs)
         const int cap = stages == 2 ? 512 : ((plain_shape && d->dbeta == nullptr) ? 864 : 720);
-        const int hi = std::min(cap / tiles, nst / 32);
-        if (hi > ksplit) ksplit = hi;
+        if (env_model != 0) {
+            const double t_stage = plain_shape ? 1.25e-6 : 1.75e-6;
+            const double dw_bytes = (double)d->ntaps * d->cout * d->cin * 4.0;
+            int ks = (int)(std::sqrt((double)nst * t_stage * 0.7e12 / dw_bytes) + 0.5);
+            ks = std::max(1, std::min(ks, std::min(std::max(1, cap / tiles), nst)));
+            ksplit = ks;
+        } else {
+            const int hi = std::min(cap / tiles, nst / 32);
+            if (hi > ksplit) ksplit = hi;
+        }
     }
     int per = ((a.M + ksplit - 1) / ksplit + 63) / 64 * 64;
     if (per < 64) per = 64;
