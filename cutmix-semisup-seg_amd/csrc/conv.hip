@@ -1593,24 +1593,45 @@ __global__ __launch_bounds__(256, DMA ? ((BETA || !PLAIN) ? 3 : 4) : 1) void con
     if (a.wdot || (BETA && do_beta)) {
 #pragma unroll
         for (int i = 0; i < TCO; ++i) {
+            if (a.wdot) {
+                // <W, G> per output channel: first ALL products of this 32-row block (32 independent 2-byte loads in
+                // flight, one wait), then the sum over the 32 lanes of a row with DPP adds (row_shr 1, 2, 4, 8 +
+                // row_bcast 15: 5 vector-ALU instructions, result in lane 31 of each half-wave). The first version
+                // paid a load round trip + 5 ds_bpermute round trips PER ROW: ~40 000 cycles per workgroup, more than
+                // the K loop of a DeepLab v3+ launch (10 890 pixels).
+                float dots[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co_l = (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                const int co = co0 + co_l;
-                if (co >= a.cout_real) continue;
-                if (a.wdot) {
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    const int co_c = min(co, a.Cout - 1);
                     float dot = 0.0f;
 #pragma unroll
                     for (int j = 0; j < TCI; ++j) {
                         const int ci = ci0 + (wci * TCI + j) * 32 + fcol;
-                        dot += acc[i][j][r] * bf16_to_f32(a.w[((size_t)tap * a.Cout + co) * a.Cin + ci]);
+                        dot += acc[i][j][r] * bf16_to_f32(a.w[((size_t)tap * a.Cout + co_c) * a.Cin + ci]);
                     }
-#pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);   // the 32 lanes of this row
-                    if (fcol == 0) atomicAdd(a.wdot + co, dot);
+                    dots[r] = dot;
                 }
-                if constexpr (BETA) {
-                    if (do_beta && fcol == 0) atomicAdd(a.dbeta + co, accb[i][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int v = __builtin_bit_cast(int, dots[r]);
+                    auto addf = [](int x, int y) { return __builtin_bit_cast(int, __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y)); };
+                    v = addf(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));     // row_shr:1
+                    v = addf(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));     // row_shr:2
+                    v = addf(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, false));     // row_shr:4, banks 1..3
+                    v = addf(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, false));     // row_shr:8, banks 2..3
+                    v = addf(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));     // row_bcast:15 into rows 1, 3
+                    const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    if (fcol == 31 && co < a.cout_real) atomicAdd(a.wdot + co, __builtin_bit_cast(float, v));
+                }
+            }
+            if constexpr (BETA) {
+                if (do_beta && fcol == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + (wco * TCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                        if (co < a.cout_real) atomicAdd(a.dbeta + co, accb[i][r]);
+                    }
                 }
             }
         }
