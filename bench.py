@@ -387,13 +387,13 @@ def run_workload(key, args, world, rank, dev):
         # Host cost of enqueueing ONE step with an empty launch queue (in the timed loop the enqueue call blocks on the
         # queue whenever the GPU is the limit, so `host_enqueue_ms_per_step` ~ `ms_per_step` says nothing about the host)
         host_ms = []
-        for i in range(4):
+        for i in range(0 if args.timed_only else 4):
             torch.cuda.synchronize()
             th = time.perf_counter()
             one_step(i)
             host_ms.append(1e3 * (time.perf_counter() - th))
         torch.cuda.synchronize()
-        host_unblocked = float(np.median(host_ms))
+        host_unblocked = float(np.median(host_ms)) if host_ms else None
         if args.copy_profile and rank == 0:          # which python lines issue device-to-device copies / fills (stderr)
             from torch.profiler import profile, ProfilerActivity
             with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
@@ -429,7 +429,7 @@ def run_workload(key, args, world, rank, dev):
         hbm_timed_pairs = list(hbm['pairs'])
         hbm_tot = (hbm['bytes'], hbm['moved'], {k: list(v) for k, v in hbm['parts'].items()})
         if world == 1 and roofline_kernel == 'conv' and not args.no_overlap and not args.no_roofline_events and has_ex \
-                and 'arch' not in wl:
+                and 'arch' not in wl and not args.timed_only:
             del conv['pairs'][:], conv['work'][:]
             cfg.overlap_teacher = False
             stu.hip_executor().overlap_wgrad = False
@@ -561,6 +561,9 @@ def main():
     ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')
     ap.add_argument('--wgrad_streams', type=int, default=0, help='experiment: streams the weight gradients are spread over')
     ap.add_argument('--no_roofline_events', action='store_true', help='skip the per-launch event brackets')
+    ap.add_argument('--timed_only', action='store_true',
+                    help='skip the extra single-stream and empty-queue steps after the timed region (so that a rocprofv3 '
+                         '--stats run of this command averages in-step launches only)')
     ap.add_argument('--copy_profile', action='store_true', help='torch.profiler: python sources of the device copies / fills of two steps (stderr)')
     ap.add_argument('--host_profile', action='store_true', help='cProfile of three steps after the timed region (stderr)')
     ap.add_argument('--roofline_sample', type=int, default=5,
