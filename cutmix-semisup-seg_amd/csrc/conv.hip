@@ -271,6 +271,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
         }
         lds_row[tid] = ri;
     }
+    stamp(13);                                             // tables written (before the barrier)
     // BN affine of the tile's channels: fetched here, so that the epilogue has no global load of its own in front of
     // its arithmetic (tools/conv_trace.py: the per-element float4 loads cost ~10k cycles per workgroup)
     static_assert(BN <= NT && (BN == 32 || 2 * BN / 64 <= NW), "scale / bias staging");
@@ -511,7 +512,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
     };
     if constexpr (GLDS) {
         if (ks_begin < ksteps) {
+            stamp(14);                                     // barrier passed, loader geometry / accumulators set up
             setup_tap();
+            stamp(15);                                     // first tap's offsets computed
             issue_loads(0);
         }
     } else {
@@ -843,7 +846,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
             out[11] = (uint32_t)t_start; out[12] = (uint32_t)(t_start >> 32);
         }
         for (int i = 4 + tid; i < CONV_TRACE_DWORDS; i += NT)
-            if (i < 8 || i >= 16) out[i] = lds_trace[i];
+            if (i < 8 || i >= 13) out[i] = lds_trace[i];
     }
 }
 

@@ -97,6 +97,8 @@ for name, N, H, W, Cin, Cout, k, dil, use_res in SHAPES:
         life.mean(), np.percentile(life, 10), np.percentile(life, 90), life.max()))
     print('   prologue {:.0f} | K loop {:.0f} | epilogue math {:.0f} | stores {:.0f}   (mean cycles)'.format(
         tr[:, 4].mean(), (tr[:, 5] - tr[:, 4]).mean(), (tr[:, 6] - tr[:, 5]).mean(), (tr[:, 7] - tr[:, 6]).mean()))
+    print('   prologue split: tables written at {:.0f} | barrier + loader geometry until {:.0f} | first tap offsets until {:.0f} | '
+          'first stage issued at {:.0f}'.format(tr[:, 13].mean(), tr[:, 14].mean(), tr[:, 15].mean(), tr[:, 4].mean()))
     print('   per K step (mean cycles): step {:.0f} = wait-own-loads {:.0f} + barrier {:.0f} + reads+MFMA {:.0f} + barrier {:.0f}'
           ' + issue {:.0f}   (MFMA floor 512)'.format(step.mean(), wait_own.mean(), bar1.mean(), mfma.mean(), bar2.mean(),
                                                     issue.mean()))
