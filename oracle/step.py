@@ -80,7 +80,7 @@ def _sgd_k(p, g, buf, lr, k, momentum, nesterov, wd):
 
 def train_iteration(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode='mix', loss_fn='var', conf_thresh=0.97,
                     conf_per_pixel=False, ramp_val=1.0, rampup=-1, cons_weight=1.0, frozen_bn=True, grads_out=None,
-                    pi_model=False):
+                    pi_model=False, storage=None, taps_out=None):
     """
     One iteration. `sup_y` int64 (N,1,H,W) with 255 = ignore; `masks` float (N,1,H,W) in {0,1}.
     In cut mode ux1/um1 are ignored. Returns dict(sup_loss, consistency_loss, conf_rate).
@@ -88,7 +88,15 @@ def train_iteration(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode='mix', loss
     -- the yardstick the tests hold the device backward pass to.
     `pi_model`: `--model pi` (train_seg_semisup_mask_mt.py:110-113): the teacher IS the student network (its forward
     passes run under no_grad with the student's current weights) and there is no EMA step.
+    `storage`: None = the fp32 restatement through torch autograd (pinned by tests/golden/step.npz). 'bf16' / 'fp32' =
+    the same iteration through the explicit forward / backward chain of oracle/deeplab2_chain.py, with ('bf16') or
+    without ('fp32') the storage roundings of the device's throughput configuration -- losses, optimizer and EMA are the
+    code below either way; `taps_out` (dict) then receives the block inputs of the student passes.
     """
+    if storage is not None:
+        return _train_iteration_chain(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode, loss_fn, conf_thresh,
+                                      conf_per_pixel, ramp_val, rampup, cons_weight, frozen_bn, grads_out, pi_model,
+                                      storage, taps_out)
     if not frozen_bn:
         raise NotImplementedError('oracle step covers the --freeze_bn configuration (cfg 2/3)')
     keys = [k for k, _, _ in S.entries]
@@ -121,9 +129,17 @@ def train_iteration(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode='mix', loss
         for k in keys:
             grads_out[k] = None if leaves[k].grad is None else leaves[k].grad.detach().clone()
 
+    _apply_updates(S, {k: leaves[k].grad for k in keys}, pi_model)
+    return dict(sup_loss=float(sup_loss.detach()),
+                consistency_loss=None if closs is None else float(closs.detach()),
+                conf_rate=None if rate is None else float(rate))
+
+
+def _apply_updates(S, grads, pi_model):
+    """optimizer step with the duplicated entries (:465; deeplab2.py:208-230) + EMA (:466-467)."""
     with torch.no_grad():
         for k, mult, base_lr in S.entries:
-            g = leaves[k].grad
+            g = grads.get(k)
             if g is None:      # ASPP d18/d24 never receive gradients and are skipped by the optimizer
                 continue
             lr = base_lr * S.lr_scale
@@ -137,6 +153,55 @@ def train_iteration(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode='mix', loss
             if t.dtype == torch.float32:
                 t.mul_(a)
                 t.add_(S.student[k] * (1.0 - a))
+
+
+def _train_iteration_chain(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode, loss_fn, conf_thresh, conf_per_pixel,
+                           ramp_val, rampup, cons_weight, frozen_bn, grads_out, pi_model, storage, taps_out=None):
+    from . import deeplab2_chain as ch
+    if not frozen_bn:
+        raise NotImplementedError('oracle step covers the --freeze_bn configuration (cfg 2/3)')
+    keys = [k for k, _, _ in S.entries]
+    stu = ch.Chain(S.student, S.num_classes, S.layers, storage)
+    size = tuple(sup_x.shape[2:4])
+
+    def leaf(lo):
+        return lo.detach().requires_grad_(True)
+
+    lo_sup, sv_sup = stu.forward(sup_x)
+    lo_sup = leaf(lo_sup)
+    sup_loss = L.supervised_ce(L.upsample(lo_sup, size), sup_y[:, 0])
+    total = sup_loss
+    closs = rate = None
+    lo_mix = sv_mix = None
+    if cons_weight > 0.0:
+        tea = stu if pi_model else ch.Chain(S.teacher, S.num_classes, S.layers, storage)
+        l0 = L.upsample(tea.forward(ux0, save=False)[0], size)
+        l1 = L.upsample(tea.forward(ux1, save=False)[0], size) if mode == 'mix' else None
+        kw = dict(loss_fn=loss_fn, conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, ramp_val=ramp_val,
+                  rampup=rampup, cons_weight=cons_weight)
+        x_in = L.paste(ux0, ux1, masks) if mode == 'mix' else ux0 * masks
+        lo_mix, sv_mix = stu.forward(x_in)
+        lo_mix = leaf(lo_mix)
+        if mode == 'mix':
+            r = L.mix_mode_loss(L.upsample(lo_mix, size), l0, l1, masks, um0, um1, **kw)
+        else:
+            r = L.cut_mode_loss(L.upsample(lo_mix, size), l0, masks, um0, **kw)
+        total = total + r['unsup_loss']
+        closs, rate = r['consistency_loss'], r['conf_rate']
+    total.backward()
+    if taps_out is not None:       # inputs of every bottleneck + the layer4 output, per student pass (per-block error curves)
+        taps_out['sup'] = stu.block_outputs(sv_sup)
+        taps_out['sup_logits'] = lo_sup.detach()
+        if sv_mix is not None:
+            taps_out['mix'] = stu.block_outputs(sv_mix)
+            taps_out['mix_logits'] = lo_mix.detach()
+    grads = stu.backward(sv_sup, lo_sup.grad)
+    if lo_mix is not None and lo_mix.grad is not None:
+        stu.backward(sv_mix, lo_mix.grad, grads)
+    if grads_out is not None:
+        for k in keys:
+            grads_out[k] = grads.get(k)
+    _apply_updates(S, grads, pi_model)
     return dict(sup_loss=float(sup_loss.detach()),
                 consistency_loss=None if closs is None else float(closs.detach()),
                 conf_rate=None if rate is None else float(rate))

@@ -217,7 +217,7 @@ def _problem(name):
     return out
 
 
-def _device_iteration(ops, P, dtype):
+def _device_iteration(ops, P, dtype, taps=None):
     from architectures import deeplab2
     import optim_weight_ema
     import evaluation
@@ -246,6 +246,12 @@ def _device_iteration(ops, P, dtype):
     ex = stu.hip_executor()
     assert ex.dtype == dtype and stu._hip_executor is ex
     grads = {k: p.grad.detach().float().cpu().clone() for k, p in stu.named_parameters() if p.grad is not None}
+    if taps is not None:
+        # the recorded student pass over [x_sup; x_mix] keeps (input, a1, a2) of every bottleneck + the layer4 output
+        progs = [p_ for k_, p_ in ex._programs.items() if k_[0] == 'fwd' and k_[2]]
+        assert len(progs) == 1
+        sv = progs[0].saved
+        taps['blocks'] = [t[0].float().cpu() for t in sv[:-1]] + [sv[-1].float().cpu()]      # NHWC, batch [sup; mix]
     stu.eval()
     with torch.no_grad():
         lo = stu.forward_lowres(cu(P['x']))
@@ -306,6 +312,70 @@ def test_bf16_hip_engine_iteration_vs_oracle_reports_errors(ops, name):
     # (cfg 3); the trained-network statement (within 0.2 pt) is tests/test_gpu_miou_training.py
     assert e['miou'] <= 1e-1, e
     assert e['grad_head'] <= 2e-2 and e['grad_mean'] <= 3e-2 and e['grad_max'] <= 1.5e-1, e
+
+
+_ORACLE16 = {}
+
+
+def _problem_bf16(name):
+    """The SAME iteration on the SAME inputs through the bf16-storage restatement (oracle/deeplab2_chain.py): what the
+    timed configuration is held to. The threshold is the fp32 problem's (median teacher confidence)."""
+    if name in _ORACLE16:
+        return _ORACLE16[name]
+    from oracle import deeplab2_chain as och, step as ostep, boxmask as obox, evaluation as oev, losses as OL
+    P = _problem(name)
+    geo = P['geo']
+    N, H, W, C = geo['N'], geo['H'], geo['W'], geo['C']
+    masks = torch.tensor(obox.rasterise(P['ranges'], (H, W), True).astype(np.float32))
+    ones = torch.ones(N, 1, H, W)
+    S = ostep.StepState(P['st'], C, LAYERS, opt='adam', lr=LR, teacher_alpha=0.99)
+    grads, taps = {}, {}
+    ref = ostep.train_iteration(S, P['x'], P['y'], P['ux0'], P['ux1'], ones, ones, masks, conf_thresh=P['tau'],
+                                grads_out=grads, storage='bf16', taps_out=taps)
+    with torch.no_grad():
+        lo = och.Chain(S.student, C, LAYERS, 'bf16').forward(P['x'], save=False)[0]
+        pred = OL.upsample(lo, (H, W)).argmax(dim=1)
+    g = torch.Generator().manual_seed(78)
+    truth = pred.clone()
+    flip = torch.rand(truth.shape, generator=g) < 0.3
+    truth[flip] = torch.randint(0, C, truth.shape, generator=g)[flip]
+    truth[P['y'][:, 0] == 255] = 255
+    acc = oev.IoUAccumulator(C)
+    for i in range(N):
+        acc.sample(truth[i].numpy(), pred[i].numpy(), ignore_value=255)
+    out = dict(P)
+    out.update(ref=ref, grads=grads, truth=truth, miou=float(acc.score().mean()), taps=taps)
+    _ORACLE16[name] = out
+    return out
+
+
+@pytest.mark.parametrize('name', sorted(GEOMETRIES))
+def test_bf16_hip_engine_iteration_matches_the_bf16_storage_oracle(ops, name):
+    """THROUGHPUT (timed) configuration against the oracle WITH the storage model: same algorithm, bf16 rounding where
+    the fused epilogues store -- what is left is fp32 summation order (and the rare bf16 tie it flips). Every loss, the
+    rate, the IoU and EVERY gradient tensor are bounded >= 10x tighter than against the fp32 oracle (VERDICT r2, item 1);
+    a wrong tap / epilogue / mask in any one of the 104 layers moves its own gradient tensor by O(1)."""
+    P = _problem_bf16(name)
+    taps = {}
+    got, grads = _device_iteration(ops, P, torch.bfloat16, taps=taps)
+    e = _errors(P, got, grads)
+    ge = {k: _rel(grads[k], w) for k, w in P['grads'].items() if w is not None}
+    worst = sorted(ge.items(), key=lambda kv: -kv[1])[:5]
+    print('\nPARITY bf16 HIP engine vs bf16-storage oracle [{}] ref={} got={} errors={} worst gradients={}'.format(
+        name, P['ref'], got, e, worst))
+    # per-block curve: input of every bottleneck (and the layer4 output), device vs bf16-storage oracle
+    n = P['geo']['N']
+    curve = []
+    for i, dev_t in enumerate(taps['blocks']):
+        want = torch.cat([P['taps']['sup'][i], P['taps']['mix'][i]], dim=0).permute(0, 2, 3, 1)
+        assert tuple(dev_t.shape) == tuple(want.shape)
+        curve.append((_rel(dev_t, want), float((dev_t != want).float().mean())))
+    print('PER-BLOCK bf16 engine vs bf16-storage oracle [{}] (relative error, fraction of differing elements): {}'.format(
+        name, ' '.join('{}:{:.1e}/{:.1e}'.format(i, a, b) for i, (a, b) in enumerate(curve))))
+    assert curve[0][0] <= 2e-3 and curve[-1][0] <= 1e-2, curve
+    assert e['sup_loss'] <= 1e-4 and e['consistency_loss'] <= 3e-3 and e['conf_rate'] <= 2e-4, e
+    assert e['miou'] <= 1e-2, e
+    assert e['grad_head'] <= 2e-3 and e['grad_mean'] <= 3e-3 and e['grad_max'] <= 1.5e-2, e
 
 
 def test_aspp_single_pass_formulation_vs_fp64(ops):
