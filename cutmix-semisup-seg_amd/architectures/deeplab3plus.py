@@ -256,11 +256,26 @@ class DeepLabv3Wrapper(nn.Module):
         super(DeepLabv3Wrapper, self).__init__()
         self.deeplab = model
         self.pretraining = pretraining
-        self.compute_dtype = torch.bfloat16
-        self.engine = None
-        self.engine_kind = 'auto'          # 'torch': library engine for every pass; 'hip_nograd': executor only without grad
-        self._hip_executor = None
-        self._hip_engine = None
+        self._init_runtime()
+
+    def _init_runtime(self):
+        """Execution state of this build (not part of the reference's module): set at construction and again after
+        unpickling a whole-module checkpoint, which does not carry it (checkpoint.py strips it on export)."""
+        d = self.__dict__
+        d.setdefault('compute_dtype', torch.bfloat16)
+        d.setdefault('engine', None)
+        # 'auto': hand-written kernels wherever a layer fits them, the library for the rest; 'hip': hand-written kernels
+        # or an error (no library convolution / BatchNorm may run); 'torch': library engine for every pass;
+        # 'hip_nograd': backbone executor only for passes without gradients
+        d.setdefault('engine_kind', 'auto')
+        d.setdefault('_hip_executor', None)
+        d.setdefault('_hip_executors', {})
+        d.setdefault('_hip_engine', None)
+        d.setdefault('_hip_engines', {})
+
+    def __setstate__(self, state):
+        super(DeepLabv3Wrapper, self).__setstate__(state)
+        self._init_runtime()
 
     # ------------------------------------------------------------------------------------------ execution
     def _engine(self, x):

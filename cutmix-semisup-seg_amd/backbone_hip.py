@@ -379,7 +379,14 @@ class DeepLabHipExecutor(object):
 
     # ------------------------------------------------------------------------------------------ backward
     def _wgrad(self, du, x, c):
-        if c.wdot is not None:
+        if c.wdot is not None and self.dtype == torch.float32:
+            # parity configuration: G = unscaled weight gradient from the f32 kernel, then <W, G> and sum_p dU as tensor ops
+            g = torch.zeros_like(self._w(c))
+            ops.conv_wgrad(du, x, c.taps, g, stride=c.stride)
+            self.arena.packed(c.wkey, self.arena.grad).add_(g * c.scale.view(1, -1, 1))
+            c.wdot.add_((g * self._w(c)).sum(dim=(0, 2)))
+            c.dbeta.add_(du.sum(dim=(0, 1, 2)))
+        elif c.wdot is not None:
             ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride, scale=c.scale,
                            w_bf16=self._w(c), wdot=c.wdot, dbeta=c.dbeta)
         else:
@@ -587,9 +594,12 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
         layer1 / layer2 boundary.
     """
 
-    def __init__(self, wrapper):
-        self._init_common(wrapper)
-        self.use_programs = True           # passes recorded once per input shape and replayed (csrc/program.hip)
+    def __init__(self, wrapper, dtype=torch.bfloat16):
+        self._init_common(wrapper, dtype)
+        # passes recorded once per input shape and replayed (csrc/program.hip). The fp32 PARITY configuration with a
+        # trainable BatchNorm affine derives d(gamma) / d(beta) with tensor ops between the launches (the f32 weight-
+        # gradient kernel has no side outputs): issued launch by launch
+        self.use_programs = not (dtype == torch.float32 and self.bn_trainable and self.trainable)
         # torchvision's stem: same 7x7/2 convolution, max-pool WITHOUT ceil_mode, trainable BatchNorm affine
         self.stem_wkey, self.stem_bn, self.stem_ceil = 'deeplab.backbone.conv1.weight', 'deeplab.backbone.bn1', False
         self.stem_w147 = None
@@ -806,9 +816,10 @@ class _V3BodyFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_low, d_out):
+        dt = ctx.executor.dtype
         dx = ctx.executor.backward_taps(ctx.saved_acts,
-                                        None if d_low is None else d_low.contiguous().to(torch.bfloat16),
-                                        None if d_out is None else d_out.contiguous().to(torch.bfloat16))
+                                        None if d_low is None else d_low.contiguous().to(dt),
+                                        None if d_out is None else d_out.contiguous().to(dt))
         ctx.saved_acts = None
         return dx, None, None
 

@@ -67,6 +67,7 @@ struct ConvArgs {
     int stagger;            // != 0: co-resident workgroups of the first dispatch round start 1/4 K-step period apart (24 / 25)
     int n_main, rem_tile_base;   // conv_igemm_mixed_kernel: workgroups of the main tile shape, first pixel tile of the rest
     int krot;               // != 0: workgroup (tile_m) starts its K loop krot * tile_m steps in and wraps (variant 20)
+    int plain;              // 1x1, stride 1, tap (0, 0), output grid == input grid: GEMM row m IS input and output pixel m
 };
 
 
@@ -251,11 +252,21 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
             lds_tap[CMS_CONV_MAX_TAPS + i] = a.tap_dx[i];
         }
     }
+    // PLAIN (pointwise convolution over an unstrided grid -- two thirds of the network's launches): the row geometry
+    // needs no division, the loader no table, and the first stage is issued BEFORE the tables are written; the first
+    // barrier of the K loop publishes them (tools/conv_trace.py: 2100 cycles of table arithmetic + 1100 of barrier and
+    // geometry + 1200 of tap offsets stood in front of the first load of every workgroup)
+    const bool plain = GLDS && BUFA && NS == 1 && a.plain != 0;
     if (tid < BM) {
         const int m = m0 + tid;
         RowInfo ri;
         ri.m = (uint32_t)m;
-        if (m < a.M) {
+        if (plain) {
+            const bool live = m < a.M;
+            ri.in_off = live ? (uint32_t)(m * a.Cin) : 0u;
+            ri.yx = live ? 0u : 0x70007000u;
+            ri.opix = live ? (uint32_t)m : 0xffffffffu;
+        } else if (m < a.M) {
             const int ox = m % a.Wo;
             const int t = m / a.Wo;
             const int oy = t % a.Ho;
@@ -293,7 +304,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
         lds_sb[tid] = use_scale ? a.scale[co0 + tid] : 1.0f;
         lds_sb[BN + tid] = use_bias ? a.bias[co0 + tid] : 0.0f;
     }
-    __syncthreads();
+    if (!plain) __syncthreads();
 
     // ---- loader geometry (fixed for the whole K loop)
     // register-staged: thread -> 16-byte chunk (tid & 7) of rows (tid >> 3) + 32*i, swizzled on the LDS side.
@@ -383,23 +394,38 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
         cur_kc = r - (r / kc_per_tap) * kc_per_tap;
     }
     auto setup_tap = [&]() {
-        const int dy = __builtin_amdgcn_readfirstlane((int)lds_tap[cur_tap]);
-        const int dx = __builtin_amdgcn_readfirstlane((int)lds_tap[CMS_CONV_MAX_TAPS + cur_tap]);
-        const int delta = (dy * a.W + dx) * a.Cin;                     // scalar element offset of this tap
         if constexpr (BUFA) {
+            // (one formula for the scalar offsets on both paths: a value merged from two branches is no longer provably
+            // wave-uniform for the "s" operand of the inline-asm loads)
             soff_x = (uint32_t)(cur_kc * BK * 2);
             soff_w = (uint32_t)((((cur_tap * a.Cout + co0) * a.Cin) + cur_kc * BK) * 2);
+            if (plain) {                       // no table read: nothing here depends on the (not yet published) LDS tables
 #pragma unroll
-            for (int i = 0; i < PA; ++i) {
-                const int row = (NW * i + wave) * LRPI + lane / CH;
-                const int c = (lane % CH) ^ ((row >> WSH) & (CH - 1));
-                const RowInfo ri = lds_row[row];
-                const uint32_t iy = (ri.yx >> 16) + (uint32_t)dy, ix = (ri.yx & 0xffffu) + (uint32_t)dx;
-                const bool ok = iy < (uint32_t)a.H && ix < (uint32_t)a.W;    // unsigned compare covers the negative side
-                xvoff[i] = ok ? (ri.in_off + (uint32_t)(c * 8) + (uint32_t)delta) * 2u : 0x80000000u;   // out of range: zeros
+                for (int i = 0; i < PA; ++i) {
+                    const int row = (NW * i + wave) * LRPI + lane / CH;
+                    const int c = (lane % CH) ^ ((row >> WSH) & (CH - 1));
+                    const int m = m0 + row;
+                    xvoff[i] = m < a.M ? (uint32_t)(m * a.Cin + c * 8) * 2u : 0x80000000u;
+                }
+            } else {
+                const int dy = __builtin_amdgcn_readfirstlane((int)lds_tap[cur_tap]);
+                const int dx = __builtin_amdgcn_readfirstlane((int)lds_tap[CMS_CONV_MAX_TAPS + cur_tap]);
+                const int delta = (dy * a.W + dx) * a.Cin;                     // scalar element offset of this tap
+#pragma unroll
+                for (int i = 0; i < PA; ++i) {
+                    const int row = (NW * i + wave) * LRPI + lane / CH;
+                    const int c = (lane % CH) ^ ((row >> WSH) & (CH - 1));
+                    const RowInfo ri = lds_row[row];
+                    const uint32_t iy = (ri.yx >> 16) + (uint32_t)dy, ix = (ri.yx & 0xffffu) + (uint32_t)dx;
+                    const bool ok = iy < (uint32_t)a.H && ix < (uint32_t)a.W;    // unsigned compare covers the negative side
+                    xvoff[i] = ok ? (ri.in_off + (uint32_t)(c * 8) + (uint32_t)delta) * 2u : 0x80000000u;   // out of range: zeros
+                }
             }
             return;
         }
+        const int dy = __builtin_amdgcn_readfirstlane((int)lds_tap[cur_tap]);
+        const int dx = __builtin_amdgcn_readfirstlane((int)lds_tap[CMS_CONV_MAX_TAPS + cur_tap]);
+        const int delta = (dy * a.W + dx) * a.Cin;                     // scalar element offset of this tap
         wt = a.w + ((size_t)cur_tap * a.Cout + co0) * a.Cin + cur_kc * BK;   // scalar base (cur_kc != 0 only when rotated)
 #pragma unroll
         for (int i = 0; i < ((GLDS && !BUFA) ? PA : 0); ++i) {
@@ -1073,6 +1099,15 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
     a.krot = d->variant == 20 ? 1 : (d->variant == 21 ? 3 : (d->variant == 22 ? 5 : (d->variant == 23 ? 11 : (d->variant == 25 ? 3 : 0))));
     a.stagger = (d->variant == 24 || d->variant == 25) ? 1 : 0;
     a.n_main = 0; a.rem_tile_base = 0;
+    // pointwise fast path of the prologue (conv_body: `plain`); CMS_CONV_PLAIN=0 switches it off (A/B, read once)
+    static int env_plain = -1;
+    if (env_plain < 0) {
+        const char* e = getenv("CMS_CONV_PLAIN");
+        env_plain = e ? atoi(e) : 1;
+    }
+    a.plain = (env_plain != 0 && d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho &&
+               d->w_in == d->wo && d->out_stride == 1 && d->out_h == d->ho && d->out_w == d->wo && a.ksplit == 1 && a.krot == 0 &&
+               (size_t)a.M * d->cin * 2 < (1ull << 31)) ? 1 : 0;
     // 30: the default kernel with per-workgroup cycle stamps into the buffer given to cms_conv_set_trace
     a.trace = (d->variant == 30 || d->variant == 41) ? g_conv_trace : nullptr;      // 41: trace of variant 40
     a.trace_wgs = g_conv_trace_wgs;

@@ -88,37 +88,57 @@ class Chain(object):
         y = F.conv2d(x, w, None, stride, pad, dil)
         return y * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
 
+    # ------------------------------------------------------------------------------------------ units (forward)
+    def stem_forward(self, x):
+        """-> (s = stored ReLU output of conv1 + bn1, p = max-pooled input of layer1)   deeplab2.py:183-186"""
+        sc, bs = self._affine('bn1')
+        s = self._R(F.relu(F.conv2d(x, self._stem_weight(), None, 2, 3) * sc.view(1, -1, 1, 1) + bs.view(1, -1, 1, 1)))
+        return s, F.max_pool2d(s, 3, 2, 1, ceil_mode=True)
+
+    def block_forward(self, bi, cur, a1_given=None, a2_given=None):
+        """One bottleneck on a GIVEN input (deeplab2.py:89-109) -> (a1, a2, out). Feeding the device's own stored input
+        here is the teacher-forced per-layer check: only fp32 summation order separates the two results. `a1_given` /
+        `a2_given`: the inputs of conv2 / conv3 are forced as well (every convolution checked on its own)."""
+        st = self.st
+        pre, stride, dil, down = self.units[bi]
+        s1, b1 = self._affine(pre + '.bn1')
+        s2, b2 = self._affine(pre + '.bn2')
+        s3, b3 = self._affine(pre + '.bn3')
+        a1 = self._R(F.relu(self._cba(cur, self._Rw(st[pre + '.conv1.weight']), s1, b1, stride, 1, 1)), bi)
+        a1_in = a1 if a1_given is None else a1_given
+        a2 = self._R(F.relu(self._cba(a1_in, self._Rw(st[pre + '.conv2.weight']), s2, b2, 1, dil, 3)), bi)
+        a2_in = a2 if a2_given is None else a2_given
+        if down:
+            sd, bd = self._affine(pre + '.downsample.1')
+            res = self._R(self._cba(cur, self._Rw(st[pre + '.downsample.0.weight']), sd, bd, stride, 1, 1), bi)
+        else:
+            res = cur
+        out = self._R(F.relu(self._cba(a2_in, self._Rw(st[pre + '.conv3.weight']), s3, b3, 1, 1, 1) + res), bi)
+        return a1, a2, out
+
+    def head_forward(self, x4):
+        """conv_d6 + conv_d12 + biases (deeplab2.py:124-128), fp32 result."""
+        st = self.st
+        logits = None
+        for i, d in enumerate(dl.ASPP_DILATIONS[:2]):
+            k = 'layer5.conv2d_list.{}'.format(i)
+            y = F.conv2d(x4, self._Rw(st[k + '.weight']), None, 1, d, d)
+            logits = y if logits is None else logits + y
+        return logits + (st['layer5.conv2d_list.0.bias'] + st['layer5.conv2d_list.1.bias']).view(1, -1, 1, 1)
+
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x, save=True):
         """x fp32 (N,3,H,W) (already holding bf16-representable values in the bf16 configuration) ->
         (low-resolution logits fp32 (N,C,h,w), saved)."""
-        st = self.st
         with torch.no_grad():
-            sc, bs = self._affine('bn1')
-            s = self._R(F.relu(F.conv2d(x, self._stem_weight(), None, 2, 3) * sc.view(1, -1, 1, 1) + bs.view(1, -1, 1, 1)))
-            p, pidx = F.max_pool2d(s, 3, 2, 1, ceil_mode=True, return_indices=True)
+            s, p = self.stem_forward(x)
             cur = p
             blocks = []
-            for bi, (pre, stride, dil, down) in enumerate(self.units):
-                s1, b1 = self._affine(pre + '.bn1')
-                s2, b2 = self._affine(pre + '.bn2')
-                s3, b3 = self._affine(pre + '.bn3')
-                a1 = self._R(F.relu(self._cba(cur, self._Rw(st[pre + '.conv1.weight']), s1, b1, stride, 1, 1)), bi)
-                a2 = self._R(F.relu(self._cba(a1, self._Rw(st[pre + '.conv2.weight']), s2, b2, 1, dil, 3)), bi)
-                if down:
-                    sd, bd = self._affine(pre + '.downsample.1')
-                    res = self._R(self._cba(cur, self._Rw(st[pre + '.downsample.0.weight']), sd, bd, stride, 1, 1), bi)
-                else:
-                    res = cur
-                out = self._R(F.relu(self._cba(a2, self._Rw(st[pre + '.conv3.weight']), s3, b3, 1, 1, 1) + res), bi)
+            for bi in range(len(self.units)):
+                a1, a2, out = self.block_forward(bi, cur)
                 blocks.append((cur, a1, a2))
                 cur = out
-            logits = None
-            for i, d in enumerate(dl.ASPP_DILATIONS[:2]):
-                k = 'layer5.conv2d_list.{}'.format(i)
-                y = F.conv2d(cur, self._Rw(st[k + '.weight']), None, 1, d, d)
-                logits = y if logits is None else logits + y
-            logits = logits + (st['layer5.conv2d_list.0.bias'] + st['layer5.conv2d_list.1.bias']).view(1, -1, 1, 1)
+            logits = self.head_forward(cur)
         saved = dict(x=x, s=s, p_shape=tuple(p.shape), blocks=blocks, x4=cur) if save else None
         return logits, saved
 
@@ -126,65 +146,75 @@ class Chain(object):
         """Input of every bottleneck (= output of the previous one; [0] is the stem output) + the layer4 output."""
         return [b[0] for b in saved['blocks']] + [saved['x4']]
 
+    # ------------------------------------------------------------------------------------------ units (backward)
+    def head_backward(self, x4, dlogits, acc):
+        """-> dC of the last bottleneck (gradient wrt its pre-ReLU sum, masked); head gradients through `acc`."""
+        st = self.st
+        nb = len(self.units)
+        D = self._R(dlogits)               # the head's backward operand is stored in the activation dtype
+        db = dlogits.sum(dim=(0, 2, 3))
+        dC = None
+        for i, d in enumerate(dl.ASPP_DILATIONS[:2]):
+            k = 'layer5.conv2d_list.{}'.format(i)
+            w = self._Rw(st[k + '.weight'])
+            acc(k + '.weight', conv2d_weight(x4, w.shape, D, 1, d, d))
+            acc(k + '.bias', db)
+            t = conv2d_input(x4.shape, w, D, 1, d, d)
+            dC = t if dC is None else dC + t
+        return self._R(dC * (x4 > 0), nb - 1)
+
+    def block_backward(self, bi, xin, a1, a2, dC, acc):
+        """Backward of one bottleneck on GIVEN activations and a GIVEN incoming gradient -> dC of the previous one."""
+        st = self.st
+        pre, stride, dil, down = self.units[bi]
+        s1, _ = self._affine(pre + '.bn1')
+        s2, _ = self._affine(pre + '.bn2')
+        s3, _ = self._affine(pre + '.bn3')
+        w1, w2, w3 = (self._Rw(st[pre + '.conv{}.weight'.format(j)]) for j in (1, 2, 3))
+        v = lambda s_: s_.view(-1, 1, 1, 1)
+        # dgrad operands: bf16(W * scale[co]) -- the BatchNorm scale is folded BEFORE the storage rounding
+        wT3, wT2, wT1 = self._Rw(w3 * v(s3)), self._Rw(w2 * v(s2)), self._Rw(w1 * v(s1))
+        dU2 = self._R(conv2d_input(a2.shape, wT3, dC) * (a2 > 0), bi)
+        dU1 = self._R(conv2d_input(a1.shape, wT2, dU2, 1, dil, dil) * (a1 > 0), bi)
+        acc(pre + '.conv3.weight', conv2d_weight(a2, w3.shape, dC) * v(s3))
+        acc(pre + '.conv2.weight', conv2d_weight(a1, w2.shape, dU2, 1, dil, dil) * v(s2))
+        if down:
+            sd, _ = self._affine(pre + '.downsample.1')
+            wd = self._Rw(st[pre + '.downsample.0.weight'])
+            acc(pre + '.downsample.0.weight', conv2d_weight(xin, wd.shape, dC, stride) * v(sd))
+            dres = self._R(conv2d_input(xin.shape, self._Rw(wd * v(sd)), dC, stride), bi)
+        else:
+            dres = dC
+        acc(pre + '.conv1.weight', conv2d_weight(xin, w1.shape, dU1, stride) * v(s1))
+        t = conv2d_input(xin.shape, wT1, dU1, stride) + dres
+        if bi > 0:
+            t = t * (xin > 0)             # (block 0: the stem's ReLU mask is applied by the max-pool backward)
+        return self._R(t, bi)
+
+    def stem_backward(self, x, s, dp, acc):
+        """max-pool backward (ties: first maximum wins, like ATen) fused with the ReLU mask, then dW of conv1."""
+        with torch.enable_grad():
+            sl = s.detach().requires_grad_(True)
+            F.max_pool2d(sl, 3, 2, 1, ceil_mode=True).backward(dp)
+        ds = self._R(sl.grad * (s > 0))
+        sc, _ = self._affine('bn1')
+        acc('conv1.weight', conv2d_weight(x, self.st['conv1.weight'].shape, ds, 2, 3) * sc.view(-1, 1, 1, 1))
+
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, saved, dlogits, grads=None):
         """dlogits fp32 (N,C,h,w) -> dict key -> gradient (accumulated into `grads` when given). Weight gradients stay
         fp32 (the device accumulates them in an fp32 arena)."""
-        st = self.st
         g = grads if grads is not None else OrderedDict()
 
         def acc(key, val):
             g[key] = val if key not in g else g[key] + val
 
         with torch.no_grad():
-            x4 = saved['x4']
-            nb = len(self.units)
-            D = self._R(dlogits)               # the head's backward operand is stored in the activation dtype
-            db = dlogits.sum(dim=(0, 2, 3))
-            dC = None
-            for i, d in enumerate(dl.ASPP_DILATIONS[:2]):
-                k = 'layer5.conv2d_list.{}'.format(i)
-                w = self._Rw(st[k + '.weight'])
-                acc(k + '.weight', conv2d_weight(x4, w.shape, D, 1, d, d))
-                acc(k + '.bias', db)
-                t = conv2d_input(x4.shape, w, D, 1, d, d)
-                dC = t if dC is None else dC + t
-            dC = self._R(dC * (x4 > 0), nb - 1)
-            for bi in range(nb - 1, -1, -1):
-                pre, stride, dil, down = self.units[bi]
+            dC = self.head_backward(saved['x4'], dlogits, acc)
+            for bi in range(len(self.units) - 1, -1, -1):
                 xin, a1, a2 = saved['blocks'][bi]
-                s1, _ = self._affine(pre + '.bn1')
-                s2, _ = self._affine(pre + '.bn2')
-                s3, _ = self._affine(pre + '.bn3')
-                w1, w2, w3 = (self._Rw(st[pre + '.conv{}.weight'.format(j)]) for j in (1, 2, 3))
-                v = lambda s_: s_.view(-1, 1, 1, 1)
-                # dgrad operands: bf16(W * scale[co]) -- the BatchNorm scale is folded BEFORE the storage rounding
-                wT3, wT2, wT1 = self._Rw(w3 * v(s3)), self._Rw(w2 * v(s2)), self._Rw(w1 * v(s1))
-                dU2 = self._R(conv2d_input(a2.shape, wT3, dC) * (a2 > 0), bi)
-                dU1 = self._R(conv2d_input(a1.shape, wT2, dU2, 1, dil, dil) * (a1 > 0), bi)
-                acc(pre + '.conv3.weight', conv2d_weight(a2, w3.shape, dC) * v(s3))
-                acc(pre + '.conv2.weight', conv2d_weight(a1, w2.shape, dU2, 1, dil, dil) * v(s2))
-                if down:
-                    sd, _ = self._affine(pre + '.downsample.1')
-                    wd = self._Rw(st[pre + '.downsample.0.weight'])
-                    acc(pre + '.downsample.0.weight', conv2d_weight(xin, wd.shape, dC, stride) * v(sd))
-                    dres = self._R(conv2d_input(xin.shape, self._Rw(wd * v(sd)), dC, stride), bi)
-                else:
-                    dres = dC
-                acc(pre + '.conv1.weight', conv2d_weight(xin, w1.shape, dU1, stride) * v(s1))
-                t = conv2d_input(xin.shape, wT1, dU1, stride) + dres
-                if bi > 0:
-                    t = t * (xin > 0)         # (block 0: the stem's ReLU mask is applied by the max-pool backward)
-                dC = self._R(t, bi)
-            # stem: max-pool backward (ties: first maximum wins, like ATen) fused with the ReLU mask, then dW
-            s = saved['s']
-            with torch.enable_grad():
-                sl = s.detach().requires_grad_(True)
-                F.max_pool2d(sl, 3, 2, 1, ceil_mode=True).backward(dC)
-            ds = self._R(sl.grad * (s > 0))
-            sc, _ = self._affine('bn1')
-            x = saved['x']
-            acc('conv1.weight', conv2d_weight(x, st['conv1.weight'].shape, ds, 2, 3) * sc.view(-1, 1, 1, 1))
+                dC = self.block_backward(bi, xin, a1, a2, dC, acc)
+            self.stem_backward(saved['x'], saved['s'], dC, acc)
         return g
 
 

@@ -239,6 +239,8 @@ def _device_iteration(ops, P, dtype, taps=None):
     ema.fuse_into(opt)
     stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()
     step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=P['tau'], compute_dtype=dtype))
+    if taps is not None:
+        stu.hip_executor().debug_capture = {}        # the recorded backward pass keeps the dC buffer of every bottleneck
     cu = lambda t: t.to(DEV).to(dtype)
     ub = UnsupBatch(cu(P['ux0']), ops.ranges_to_device(P['ranges'], DEV), x1_tea=cu(P['ux1']))
     r = step(cu(P['x']), P['y'].to(torch.uint8).to(DEV), [ub])
@@ -252,6 +254,14 @@ def _device_iteration(ops, P, dtype, taps=None):
         assert len(progs) == 1
         sv = progs[0].saved
         taps['blocks'] = [t[0].float().cpu() for t in sv[:-1]] + [sv[-1].float().cpu()]      # NHWC, batch [sup; mix]
+        taps['a1'] = [t[1].float().cpu() for t in sv[:-1]]
+        taps['a2'] = [t[2].float().cpu() for t in sv[:-1]]
+        taps['logits'] = progs[0].logits.float().cpu()
+        bw = list(progs[0].bwd.values())
+        assert len(bw) == 1
+        taps['dlg'], taps['dx'] = bw[0].dlg.float().cpu(), bw[0].dx.float().cpu()
+        taps['dC'] = {bi: t.float().cpu() for bi, t in ex.debug_capture.items()}
+        taps['x_stu'] = torch.cat([cu(P['x']), ops.cutmix_paste(cu(P['ux0']), cu(P['ux1']), ranges=ub.ranges, invert=True)]).float().cpu()
     stu.eval()
     with torch.no_grad():
         lo = stu.forward_lowres(cu(P['x']))
@@ -372,10 +382,76 @@ def test_bf16_hip_engine_iteration_matches_the_bf16_storage_oracle(ops, name):
         curve.append((_rel(dev_t, want), float((dev_t != want).float().mean())))
     print('PER-BLOCK bf16 engine vs bf16-storage oracle [{}] (relative error, fraction of differing elements): {}'.format(
         name, ' '.join('{}:{:.1e}/{:.1e}'.format(i, a, b) for i, (a, b) in enumerate(curve))))
-    assert curve[0][0] <= 2e-3 and curve[-1][0] <= 1e-2, curve
-    assert e['sup_loss'] <= 1e-4 and e['consistency_loss'] <= 3e-3 and e['conf_rate'] <= 2e-4, e
-    assert e['miou'] <= 1e-2, e
-    assert e['grad_head'] <= 2e-3 and e['grad_mean'] <= 3e-3 and e['grad_max'] <= 1.5e-2, e
+    # The two pipelines agree almost bit for bit after the stem and then DECORRELATE: one bf16 tie flipped by fp32
+    # summation order perturbs every later tensor by as much as the storage noise itself (measured: 1e-5 of the elements
+    # differ after the stem, 30 % after 8 bottlenecks, 63 % at the end; relative distance 9.7e-3 = the distance of either
+    # from the fp32 oracle). Whole-network quantities are therefore two samples of the same noise: the cross-entropy loss
+    # (a mean over all pixels) meets the 1e-4 bar, the rest is bounded at the noise level -- the tight per-layer statement
+    # is test_bf16_engine_every_layer_teacher_forced_vs_bf16_storage_oracle below.
+    assert curve[0][0] <= 2e-4 and curve[0][1] <= 2e-4 and curve[-1][0] <= 2e-2, curve
+    assert e['sup_loss'] <= 1e-4 and e['consistency_loss'] <= 3e-2 and e['conf_rate'] <= 2e-3, e
+    assert e['miou'] <= 3e-2, e
+    assert e['grad_head'] <= 2e-3 and e['grad_mean'] <= 1.5e-2 and e['grad_max'] <= 8e-2, e
+
+
+@pytest.mark.parametrize('name', sorted(GEOMETRIES))
+def test_bf16_engine_every_layer_teacher_forced_vs_bf16_storage_oracle(ops, name):
+    """The tight statement about the TIMED configuration. Whole-network comparisons of two bf16 pipelines decorrelate
+    (one flipped bf16 tie perturbs every later tensor by as much as the storage noise itself: the PER-BLOCK line of the test
+    above), so every unit is checked on its own instead: each convolution of each of the 33 bottlenecks, the stem, the head
+    and every stage of the backward chain is recomputed by the bf16-storage oracle FROM THE DEVICE'S OWN STORED INPUTS of
+    that unit (forward: the block input, a1, a2 kept for the backward pass; backward: the dC buffer of the block), and
+    must match to the few bf16 ties that fp32 summation order flips. A wrong tap, mask, residual, scale or rounding point
+    in any one layer is an O(1e-2 .. 1) error here."""
+    from oracle import deeplab2_chain as och
+    P = _problem_bf16(name)
+    taps = {}
+    _, grads = _device_iteration(ops, P, torch.bfloat16, taps=taps)
+    C = P['geo']['C']
+    chain = och.Chain(P['st'], C, LAYERS, 'bf16')
+    nchw = lambda t: t.permute(0, 3, 1, 2).contiguous()
+    frac = lambda a, b: float((a != b).float().mean())
+    nb = len(chain.units)
+    fwd, bwd, wg = [], [], {}
+    with torch.no_grad():
+        s_o, p_o = chain.stem_forward(taps['x_stu'])
+        stem_err = (_rel(nchw(taps['blocks'][0]), p_o), frac(nchw(taps['blocks'][0]), p_o))
+        for bi in range(nb):
+            xin, a1d, a2d = nchw(taps['blocks'][bi]), nchw(taps['a1'][bi]), nchw(taps['a2'][bi])
+            a1, a2, out = chain.block_forward(bi, xin, a1_given=a1d, a2_given=a2d)
+            outd = nchw(taps['blocks'][bi + 1])
+            fwd.append((max(_rel(a1d, a1), _rel(a2d, a2), _rel(outd, out)), max(frac(a1d, a1), frac(a2d, a2), frac(outd, out))))
+        x4 = nchw(taps['blocks'][nb])
+        head_err = _rel(taps['logits'], chain.head_forward(x4))
+        g = {}
+
+        def acc(key, val):
+            g[key] = val if key not in g else g[key] + val
+        dC = chain.head_backward(x4, taps['dlg'], acc)
+        bwd.append((_rel(nchw(taps['dC'][nb - 1]), dC), frac(nchw(taps['dC'][nb - 1]), dC)))
+        for bi in range(nb - 1, -1, -1):
+            dprev = chain.block_backward(bi, nchw(taps['blocks'][bi]), nchw(taps['a1'][bi]), nchw(taps['a2'][bi]),
+                                         nchw(taps['dC'][bi]), acc)
+            want = nchw(taps['dC'][bi - 1]) if bi > 0 else nchw(taps['dx'])
+            bwd.append((_rel(want, dprev), frac(want, dprev)))
+        chain.stem_backward(taps['x_stu'], s_o, nchw(taps['dx']), acc)
+    for k, v in g.items():
+        wg[k] = _rel(grads[k], v)
+    worst = sorted(wg.items(), key=lambda kv: -kv[1])[:4]
+    fmax, bmax = max(a for a, _ in fwd), max(a for a, _ in bwd)
+    print('\nPARITY teacher-forced bf16 engine vs bf16-storage oracle [{}]: stem {:.1e}/{:.1e} forward max rel {:.2e} '
+          '(max differing fraction {:.1e}) head logits {:.1e} backward dC max rel {:.2e} ({:.1e}) weight gradients: max '
+          '{:.2e} mean {:.2e} worst {}'.format(name, stem_err[0], stem_err[1], fmax, max(b for _, b in fwd), head_err, bmax,
+                                              max(b for _, b in bwd), max(wg.values()), float(np.mean(list(wg.values()))), worst))
+    print('PER-BLOCK teacher-forced forward rel: ' + ' '.join('{:.1e}'.format(a) for a, _ in fwd))
+    print('PER-BLOCK teacher-forced backward rel (head, then block 32 .. 0): ' + ' '.join('{:.1e}'.format(a) for a, _ in bwd))
+    assert len(wg) == 103 + 1 + 4                 # 103 body convolutions + the stem + 2 x (weight, bias) of the live head branches
+    # measured on MI355X (profiles/r03b_*): every convolution of the forward pass <= 4.6e-5 (<= 1.3e-4 of the elements
+    # differ, by one bf16 ulp), head logits 4e-7, block-level backward <= 7.8e-4, EVERY weight-gradient tensor <= 8.1e-5
+    assert stem_err[0] <= 1e-4 and head_err <= 2e-6
+    assert fmax <= 1.5e-4 and max(b for _, b in fwd) <= 1e-3, fwd
+    assert bmax <= 2e-3, bwd
+    assert max(wg.values()) <= 3e-4, worst
 
 
 def test_aspp_single_pass_formulation_vs_fp64(ops):
