@@ -130,6 +130,7 @@ PROTOTYPES = {
     'cms_conv_igemm': (c_int, [_P(ConvDesc), c_void_p]),
     'cms_conv_set_trace': (c_int, [c_void_p, c_int]),
     'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
+    'cms_conv_wgrad_workspace_bytes': (C.c_longlong, [_P(WgradDesc)]),
     'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'cms_conv_pack_transpose_batch': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'cms_augment_batch': (c_int, [_P(AugmentDesc), c_void_p]),

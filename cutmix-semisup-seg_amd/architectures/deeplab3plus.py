@@ -163,8 +163,10 @@ class DeepLabHeadV3Plus(nn.Module):
         y = eng.conv_bn_act(y, self.classifier[3], self.classifier[4], relu=True)
         last = self.classifier[6]
         clf = getattr(eng, 'classifier', None)
-        if clf is not None and y.is_cuda and y.dtype == torch.bfloat16 and last.out_channels <= 64 and last.in_channels % 64 == 0:
+        if clf is not None and y.is_cuda and y.dtype == eng.dtype and last.out_channels <= 64 and last.in_channels % 64 == 0:
             return clf(y, last)                                 # MFMA kernel, fp32 NCHW logits from the epilogue
+        if getattr(eng, 'strict', False):
+            raise RuntimeError('engine_kind = "hip": classifier {} has no hand-written kernel'.format(last))
         y = F.conv2d(y, last.weight.to(y.dtype), None)
         return y.float() + last.bias.view(1, -1, 1, 1)
 
@@ -190,28 +192,91 @@ class _ToChannelsLast(torch.autograd.Function):
 
 
 class HipConvEngine(TorchEngine):
-    """The library engine with its eligible convolutions (stride 1, 'same' padding, channel counts in multiples of 64:
-    the ASPP branches, the ASPP projection, the second classifier 3x3) re-routed to the MFMA kernels; BatchNorm on batch
-    statistics, the 304-channel concat convolution and the 48 / num_classes wide 1x1s stay with the library."""
+    """The engine of the networks that run layer by layer (DeepLab v3+ head, the U-Nets), in bf16 (throughput) or fp32
+    (parity configuration, csrc/conv_f32.hip):
 
-    def __init__(self, dtype, wrapper):
+      strict = False ('auto')  convolutions the MFMA kernels run well (stride 1, 'same' padding, wide channel counts: the
+                               ASPP branches and projection, the decoder 3x3s, DenseNet's bottleneck 1x1s) go there, the
+                               rest (stems, strided and narrow layers) to the library;
+      strict = True  ('hip')   EVERY convolution runs on the hand-written kernels (backbone_hip._HipConvGeneralFn: channel
+                               padding, tap chunks, strided phases) and every batch-statistics BatchNorm on csrc/bn.hip --
+                               a layer that cannot raises instead of reaching the library. This is what the oracle
+                               comparisons of these networks run on.
+    """
+
+    def __init__(self, dtype, wrapper, strict=False):
         super(HipConvEngine, self).__init__(dtype)
         from ..arena import ensure_arena
-        self.arena = ensure_arena(wrapper, with_grad=any(p.requires_grad for p in wrapper.parameters()), with_bf16=True)
+        self.strict = strict
+        self.arena = ensure_arena(wrapper, with_grad=any(p.requires_grad for p in wrapper.parameters()),
+                                  with_bf16=(dtype == torch.bfloat16))
         self.keys = {id(m): name + '.weight' for name, m in wrapper.named_modules() if isinstance(m, nn.Conv2d)}
+        self.library_convs = 0          # convolutions this engine handed to the library (0 in strict mode, by construction)
+
+    def prepare_input(self, x):
+        return x.to(dtype=self.dtype, memory_format=torch.channels_last)
 
     def conv2d(self, x, conv):
         from ..backbone_hip import hip_conv2d, hip_conv2d_eligible
         key = self.keys.get(id(conv))
-        if key is not None and hip_conv2d_eligible(x, conv):
-            return hip_conv2d(x, conv, self.arena, key)
+        if self.strict:
+            if key is None:
+                raise RuntimeError('engine_kind = "hip": convolution {} is not a registered layer of this network'.format(conv))
+            return hip_conv2d(x, conv, self.arena, key, self.dtype)
+        if key is not None and hip_conv2d_eligible(x, conv, self.dtype):
+            return hip_conv2d(x, conv, self.arena, key, self.dtype)
+        self.library_convs += 1
         return super(HipConvEngine, self).conv2d(x, conv)
 
+    def bn_act(self, y, bn, relu, residual=None):
+        if self.strict and bn is not None and bn.training:
+            yh = y.permute(0, 2, 3, 1)
+            if not (yh.is_contiguous() and y.shape[1] % 8 == 0 and bn.momentum is not None and bn.running_mean is not None):
+                raise RuntimeError('engine_kind = "hip": BatchNorm over {} channels ({}) has no hand-written kernel '
+                                   '(channels-last input with channels % 8 == 0 needed)'.format(y.shape[1], bn))
+        return super(HipConvEngine, self).bn_act(y, bn, relu, residual)
+
     def classifier(self, x, conv):
-        """1x1 convolution with bias to <= 64 classes -> fp32 NCHW logits (csrc/conv.hip epilogue)."""
+        """1x1 convolution with bias to <= 64 classes -> fp32 NCHW logits (convolution epilogue)."""
         from ..backbone_hip import hip_classifier
         key = self.keys[id(conv)]
-        return hip_classifier(x, conv, self.arena, key, key[:-len('weight')] + 'bias')
+        return hip_classifier(x, conv, self.arena, key, key[:-len('weight')] + 'bias', self.dtype)
+
+
+def _engine_of(net, x):
+    """Engine selection shared by DeepLabv3Wrapper and the U-Nets (`EngineNetMixin`): an explicit `net.engine`, the
+    library engine for engine_kind 'torch', otherwise the HipConvEngine of (compute dtype, strictness)."""
+    if net.engine is not None:
+        return net.engine
+    if not x.is_cuda:
+        raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
+                           'fallback'.format(x.device))
+    if net.compute_dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError('compute_dtype must be torch.bfloat16 or torch.float32')
+    if net.engine_kind == 'torch':
+        key = ('torch', net.compute_dtype)
+        if key not in _ENGINES:
+            _ENGINES[key] = TorchEngine(net.compute_dtype)
+        return _ENGINES[key]
+    strict = net.engine_kind == 'hip'
+    # 'auto' in fp32 keeps the library (comparison runs of the bf16 'auto' engine against fp32 library kernels); the
+    # hand-written fp32 path is asked for by name
+    if not strict and net.compute_dtype == torch.float32:
+        key = ('torch', net.compute_dtype)
+        if key not in _ENGINES:
+            _ENGINES[key] = TorchEngine(net.compute_dtype)
+        return _ENGINES[key]
+    engines = net.__dict__.setdefault('_hip_engines', {})
+    ek = (net.compute_dtype, strict)
+    eng = engines.get(ek)
+    if eng is None:
+        eng = engines[ek] = HipConvEngine(net.compute_dtype, net, strict=strict)
+        if not net.__dict__.get('_hip_engine_hooked', False):
+            # weights loaded behind the arena's back: refresh the bf16 operand copy
+            net.register_load_state_dict_post_hook(lambda module, incompatible: module._cms_arena.refresh_bf16())
+            net.__dict__['_hip_engine_hooked'] = True
+    net._hip_engine = eng
+    return eng
 
 
 class EngineNetMixin(object):
@@ -222,28 +287,18 @@ class EngineNetMixin(object):
         d = self.__dict__
         d.setdefault('compute_dtype', torch.bfloat16)
         d.setdefault('engine', None)            # set to an engine object to override the default
-        d.setdefault('engine_kind', 'auto')     # 'torch': library convolutions only
+        # 'auto': MFMA kernels where a layer fits them well, the library for the rest; 'hip': hand-written kernels for
+        # every convolution and BatchNorm, or an error; 'torch': library convolutions only
+        d.setdefault('engine_kind', 'auto')
         d.setdefault('_hip_engine', None)
+        d.setdefault('_hip_engines', {})
 
     def __setstate__(self, state):
         super(EngineNetMixin, self).__setstate__(state)
         self._init_runtime()
 
     def _engine(self, x):
-        if self.engine is not None:
-            return self.engine
-        if not x.is_cuda:
-            raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
-                               'fallback'.format(x.device))
-        if self.engine_kind != 'torch' and self.compute_dtype == torch.bfloat16:
-            if self._hip_engine is None:
-                self._hip_engine = HipConvEngine(self.compute_dtype, self)
-                self.register_load_state_dict_post_hook(lambda module, incompatible: self._hip_engine.arena.refresh_bf16())
-            return self._hip_engine
-        key = ('torch', self.compute_dtype)
-        if key not in _ENGINES:
-            _ENGINES[key] = TorchEngine(self.compute_dtype)
-        return _ENGINES[key]
+        return _engine_of(self, x)
 
 
 class DeepLabv3Wrapper(nn.Module):
@@ -279,37 +334,28 @@ class DeepLabv3Wrapper(nn.Module):
 
     # ------------------------------------------------------------------------------------------ execution
     def _engine(self, x):
-        if self.engine is not None:
-            return self.engine
-        if not x.is_cuda:
-            raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
-                               'fallback'.format(x.device))
-        if self.engine_kind != 'torch' and self.compute_dtype == torch.bfloat16:
-            if self._hip_engine is None:
-                self._hip_engine = HipConvEngine(self.compute_dtype, self)
-                # weights loaded behind the arena's back: refresh the bf16 operand copy
-                self.register_load_state_dict_post_hook(lambda module, incompatible: self._hip_engine.arena.refresh_bf16())
-            return self._hip_engine
-        key = ('torch', self.compute_dtype)
-        if key not in _ENGINES:
-            _ENGINES[key] = TorchEngine(self.compute_dtype)
-        return _ENGINES[key]
+        return _engine_of(self, x)
 
     def _use_hip_backbone(self):
         """The MFMA executor (backbone_hip.DeepLabV3PlusBackboneExecutor) runs the backbone whenever its BatchNorm
-        statistics are frozen and compute is bf16 -- training passes included; `engine_kind = 'hip_nograd'` restricts
-        it to passes that need no gradient, 'torch' switches it off."""
-        if self.engine is not None or self.engine_kind == 'torch' or self.compute_dtype != torch.bfloat16:
+        statistics are frozen -- training passes included -- in bf16 (throughput) or, with engine_kind 'hip', in fp32
+        (parity configuration); `engine_kind = 'hip_nograd'` restricts it to passes that need no gradient, 'torch'
+        switches it off. With engine_kind 'hip' a backbone on batch statistics runs layer by layer on the strict engine."""
+        if self.engine is not None or self.engine_kind == 'torch':
+            return False
+        if self.compute_dtype == torch.float32 and self.engine_kind != 'hip':
             return False
         if self.engine_kind == 'hip_nograd' and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return False
         return all(not m.training for m in self.deeplab.backbone.modules() if isinstance(m, nn.BatchNorm2d))
 
     def hip_executor(self):
-        if self._hip_executor is None:
+        ex = self._hip_executors.get(self.compute_dtype)
+        if ex is None:
             from ..backbone_hip import DeepLabV3PlusBackboneExecutor
-            self._hip_executor = DeepLabV3PlusBackboneExecutor(self)
-        return self._hip_executor
+            ex = self._hip_executors[self.compute_dtype] = DeepLabV3PlusBackboneExecutor(self, dtype=self.compute_dtype)
+        self._hip_executor = ex
+        return ex
 
     def forward_lowres(self, x):
         """(N,3,H,W) -> fp32 (N,C,h,w) logits at the low-level feature size (the reference's tensor just before its
@@ -380,6 +426,15 @@ def _deeplabv3plus(num_classes, output_stride=8, layers=(3, 4, 23, 3)):
     backbone = ResNetTaps(layers)
     classifier = DeepLabHeadV3Plus(2048, 256, num_classes, (12, 24, 36))
     return DeepLabV3Plus(backbone, classifier)
+
+
+# whole-module pickles name the reference's OWN classes by the reference's module path (architectures/deeplab3plus.py:26-158;
+# the root-level `architectures/deeplab3plus.py` re-exports these very objects). The torchvision parts the reference
+# assembles the model from (ResNet, IntermediateLayerGetter, ASPP) are restated in this file and pickle under this
+# package's path: torchvision is absent, so the reference's code can take a v3+ checkpoint of this build as a state dict
+# (identical keys), not as a whole-module pickle.
+for _cls in (DeepLabHeadV3Plus, DeepLabV3Plus, DeepLabv3Wrapper):
+    _cls.__module__ = 'architectures.deeplab3plus'
 
 
 def resnet101_deeplabv3plus_imagenet(num_classes, pretrained=True):

@@ -52,6 +52,11 @@ def unet_tail(net, x, eng):
     x = F.dropout(x, net.final_dec_drop.p, net.final_dec_drop.training)
     x = eng.bn_act(x, net.final_dec_bn, relu=True)
     clf = net.final_clf
+    hip_clf = getattr(eng, 'classifier', None)
+    if hip_clf is not None and x.is_cuda and x.dtype == eng.dtype and clf.out_channels <= 64 and clf.in_channels % 64 == 0:
+        return hip_clf(x, clf)                                  # MFMA kernel, fp32 NCHW logits from the epilogue
+    if getattr(eng, 'strict', False):
+        raise RuntimeError('engine_kind = "hip": classifier {} has no hand-written kernel'.format(clf))
     y = F.conv2d(x, clf.weight.to(x.dtype), None)
     return y.float() + clf.bias.view(1, -1, 1, 1)
 

@@ -831,57 +831,63 @@ def run_v3_body(executor, x_nhwc):
     return _V3BodyFn.apply(x_nhwc, executor, need_grad)
 
 
-class _HipConv2dFn(torch.autograd.Function):
-    """One stride-1 'same' convolution (no bias, no folded BatchNorm) on the MFMA kernels as an autograd node: forward
-    cms_conv_igemm, backward cms_conv_igemm (data gradient on the packed-transposed weights) + cms_conv_wgrad straight
-    into the gradient arena. For layers whose BatchNorm runs on batch statistics (the DeepLab v3+ head): the
-    normalisation itself stays with the library, the GEMM -- 95 % of the head's time -- does not."""
+def _wbuf_of(arena, dtype):
+    """Flat operand buffer of `dtype`: the bf16 copy the fused optimizer maintains, or the fp32 master arena itself."""
+    return arena.bf16 if dtype == torch.bfloat16 else arena.flat
+
+
+_MAX_TAPS = 18            # CMS_CONV_MAX_TAPS: larger kernels (7 x 7) are issued as chunks of taps that accumulate
+
+
+def _tap_chunks(n):
+    return [(t0, min(n, t0 + _MAX_TAPS)) for t0 in range(0, n, _MAX_TAPS)]
+
+
+def _pad64(c):
+    return (c + 63) // 64 * 64
+
+
+class _HipConvGeneralFn(torch.autograd.Function):
+    """`conv(x)` for ANY bias-free, ungrouped nn.Conv2d with a square kernel and symmetric stride / padding / dilation on
+    the hand-written MFMA kernels (csrc/conv.hip for bf16, csrc/conv_f32.hip for the fp32 parity configuration), forward,
+    data gradient and weight gradient -- the engine of the networks that run layer by layer (DeepLab v3+ head, the
+    U-Nets' encoders and decoders: architectures/deeplab3plus.py:26-101, resunet.py:36-108, denseunet.py:36-143).
+
+      * channel counts are zero-padded to multiples of 64 for the call (DenseNet's 48-multiples, the 304-channel concat
+        of the v3+ decoder, 3-channel images); the weight gradient of a padded layer comes back through an fp32 scratch;
+      * kernels with more than 18 taps (the 7 x 7 stems) run as chunks of taps, each launch adding to the previous one
+        through the residual input of the epilogue;
+      * strided convolutions gather with `stride` in the forward pass; their data gradient is the transposed convolution
+        as stride x stride PHASES (pixel s*a + p receives the taps k with (p + pad - k*dil) % s == 0 from dy[a + (p + pad -
+        k*dil) / s]), each a stride-1 launch scattered to every s-th pixel.
+    """
 
     @staticmethod
-    def forward(ctx, x, weight, arena, key, taps):
-        # x: (N, Cin, H, W) channels-last bf16; weight only ties the node to the parameter for autograd
-        xh = x.permute(0, 2, 3, 1).contiguous()
-        y = ops.conv_igemm(xh, arena.packed(key, arena.bf16), taps)
-        ctx.arena, ctx.key, ctx.taps = arena, key, taps
-        ctx.need_w = weight.requires_grad and arena.grad is not None
-        ctx.save_for_backward(xh)
-        return y.permute(0, 3, 1, 2)
-
-    @staticmethod
-    def backward(ctx, dy):
-        xh, = ctx.saved_tensors
-        a = ctx.arena
-        dyh = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wT = ops.conv_pack_transpose(a.packed(ctx.key, a.bf16), flip=False)
-            dx = ops.conv_igemm(dyh, wT, [(-dy_, -dx_) for dy_, dx_ in ctx.taps], mode=1).permute(0, 3, 1, 2)
-        if ctx.need_w:
-            ops.conv_wgrad(dyh, xh, ctx.taps, a.packed(ctx.key, a.grad))     # accumulates into the .grad storage
-        return dx, None, None, None, None
-
-
-class _HipConv2dPaddedFn(torch.autograd.Function):
-    """The same for channel counts that are not multiples of 64 (DeepLab v3+ head: the 48 + 256 = 304-channel concat
-    convolution, the 256 -> 48 low-level projection): activations, gradients and the bf16 weight operand are
-    zero-padded along Cin / Cout to the next multiple of 64 for the call; the weight gradient comes back through a
-    padded fp32 scratch."""
-
-    @staticmethod
-    def forward(ctx, x, weight, arena, key, taps):
-        n, cin, h, w = x.shape
-        wp = arena.packed(key, arena.bf16)                            # (taps, Cout, Cin)
+    def forward(ctx, x, weight, arena, key, geom, dtype):
+        k, stride, pad, dil = geom
+        n, cin, h, w = (int(v) for v in x.shape)
+        wp = arena.packed(key, _wbuf_of(arena, dtype))                 # (taps, Cout, Cin)
         cout = int(wp.shape[1])
-        cpad, opad = (cin + 63) // 64 * 64, (cout + 63) // 64 * 64
+        cpad, opad = _pad64(cin), _pad64(cout)
         if cpad != cin:
-            xh = torch.zeros((n, h, w, cpad), dtype=torch.bfloat16, device=x.device)
+            xh = torch.zeros((n, h, w, cpad), dtype=dtype, device=x.device)
             xh[..., :cin] = x.permute(0, 2, 3, 1)
         else:
-            xh = x.permute(0, 2, 3, 1).contiguous()
-        wpad = torch.zeros((wp.shape[0], opad, cpad), dtype=torch.bfloat16, device=x.device)
-        wpad[:, :cout, :cin] = wp
-        y = ops.conv_igemm(xh, wpad, taps)
-        ctx.arena, ctx.key, ctx.taps, ctx.cin, ctx.cout = arena, key, taps, cin, cout
+            xh = x.permute(0, 2, 3, 1).contiguous().to(dtype)
+        if cpad != cin or opad != cout:
+            wpad = torch.zeros((wp.shape[0], opad, cpad), dtype=dtype, device=x.device)
+            wpad[:, :cout, :cin] = wp
+        else:
+            wpad = wp
+        taps = ops.conv_taps(k, k, dil, pad)
+        ho = (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        wo = (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        y = None
+        for t0, t1 in _tap_chunks(len(taps)):
+            wc = wpad if (t0 == 0 and t1 == len(taps)) else wpad[t0:t1].contiguous()
+            y = ops.conv_igemm(xh, wc, taps[t0:t1], stride=stride, out_hw=(ho, wo), res=y)
+        ctx.arena, ctx.key, ctx.geom, ctx.dtype = arena, key, geom, dtype
+        ctx.cin, ctx.cout, ctx.in_hw = cin, cout, (h, w)
         ctx.need_w = weight.requires_grad and arena.grad is not None
         ctx.save_for_backward(xh, wpad)
         if opad != cout:
@@ -891,42 +897,73 @@ class _HipConv2dPaddedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xh, wpad = ctx.saved_tensors
-        a, cin, cout = ctx.arena, ctx.cin, ctx.cout
-        opad = int(wpad.shape[1])
+        a, cin, cout, dtype = ctx.arena, ctx.cin, ctx.cout, ctx.dtype
+        k, stride, pad, dil = ctx.geom
+        h, w = ctx.in_hw
+        ntaps, opad, cpad = (int(v) for v in wpad.shape)
+        n, ho, wo = int(dy.shape[0]), int(dy.shape[2]), int(dy.shape[3])
         if opad != cout:
-            dyh = torch.zeros(tuple(xh.shape[:3]) + (opad,), dtype=torch.bfloat16, device=dy.device)
+            dyh = torch.zeros((n, ho, wo, opad), dtype=dtype, device=dy.device)
             dyh[..., :cout] = dy.permute(0, 2, 3, 1)
         else:
-            dyh = dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+            dyh = dy.permute(0, 2, 3, 1).contiguous().to(dtype)
+        taps = ops.conv_taps(k, k, dil, pad)
         dx = None
         if ctx.needs_input_grad[0]:
-            wT = ops.conv_pack_transpose(wpad, flip=False)
-            dxp = ops.conv_igemm(dyh, wT, [(-dy_, -dx_) for dy_, dx_ in ctx.taps], mode=1)
-            dx = (dxp[..., :cin] if dxp.shape[-1] != cin else dxp).permute(0, 3, 1, 2)
+            wT = ops.conv_pack_transpose(wpad, flip=False, out_dtype=torch.float32 if dtype == torch.float32 else None)
+            if stride == 1:
+                dxp = None
+                for t0, t1 in _tap_chunks(ntaps):
+                    wc = wT if (t0 == 0 and t1 == ntaps) else wT[t0:t1].contiguous()
+                    dxp = ops.conv_igemm(dyh, wc, [(-ty, -tx) for ty, tx in taps[t0:t1]], mode=1, res=dxp)
+            else:
+                dxp = torch.zeros((n, h, w, cpad), dtype=dtype, device=dy.device)
+                for py in range(stride):
+                    for px in range(stride):
+                        ha, wb = (h - py + stride - 1) // stride, (w - px + stride - 1) // stride
+                        if ha <= 0 or wb <= 0:
+                            continue
+                        sel = [(ky, kx) for ky in range(k) for kx in range(k)
+                               if (py + pad - ky * dil) % stride == 0 and (px + pad - kx * dil) % stride == 0]
+                        if not sel:
+                            continue                       # pixels of this phase receive nothing: they stay zero
+                        idx = torch.tensor([ky * k + kx for ky, kx in sel], dtype=torch.long, device=dy.device)
+                        wsub = wT.index_select(0, idx)
+                        offs = [((py + pad - ky * dil) // stride, (px + pad - kx * dil) // stride) for ky, kx in sel]
+                        first = True
+                        for t0, t1 in _tap_chunks(len(sel)):
+                            wc = wsub if (t0 == 0 and t1 == len(sel)) else wsub[t0:t1].contiguous()
+                            ops.conv_igemm(dyh, wc, offs[t0:t1], mode=1, out=dxp, out_hw=(ha, wb), out_stride=stride,
+                                           out_full_hw=(h, w), out_pixel_offset=py * w + px, res=None if first else dxp)
+                            first = False
+            dx = (dxp[..., :cin] if cpad != cin else dxp).permute(0, 3, 1, 2)
         if ctx.need_w:
-            tmp = torch.zeros(wpad.shape, dtype=torch.float32, device=dyh.device)
-            ops.conv_wgrad(dyh, xh, ctx.taps, tmp)
-            a.packed(ctx.key, a.grad).add_(tmp[:, :cout, :cin])
-        return dx, None, None, None, None
+            padded = opad != cout or cpad != cin
+            dw = torch.zeros(wpad.shape, dtype=torch.float32, device=dyh.device) if padded else a.packed(ctx.key, a.grad)
+            for t0, t1 in _tap_chunks(ntaps):
+                ops.conv_wgrad(dyh, xh, taps[t0:t1], dw[t0:t1], stride=stride)
+            if padded:
+                a.packed(ctx.key, a.grad).add_(dw[:, :cout, :cin])
+        return dx, None, None, None, None, None
 
 
 class _HipClassifierFn(torch.autograd.Function):
-    """The final 1x1 classifier with bias (DeepLab v3+ head, deeplab3plus.py:47: 256 -> num_classes): class axis padded
-    to 64 for the MFMA kernels, fp32 NCHW logits straight out of the convolution epilogue."""
+    """A 1x1 classifier with bias (DeepLab v3+ head, deeplab3plus.py:47: 256 -> num_classes; the U-Nets' final_clf): class
+    axis padded to 64 for the MFMA kernels, fp32 NCHW logits straight out of the convolution epilogue."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, arena, wkey, bkey):
+    def forward(ctx, x, weight, bias, arena, wkey, bkey, dtype):
         n, cin, h, w = x.shape
-        xh = x.permute(0, 2, 3, 1).contiguous()
-        wp = arena.packed(wkey, arena.bf16)                            # (1, C, Cin)
+        xh = x.permute(0, 2, 3, 1).contiguous().to(dtype)
+        wp = arena.packed(wkey, _wbuf_of(arena, dtype))                # (1, C, Cin)
         c = int(wp.shape[1])
-        wpad = torch.zeros((1, 64, cin), dtype=torch.bfloat16, device=x.device)
+        wpad = torch.zeros((1, 64, cin), dtype=dtype, device=x.device)
         wpad[:, :c] = wp
         bpad = torch.zeros(64, dtype=torch.float32, device=x.device)
         bpad[:c] = arena.view(bkey)
         logits = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
         ops.conv_igemm(xh, wpad, [(0, 0)], bias=bpad, out_f32_nchw=logits, cout_real=c)
-        ctx.arena, ctx.wkey, ctx.bkey, ctx.c = arena, wkey, bkey, c
+        ctx.arena, ctx.wkey, ctx.bkey, ctx.c, ctx.dtype = arena, wkey, bkey, c, dtype
         ctx.need_w = weight.requires_grad and arena.grad is not None
         ctx.save_for_backward(xh, wpad)
         return logits
@@ -934,38 +971,50 @@ class _HipClassifierFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dl):
         xh, wpad = ctx.saved_tensors
-        a, c = ctx.arena, ctx.c
-        dlh = torch.zeros(tuple(xh.shape[:3]) + (64,), dtype=torch.bfloat16, device=dl.device)
+        a, c, dtype = ctx.arena, ctx.c, ctx.dtype
+        dlh = torch.zeros(tuple(xh.shape[:3]) + (64,), dtype=dtype, device=dl.device)
         dlh[..., :c] = dl.permute(0, 2, 3, 1)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv_igemm(dlh, ops.conv_pack_transpose(wpad, flip=False), [(0, 0)], mode=1).permute(0, 3, 1, 2)
+            wT = ops.conv_pack_transpose(wpad, flip=False, out_dtype=torch.float32 if dtype == torch.float32 else None)
+            dx = ops.conv_igemm(dlh, wT, [(0, 0)], mode=1).permute(0, 3, 1, 2)
         if ctx.need_w:
             tmp = torch.zeros(wpad.shape, dtype=torch.float32, device=dl.device)
             ops.conv_wgrad(dlh, xh, [(0, 0)], tmp)
             a.packed(ctx.wkey, a.grad).add_(tmp[:, :c])
             a.view(ctx.bkey, a.grad).add_(dl.float().sum(dim=(0, 2, 3)))
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
-def hip_classifier(x, conv, arena, wkey, bkey):
+def hip_classifier(x, conv, arena, wkey, bkey, dtype=torch.bfloat16):
     """`conv(x)` for a 1x1 nn.Conv2d WITH bias and <= 64 output channels -> fp32 NCHW."""
-    return _HipClassifierFn.apply(x, conv.weight, conv.bias, arena, wkey, bkey)
+    return _HipClassifierFn.apply(x, conv.weight, conv.bias, arena, wkey, bkey, dtype)
 
 
-def hip_conv2d(x, conv, arena, key):
-    """`conv(x)` for a stride-1, 'same'-padded, bias-free nn.Conv2d whose weight lives in `arena` under `key`."""
+def hip_conv_geometry(conv):
+    """(k, stride, pad, dil) of an nn.Conv2d the general path can run, or None."""
     kh, kw = conv.kernel_size
-    taps = ops.conv_taps(kh, kw, conv.dilation[0], conv.padding[0])
-    fn = _HipConv2dFn if (conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0) else _HipConv2dPaddedFn
-    return fn.apply(x, conv.weight, arena, key, taps)
+    if conv.groups != 1 or kh != kw or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] \
+            or conv.dilation[0] != conv.dilation[1] or isinstance(conv.padding, str) \
+            or getattr(conv, 'padding_mode', 'zeros') != 'zeros':
+        return None
+    return int(kh), int(conv.stride[0]), int(conv.padding[0]), int(conv.dilation[0])
 
 
-def hip_conv2d_eligible(x, conv):
-    """Stride 1, 'same' padding, no bias, >= 128 input channels (padded to a multiple of 64 if need be), output
-    channels in multiples of 64."""
+def hip_conv2d(x, conv, arena, key, dtype=torch.bfloat16):
+    """`conv(x)` WITHOUT its bias (the engines add biases themselves) on the hand-written kernels."""
+    geom = hip_conv_geometry(conv)
+    if geom is None:
+        raise NotImplementedError('no hand-written kernel for this convolution geometry: {}'.format(conv))
+    return _HipConvGeneralFn.apply(x, conv.weight, arena, key, geom, dtype)
+
+
+def hip_conv2d_eligible(x, conv, dtype=torch.bfloat16):
+    """The layers the 'auto' engine sends to the MFMA kernels: stride 1, 'same' padding, >= 128 input channels (padded to
+    a multiple of 64 if need be), output channels in multiples of 64 (or >= 32, padded), >= 64 pixels -- where the
+    padding copies cost less than the kernels gain. (`engine_kind = 'hip'` sends EVERY convolution there.)"""
     kh, kw = conv.kernel_size
-    return (x.is_cuda and x.dtype == torch.bfloat16 and conv.bias is None and conv.groups == 1
+    return (x.is_cuda and x.dtype == dtype and conv.groups == 1
             and conv.stride == (1, 1) and kh == kw and kh * kw <= 18
             and conv.padding == (conv.dilation[0] * (kh - 1) // 2,) * 2 and conv.dilation[0] == conv.dilation[1]
             and (conv.in_channels % 64 == 0 or conv.in_channels >= 128)

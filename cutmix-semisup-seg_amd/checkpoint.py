@@ -21,7 +21,8 @@ from collections import OrderedDict
 import torch
 
 # attributes of this build's runtime that must not travel in a pickle
-RUNTIME_ATTRS = ('_hip_executor', '_hip_executors', '_cms_arena', '_hip_engine', 'engine', '_sentinel', '_data_grad_only')
+RUNTIME_ATTRS = ('_hip_executor', '_hip_executors', '_cms_arena', '_hip_engine', '_hip_engines', '_hip_engine_hooked', 'engine',
+                 '_sentinel', '_data_grad_only')
 
 
 def export_module(net):

@@ -18,6 +18,7 @@
 // (dy, x, y) twice and writes dx once. Threads own 8 consecutive channels of a pixel (16-byte bf16 / 32-byte fp32
 // vectors, coalesced along the channel axis); the per-channel reduction over pixels is per-thread accumulation, then a
 // cross-lane tree (__shfl_xor over the lanes of a wave that hold the same channel group) and LDS across waves.
+#include <algorithm>
 #include "common.hpp"
 
 namespace cms {
@@ -56,17 +57,20 @@ template <class T, int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                         const T* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, double* __restrict__ sums,
-                                                        size_t P, int C) {
+                                                        size_t P, int C, int pitch) {
+    // C = channels of THIS launch (<= 2048: layers wider than that -- DenseNet-161's transition3 / denseblock4 / norm5 with
+    // 2112 .. 2208 channels -- are reduced as channel slices, one launch each: x, dy, y, mean, rstd and sums arrive
+    // offset by the slice's first channel); pitch = channels per pixel row of the tensors = plane stride of `sums`
     extern __shared__ float red[];                    // [slots][CG][16]
     const int CG = C / 8;
     const int slots = CG >= 256 ? 1 : 256 / CG;       // pixels handled side by side by one block
     const int tid = threadIdx.x;
     const int cg = tid % CG, slot = tid / CG;
-    const bool active = slot < slots && (CG <= 256);
+    const bool active = slot < slots;
     float a0[8], a1[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.0f;
-    if (CG <= 256) {
+    {
         float mu[8], rs[8];
         if (MODE == 1 && active) {
             load8(mean + cg * 8, mu);
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
         }
         if (active) {
             for (size_t p = (size_t)blockIdx.x * slots + slot; p < P; p += (size_t)gridDim.x * slots) {
-                const size_t o = p * C + (size_t)cg * 8;
+                const size_t o = p * (size_t)pitch + (size_t)cg * 8;
                 float xv[8];
                 load8(x + o, xv);
                 if (MODE == 0) {
@@ -118,39 +122,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
             float s = 0.0f;
             for (int sl = 0; sl < slots; sl += step) s += red[(sl * CG + g) * 16 + e];
             const int c = g * 8 + (e & 7);
-            atomicAdd(sums + (size_t)(e >> 3) * C + c, (double)s);
-        }
-    } else {
-        // more than 2048 channels: a block walks the channel groups in turn (not used by the networks of this build)
-        for (int g = tid; g < CG; g += 256) {
-            float mu[8], rs[8];
-            if (MODE == 1) { load8(mean + g * 8, mu); load8(rstd + g * 8, rs); }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.0f;
-            for (size_t p = blockIdx.x; p < P; p += gridDim.x) {
-                const size_t o = p * C + (size_t)g * 8;
-                float xv[8];
-                load8(x + o, xv);
-                if (MODE == 0) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] = fmaf(xv[e], xv[e], a1[e]); }
-                } else {
-                    float dv[8], yv[8];
-                    load8(dy + o, dv);
-                    if (y) load8(y + o, yv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float d = (y == nullptr || yv[e] > 0.0f) ? dv[e] : 0.0f;
-                        a0[e] += d;
-                        a1[e] = fmaf(d, (xv[e] - mu[e]) * rs[e], a1[e]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                atomicAdd(sums + g * 8 + e, (double)a0[e]);
-                atomicAdd(sums + (size_t)C + g * 8 + e, (double)a1[e]);
-            }
+            atomicAdd(sums + (size_t)(e >> 3) * pitch + c, (double)s);
         }
     }
 }
@@ -248,17 +220,28 @@ extern "C" int cms_bn_reduce(const void* x, const void* dy, const void* y, int d
     CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_reduce: bad dtype");
     CMS_REQUIRE(bn_geo_ok(n_pixels, c), "bn_reduce: bad geometry (channels %% 8 == 0)");
     CMS_REQUIRE(mode == 0 || (mode == 1 && dy && mean && rstd), "bn_reduce: mode 1 needs dy, mean, rstd");
-    const int CG = c / 8;
-    const int slots = CG >= 256 ? 1 : 256 / CG;
-    size_t want = (n_pixels + slots - 1) / slots;
-    if (want > 1024) want = 1024;
-    const dim3 grid((unsigned)want);
-    const size_t lds = CG <= 256 ? (size_t)slots * CG * 16 * sizeof(float) : 0;
     hipStream_t s = (hipStream_t)stream;
-#define CMS_BN_RED(T, M) hipLaunchKernelGGL((bn_reduce_kernel<T, M>), grid, dim3(256), lds, s, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, sums, n_pixels, c)
-    if (dtype == CMS_F32) { if (mode == 0) CMS_BN_RED(float, 0); else CMS_BN_RED(float, 1); }
-    else { if (mode == 0) CMS_BN_RED(uint16_t, 0); else CMS_BN_RED(uint16_t, 1); }
+    const size_t esz = dtype == CMS_F32 ? 4 : 2;
+    // channel slices of <= 2048 (= 256 groups of 8: one thread per group); every network layer but DenseNet-161's widest
+    // is one slice
+    for (int c0 = 0; c0 < c; c0 += 2048) {
+        const int cs = std::min(2048, c - c0);
+        const int CG = cs / 8;
+        const int slots = CG >= 256 ? 1 : 256 / CG;
+        size_t want = (n_pixels + slots - 1) / slots;
+        if (want > 1024) want = 1024;
+        const dim3 grid((unsigned)want);
+        const size_t lds = (size_t)slots * CG * 16 * sizeof(float);
+        const char* xs = (const char*)x + (size_t)c0 * esz;
+        const char* dys = dy ? (const char*)dy + (size_t)c0 * esz : nullptr;
+        const char* ys = y ? (const char*)y + (size_t)c0 * esz : nullptr;
+        const float* ms = mean ? mean + c0 : nullptr;
+        const float* rs = rstd ? rstd + c0 : nullptr;
+#define CMS_BN_RED(T, M) hipLaunchKernelGGL((bn_reduce_kernel<T, M>), grid, dim3(256), lds, s, (const T*)xs, (const T*)dys, (const T*)ys, ms, rs, sums + c0, n_pixels, cs, c)
+        if (dtype == CMS_F32) { if (mode == 0) CMS_BN_RED(float, 0); else CMS_BN_RED(float, 1); }
+        else { if (mode == 0) CMS_BN_RED(uint16_t, 0); else CMS_BN_RED(uint16_t, 1); }
 #undef CMS_BN_RED
+    }
     return launch_status("cms_bn_reduce");
 }
 

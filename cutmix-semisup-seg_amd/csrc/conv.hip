@@ -1754,6 +1754,83 @@ static void wgrad_launch(dim3 grid, size_t lds, hipStream_t s, const WgradArgs& 
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
 }
 
+// Number of pixel slices (split-K) of a weight-gradient launch and the pixels per slice -- shared by the launch and by
+// cms_conv_wgrad_workspace_bytes (a caller sizing the slab of the deterministic combine).
+static int wgrad_plan(const cms_wgrad_desc* d, int* per_out, bool* dma_out, int* stages_out) {
+    const int M = d->n * d->ho * d->wo;
+    const int bco = d->cout % 128 == 0 ? 128 : 64, bci = d->cin % 128 == 0 ? 128 : 64;
+    const int tiles = (d->cout / bco) * (d->cin / bci) * d->ntaps;
+    // split the pixel axis so that the grid has ~1.5 workgroups per CU (more slices only add atomic traffic and
+    // per-workgroup prologue / epilogue); each slice is a multiple of 64 pixels
+    // direct-to-LDS loader (buffer addressing: both tensors below 2 GB); CMS_WGRAD_DMA=0 forces the register loader and
+    // CMS_WGRAD_TARGET the workgroup count the automatic split aims at (A/B switches, read once)
+    static int env_dma = -1, env_target = -1, env_stages = 1;
+    if (env_dma < 0) {
+        const char* e = getenv("CMS_WGRAD_DMA");
+        env_dma = e ? atoi(e) : 1;
+        const char* g = getenv("CMS_WGRAD_STAGES");
+        env_stages = g ? atoi(g) : 1;
+        const char* t = getenv("CMS_WGRAD_TARGET");
+        env_target = t ? atoi(t) : 0;
+    }
+    const bool dma = env_dma != 0 && (size_t)M * d->cout * 2 < (1ull << 31) &&
+                     (size_t)d->n * d->h * d->w_in * d->cin * 2 < (1ull << 31);
+    const int target = env_target > 0 ? env_target : 384;
+    // one stage by default: alone on the chip two stages are ~8 % faster (5.5 vs 6.0 ms over the DeepLab v2 layer
+    // list), inside the step -- where the weight gradients share the CUs with the data-gradient convolutions of the
+    // other stream -- the 64 KB of LDS per workgroup cost 3-4 % of the step (profiles/r02u_*)
+    const int stages = env_stages == 2 ? 2 : 1;
+    int ksplit = d->ksplit > 0 ? d->ksplit : (target + tiles - 1) / tiles;
+    const bool plain_shape = d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho &&
+                             d->w_in == d->wo;
+    if (d->ksplit <= 0 && dma && env_target <= 0) {
+        // Number of pixel slices from a two-term model (env CMS_WGRAD_MODEL=0: the sweep-tuned rule of profiles/r02r):
+        //   the slices' K loops run side by side (<= `cap` resident workgroups): nst / ks stages of t_stage each;
+        //   their atomics are served by the memory-side units at ~0.7 TB/s IN TOTAL (tools/atomic_probe.hip): ks * |dW|.
+        // The sum is smallest at ks = sqrt(nst * t_stage * 0.7e12 / |dW| bytes). It reproduces the tuned values at
+        // the 321 x 321 shapes (21 / 16 / 8 / 10 slices for the 1x1 1024->256, 3x3 256->256, 3x3 512->512, 1x1 2048->512
+        // layers) and follows M where the tuning did not go: DeepLab v3+ at 513 x 513 has 10 890 pixels per layer-3/4
+        // launch, where 24 slices of 7 stages each spent their time in the atomics.
+        static int env_model = -1;
+        if (env_model < 0) {
+            const char* e = getenv("CMS_WGRAD_MODEL");
+            env_model = e ? atoi(e) : 1;
+        }
+        const int nst = (M + 63) / 64;
+        // resident workgroups: 2 per CU with two stages (LDS), 3 where the register budget is 168 (taps / side outputs)
+        const int cap = stages == 2 ? 512 : ((plain_shape && d->dbeta == nullptr) ? 864 : 720);
+        if (env_model != 0) {
+            const double t_stage = plain_shape ? 1.25e-6 : 1.75e-6;
+            const double dw_bytes = (double)d->ntaps * d->cout * d->cin * 4.0;
+            int ks = (int)(std::sqrt((double)nst * t_stage * 0.7e12 / dw_bytes) + 0.5);
+            ks = std::max(1, std::min(ks, std::min(std::max(1, cap / tiles), nst)));
+            ksplit = ks;
+        } else {
+            const int hi = std::min(cap / tiles, nst / 32);
+            if (hi > ksplit) ksplit = hi;
+        }
+    }
+    int per = ((M + ksplit - 1) / ksplit + 63) / 64 * 64;
+    if (per < 64) per = 64;
+    ksplit = (M + per - 1) / per;
+    if (per_out) *per_out = per;
+    if (dma_out) *dma_out = dma;
+    if (stages_out) *stages_out = stages;
+    return ksplit;
+}
+
+// Bytes of caller-owned scratch that make this launch DETERMINISTIC: with a workspace of at least this size the pixel
+// slices write their partial sums as plain stores ([slice][tap][Cout][Cin] fp32) and a second launch on the same stream
+// adds them to dw in slice order; without one (NULL) they are combined with fp32 atomics, whose order varies from run to
+// run. 0 = the launch has one slice and is deterministic as it is.
+extern "C" long long cms_conv_wgrad_workspace_bytes(const cms_wgrad_desc* d) {
+    if (!d || d->cin % 64 != 0 || d->cout % 64 != 0 || d->ntaps <= 0 || d->ntaps > CMS_CONV_MAX_TAPS || d->n <= 0 || d->ho <= 0 ||
+        d->wo <= 0 || d->cin % 4 != 0)
+        return 0;
+    const int ks = wgrad_plan(d, nullptr, nullptr, nullptr);
+    return ks > 1 ? (long long)ks * d->ntaps * d->cout * d->cin * (long long)sizeof(float) : 0;
+}
+
 extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     CMS_REQUIRE(d && d->du && d->x && d->dw, "conv_wgrad: NULL pointer");
     CMS_REQUIRE(d->cin % 64 == 0 && d->cout % 64 == 0, "conv_wgrad: Cin (%d) and Cout (%d) must be multiples of 64", d->cin,
@@ -1778,75 +1855,20 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     const int tiles = (d->cout / bco) * (d->cin / bci) * d->ntaps;
     CMS_REQUIRE((size_t)d->n * d->h * d->w_in * d->cin < (1u << 31) && (size_t)d->n * d->ho * d->wo * d->cout < (1u << 31),
                 "conv_wgrad: tensors must have < 2^31 elements");
-    // split the pixel axis so that the grid has ~1.5 workgroups per CU (more slices only add atomic traffic and
-    // per-workgroup prologue / epilogue); each slice is a multiple of 64 pixels
-    // direct-to-LDS loader (buffer addressing: both tensors below 2 GB); CMS_WGRAD_DMA=0 forces the register loader and
-    // CMS_WGRAD_TARGET the workgroup count the automatic split aims at (A/B switches, read once)
-    static int env_dma = -1, env_target = -1, env_stages = 1;
-    if (env_dma < 0) {
-        const char* e = getenv("CMS_WGRAD_DMA");
-        env_dma = e ? atoi(e) : 1;
-        const char* g = getenv("CMS_WGRAD_STAGES");
-        env_stages = g ? atoi(g) : 1;
-        const char* t = getenv("CMS_WGRAD_TARGET");
-        env_target = t ? atoi(t) : 0;
-    }
-    const bool dma = env_dma != 0 && (size_t)a.M * d->cout * 2 < (1ull << 31) &&
-                     (size_t)d->n * d->h * d->w_in * d->cin * 2 < (1ull << 31);
-    const int target = env_target > 0 ? env_target : 384;
-    // one stage by default: alone on the chip two stages are ~8 % faster (5.5 vs 6.0 ms over the DeepLab v2 layer
-    // list), inside the step -- where the weight gradients share the CUs with the data-gradient convolutions of the
-    // other stream -- the 64 KB of LDS per workgroup cost 3-4 % of the step (profiles/r02u_*)
-    const int stages = env_stages == 2 ? 2 : 1;
-    int ksplit = d->ksplit > 0 ? d->ksplit : (target + tiles - 1) / tiles;
-    const bool plain_shape = d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho &&
-                             d->w_in == d->wo;
-    if (d->ksplit <= 0 && dma && env_target <= 0) {
-        // Number of pixel slices from a two-term model (env CMS_WGRAD_MODEL=0: the sweep-tuned rule of profiles/r02r):
-        //   the slices' K loops run side by side (<= `cap` resident workgroups): nst / ks stages of t_stage each;
-        //   their atomics are served by the memory-side units at ~0.7 TB/s IN TOTAL (tools/atomic_probe.hip): ks * |dW|.
-        // The sum is smallest at ks = sqrt(nst * t_stage * 0.7e12 / |dW| bytes). It reproduces the tuned values at
-        // the 321 x 321 shapes (21 / 16 / 8 / 10 slices for the 1x1 1024->256, 3x3 256->256, 3x3 512->512, 1x1 2048->512
-        // layers) and follows M where the tuning did not go: DeepLab v3+ at 513 x 513 has 10 890 pixels per layer-3/4
-        // launch, where 24 slices of 7 stages each spent their time in the atomics.
-        static int env_model = -1;
-        if (env_model < 0) {
-            const char* e = getenv("CMS_WGRAD_MODEL");
-            env_model = e ? atoi(e) : 1;
-        }
-        const int nst = (a.M + 63) / 64;
-        // resident workgroups: 2 per CU with two stages (LDS), 3 where the register budget is 168 (taps / side outputs)
-        const int cap = stages == 2 ? 512 : ((plain_shape && d->dbeta == nullptr) ? 864 : 720);
-        if (env_model != 0) {
-            const double t_stage = plain_shape ? 1.25e-6 : 1.75e-6;
-            const double dw_bytes = (double)d->ntaps * d->cout * d->cin * 4.0;
-            int ks = (int)(std::sqrt((double)nst * t_stage * 0.7e12 / dw_bytes) + 0.5);
-            ks = std::max(1, std::min(ks, std::min(std::max(1, cap / tiles), nst)));
-            ksplit = ks;
-        } else {
-            const int hi = std::min(cap / tiles, nst / 32);
-            if (hi > ksplit) ksplit = hi;
-        }
-    }
-    int per = ((a.M + ksplit - 1) / ksplit + 63) / 64 * 64;
-    if (per < 64) per = 64;
-    ksplit = (a.M + per - 1) / per;
+    int per = 64, stages = 1;
+    bool dma = false;
+    int ksplit = wgrad_plan(d, &per, &dma, &stages);
     a.ksplit = ksplit;
     a.pix_per_split = per;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(tiles * ksplit);
-    // split-K combine through slabs + a reduce launch (CMS_WGRAD_SLAB=1, needs the caller's workspace) instead of fp32
-    // atomics. Measured: alone the layer list is 6 % faster (5.71 vs 6.06 ms) and the sums become order-deterministic;
-    // inside the step it is 1.5 % SLOWER (488 vs 496 img/s, profiles/r02ah_*): the atomics are fire-and-forget work
-    // for the otherwise idle memory-side units while the other stream computes, the slabs cost HBM bandwidth and one
-    // more launch per layer. Default: atomics.
-    static int env_slab = -1;
-    if (env_slab < 0) {
-        const char* e = getenv("CMS_WGRAD_SLAB");
-        env_slab = e ? atoi(e) : 0;
-    }
+    // split-K combine: fp32 atomics (default), or -- when the caller hands over a workspace (cms_conv_wgrad_workspace_bytes)
+    // -- slabs + a reduce launch in slice order: DETERMINISTIC sums. Measured (profiles/r02ah_*, r03a_*): alone the layer
+    // list is 6 % faster with slabs (5.71 vs 6.06 ms); inside the two-stream step 1.5-2 % slower (497 vs 507 img/s): the
+    // atomics are fire-and-forget work for the otherwise idle memory-side units while the other stream computes, the slabs
+    // cost HBM bandwidth and one more launch per layer. Throughput runs pass no workspace.
     const size_t slice_elems = (size_t)d->ntaps * d->cout * d->cin;
-    const bool use_slab = env_slab != 0 && d->workspace != nullptr && ksplit > 1 && d->cin % 4 == 0 &&
+    const bool use_slab = d->workspace != nullptr && ksplit > 1 && d->cin % 4 == 0 &&
                           (unsigned long long)d->workspace_bytes >= (unsigned long long)ksplit * slice_elems * sizeof(float);
     a.slab = use_slab ? (float*)d->workspace : nullptr;
     a.slab_stride = slice_elems;

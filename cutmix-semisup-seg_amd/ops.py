@@ -871,17 +871,37 @@ class PackTransposePlan(object):
                                                   _stream()), 'cms_conv_pack_transpose_batch')
 
 
-_WGRAD_WS = {}            # (device index, stream handle) -> uint8 scratch for the split-K partial sums
-WGRAD_WORKSPACE_BYTES = 160 << 20
+# Deterministic weight gradients (csrc/conv.hip: split-K partial sums through slabs + an ordered reduce instead of fp32
+# atomics). Off by default: inside the two-stream step the atomics are 1.5-2 % faster (profiles/r03a_*). Switch on with
+# `set_deterministic_wgrad(True)` (StepConfig.deterministic, the trainers' --deterministic) or CMS_WGRAD_SLAB=1.
+import os as _os
+_WGRAD_DETERMINISTIC = _os.environ.get('CMS_WGRAD_SLAB', '0') not in ('', '0')
+_WGRAD_WS = {}            # (device index, stream handle) -> uint8 scratch of eagerly issued launches
 
 
-def _wgrad_workspace(device, stream_handle):
-    """One scratch buffer per stream (launches on one stream are serialised; the recorded programs keep pointing into
-    it, so it is never reallocated). Largest need at the BASELINE shapes: 6 slices x 9 x 512 x 512 floats = 57 MB."""
-    key = (device.index, int(stream_handle))
+def set_deterministic_wgrad(on):
+    """Run-to-run deterministic weight gradients for every launch issued (or RECORDED) from now on."""
+    global _WGRAD_DETERMINISTIC
+    _WGRAD_DETERMINISTIC = bool(on)
+
+
+def deterministic_wgrad():
+    return _WGRAD_DETERMINISTIC
+
+
+def _wgrad_workspace(d, device, recording):
+    """Scratch of exactly the size this launch needs (cms_conv_wgrad_workspace_bytes). A recorded launch owns its slab
+    (kept alive by the program; replays on any stream never share it); eager launches reuse one buffer per stream
+    (launches on one stream are serialised), grown on demand."""
+    need = int(fn['cms_conv_wgrad_workspace_bytes'](C.byref(d)))
+    if need <= 0:
+        return None
+    if recording:
+        return torch.empty(need, dtype=torch.uint8, device=device)
+    key = (device.index, int(torch.cuda.current_stream().cuda_stream))
     ws = _WGRAD_WS.get(key)
-    if ws is None:
-        ws = _WGRAD_WS[key] = torch.empty(WGRAD_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    if ws is None or ws.numel() < need:
+        ws = _WGRAD_WS[key] = torch.empty(need, dtype=torch.uint8, device=device)
     return ws
 
 
@@ -921,16 +941,17 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
     d.wdot = wdot.data_ptr() if wdot is not None else None
     d.dbeta = dbeta.data_ptr() if dbeta is not None else None
     d.dw_cout = 0 if dw_cout is None else int(dw_cout)
-    if not f32:
-        # (while recording, the current stream IS the stream the op is recorded for)
-        ws = _wgrad_workspace(du.device, torch.cuda.current_stream().cuda_stream)
-        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    ws = None
+    if not f32 and _WGRAD_DETERMINISTIC:
+        ws = _wgrad_workspace(d, du.device, _REC is not None)
+        if ws is not None:
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     if _REC is not None:
         prog = _REC[0]
         idx = fn['cms_program_add_wgrad'](prog.h, C.byref(d), int(f32), _rec_stream_index(), prog.group)
         if idx < 0:
             check(idx, 'cms_program_add_wgrad')
-        prog.keep += [t for t in (du, x, dw, scale, w_bf16, wdot, dbeta) if t is not None]
+        prog.keep += [t for t in (du, x, dw, scale, w_bf16, wdot, dbeta, ws) if t is not None]
         prog.flops += 2.0 * n * ho * wo * cout * cin * len(taps)
         return dw
     name = 'cms_conv_wgrad_f32' if f32 else 'cms_conv_wgrad'

@@ -307,16 +307,19 @@ typedef struct cms_wgrad_desc {
     int dw_cout;           /* rows per tap of the dw TENSOR when it is narrower than the GEMM's (padded) cout: the ASPP
                               head computes 64 padded class rows and writes the cout_real live ones straight into the
                               (9, C, 2048) gradient tensor; 0 = cout                                               */
-    void* workspace;       /* optional scratch for the split-K partial sums (bf16 entry point), used under
-                              CMS_WGRAD_SLAB=1 when it holds at least ksplit * ntaps * cout * cin floats: the pixel
-                              slices write their tiles there with plain stores and a second launch on the same stream
-                              adds their sum to dw (order-deterministic; 6 % faster alone, 1.5 % slower inside the
-                              two-stream step than the default fp32 atomics). NULL or too small: atomics. One workspace
-                              per stream (launches on one stream are serialised).                                      */
+    void* workspace;       /* optional scratch for the split-K partial sums (bf16 entry point), at least
+                              cms_conv_wgrad_workspace_bytes(d) long: the pixel slices then write their tiles there with
+                              plain stores and a second launch on the same stream adds them to dw IN SLICE ORDER --
+                              run-to-run deterministic weight gradients (train_seg_semisup_mask_mt.py:459,465 on the
+                              reference's CPU path are deterministic too). NULL or too small: fp32 atomics, whose order
+                              varies from run to run (6 % slower alone, 1.5-2 % FASTER inside the two-stream step: the
+                              throughput default). The scratch must not be shared by launches that may overlap.       */
     long long workspace_bytes;
 } cms_wgrad_desc;
 
 int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream);
+/* bytes of `workspace` that make the launch deterministic (0: it has a single pixel slice and already is) */
+long long cms_conv_wgrad_workspace_bytes(const cms_wgrad_desc* d);
 
 /* ------------------------------------------------------------------------------------------------------------
  * The same convolution family in fp32 on the f32-input MFMA (v_mfma_f32_32x32x2_f32): the PARITY configuration

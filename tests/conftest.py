@@ -47,3 +47,46 @@ def golden():
 @pytest.fixture(scope='session')
 def golden_json():
     return load_golden_json
+
+
+class _NoLibraryConvolutions(object):
+    """Context manager: inside it, any call that would reach the library's convolution / BatchNorm kernels (MIOpen through
+    torch.nn.functional.conv2d / conv_transpose2d / batch_norm, torch.conv2d, nn.Conv2d.forward, nn.BatchNorm2d.forward)
+    raises -- what passes ran on the hand-written kernels only. (A context, not a whole-test patch: the CPU oracle of the
+    same test is made of exactly those calls.) `.refused` counts the calls that were turned away."""
+    TARGETS = (('torch.nn.functional', 'conv2d'), ('torch.nn.functional', 'conv_transpose2d'),
+               ('torch.nn.functional', 'batch_norm'), ('torch', 'conv2d'), ('torch', 'batch_norm'), ('torch', 'convolution'),
+               ('torch', 'conv_transpose2d'))
+
+    def __init__(self):
+        self.refused = 0
+        self._saved = []
+
+    def _refuse(self, name):
+        def f(*a, **k):
+            self.refused += 1
+            raise AssertionError('library kernel reached: ' + name)
+        return f
+
+    def __enter__(self):
+        import importlib
+        import torch
+        for modname, name in self.TARGETS:
+            mod = importlib.import_module(modname)
+            self._saved.append((mod, name, getattr(mod, name)))
+            setattr(mod, name, self._refuse(modname + '.' + name))
+        for cls in (torch.nn.Conv2d, torch.nn.BatchNorm2d):
+            self._saved.append((cls, 'forward', cls.forward))
+            cls.forward = self._refuse(cls.__name__ + '.forward')
+        return self
+
+    def __exit__(self, *exc):
+        for obj, name, val in reversed(self._saved):
+            setattr(obj, name, val)
+        self._saved = []
+        return False
+
+
+@pytest.fixture
+def no_library_convolutions():
+    return _NoLibraryConvolutions()

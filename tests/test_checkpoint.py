@@ -134,3 +134,36 @@ torch.save(y, %r)
     x = torch.sin(0.3 + 0.61803398875 * idx).reshape(2, 3, 33, 33).float() * 1.5
     want = odl.forward(x, odl.closed_form_state(5, [1, 1, 1, 1]), [1, 1, 1, 1], frozen=True)
     torch.testing.assert_close(y, want, rtol=1e-4, atol=1e-5)
+
+
+def test_deeplab_v3plus_wrapper_round_trips_with_its_runtime_state_restored():
+    """`export_module` strips the runtime attributes; DeepLabv3Wrapper restores them in `_init_runtime`
+    / `__setstate__` like the other networks, and the reference's OWN classes (architectures/deeplab3plus.py:26-158)
+    pickle under the reference's module path."""
+    import zipfile
+    from architectures import deeplab3plus as d3
+    from cutmix_semisup_seg_amd import checkpoint
+    torch.manual_seed(0)
+    net = d3.DeepLabv3Wrapper(d3._deeplabv3plus(5, 8, (1, 1, 1, 1)))
+    net._hip_executors = {'fake': object()}
+    net._hip_engine = object()
+    net._cms_arena = object()
+    buf = io.BytesIO()
+    torch.save(checkpoint.export_module(net), buf)
+    assert net._hip_executors and net._cms_arena is not None            # the live network keeps its runtime state
+    zf = zipfile.ZipFile(io.BytesIO(buf.getvalue()))
+    pkl = zf.read([n for n in zf.namelist() if n.endswith('data.pkl')][0])
+    names = {arg for op, arg, _ in pickletools.genops(pkl) if isinstance(arg, str) and 'deeplab3plus' in arg}
+    assert {'architectures.deeplab3plus DeepLabv3Wrapper', 'architectures.deeplab3plus DeepLabV3Plus',
+            'architectures.deeplab3plus DeepLabHeadV3Plus'} <= names, names
+    buf.seek(0)
+    back = checkpoint.load_model(buf)
+    assert type(back) is d3.DeepLabv3Wrapper
+    assert back.engine_kind == 'auto' and back.engine is None and back.compute_dtype == torch.bfloat16
+    assert back._hip_executor is None and back._hip_executors == {} and back._hip_engine is None and back._hip_engines == {}
+    assert not hasattr(back, '_cms_arena')
+    for (k, a), (_, b) in zip(net.state_dict().items(), back.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert back.pretrained_parameters() == [] and len(back.new_parameters()) == len(list(back.parameters()))
+    # the methods the first forward pass calls find their attributes (they raised AttributeError before)
+    assert back._use_hip_backbone() in (True, False)

@@ -31,7 +31,7 @@ def _reference(x, gamma, beta, res, relu, rm, rv, momentum, eps, dy):
     return (nhwc(y.detach()), rm2, rv2, nhwc(xd.grad), gd.grad, bd.grad, None if rd is None else nhwc(rd.grad))
 
 
-@pytest.mark.parametrize('C', [48, 64, 256, 2048])
+@pytest.mark.parametrize('C', [48, 64, 256, 2048, 2208])      # 2208 = DenseNet-161's norm5: two channel slices
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
 @pytest.mark.parametrize('relu,with_res', [(True, True), (False, False), (True, False)])
 def test_batch_norm_act_vs_fp64(C, dtype, relu, with_res):

@@ -1,8 +1,9 @@
 """
-GPU: DeepLab v3+ (BASELINE configs[3]) through the product path -- library convolutions for the
-network, the hand-written kernels for paste / losses (with the in-kernel align_corners=False upsample from 1/4
-resolution) / Adam + EMA -- against the CPU oracle (oracle/deeplab3plus.py, oracle/step_v3plus.py; parity unpinned,
-see there).
+GPU: DeepLab v3+ (BASELINE configs[3]) through the product path against the CPU oracle
+(oracle/deeplab3plus.py, oracle/step_v3plus.py; parity unpinned, see there). The tight (fp32) comparisons run with
+engine_kind = 'hip': backbone on the MFMA executor in its fp32 parity configuration, every head convolution on
+csrc/conv_f32.hip, BatchNorm on csrc/bn.hip -- inside the `no_library_convolutions` context any library convolution /
+BatchNorm call fails the test. The bf16 runs use the default ('auto') engine.
 """
 import numpy as np
 import pytest
@@ -34,37 +35,44 @@ def _he_state(C, layers):
     return st
 
 
-def _net(C, layers, dtype, state):
+def _net(C, layers, dtype, state, kind=None):
     from architectures import deeplab3plus as d3
     net = d3.DeepLabv3Wrapper(d3._deeplabv3plus(C, 8, layers))
     net.load_state_dict(state)
     net = net.to(DEV)
     net.compute_dtype = dtype
+    if kind is not None:
+        net.engine_kind = kind
     for m in net.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0                       # the oracle takes dropout as off
     return net
 
 
-def test_forward_matches_the_oracle_eval_and_train_mode():
+def test_forward_matches_the_oracle_eval_and_train_mode(no_library_convolutions):
     from oracle import deeplab3plus as o3
+    from cutmix_semisup_seg_amd.backbone_hip import DeepLabV3PlusBackboneExecutor
     layers, C = (1, 2, 2, 1), 7
     st = o3.closed_form_state(C, layers)
-    net = _net(C, layers, torch.float32, st)
+    net = _net(C, layers, torch.float32, st, kind='hip')
     g = torch.Generator().manual_seed(5)
     x = torch.randn(3, 3, 65, 97, generator=g)
     net.eval()
     with torch.no_grad():
-        lo = net.forward_lowres(x.to(DEV)).cpu()
+        with no_library_convolutions:
+            lo = net.forward_lowres(x.to(DEV)).cpu()
+            full = net(x.to(DEV)).cpu()                  # cms_upsample_bilinear, align_corners = False
         ref = o3.forward_lowres(x, st, layers)
         assert lo.shape == ref.shape == (3, C, 17, 25)
         assert float((lo - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-4
-        full = net(x.to(DEV)).cpu()                      # cms_upsample_bilinear, align_corners = False
         assert float((full - o3.forward(x, st, layers)).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-4
+    assert isinstance(net._hip_executor, DeepLabV3PlusBackboneExecutor) and net._hip_executor.dtype == torch.float32
+    assert net._hip_engine.strict and net._hip_engine.library_convs == 0
     net.train()
     net.freeze_batchnorm()
     ns = {}
-    lo = net.forward_lowres(x.to(DEV))
+    with no_library_convolutions:
+        lo = net.forward_lowres(x.to(DEV))
     ref = o3.forward_lowres(x, st, layers, backbone_frozen=True, head_frozen=False, new_stats=ns)
     assert float((lo.detach().cpu() - ref).abs().max()) <= 5e-3 * float(ref.abs().max()) + 1e-3
     sd = net.state_dict()
@@ -81,7 +89,7 @@ def test_forward_matches_the_oracle_eval_and_train_mode():
     assert float((lo16 - ref).abs().max()) <= 0.15 * float(ref.abs().max())
 
 
-def test_training_iteration_matches_the_oracle_step():
+def test_training_iteration_matches_the_oracle_step(no_library_convolutions):
     """Non-fused passes in the reference's order (batch-statistics head), fused loss kernels, fused Adam + EMA.
     Losses, gradients and running statistics are compared with the oracle; the first Adam update moves every weight
     by ~lr * sign(g), which turns noise-level gradient components into O(lr) differences, so the update itself is
@@ -93,7 +101,7 @@ def test_training_iteration_matches_the_oracle_step():
     import optim_weight_ema
     layers, C, lr = (1, 1, 1, 1), 4, 1e-3
     st = _he_state(C, layers)
-    stu, tea = _net(C, layers, torch.float32, st), _net(C, layers, torch.float32, st)
+    stu, tea = _net(C, layers, torch.float32, st, kind='hip'), _net(C, layers, torch.float32, st, kind='hip')
     opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=lr * 0.1),
                              dict(params=list(stu.new_parameters()), lr=lr)])
     for p in tea.parameters():
@@ -119,7 +127,9 @@ def test_training_iteration_matches_the_oracle_step():
     want = sv.train_iteration(S, x, y, x0, x1, um0, um1, m, conf_thresh=0.0)
     tea_before = {k: v.clone() for k, v in tea.state_dict().items()}
     ub = UnsupBatch(x0.to(DEV), ops.ranges_to_device(ranges, DEV), um0=um0.to(DEV), x1_tea=x1.to(DEV), um1=um1.to(DEV))
-    got = step(x.to(DEV), y.to(DEV), [ub])
+    with no_library_convolutions:                       # student and teacher passes, backward, optimizer: hand-written only
+        got = step(x.to(DEV), y.to(DEV), [ub])
+    assert no_library_convolutions.refused == 0 and stu._hip_executor.dtype == torch.float32
     assert abs(float(got['sup_loss']) - want['sup_loss']) <= 2e-3 * abs(want['sup_loss']) + 1e-4
     assert abs(float(got['consistency_loss']) - want['consistency_loss']) <= 5e-3 * abs(want['consistency_loss']) + 1e-5
     # (no confidence threshold here: with near-uniform random-init predictions any threshold sits in the dense part of
@@ -285,6 +295,40 @@ def test_training_pass_on_the_executor_matches_the_library_gradients():
     for k in ('deeplab.backbone.layer2.0.bn2.weight', 'deeplab.backbone.layer3.1.bn3.bias',
               'deeplab.backbone.layer1.0.downsample.1.weight'):
         assert float(hip[k].abs().max()) > 0
+
+
+def test_fp32_hand_written_backward_matches_the_oracle_autograd(no_library_convolutions):
+    """The whole network (backbone executor incl. the four-phase strided data gradient and the BatchNorm-affine gradients,
+    head on csrc/conv_f32.hip) in the fp32 parity configuration, forward + backward, against the ORACLE's autograd -- not
+    the library's kernels -- tensor by tensor. Every BatchNorm on running statistics: a clean comparison."""
+    from oracle import deeplab3plus as o3
+    layers, C = (2, 2, 3, 2), 6
+    st = _he_state(C, layers)
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(2, 3, 97, 129, generator=g)
+    tgt = torch.randn(2, C, 25, 33, generator=g)
+    net = _net(C, layers, torch.float32, st, kind='hip')
+    net.eval()
+    with no_library_convolutions:
+        out = net.forward_lowres(x.to(DEV))
+        ((out - tgt.to(DEV)) ** 2).mean().backward()
+    assert no_library_convolutions.refused == 0 and net._hip_engine.library_convs == 0
+    leaves = {k: v.clone().requires_grad_(True) for k, v in st.items()
+              if v.dtype == torch.float32 and 'running' not in k}
+    st2 = dict(st)
+    st2.update(leaves)
+    ref = o3.forward_lowres(x, st2, layers)
+    ((ref - tgt) ** 2).mean().backward()
+    assert float((out.detach().cpu() - ref.detach()).norm() / ref.detach().norm()) <= 2e-5
+    rels = {}
+    for k, p in net.named_parameters():
+        want = leaves[k].grad
+        assert want is not None and p.grad is not None, k
+        rels[k] = float((p.grad.cpu() - want).norm() / (want.norm() + 1e-30))
+    worst = sorted(rels.items(), key=lambda kv: -kv[1])[:4]
+    print('\nv3+ fp32 hand-written backward vs oracle autograd: max {:.2e} mean {:.2e} worst {}'.format(
+        max(rels.values()), float(np.mean(list(rels.values()))), worst))
+    assert max(rels.values()) <= 2e-3 and float(np.mean(list(rels.values()))) <= 2e-4, worst
 
 
 def test_recorded_backbone_passes_equal_the_launch_by_launch_passes():

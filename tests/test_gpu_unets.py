@@ -29,7 +29,10 @@ def _randomise(net, seed):
 
 @pytest.mark.parametrize('arch,shape', [('resnet50unet_imagenet', (4, 3, 64, 96)), ('densenet161unet', (2, 3, 64, 64))])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
-def test_unet_forward_backward_vs_oracle(arch, shape, dtype):
+def test_unet_forward_backward_vs_oracle(arch, shape, dtype, no_library_convolutions):
+    """Both configurations run with engine_kind = 'hip': EVERY convolution (7 x 7 stems as tap chunks, strided 3 x 3s and
+    1 x 1s with their phase-decomposed data gradients, DenseNet's 48-multiple channel counts zero-padded to 64) and every
+    BatchNorm on the hand-written kernels -- the fixture turns any library convolution / BatchNorm call into a failure."""
     from architectures import network_architectures
     from oracle import unets
     torch.manual_seed(3)
@@ -38,14 +41,16 @@ def test_unet_forward_backward_vs_oracle(arch, shape, dtype):
     st = {k: v.clone() for k, v in net.state_dict().items()}
     net = net.to(DEV)
     net.compute_dtype = dtype
+    net.engine_kind = 'hip'
     net.train()
     net.final_dec_drop.eval()                                  # dropout off for the comparison
     g = torch.Generator().manual_seed(5)
     x = torch.randn(shape, generator=g).bfloat16().float()
     gr = torch.randn(shape[0], 2, shape[2], shape[3], generator=g)
-    lo = net.forward_lowres(x.to(DEV).to(dtype))
-    assert lo.dtype == torch.float32 and tuple(lo.shape) == tuple(gr.shape)
-    lo.backward(gr.to(DEV))
+    with no_library_convolutions:
+        lo = net.forward_lowres(x.to(DEV).to(dtype))
+        assert lo.dtype == torch.float32 and tuple(lo.shape) == tuple(gr.shape)
+        lo.backward(gr.to(DEV))
     leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if v.dtype == torch.float32 and 'running' not in k}
     st2 = dict(st)
     st2.update(leaves)
@@ -62,6 +67,8 @@ def test_unet_forward_backward_vs_oracle(arch, shape, dtype):
          'decoder_blocks.2.conv.weight']
     ge = {k: _rel(named[k].grad, leaves[k].grad) for k in keys}
     print('\n{} {}: logits rel err {:.2e}; gradient rel errs {}'.format(arch, dtype, e, {k: round(v, 5) for k, v in ge.items()}))
+    eng = net._hip_engine
+    assert eng is not None and eng.strict and eng.dtype == dtype and eng.library_convs == 0 and no_library_convolutions.refused == 0
     if dtype == torch.float32:
         assert e <= 2e-3 and max(ge.values()) <= 2e-2, (e, ge)
     else:
