@@ -95,6 +95,54 @@ def cpu_baseline(workload, seconds_budget=30.0):
                            N, H, W, workload['batch'], len(times), t))
 
 
+def measure_traffic(key):
+    """-> {'traffic': HBM bytes per convolution launch or None, 'traffic_source': how}. Runs `bench.py --workload <key>
+    --steps 2 --timed_only --no_overlap` twice under `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE, then
+    WRITE_SIZE: they do not fit one pass; kernel trace only, serial streams so that a dispatch's counters are its own) and
+    averages the counters over the conv_igemm launches. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts a
+    128-byte read request as 64 bytes -> doubled. Any failure (no rocprofv3, counters unavailable, timeout) gives None with
+    the reason -- never a number from a file."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(rocprof):
+        return {'traffic': None, 'traffic_source': 'rocprofv3 not found'}
+    kb = {}
+    launches = 0
+    tmp = tempfile.mkdtemp(prefix='cms_pmc_', dir='/tmp')
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            outdir = os.path.join(tmp, counter)
+            cmd = [rocprof, '--kernel-trace', '--pmc', counter, '-d', outdir, '-o', 'p', '--output-format', 'csv', '--',
+                   sys.executable, os.path.abspath(__file__), '--workload', key, '--steps', '2', '--warmup', '1',
+                   '--no_cpu_baseline', '--no_overlap', '--no_roofline_events', '--timed_only', '--traffic', 'omit']
+            env = dict(os.environ, TMPDIR='/tmp')
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+            vals = []
+            for f in glob.glob(os.path.join(outdir, '**', '*counter_collection.csv'), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get('Counter_Name') == counter and 'conv_igemm' in row.get('Kernel_Name', ''):
+                        vals.append(float(row['Counter_Value']))
+            if r.returncode != 0 or not vals:
+                return {'traffic': None, 'traffic_source': 'rocprofv3 --pmc {} pass gave no conv_igemm rows (rc {})'.format(
+                    counter, r.returncode)}
+            kb[counter] = sum(vals) / len(vals)
+            launches = len(vals)
+    except Exception as e:                                   # noqa: BLE001 (a profiler hiccup must not lose the bench line)
+        return {'traffic': None, 'traffic_source': 'traffic measurement failed: {}'.format(type(e).__name__)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = (2.0 * kb['FETCH_SIZE'] + kb['WRITE_SIZE']) * 1024.0
+    return {'traffic': traffic, 'traffic_launches': launches,
+            'traffic_fetch_kb_per_launch': kb['FETCH_SIZE'], 'traffic_write_kb_per_launch': kb['WRITE_SIZE'],
+            'traffic_source': 'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes of '
+                              'bench.py --workload {} --steps 2 --no_overlap), averaged over the conv_igemm launches; gfx950: '
+                              'FETCH_SIZE doubled (128-byte requests counted at 64)'.format(key)}
+
+
 def self_launch(args):
     """`--gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same flags>`."""
     import socket
@@ -162,8 +210,10 @@ def run_workload(key, args, world, rank, dev):
     stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()      # --freeze_bn
     cfg = StepConfig(mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.97, conf_per_pixel=False,
                      fuse_batches=not args.no_fuse_batches, compute_dtype=dtype,
-                     overlap_teacher=not args.no_overlap)
+                     overlap_teacher=not args.no_overlap, allreduce_dtype=args.allreduce_dtype,
+                     deterministic=args.deterministic)
     step = CutMixMeanTeacherStep(stu, tea, opt, ema, cfg)
+    step.time_buckets = world > 1            # (bytes, issue-to-wait) of every gradient bucket of the LAST timed step
     has_ex = hasattr(stu, 'hip_executor')
     if args.no_overlap and has_ex:
         stu.hip_executor().overlap_wgrad = False
@@ -484,7 +534,9 @@ def run_workload(key, args, world, rank, dev):
                        'fuse_batches': not args.no_fuse_batches, 'stream_overlap': not args.no_overlap,
                        'host_enqueue_ms_per_step': 1e3 * t_enqueue / args.steps,
                        'host_enqueue_ms_per_step_empty_queue': host_unblocked,
-                       'last_losses': last},
+                       'last_losses': last,
+                       'allreduce': {'dtype': args.allreduce_dtype, 'buckets_last_step': step.bucket_timing()},
+                       'deterministic_wgrad': bool(args.deterministic)},
             'roofline': {'bound': roof['bound'], 'kernel': kname, 'achieved': achieved, 'peak': roof['peak'],
                          'unit': roof['unit'], 'frac': achieved / roof['peak'], 'traffic': None,
                          'avg_launch_ms': ms_kernel,
@@ -495,16 +547,12 @@ def run_workload(key, args, world, rank, dev):
         }
         if roofline_kernel == 'conv' and timed['launches']:
             out['roofline']['algorithmic_bytes_per_launch'] = timed['bytes'] / timed['launches']
-            import glob
-            cands = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_traffic.json')))
-            pmc = cands[-1] if cands else ''
-            if key == 'pascal' and pmc:
-                # HBM bytes per launch from the TCC memory-side counters (separate FETCH_SIZE / WRITE_SIZE passes of
-                # this command under rocprofv3, gfx950 correction applied; tools/gpu_pmc_traffic.sh)
-                t = json.load(open(pmc))
-                out['roofline']['traffic'] = t['traffic_bytes_per_launch']
-                out['roofline']['traffic_source'] = 'profiles/{} (rocprofv3 --pmc, bytes per launch)'.format(
-                    os.path.basename(pmc))
+            if key == 'pascal' and getattr(args, 'traffic', 'omit') == 'measure' and world == 1:
+                # HBM bytes per launch of THIS build's kernels, measured now: two more runs of this script (2 steps each)
+                # under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM / PMC slots)
+                out['roofline'].update(measure_traffic(key))
+            else:
+                out['roofline']['traffic_source'] = 'not measured in this run (--traffic measure, single GPU, workload pascal)'
         if isolated is not None:
             out['roofline']['isolated'] = isolated
         if timed['flops'] > 0:
@@ -555,7 +603,14 @@ def main():
     ap.add_argument('--roofline_kernel', choices=['conv', 'adam_ema'], default=None,
                     help='default: conv (the MFMA convolution) for the DeepLab v2 workloads, adam_ema otherwise')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--traffic', choices=['measure', 'omit'], default='measure',
+                    help='roofline.traffic: measure it now with two rocprofv3 --pmc passes of this script (single GPU, '
+                         'workload pascal; ~1.5 min), or leave it null')
     ap.add_argument('--no_fuse_batches', action='store_true')
+    ap.add_argument('--allreduce_dtype', choices=['fp32', 'bf16'], default='fp32',
+                    help='data-parallel gradient exchange: the fp32 arena (177 MB per step) or a bf16 staging copy (86 MB)')
+    ap.add_argument('--deterministic', action='store_true',
+                    help='run-to-run deterministic weight gradients (slab + ordered reduce instead of fp32 atomics)')
     ap.add_argument('--conv_tile', type=int, default=0, help='experiment: force a conv tile code (256, 1128, 128)')
     ap.add_argument('--tile_rule', default='', help='experiment: cout:tile[,cout:tile...] per-layer tile codes')
     ap.add_argument('--no_overlap', action='store_true', help='single stream: no teacher / weight-gradient overlap')

@@ -66,6 +66,7 @@ class ParamArena(object):
                                          bool(key in params and params[key].requires_grad)))
             off += (cnt + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
+        self._params = None          # [(segment, parameter)] of the trainable segments, built on first use
         self.by_key = {s.key: s for s in self.segments}
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev) if with_grad else None
@@ -108,13 +109,20 @@ class ParamArena(object):
         the caller, clear what the arena still holds for those parameters."""
         if self.grad is None:
             return
-        params = dict(self.module.named_parameters())
-        for s in self.segments:
-            if s.requires_grad:
-                p = params[s.key]
-                if p.grad is None:
-                    self.grad[s.offset:s.offset + s.count].zero_()
-                    p.grad = _logical_view(self.grad[s.offset:s.offset + s.count], s.shape)
+        if self._params is None:
+            params = dict(self.module.named_parameters())
+            self._params = [(s, params[s.key]) for s in self.segments if s.requires_grad]
+        base = self.grad.data_ptr()
+        for s, p in self._params:
+            g = p.grad
+            if g is None:
+                self.grad[s.offset:s.offset + s.count].zero_()
+                p.grad = _logical_view(self.grad[s.offset:s.offset + s.count], s.shape)
+            elif g.data_ptr() != base + 4 * s.offset:
+                # a foreign gradient tensor (autograd made it while the view was gone): fold it in, then re-home
+                view = _logical_view(self.grad[s.offset:s.offset + s.count], s.shape)
+                view.add_(g.to(view.dtype))
+                p.grad = view
 
     def keys(self):
         return [s.key for s in self.segments]

@@ -316,15 +316,43 @@ class DeepLabHipExecutor(object):
     def _tile_key(self):
         return (self.conv_tile, tuple(sorted(self.tile_rules.items())))
 
+    MAX_PROGRAMS = 8
+
+    def _program_lookup(self, key):
+        """Cached program for `key`, marked most recently used -- or None after making room for a new recording (the
+        LEAST recently used program goes; its buffers may still be in flight, hence the synchronisation)."""
+        prog = self._programs.get(key)
+        if prog is not None:
+            self._programs[key] = self._programs.pop(key)          # dict order = recency
+            return prog
+        if len(self._programs) >= self.MAX_PROGRAMS:
+            torch.cuda.synchronize()
+            self._programs.pop(next(iter(self._programs)))
+        return None
+
+    def _eager_this_time(self, kind, shape, save):
+        """Passes that keep activations for a backward pass (training shapes: they repeat every iteration) are recorded at
+        once. A pass WITHOUT gradients is recorded only when its shape comes back: evaluating variable-sized images (the
+        reference's Pascal validation loop, train_seg_semisup_mask_mt.py:484-517) then runs launch by launch instead of
+        synchronising, evicting and re-recording on almost every image, and pins no activation sets in HBM."""
+        if save:
+            return False
+        key = (kind, tuple(int(v) for v in shape), False, self._tile_key())
+        if key in self._programs:
+            return False
+        seen = self.__dict__.setdefault('_seen_shapes', {})
+        n = seen.get(key, 0) + 1
+        if len(seen) > 256:
+            seen.clear()
+        seen[key] = n
+        return n < 2
+
     def forward_program(self, shape, save):
         """The recorded forward pass for an input of `shape` (N, h, w, 64) -- recorded on first use, on the CURRENT
         stream (its stream 0). Attributes: x_in (persistent input buffer), logits, saved."""
         key = ('fwd', tuple(int(v) for v in shape), bool(save), self._tile_key())
-        prog = self._programs.get(key)
+        prog = self._program_lookup(key)
         if prog is None:
-            if len(self._programs) >= 8:          # shapes come and go (evaluation crops): drop the oldest recording
-                torch.cuda.synchronize()
-                self._programs.pop(next(iter(self._programs)))
             self._prepare_forward()
             prog = ops.Program()
             x_in = torch.empty(tuple(shape), dtype=self.dtype, device=self.arena.device)
@@ -364,7 +392,7 @@ class DeepLabHipExecutor(object):
 
     def forward(self, x, save):
         """-> (logits fp32 NCHW, token for `backward`)."""
-        if not self.use_programs:
+        if not self.use_programs or self._eager_this_time('fwd', x.shape, save):
             st = self.fwd_begin(x, save)
             for bi in range(len(self.blocks)):
                 self.fwd_block(st, bi)
@@ -629,11 +657,8 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
     def taps_program(self, shape, save):
         """The recorded backbone pass for a stem output of `shape`: x_in (persistent input), low, out, saved."""
         key = ('taps', tuple(int(v) for v in shape), bool(save), self._tile_key())
-        prog = self._programs.get(key)
+        prog = self._program_lookup(key)
         if prog is None:
-            if len(self._programs) >= 8:
-                torch.cuda.synchronize()
-                self._programs.pop(next(iter(self._programs)))
             self._prepare_forward()
             prog = ops.Program()
             x_in = torch.empty(tuple(shape), dtype=self.dtype, device=self.arena.device)
@@ -649,7 +674,7 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
         """x: bf16 NHWC stem output -> (low_level (N,h/4,w/4,256), out (N,h/8,w/8,2048)) bf16 NHWC [, saved].
         With programs the two taps are the program's own buffers: valid until the next pass of the same shape through
         this executor is ENQUEUED behind their consumers (stream order), which is how the head uses them."""
-        if not self.use_programs:
+        if not self.use_programs or self._eager_this_time('taps', x.shape, save):
             low, out, saved = self._taps_pass(x, save)
             return (low, out, saved) if save else (low, out)
         prog = self.taps_program(x.shape, save)

@@ -89,6 +89,12 @@ class _FusedOptimizer(object):
 
     # -- torch.optim-like surface
     def zero_grad(self, set_to_none=False):
+        """Clears the gradient arena. The fused kernels read gradients from the ARENA only, so every parameter's `.grad`
+        must be its view of it: if somebody dropped the views (`module.zero_grad(set_to_none=True)`, `p.grad = None`),
+        autograd would create fresh `.grad` tensors outside the arena for the parameters it owns (head, BatchNorm,
+        decoder layers) and their updates would be silently lost -- the views are re-homed here, at the start of
+        every step, over ALL segments."""
+        self.arena.ensure_grads_attached()
         self.arena.zero_grad()
 
     def attach_ema(self, ema_optimizer):

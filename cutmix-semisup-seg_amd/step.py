@@ -31,7 +31,7 @@ from . import ops
 class StepConfig(object):
     def __init__(self, mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.97, conf_per_pixel=False,
                  rampup=-1, unsup_batch_ratio=1, invert=True, fuse_batches=True, compute_dtype=torch.bfloat16,
-                 overlap_teacher=True, bucketed_allreduce=True):
+                 overlap_teacher=True, bucketed_allreduce=True, allreduce_dtype='fp32', deterministic=False):
         if mask_mode not in ('mix', 'zero', 'cut'):
             raise ValueError('Unknown mask_mode {}'.format(mask_mode))
         self.mix = mask_mode == 'mix'
@@ -41,6 +41,14 @@ class StepConfig(object):
         self.fuse_batches = bool(fuse_batches)
         self.overlap_teacher = bool(overlap_teacher)
         self.bucketed_allreduce = bool(bucketed_allreduce)
+        # data-parallel gradient exchange: 'fp32' (the arena itself, 177 MB per step for DeepLab v2) or 'bf16' (a bf16
+        # staging copy: 86 MB on the xGMI links; the sum over ranks is then rounded -- not the parity
+        # configuration)
+        if allreduce_dtype not in ('fp32', 'bf16'):
+            raise ValueError('allreduce_dtype must be fp32 or bf16')
+        self.allreduce_dtype = allreduce_dtype
+        # run-to-run deterministic weight gradients (ops.set_deterministic_wgrad): 1.5-2 % slower inside the step
+        self.deterministic = bool(deterministic)
         self.compute_dtype = compute_dtype
         self.cons = ops.ConsistencyConfig(mode='mix' if self.mix else 'cut', loss_fn=cons_loss_fn,
                                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, invert=invert)
@@ -72,37 +80,67 @@ class GradBuckets(object):
     gradient comes last) and makes the current stream wait for all of it. Every element is reduced exactly once.
     """
 
-    def __init__(self, grad, block_offsets, bucket_starts, group=None):
+    def __init__(self, grad, block_offsets, bucket_starts, group=None, dtype='fp32', timing=False):
         self.grad = grad
         self.block_offsets = list(block_offsets)
         self.starts = set(int(b) for b in bucket_starts)
         self.group = group
         self.hi = int(grad.numel())
         self.works = []
+        # bf16 exchange: each bucket is copied into a bf16 staging arena, reduced there, and copied back after its wait
+        self.stage = torch.empty(grad.numel(), dtype=torch.bfloat16, device=grad.device) if dtype == 'bf16' else None
+        # per-bucket record for the bench line: (bytes on the wire, event at issue, event after the wait)
+        self.timing = bool(timing)
+        self.records = []
 
     def begin(self):
         self.hi = int(self.grad.numel())
         self.works = []
+        self.records = []
+
+    def _issue(self, lo, hi):
+        import torch.distributed as dist
+        if self.stage is not None:
+            buf = self.stage[lo:hi]
+            buf.copy_(self.grad[lo:hi])
+        else:
+            buf = self.grad[lo:hi]
+        ev = None
+        if self.timing:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.works.append((work, lo, hi, ev, buf.numel() * buf.element_size()))
 
     def on_block(self, bi):
         if bi not in self.starts:
             return
-        import torch.distributed as dist
         lo = int(self.block_offsets[bi])
         if lo < self.hi:
-            self.works.append(dist.all_reduce(self.grad[lo:self.hi], op=dist.ReduceOp.SUM, group=self.group,
-                                              async_op=True))
+            self._issue(lo, self.hi)
             self.hi = lo
 
     def finish(self):
-        import torch.distributed as dist
         if self.hi > 0:
-            self.works.append(dist.all_reduce(self.grad[0:self.hi], op=dist.ReduceOp.SUM, group=self.group,
-                                              async_op=True))
+            self._issue(0, self.hi)
             self.hi = 0
-        for w in self.works:
-            w.wait()
+        for work, lo, hi, ev, nbytes in self.works:
+            work.wait()
+            if self.stage is not None:
+                self.grad[lo:hi].copy_(self.stage[lo:hi])
+            if ev is not None:
+                done = torch.cuda.Event(enable_timing=True)
+                done.record()
+                self.records.append((nbytes, ev, done))
         self.works = []
+
+    def read_timing(self):
+        """[{'bytes', 'issue_to_wait_ms'}] of the buckets of the last step (waits for their events)."""
+        out = []
+        for nbytes, e0, e1 in self.records:
+            e1.synchronize()
+            out.append({'bytes': int(nbytes), 'issue_to_wait_ms': float(e0.elapsed_time(e1))})
+        return out
 
 
 class CutMixMeanTeacherStep(object):
@@ -122,6 +160,10 @@ class CutMixMeanTeacherStep(object):
         self._side = None
         self._buckets = None
         self._bucket_obj = None
+        self._whole = None
+        self.time_buckets = False           # bench.py: keep a (bytes, issue-to-wait) record per gradient bucket
+        if cfg.deterministic:
+            ops.set_deterministic_wgrad(True)
 
     # ------------------------------------------------------------------------------------------ helpers
     def _allreduce_grads(self):
@@ -129,9 +171,20 @@ class CutMixMeanTeacherStep(object):
             if self._buckets is not None:
                 self._buckets.finish()
             else:
-                import torch.distributed as dist
-                dist.all_reduce(self.student_optim.arena.grad, op=dist.ReduceOp.SUM, group=self.group)
+                # one exchange of the whole arena after the backward pass(es) (non-fused steps, engines without hooks)
+                if self._whole is None:
+                    g = self.student_optim.arena.grad
+                    self._whole = GradBuckets(g, [0], [0], group=self.group, dtype=self.cfg.allreduce_dtype,
+                                              timing=self.time_buckets)
+                self._whole.timing = self.time_buckets
+                self._whole.begin()
+                self._whole.finish()
             self.student_optim.grad_scale = 1.0 / self.world
+
+    def bucket_timing(self):
+        """Per-bucket records of the last step's gradient exchange (empty on one GPU / when `time_buckets` is off)."""
+        b = self._buckets if self._buckets is not None else self._whole
+        return [] if b is None else b.read_timing()
 
     def _arm_buckets(self):
         """Overlap the gradient all-reduce with the (single) backward pass of the fused-batch step on the executor."""
@@ -146,7 +199,9 @@ class CutMixMeanTeacherStep(object):
             offs = ex.block_grad_offsets()
             # [layer4 + head], the two halves of layer3, [layer1 - layer2]: the executor orders its weight-gradient
             # streams at exactly these bottlenecks (backbone_hip.bucket_starts)
-            self._bucket_obj = GradBuckets(self.student_optim.arena.grad, offs, ex.bucket_starts(), group=self.group)
+            self._bucket_obj = GradBuckets(self.student_optim.arena.grad, offs, ex.bucket_starts(), group=self.group,
+                                           dtype=self.cfg.allreduce_dtype, timing=self.time_buckets)
+        self._bucket_obj.timing = self.time_buckets
         self._buckets = self._bucket_obj
         self._buckets.begin()
         ex.grad_hook = self._buckets.on_block

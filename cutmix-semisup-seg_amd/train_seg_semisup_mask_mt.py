@@ -35,7 +35,8 @@ def train_seg_semisup_mask_mt(submit_config, dataset, model, arch, freeze_bn,
                               n_sup, n_unsup, n_val, split_seed, split_path, val_seed, save_preds, save_model,
                               num_workers,
                               synthetic=False, synthetic_n_classes=21, synthetic_val_batches=2, compute_dtype='bf16',
-                              no_fuse_batches=False, synthetic_source_size=''):
+                              no_fuse_batches=False, synthetic_source_size='', deterministic=False,
+                              allreduce_dtype='fp32'):
     settings = locals().copy()
     del settings['submit_config']
 
@@ -135,7 +136,8 @@ def train_seg_semisup_mask_mt(submit_config, dataset, model, arch, freeze_bn,
     step_cfg = StepConfig(mask_mode=mask_mode, cons_loss_fn=cons_loss_fn, cons_weight=cons_weight,
                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, rampup=rampup,
                           unsup_batch_ratio=unsup_batch_ratio, invert=not boxmask_no_invert,
-                          fuse_batches=bool(freeze_bn) and not no_fuse_batches, compute_dtype=dtype)
+                          fuse_batches=bool(freeze_bn) and not no_fuse_batches, compute_dtype=dtype,
+                          deterministic=deterministic, allreduce_dtype=allreduce_dtype)
     step = CutMixMeanTeacherStep(student_net, teacher_net, student_optim, teacher_optim, step_cfg)
 
     # synthetic data: N(0,1) images, uniform labels with 5 % ignore, all-ones validity masks
@@ -343,6 +345,10 @@ _OPTIONS = [
     click.option('--synthetic_val_batches', type=int, default=2),
     click.option('--compute_dtype', type=click.Choice(['bf16', 'fp32']), default='bf16'),
     click.option('--no_fuse_batches', is_flag=True, default=False),
+    # run-to-run deterministic weight gradients (slab + ordered reduce instead of fp32 atomics; 1.5-2 % slower)
+    click.option('--deterministic', is_flag=True, default=False),
+    # data-parallel gradient exchange: the fp32 arena (default) or a bf16 staging copy (half the bytes on xGMI)
+    click.option('--allreduce_dtype', type=click.Choice(['fp32', 'bf16']), default='fp32'),
 ]
 
 
