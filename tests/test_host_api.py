@@ -244,7 +244,7 @@ def test_cli_surface_matches_reference():
             assert list(p.type.choices) == o['choices']
     extra = set(mine) - {o['name'] for o in ref}
     assert extra == {'synthetic', 'synthetic_n_classes', 'synthetic_val_batches', 'compute_dtype', 'no_fuse_batches',
-                     'synthetic_source_size'}
+                     'synthetic_source_size', 'deterministic', 'allreduce_dtype'}
 
 
 def test_job_helper_log_layout_and_skip(tmp_path, monkeypatch, capsys):
