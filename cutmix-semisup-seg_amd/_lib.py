@@ -25,7 +25,7 @@ LABEL_U8, LABEL_I64 = 0, 1
 LOSS_IDS = {'var': 0, 'logits_var': 1, 'logits_smoothl1': 2, 'bce': 3, 'kld': 4}
 MODE_MIX, MODE_CUT = 0, 1
 OPT_CHUNK = 2048
-AUG_PARAMS = 16
+AUG_PARAMS = 24
 
 c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -154,6 +154,9 @@ PROTOTYPES = {
     'cms_maxpool3x3s2_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                           c_int, c_void_p]),
     'cms_stem_wgrad': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'cms_stem_wgrad_workspace_bytes': (C.c_longlong, [c_int, c_int, c_int, c_int, c_int]),
+    'cms_stem_wgrad_ws': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                          C.c_longlong, c_void_p]),
     'cms_stem_dgrad': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'cms_program_create': (c_int, [_P(c_void_p)]),
     'cms_program_destroy': (c_int, [c_void_p]),

@@ -93,9 +93,11 @@ class Classifier_Module(nn.Module):
 
 class TorchEngine(object):
     """
-    Executes conv(+frozen-BN affine)(+residual)(+ReLU) units with library kernels (MIOpen / hipBLASLt via torch) in
-    `dtype`, channels-last. Interim executor for the backbone until the hand-written MFMA implicit-GEMM kernels
-    (csrc/conv.hip) cover a layer; numerics reference for them on the GPU.
+    Executes conv(+BatchNorm)(+residual)(+ReLU) units layer by layer with LIBRARY convolutions (MIOpen via torch) in
+    `dtype`, channels-last; batch-statistics BatchNorm on csrc/bn.hip. What it is for: the comparison engine of the GPU
+    tests (`engine_kind = 'torch'`), and the base class of deeplab3plus.HipConvEngine, which re-routes the convolutions
+    to the hand-written kernels (all of them with `engine_kind = 'hip'`). The frozen-BatchNorm DeepLab v2 does not come
+    here at all: it runs on the static MFMA executor (backbone_hip.py).
     """
 
     def __init__(self, dtype=torch.bfloat16):
@@ -212,6 +214,8 @@ class ResNetDeepLab(nn.Module):
         d.setdefault('stem_kind', 'hip')      # 'torch': stem through the library engine (comparison runs)
         d.setdefault('_hip_executor', None)   # the executor used last
         d.setdefault('_hip_executors', {})    # compute dtype -> executor
+        d.setdefault('_hip_engine', None)     # the layer-by-layer engine used last (batch-statistics passes)
+        d.setdefault('_hip_engines', {})
         if 'num_classes' not in d:            # a reference-made pickle: read it off the head
             d['num_classes'] = self.layer5.conv2d_list[0].out_channels
 
@@ -233,25 +237,24 @@ class ResNetDeepLab(nn.Module):
 
     # ------------------------------------------------------------------------------------------ execution
     def _engine(self, x):
-        if self.engine is not None:
-            return self.engine
-        if not x.is_cuda:
-            raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
-                               'fallback'.format(x.device))
-        key = ('torch', self.compute_dtype)
-        if key not in _ENGINES:
-            _ENGINES[key] = TorchEngine(self.compute_dtype)
-        return _ENGINES[key]
+        """The layer-by-layer engine of the passes the static executor does not take: BatchNorm on BATCH STATISTICS (the
+        reference CLI's default, no --freeze_bn: deeplab2.py:72-84, train_seg_semisup_mask_mt.py:268-275,587). 'auto' in
+        bf16: MFMA kernels for the convolutions that fit them well, csrc/bn.hip for BatchNorm; 'hip': every convolution
+        (stem as tap chunks, strided 1x1s, the class-wide head) and every BatchNorm on the hand-written kernels, in bf16
+        or fp32, or an error; 'torch' (and 'auto' in fp32): library convolutions."""
+        from .deeplab3plus import _engine_of
+        return _engine_of(self, x)
 
     def _use_hip_body(self):
+        """True: the static MFMA executor (backbone_hip.DeepLabHipExecutor) runs stem, body and head -- whenever every
+        BatchNorm is frozen (running statistics fold into the convolution epilogues)."""
         if self.engine_kind == 'torch' or self.engine is not None:
             return False
         frozen = all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
-        ok = frozen and self.compute_dtype in (torch.bfloat16, torch.float32) and self.num_classes <= 32
-        if self.engine_kind == 'hip' and not ok:
-            raise RuntimeError('the MFMA executor needs frozen BatchNorm (freeze_batchnorm()), bf16 or fp32 compute '
-                               'and <= 32 classes')
-        return ok
+        if frozen and self.engine_kind == 'hip' and (self.compute_dtype not in (torch.bfloat16, torch.float32)
+                                                     or self.num_classes > 32):
+            raise RuntimeError('the MFMA executor needs bf16 or fp32 compute and <= 32 classes')
+        return frozen and self.compute_dtype in (torch.bfloat16, torch.float32) and self.num_classes <= 32
 
     def hip_executor(self):
         # one executor per compute dtype (bf16: throughput configuration; fp32: parity configuration on the f32-input
@@ -275,11 +278,10 @@ class ResNetDeepLab(nn.Module):
 
     def forward_lowres(self, x):
         """(N,3,H,W) -> (N,C,h,w) fp32 head output (the reference's `x` just before its interpolate, :193)."""
-        eng = self._engine(x)
-        use_hip = self._use_hip_body()
-        if use_hip:
+        if self._use_hip_body():
             from ..backbone_hip import run_body
             return run_body(self.hip_executor(), self.stem_nhwc(x))
+        eng = self._engine(x)
         x = eng.prepare_input(x)
         x = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         x = eng.maxpool(x)

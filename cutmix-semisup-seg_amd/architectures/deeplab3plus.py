@@ -236,6 +236,19 @@ class HipConvEngine(TorchEngine):
                                    '(channels-last input with channels % 8 == 0 needed)'.format(y.shape[1], bn))
         return super(HipConvEngine, self).bn_act(y, bn, relu, residual)
 
+    def aspp_head(self, x, convs):
+        """DeepLab v2's head (deeplab2.py:124-128: the live dilated 3x3 branches, class axis padded to 64, summed; biases
+        added in fp32) on the hand-written kernels."""
+        from ..backbone_hip import hip_conv2d
+        if not self.strict and not all(id(c) in self.keys for c in convs):
+            return super(HipConvEngine, self).aspp_head(x, convs)
+        out = None
+        for conv in convs:
+            y = hip_conv2d(x, conv, self.arena, self.keys[id(conv)], self.dtype).float()
+            out = y if out is None else out + y
+        bias = sum(c.bias for c in convs)
+        return out + bias.view(1, -1, 1, 1)
+
     def classifier(self, x, conv):
         """1x1 convolution with bias to <= 64 classes -> fp32 NCHW logits (convolution epilogue)."""
         from ..backbone_hip import hip_classifier

@@ -66,6 +66,21 @@ __device__ __forceinline__ void put(void* base, size_t idx, float v) {
     else reinterpret_cast<uint16_t*>(base)[idx] = f32_to_bf16(v);
 }
 
+// cv2.BORDER_REFLECT_101: ... 2 1 | 0 1 2 ... n-1 | n-2 n-3 ... (period 2n - 2), any distance outside
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    const int period = 2 * n - 2;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+
+// AFFINE WARP geometry (params slot 15 == 1): source position of (flip-undone) output pixel (cx, cy)
+__device__ __forceinline__ void warp_src(const float* p, int cx, int cy, float& sx, float& sy) {
+    sx = fmaf(p[16], (float)cx, fmaf(p[17], (float)cy, p[18]));
+    sy = fmaf(p[19], (float)cx, fmaf(p[20], (float)cy, p[21]));
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
     const size_t total = (size_t)a.N * a.H * a.W;
@@ -82,36 +97,71 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
         if (p[5] != 0.0f) cy = a.H - 1 - cy;
         if (p[4] != 0.0f) cx = a.W - 1 - cx;
         const float y0 = p[0], x0 = p[1], sh = p[2], sw = p[3];
-        // bilinear tap positions inside the source window (cv2.INTER_LINEAR: half-pixel centres, border replicated)
-        float fy = ((float)cy + 0.5f) * (sh / (float)a.H) - 0.5f, fx = ((float)cx + 0.5f) * (sw / (float)a.W) - 0.5f;
-        fy = fminf(fmaxf(fy, 0.0f), sh - 1.0f);
-        fx = fminf(fmaxf(fx, 0.0f), sw - 1.0f);
-        const int iy0 = (int)floorf(fy), ix0 = (int)floorf(fx);
-        const float wy = fy - (float)iy0, wx = fx - (float)ix0;
-        const int iy1 = min(iy0 + 1, (int)sh - 1), ix1 = min(ix0 + 1, (int)sw - 1);
-        const int Y0 = iy0 + (int)y0, Y1 = iy1 + (int)y0, X0 = ix0 + (int)x0, X1 = ix1 + (int)x0;
+        const bool warp = p[15] != 0.0f;
         float rgb[3] = {0.0f, 0.0f, 0.0f};
         float alpha = 0.0f;
         const uint8_t* img = a.src + (size_t)n * a.Hs * a.Ws * 3;
-        auto tap = [&](int Y, int X, float w) {
-            if (w != 0.0f && (unsigned)Y < (unsigned)a.Hs && (unsigned)X < (unsigned)a.Ws) {
-                const uint8_t* q = img + ((size_t)Y * a.Ws + X) * 3;
-                rgb[0] += w * (float)q[0];
-                rgb[1] += w * (float)q[1];
-                rgb[2] += w * (float)q[2];
-                alpha += w;
+        float img_alpha = 1.0f;                 // factor of the mean in the standardisation (window mode: zero padding)
+        int ny = 0, nx = 0;                     // nearest source pixel for the labels
+        if (warp) {
+            // datapipe/seg_transforms_cv.py:344-362: cv2.warpAffine(image, local_xf, crop, flags=interp, BORDER_REFLECT_101),
+            // labels INTER_NEAREST / constant 255, mask constant 0
+            float sx, sy;
+            warp_src(p, cx, cy, sx, sy);
+            nx = (int)floorf(sx + 0.5f);
+            ny = (int)floorf(sy + 0.5f);
+            if (p[22] == 0.0f) {
+                const uint8_t* q = img + ((size_t)reflect101(ny, a.Hs) * a.Ws + reflect101(nx, a.Ws)) * 3;
+                rgb[0] = (float)q[0]; rgb[1] = (float)q[1]; rgb[2] = (float)q[2];
+                alpha = ((unsigned)ny < (unsigned)a.Hs && (unsigned)nx < (unsigned)a.Ws) ? 1.0f : 0.0f;
+            } else {
+                const int ix0 = (int)floorf(sx), iy0 = (int)floorf(sy);
+                const float wx = sx - (float)ix0, wy = sy - (float)iy0;
+                auto wtap = [&](int Y, int X, float w) {
+                    const uint8_t* q = img + ((size_t)reflect101(Y, a.Hs) * a.Ws + reflect101(X, a.Ws)) * 3;
+                    rgb[0] += w * (float)q[0];
+                    rgb[1] += w * (float)q[1];
+                    rgb[2] += w * (float)q[2];
+                    if ((unsigned)Y < (unsigned)a.Hs && (unsigned)X < (unsigned)a.Ws) alpha += w;
+                };
+                wtap(iy0, ix0, (1.0f - wy) * (1.0f - wx));
+                wtap(iy0, ix0 + 1, (1.0f - wy) * wx);
+                wtap(iy0 + 1, ix0, wy * (1.0f - wx));
+                wtap(iy0 + 1, ix0 + 1, wy * wx);
             }
-        };
-        tap(Y0, X0, (1.0f - wy) * (1.0f - wx));
-        tap(Y0, X1, (1.0f - wy) * wx);
-        tap(Y1, X0, wy * (1.0f - wx));
-        tap(Y1, X1, wy * wx);
+        } else {
+            // bilinear tap positions inside the source window (cv2.INTER_LINEAR: half-pixel centres, border replicated)
+            float fy = ((float)cy + 0.5f) * (sh / (float)a.H) - 0.5f, fx = ((float)cx + 0.5f) * (sw / (float)a.W) - 0.5f;
+            fy = fminf(fmaxf(fy, 0.0f), sh - 1.0f);
+            fx = fminf(fmaxf(fx, 0.0f), sw - 1.0f);
+            const int iy0 = (int)floorf(fy), ix0 = (int)floorf(fx);
+            const float wy = fy - (float)iy0, wx = fx - (float)ix0;
+            const int iy1 = min(iy0 + 1, (int)sh - 1), ix1 = min(ix0 + 1, (int)sw - 1);
+            const int Y0 = iy0 + (int)y0, Y1 = iy1 + (int)y0, X0 = ix0 + (int)x0, X1 = ix1 + (int)x0;
+            auto tap = [&](int Y, int X, float w) {
+                if (w != 0.0f && (unsigned)Y < (unsigned)a.Hs && (unsigned)X < (unsigned)a.Ws) {
+                    const uint8_t* q = img + ((size_t)Y * a.Ws + X) * 3;
+                    rgb[0] += w * (float)q[0];
+                    rgb[1] += w * (float)q[1];
+                    rgb[2] += w * (float)q[2];
+                    alpha += w;
+                }
+            };
+            tap(Y0, X0, (1.0f - wy) * (1.0f - wx));
+            tap(Y0, X1, (1.0f - wy) * wx);
+            tap(Y1, X0, wy * (1.0f - wx));
+            tap(Y1, X1, wy * wx);
+            img_alpha = alpha;
+            // cv2.INTER_NEAREST: floor(dst * scale)
+            ny = min((int)((float)cy * (sh / (float)a.H)), (int)sh - 1) + (int)y0;
+            nx = min((int)((float)cx * (sw / (float)a.W)), (int)sw - 1) + (int)x0;
+        }
         float r = rgb[0] * (1.0f / 255.0f), g = rgb[1] * (1.0f / 255.0f), b = rgb[2] * (1.0f / 255.0f);
         const size_t o = (size_t)n * 3 * plane + (size_t)oy * a.W + ox;
         if (a.out0) {
-            put<T>(a.out0, o, (r - a.mean[0] * alpha) * a.inv_std[0]);
-            put<T>(a.out0, o + plane, (g - a.mean[1] * alpha) * a.inv_std[1]);
-            put<T>(a.out0, o + 2 * plane, (b - a.mean[2] * alpha) * a.inv_std[2]);
+            put<T>(a.out0, o, (r - a.mean[0] * img_alpha) * a.inv_std[0]);
+            put<T>(a.out0, o + plane, (g - a.mean[1] * img_alpha) * a.inv_std[1]);
+            put<T>(a.out0, o + 2 * plane, (b - a.mean[2] * img_alpha) * a.inv_std[2]);
         }
         if (a.out1) {
             if (p[12] != 0.0f) {                       // ColorJitter applied (RandomApply, p = aug_colour_prob)
@@ -140,15 +190,12 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
                 const float gr = gray_of(r, g, b);
                 r = g = b = gr;
             }
-            put<T>(a.out1, o, (r - a.mean[0] * alpha) * a.inv_std[0]);
-            put<T>(a.out1, o + plane, (g - a.mean[1] * alpha) * a.inv_std[1]);
-            put<T>(a.out1, o + 2 * plane, (b - a.mean[2] * alpha) * a.inv_std[2]);
+            put<T>(a.out1, o, (r - a.mean[0] * img_alpha) * a.inv_std[0]);
+            put<T>(a.out1, o + plane, (g - a.mean[1] * img_alpha) * a.inv_std[1]);
+            put<T>(a.out1, o + 2 * plane, (b - a.mean[2] * img_alpha) * a.inv_std[2]);
         }
         if (a.out_mask) a.out_mask[(size_t)n * plane + (size_t)oy * a.W + ox] = alpha;
         if (a.out_labels) {
-            // cv2.INTER_NEAREST: floor(dst * scale)
-            const int ny = min((int)((float)cy * (sh / (float)a.H)), (int)sh - 1) + (int)y0;
-            const int nx = min((int)((float)cx * (sw / (float)a.W)), (int)sw - 1) + (int)x0;
             uint8_t lab = 255;
             if (a.src_labels && (unsigned)ny < (unsigned)a.Hs && (unsigned)nx < (unsigned)a.Ws)
                 lab = a.src_labels[((size_t)n * a.Hs + ny) * a.Ws + nx];
@@ -167,6 +214,14 @@ __global__ __launch_bounds__(256) void augment_luma_kernel(AugArgs a, float* __r
     float acc = 0.0f;
     for (int i = threadIdx.x; i < a.H * a.W; i += blockDim.x) {
         const int cy = i / a.W, cx = i % a.W;           // (flips do not change the mean)
+        if (p[15] != 0.0f) {                            // affine warp: nearest tap, reflected border
+            float sx, sy;
+            warp_src(p, cx, cy, sx, sy);
+            const uint8_t* q = img + ((size_t)reflect101((int)floorf(sy + 0.5f), a.Hs) * a.Ws +
+                                      reflect101((int)floorf(sx + 0.5f), a.Ws)) * 3;
+            acc += gray_of((float)q[0], (float)q[1], (float)q[2]) * (1.0f / 255.0f);
+            continue;
+        }
         float fy = ((float)cy + 0.5f) * (sh / (float)a.H) - 0.5f, fx = ((float)cx + 0.5f) * (sw / (float)a.W) - 0.5f;
         fy = fminf(fmaxf(fy, 0.0f), sh - 1.0f);
         fx = fminf(fmaxf(fx, 0.0f), sw - 1.0f);

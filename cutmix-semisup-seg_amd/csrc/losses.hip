@@ -14,6 +14,7 @@
 // Backward: the per-pixel gradient vector is scattered to the low-res logits through an LDS-tiled separable
 // adjoint of the bilinear upsample (x-reduce, then y-reduce, fixed order inside a tile), so global atomics are
 // issued per low-res cell per tile instead of per pixel per tap.
+#include <algorithm>
 #include "common.hpp"
 
 namespace cms {
@@ -47,6 +48,9 @@ __device__ __forceinline__ void fill(RegVec<CT>& r, const Gather<IDENT>& g) {
 struct Geo {
     int n, c, h, w, H, W, align;
     float sy, sx;
+    // tiled backward: this launch covers the tiles (col_x + i * col_kx, col_y + j * col_ky) -- one COLOUR class of the tile
+    // grid, chosen on the host so that no two tiles of a launch touch the same low-resolution cell (see tiled_launches)
+    int col_kx, col_ky, col_x, col_y;
 };
 
 // ------------------------------------------------------------------------------------------------ consistency
@@ -240,7 +244,10 @@ __global__ __launch_bounds__(256) void cons_bwd_ident_kernel(ConsArgs a, const f
 //   phase 1  every thread computes the gradient vector of its 2 pixels -> G[row][class][col]        (LDS)
 //   phase 2  x-adjoint:  R[row][class][j] = sum_col wx(col -> cell j) * G[row][class][col]          (LDS)
 //   phase 3  y-adjoint:  out[class][i][j] = sum_row wy(row -> cell i) * R[row][class][j]  -> one global atomicAdd
-// Summation order inside a tile is fixed; only the few tiles that share a low-res cell meet in the atomics.
+// Summation order inside a tile is fixed. Neighbouring tiles share low-resolution cells; so that their sums do not meet in
+// an order that changes from run to run, the tile grid is issued as kx * ky COLOUR classes, one launch each, in a fixed
+// order on the stream: within a launch every cell receives exactly one add (round 3: the logit gradients, and with them
+// every weight gradient downstream, are run-to-run reproducible).
 constexpr int TILE_W = 64;
 constexpr int TILE_H = 8;
 constexpr int G_LD = TILE_W + 1;  // +1 float: conflict-free column access for class-major readers
@@ -269,11 +276,13 @@ __device__ __forceinline__ void tiled_scatter(const Geo& g, PixelGrad pixel_grad
     __shared__ TileTables tb;
     const int tiles_x = (g.W + TILE_W - 1) / TILE_W;
     const int tiles_y = (g.H + TILE_H - 1) / TILE_H;
+    const int ctx = (tiles_x - g.col_x + g.col_kx - 1) / g.col_kx;      // tiles of this colour class per row / column
+    const int cty = (tiles_y - g.col_y + g.col_ky - 1) / g.col_ky;
     int b = blockIdx.x;
-    const int tx_i = b % tiles_x;
-    b /= tiles_x;
-    const int ty_i = b % tiles_y;
-    const int n = b / tiles_y;
+    const int tx_i = g.col_x + (b % ctx) * g.col_kx;
+    b /= ctx;
+    const int ty_i = g.col_y + (b % cty) * g.col_ky;
+    const int n = b / cty;
     const int x0 = tx_i * TILE_W, y0 = ty_i * TILE_H;
     const int tw = min(TILE_W, g.W - x0), th = min(TILE_H, g.H - y0);
     const int C = g.c;
@@ -374,6 +383,38 @@ __device__ __forceinline__ void tiled_scatter(const Geo& g, PixelGrad pixel_grad
         }
         if (s != 0.0f) atomicAdd(out_n + (size_t)k * plane + (size_t)Y * g.w + (tb.x_lo + j), s);
     }
+}
+
+// Smallest tile distance k along one axis such that tiles t and t + k never touch the same low-resolution cell.
+inline int tile_colour_period(int full, int low, float scale, bool align, int tile) {
+    const int T = (full + tile - 1) / tile;
+    int k = 1;
+    for (;;) {
+        bool clash = false;
+        for (int t = 0; t + k < T && !clash; ++t) {
+            const Tap hi = bilin_tap(std::min(t * tile + tile - 1, full - 1), scale, low, align);
+            const Tap lo = bilin_tap((t + k) * tile, scale, low, align);
+            clash = lo.i0 <= hi.i1;
+        }
+        if (!clash || k >= T) return k;
+        ++k;
+    }
+}
+
+// Issues `launch(geo, tiles)` once per colour class of the tile grid, in a fixed order.
+template <class F>
+inline void tiled_launches(Geo g, F launch) {
+    const int tiles_x = (g.W + TILE_W - 1) / TILE_W, tiles_y = (g.H + TILE_H - 1) / TILE_H;
+    g.col_kx = tile_colour_period(g.W, g.w, g.sx, g.align != 0, TILE_W);
+    g.col_ky = tile_colour_period(g.H, g.h, g.sy, g.align != 0, TILE_H);
+    for (int cy = 0; cy < g.col_ky; ++cy)
+        for (int cx = 0; cx < g.col_kx; ++cx) {
+            const int ctx = (tiles_x - cx + g.col_kx - 1) / g.col_kx, cty = (tiles_y - cy + g.col_ky - 1) / g.col_ky;
+            if (ctx <= 0 || cty <= 0) continue;
+            g.col_x = cx;
+            g.col_y = cy;
+            launch(g, ctx * cty * g.n);
+        }
 }
 
 template <int CT>
@@ -542,6 +583,8 @@ __global__ __launch_bounds__(256) void ce_bwd_tiled_kernel(CeArgs a, const float
 static Geo make_geo(int n, int c, int h, int w, int H, int W, int align) {
     Geo g;
     g.n = n; g.c = c; g.h = h; g.w = w; g.H = H; g.W = W; g.align = align;
+    g.col_kx = g.col_ky = 1;
+    g.col_x = g.col_y = 0;
     g.sy = bilin_scale(h, H, align != 0);
     g.sx = bilin_scale(w, W, align != 0);
     return g;
@@ -633,12 +676,15 @@ extern "C" int cms_consistency_bwd(const cms_consistency_desc* d, const float* s
     } else {
         const size_t lds = tile_lds_bytes(d->c, a.g.sy, a.g.sx);
         CMS_REQUIRE(lds <= 160 * 1024 - 4096, "consistency_bwd: %d classes at this scale need %zu B of LDS", d->c, lds);
-        const int tiles = ((d->W + TILE_W - 1) / TILE_W) * ((d->H + TILE_H - 1) / TILE_H) * d->n;
         CMS_DISPATCH_C(d->c, {
             if (lds > 48 * 1024)
                 (void)hipFuncSetAttribute((const void*)cons_bwd_tiled_kernel<CT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((cons_bwd_tiled_kernel<CT>), dim3(tiles), dim3(256), lds, s, a, scalars, grad_l_stu);
+            tiled_launches(a.g, [&](const Geo& gc, int tiles) {
+                ConsArgs ac = a;
+                ac.g = gc;
+                hipLaunchKernelGGL((cons_bwd_tiled_kernel<CT>), dim3(tiles), dim3(256), lds, s, ac, scalars, grad_l_stu);
+            });
         });
     }
     return launch_status("cms_consistency_bwd");
@@ -700,12 +746,15 @@ extern "C" int cms_ce_bwd(const cms_ce_desc* d, const float* scalars, float* gra
     } else {
         const size_t lds = tile_lds_bytes(d->c, a.g.sy, a.g.sx);
         CMS_REQUIRE(lds <= 160 * 1024 - 4096, "ce_bwd: %d classes at this scale need %zu B of LDS", d->c, lds);
-        const int tiles = ((d->W + TILE_W - 1) / TILE_W) * ((d->H + TILE_H - 1) / TILE_H) * d->n;
         CMS_DISPATCH_C(d->c, {
             if (lds > 48 * 1024)
                 (void)hipFuncSetAttribute((const void*)ce_bwd_tiled_kernel<CT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((ce_bwd_tiled_kernel<CT>), dim3(tiles), dim3(256), lds, s, a, scalars, grad_logits);
+            tiled_launches(a.g, [&](const Geo& gc, int tiles) {
+                CeArgs ac = a;
+                ac.g = gc;
+                hipLaunchKernelGGL((ce_bwd_tiled_kernel<CT>), dim3(tiles), dim3(256), lds, s, ac, scalars, grad_logits);
+            });
         });
     }
     return launch_status("cms_ce_bwd");

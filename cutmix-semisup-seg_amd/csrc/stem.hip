@@ -296,7 +296,7 @@ constexpr int SW_PW = (SW_TW - 1) * 2 + STEM_K;            // 37
 template <class TX, class TS>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TX* __restrict__ x, const TS* __restrict__ ds,
                                                          float* __restrict__ dw, const float* __restrict__ scale, int N,
-                                                         int H, int W, int Ho, int Wo) {
+                                                         int H, int W, int Ho, int Wo, float* __restrict__ slab) {
     __shared__ float dst[SW_TH * SW_TW][STEM_CO];          // 32 KB
     __shared__ float patch[3][SW_PH][SW_PW + 1];
     const int tid = threadIdx.x, co = tid & 63, g = tid >> 6;     // g = wave index: wave-uniform
@@ -348,8 +348,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const TX* __restrict__ 
         if (i < nr) {
             const int r = r0 + i, c = r / 7, ky = r % 7;
 #pragma unroll
-            for (int k = 0; k < 7; ++k)
-                atomicAdd(dw + ((size_t)(ky * 7 + k) * STEM_CO + co) * 3 + c, acc[i][k] * sc);
+            for (int k = 0; k < 7; ++k) {
+                const size_t e = ((size_t)(ky * 7 + k) * STEM_CO + co) * 3 + c;
+                if (slab) slab[(size_t)blockIdx.x * (49 * STEM_CO * 3) + e] = acc[i][k] * sc;     // deterministic combine
+                else atomicAdd(dw + e, acc[i][k] * sc);
+            }
         }
     }
 }
@@ -369,7 +372,7 @@ constexpr int SWM_P_PITCH = 400;               // bytes per pixel row of the im2
 
 __global__ __launch_bounds__(256, 2) void stem_wgrad_mfma_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ ds,
                                                                  float* __restrict__ dw, const float* __restrict__ scale, int N,
-                                                                 int H, int W, int Ho, int Wo) {
+                                                                 int H, int W, int Ho, int Wo, float* __restrict__ slab) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SF_P * SM_PITCH * 2 + 64 * SWM_DS_PITCH + 64 * SWM_P_PITCH];
     uint16_t* patch = reinterpret_cast<uint16_t*>(smem);                           // [3][37][40] bf16
     unsigned char* lds_ds = smem + 3 * SF_P * SM_PITCH * 2;                        // [64 px][144 B]
@@ -474,7 +477,20 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_mfma_kernel(const uint16_t*
         }
     }
     __syncthreads();
-    for (int i = tid; i < 49 * STEM_CO * 3; i += 256) atomicAdd(dw + i, lds_out[i]);
+    if (slab) {                                            // deterministic combine: this block's partial sums, plain stores
+        for (int i = tid; i < 49 * STEM_CO * 3; i += 256) slab[(size_t)blockIdx.x * (49 * STEM_CO * 3) + i] = lds_out[i];
+    } else {
+        for (int i = tid; i < 49 * STEM_CO * 3; i += 256) atomicAdd(dw + i, lds_out[i]);
+    }
+}
+
+// dw[i] += sum over blocks of slab[b][i], in block order (the deterministic combine of the two kernels above)
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nblocks) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 49 * STEM_CO * 3) return;
+    float s = 0.0f;
+    for (int b = 0; b < nblocks; ++b) s += slab[(size_t)b * (49 * STEM_CO * 3) + i];
+    dw[i] += s;
 }
 
 // ---- gradient wrt the image: dx[n,c,iy,ix] = sum_{ky,kx,co} dS[n,(iy+3-ky)/2,(ix+3-kx)/2,co] * scale[co]-folded w
@@ -621,35 +637,67 @@ extern "C" int cms_maxpool3x3s2_relu_bwd(const void* dp_nhwc, const uint8_t* arg
     return launch_status("cms_maxpool3x3s2_relu_bwd");
 }
 
-extern "C" int cms_stem_wgrad(const void* x_nchw, int x_dtype, const void* ds_nhwc, int ds_dtype, float* dw_khkwcoci,
-                              const float* scale, int n, int h, int w, void* stream) {
-    CMS_REQUIRE(x_nchw && ds_nhwc && dw_khkwcoci, "stem_wgrad: NULL pointer");
-    CMS_REQUIRE(dt_ok(x_dtype) && dt_ok(ds_dtype), "stem_wgrad: bad dtype");
-    CMS_REQUIRE(n > 0 && h > 0 && w > 0, "stem_wgrad: bad geometry");
+static int stem_wgrad_blocks(int x_dtype, int ds_dtype, int n, int h, int w, bool* mfma_out) {
     int Ho, Wo;
     cms_stem_out_hw(h, w, &Ho, &Wo, nullptr, nullptr);
-    const int ntiles = n * ((Ho + SW_TH - 1) / SW_TH) * ((Wo + SW_TW - 1) / SW_TW);
-    const dim3 grid(ntiles < 768 ? ntiles : 768);            // 3 blocks per CU (41 KB of LDS each), persistent over the tiles
-    hipStream_t s = (hipStream_t)stream;
     static int env_mfma = -1;                   // CMS_STEM_MFMA=0: the VALU kernel also for bf16 (A/B switch)
     if (env_mfma < 0) {
         const char* e = getenv("CMS_STEM_MFMA");
         env_mfma = e ? atoi(e) : 1;
     }
-    if (x_dtype == CMS_BF16 && ds_dtype == CMS_BF16 && env_mfma != 0) {
+    const bool mfma = x_dtype == CMS_BF16 && ds_dtype == CMS_BF16 && env_mfma != 0;
+    if (mfma_out) *mfma_out = mfma;
+    if (mfma) {
         const int nt = n * ((Ho + SF_T - 1) / SF_T) * ((Wo + SF_T - 1) / SF_T);
-        hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nt < 256 ? nt : 256), dim3(256), 0, s, (const uint16_t*)x_nchw,
-                           (const uint16_t*)ds_nhwc, dw_khkwcoci, scale, n, h, w, Ho, Wo);
-        return launch_status("cms_stem_wgrad");
+        return nt < 256 ? nt : 256;
     }
+    const int ntiles = n * ((Ho + SW_TH - 1) / SW_TH) * ((Wo + SW_TW - 1) / SW_TW);
+    return ntiles < 768 ? ntiles : 768;          // 3 blocks per CU (41 KB of LDS each), persistent over the tiles
+}
+
+// Bytes of scratch that make cms_stem_wgrad_ws deterministic: one [49][64][3] fp32 slab per (persistent) block.
+extern "C" long long cms_stem_wgrad_workspace_bytes(int x_dtype, int ds_dtype, int n, int h, int w) {
+    if (n <= 0 || h <= 0 || w <= 0 || !dt_ok(x_dtype) || !dt_ok(ds_dtype)) return 0;
+    return (long long)stem_wgrad_blocks(x_dtype, ds_dtype, n, h, w, nullptr) * 49 * STEM_CO * 3 * (long long)sizeof(float);
+}
+
+// `workspace` (>= cms_stem_wgrad_workspace_bytes, or NULL): with it the blocks write their partial sums there with plain
+// stores and a second launch adds them to dw in block order -- run-to-run deterministic; without it, fp32 atomics.
+extern "C" int cms_stem_wgrad_ws(const void* x_nchw, int x_dtype, const void* ds_nhwc, int ds_dtype, float* dw_khkwcoci,
+                                 const float* scale, int n, int h, int w, void* workspace, long long workspace_bytes,
+                                 void* stream) {
+    CMS_REQUIRE(x_nchw && ds_nhwc && dw_khkwcoci, "stem_wgrad: NULL pointer");
+    CMS_REQUIRE(dt_ok(x_dtype) && dt_ok(ds_dtype), "stem_wgrad: bad dtype");
+    CMS_REQUIRE(n > 0 && h > 0 && w > 0, "stem_wgrad: bad geometry");
+    int Ho, Wo;
+    cms_stem_out_hw(h, w, &Ho, &Wo, nullptr, nullptr);
+    bool mfma = false;
+    const int nblk = stem_wgrad_blocks(x_dtype, ds_dtype, n, h, w, &mfma);
+    const dim3 grid(nblk);
+    hipStream_t s = (hipStream_t)stream;
+    CMS_REQUIRE(workspace == nullptr || workspace_bytes >= cms_stem_wgrad_workspace_bytes(x_dtype, ds_dtype, n, h, w),
+                "stem_wgrad: workspace of %lld bytes is too small", workspace_bytes);
+    float* slab = (float*)workspace;
+    if (mfma) {
+        hipLaunchKernelGGL(stem_wgrad_mfma_kernel, grid, dim3(256), 0, s, (const uint16_t*)x_nchw,
+                           (const uint16_t*)ds_nhwc, dw_khkwcoci, scale, n, h, w, Ho, Wo, slab);
+    } else {
 #define CMS_STEM_WG(TX, TS) \
-    hipLaunchKernelGGL((stem_wgrad_kernel<TX, TS>), grid, dim3(256), 0, s, (const TX*)x_nchw, (const TS*)ds_nhwc, dw_khkwcoci, scale, n, h, w, Ho, Wo)
-    if (x_dtype == CMS_F32 && ds_dtype == CMS_F32) CMS_STEM_WG(float, float);
-    else if (x_dtype == CMS_F32) CMS_STEM_WG(float, uint16_t);
-    else if (ds_dtype == CMS_F32) CMS_STEM_WG(uint16_t, float);
-    else CMS_STEM_WG(uint16_t, uint16_t);
+    hipLaunchKernelGGL((stem_wgrad_kernel<TX, TS>), grid, dim3(256), 0, s, (const TX*)x_nchw, (const TS*)ds_nhwc, dw_khkwcoci, scale, n, h, w, Ho, Wo, slab)
+        if (x_dtype == CMS_F32 && ds_dtype == CMS_F32) CMS_STEM_WG(float, float);
+        else if (x_dtype == CMS_F32) CMS_STEM_WG(float, uint16_t);
+        else if (ds_dtype == CMS_F32) CMS_STEM_WG(uint16_t, float);
+        else CMS_STEM_WG(uint16_t, uint16_t);
 #undef CMS_STEM_WG
+    }
+    if (slab)
+        hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((49 * STEM_CO * 3 + 255) / 256), dim3(256), 0, s, slab, dw_khkwcoci, nblk);
     return launch_status("cms_stem_wgrad");
+}
+
+extern "C" int cms_stem_wgrad(const void* x_nchw, int x_dtype, const void* ds_nhwc, int ds_dtype, float* dw_khkwcoci,
+                              const float* scale, int n, int h, int w, void* stream) {
+    return cms_stem_wgrad_ws(x_nchw, x_dtype, ds_nhwc, ds_dtype, dw_khkwcoci, scale, n, h, w, nullptr, 0, stream);
 }
 
 extern "C" int cms_stem_dgrad(const void* ds_nhwc, int ds_dtype, const float* w_packed, const float* scale, float* dx_nchw,

@@ -525,8 +525,15 @@ def stem_wgrad(x, ds, dw_khkwcoci, scale):
     if tuple(dw_khkwcoci.shape) != (49, 64, 3) or dw_khkwcoci.dtype != torch.float32 or not dw_khkwcoci.is_contiguous():
         raise ValueError('stem_wgrad: contiguous fp32 (49, 64, 3) gradient view required')
     n, _, h, w = (int(v) for v in x.shape)
-    check(fn['cms_stem_wgrad'](_ptr(x), _dtype_code(x), _ptr(ds), _dtype_code(ds), _ptr(dw_khkwcoci), _ptr(scale), n, h, w,
-                               _stream()), 'cms_stem_wgrad')
+    ws, nbytes = None, 0
+    if deterministic_wgrad():
+        nbytes = int(fn['cms_stem_wgrad_workspace_bytes'](_dtype_code(x), _dtype_code(ds), n, h, w))
+        key = ('stem', x.device.index, int(torch.cuda.current_stream().cuda_stream))
+        ws = _WGRAD_WS.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = _WGRAD_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(fn['cms_stem_wgrad_ws'](_ptr(x), _dtype_code(x), _ptr(ds), _dtype_code(ds), _ptr(dw_khkwcoci), _ptr(scale), n, h, w,
+                                  _ptr(ws), nbytes, _stream()), 'cms_stem_wgrad_ws')
 
 
 def stem_dgrad(ds, w147, scale, x_shape):

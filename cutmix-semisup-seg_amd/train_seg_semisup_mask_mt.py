@@ -165,10 +165,8 @@ def train_seg_semisup_mask_mt(submit_config, dataset, model, arch, freeze_bn,
                                   hvflip=aug_hvflip, strong_colour=aug_strong_colour, brightness=aug_colour_brightness,
                                   contrast=aug_colour_contrast, saturation=aug_colour_saturation, hue=aug_colour_hue,
                                   colour_prob=aug_colour_prob, greyscale_prob=aug_colour_greyscale_prob, out_dtype=dtype,
-                                  rng=np.random.RandomState(54321 + rank), colour_rng=np.random.RandomState(99 + rank))
-        if aug_max_scale != 1.0 or aug_rot_mag != 0.0:
-            raise NotImplementedError('the device-side staging covers crop / Hung scale / flips / colour; rotation and '
-                                      'free scaling (--aug_max_scale, --aug_rot_mag) are not built')
+                                  rng=np.random.RandomState(54321 + rank), colour_rng=np.random.RandomState(99 + rank),
+                                  rot_mag=aug_rot_mag, max_scale=aug_max_scale)
         src_pool = torch.randint(0, 256, (4 * batch_size, hs, ws, 3), generator=gen, device=torch_device, dtype=torch.uint8)
         lab_pool = torch.randint(0, n_classes, (4 * batch_size, hs, ws), generator=gen, device=torch_device).to(torch.uint8)
         pool_pos = [0]

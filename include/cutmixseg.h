@@ -345,10 +345,15 @@ int cms_conv_pack_transpose_batch_f32(const cms_pack_item* items_dev, int n_item
  *                label 255, mask 0)         2 sc_h, 3 sc_w   window size (== h, w without random scale)
  *   4 flip_x, 5 flip_y, 6 transpose (0/1)   7 brightness, 8 contrast, 9 saturation factors, 10 hue shift (turns)
  *   11 greyscale (0/1)   12 colour jitter applied (0/1)   13 order of the four jitter ops, base-4 digits
- *   14 contrast pivot (mean luminance; fill with cms_augment_luma x brightness when brightness comes first)   15 reserved
+ *   14 contrast pivot (mean luminance; fill with cms_augment_luma x brightness when brightness comes first)
+ *   15 geometry: 0 = the axis-aligned window of slots 0..3 (crop / Hung scale, above); 1 = AFFINE WARP, the random
+ *      rotate + scale crop of datapipe/seg_transforms_cv.py:306-372 (cv2.warpAffine): output pixel (x, y) samples the
+ *      source at (a00 x + a01 y + a02, a10 x + a11 y + a12) with slots 16..21 = a00 a01 a02 a10 a11 a12 (the INVERSE of
+ *      the reference's local_xf), slot 22 = interpolation of the image (0 nearest: floor(s + 0.5); 1 bilinear), image
+ *      border REFLECT_101, labels nearest with 255 outside, mask = in-bounds weight (constant border 0); 23 reserved
  * out0 = geometric transform only (teacher view), out1 = + colour augmentation (student view); either may be NULL.
  * ------------------------------------------------------------------------------------------------------------ */
-#define CMS_AUG_PARAMS 16
+#define CMS_AUG_PARAMS 24
 typedef struct cms_augment_desc {
     const uint8_t* src;         /* uint8 [N][hs][ws][3]                                  */
     const uint8_t* src_labels;  /* uint8 [N][hs][ws] or NULL                             */
@@ -423,6 +428,11 @@ int cms_maxpool3x3s2_relu_bwd(const void* dp_nhwc, const uint8_t* argmax, const 
 /* dw[ky][kx][co][c] (fp32, accumulated with atomics) += scale[co] * sum_pixels ds[pix][co] * x[c][2oy-3+ky][2ox-3+kx] */
 int cms_stem_wgrad(const void* x_nchw, int x_dtype, const void* ds_nhwc, int ds_dtype, float* dw_khkwcoci,
                    const float* scale, int n, int h, int w, void* stream);
+/* The same with an optional scratch buffer (>= cms_stem_wgrad_workspace_bytes): the persistent blocks then write their
+ * partial sums there and a second launch adds them to dw in block order -- run-to-run DETERMINISTIC (NULL: fp32 atomics). */
+long long cms_stem_wgrad_workspace_bytes(int x_dtype, int ds_dtype, int n, int h, int w);
+int cms_stem_wgrad_ws(const void* x_nchw, int x_dtype, const void* ds_nhwc, int ds_dtype, float* dw_khkwcoci,
+                      const float* scale, int n, int h, int w, void* workspace, long long workspace_bytes, void* stream);
 /* dx (fp32 NCHW) = gradient wrt the image (VAT direction pass, train_seg_semisup_vat_mt.py:244-268) */
 int cms_stem_dgrad(const void* ds_nhwc, int ds_dtype, const float* w_packed, const float* scale, float* dx_nchw, int n,
                    int h, int w, void* stream);

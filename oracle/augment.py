@@ -62,16 +62,67 @@ def _hue(rgb, dh):
     return out
 
 
+def _reflect101(i, n):
+    """cv2.BORDER_REFLECT_101 index map (period 2n - 2)."""
+    if n == 1:
+        return np.zeros_like(i)
+    period = 2 * n - 2
+    i = np.mod(i, period)
+    return np.where(i < n, i, period - i)
+
+
+def _warp(src, labels_u8, p, H, W):
+    """cv2.warpAffine of datapipe/seg_transforms_cv.py:358-366 for ONE sample from the INVERSE matrix in p[16:22]:
+    output pixel (x, y) samples the source at (a00 x + a01 y + a02, a10 x + a11 y + a12). Image: nearest (floor(s + 0.5))
+    or bilinear (p[22]), BORDER_REFLECT_101; labels: nearest, constant 255; mask: in-bounds weight (constant 0).
+    Unpinned (cv2 absent): OpenCV evaluates the coordinates in 1/1024 fixed point and the bilinear weights in 1/32 steps;
+    this is the exact-arithmetic definition."""
+    Hs, Ws = src.shape[:2]
+    a = np.asarray(p[16:22], dtype=np.float64)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing='ij')
+    sx = a[0] * xx + a[1] * yy + a[2]
+    sy = a[3] * xx + a[4] * yy + a[5]
+    nx, ny = np.floor(sx + 0.5).astype(np.int64), np.floor(sy + 0.5).astype(np.int64)
+    inside = lambda Y, X: ((Y >= 0) & (Y < Hs) & (X >= 0) & (X < Ws))
+    if int(p[22]) == 0:
+        rgb = src[_reflect101(ny, Hs), _reflect101(nx, Ws)]
+        alpha = inside(ny, nx).astype(np.float64)
+    else:
+        ix0, iy0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+        wx, wy = sx - ix0, sy - iy0
+        rgb = np.zeros((H, W, src.shape[2]))
+        alpha = np.zeros((H, W))
+        for Y, wy_ in ((iy0, 1.0 - wy), (iy0 + 1, wy)):
+            for X, wx_ in ((ix0, 1.0 - wx), (ix0 + 1, wx)):
+                wgt = wy_ * wx_
+                rgb += src[_reflect101(Y, Hs), _reflect101(X, Ws)] * wgt[..., None]
+                alpha += inside(Y, X) * wgt
+    lab = None
+    if labels_u8 is not None:
+        ok = inside(ny, nx)
+        lab = np.full((H, W), 255, dtype=np.uint8)
+        lab[ok] = labels_u8[ny[ok], nx[ok]]
+    return rgb, alpha, lab
+
+
 def augment_sample(src_u8, labels_u8, p, crop_hw, mean, std, pivot=None):
     """One sample. src_u8 (Hs, Ws, 3) uint8, labels_u8 (Hs, Ws) uint8 or None, p = one row of the parameter table.
     -> (image (3,H,W), image_colour (3,H,W), labels (H,W) uint8 | None, mask (H,W))."""
     H, W = crop_hw
     y0, x0, sh, sw = int(p[0]), int(p[1]), int(p[2]), int(p[3])
     fx, fy, fd = bool(p[4]), bool(p[5]), bool(p[6])
-    rgb, alpha = _bilinear_window(src_u8.astype(np.float64) / 255.0, y0, x0, sh, sw, H, W)
+    warp = len(p) > 15 and p[15] != 0
+    warp_lab = None
+    if warp:
+        rgb, alpha, warp_lab = _warp(src_u8.astype(np.float64) / 255.0, labels_u8, p, H, W)
+    else:
+        rgb, alpha = _bilinear_window(src_u8.astype(np.float64) / 255.0, y0, x0, sh, sw, H, W)
     rgb, alpha = _flip(rgb, fx, fy, fd), _flip(alpha, fx, fy, fd)
     mean, std = np.asarray(mean, dtype=np.float64), np.asarray(std, dtype=np.float64)
-    img0 = (rgb - mean * alpha[..., None]) / std
+    # (window crops zero-pad through an alpha channel, :46-52, 600-608; the warp reflects the image and only the MASK knows
+    # what lies outside)
+    img_alpha = np.ones_like(alpha) if warp else alpha
+    img0 = (rgb - mean * img_alpha[..., None]) / std
     col = rgb.copy()
     if p[12]:
         order = int(p[13])
@@ -88,9 +139,11 @@ def augment_sample(src_u8, labels_u8, p, crop_hw, mean, std, pivot=None):
                 col = _hue(col, float(p[10]))
     if p[11]:
         col = np.repeat((col @ GREY)[..., None], 3, axis=2)
-    img1 = (col - mean * alpha[..., None]) / std
+    img1 = (col - mean * img_alpha[..., None]) / std
     lab = None
-    if labels_u8 is not None:
+    if warp_lab is not None:
+        lab = np.ascontiguousarray(_flip(warp_lab, fx, fy, fd))
+    elif labels_u8 is not None:
         Hs, Ws = labels_u8.shape
         # crop + nearest resize first (cv2.INTER_NEAREST: floor(dst * scale)), then the flips, as the reference does
         cy, cx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')

@@ -97,30 +97,45 @@ def train_iteration(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode='mix', loss
         return _train_iteration_chain(S, sup_x, sup_y, ux0, ux1, um0, um1, masks, mode, loss_fn, conf_thresh,
                                       conf_per_pixel, ramp_val, rampup, cons_weight, frozen_bn, grads_out, pi_model,
                                       storage, taps_out)
-    if not frozen_bn:
-        raise NotImplementedError('oracle step covers the --freeze_bn configuration (cfg 2/3)')
     keys = [k for k, _, _ in S.entries]
     leaves = {k: S.student[k].clone().requires_grad_(True) for k in keys}
     st = OrderedDict(S.student)
     st.update(leaves)
+    frozen = bool(frozen_bn)
 
-    logits_sup = dl.forward(sup_x, st, S.layers, frozen=True)
+    def run(x, state, target):
+        """One forward pass. Without --freeze_bn (the reference CLI's default, train_seg_semisup_mask_mt.py:587) every
+        BatchNorm normalises with BATCH statistics and moves its running statistics (momentum 0.1) -- in the teacher too,
+        which the loop keeps in train mode (:269-270); the affine parameters never train (deeplab2.py:72-84).
+        The passes update `target`'s running statistics one after the other, in the reference's order."""
+        if frozen:
+            return dl.forward(x, state, S.layers, frozen=True)
+        ns = {}
+        out = dl.forward(x, state, S.layers, frozen=False, new_stats=ns)
+        for k, v in ns.items():
+            target[k] = v.detach()
+            if state is not target:
+                state[k] = target[k]
+        return out
+
+    logits_sup = run(sup_x, st, S.student)
     sup_loss = L.supervised_ce(logits_sup, sup_y[:, 0])
     total = sup_loss
     closs = None
     rate = None
     if cons_weight > 0.0:
-        tea = S.student if pi_model else S.teacher
+        tea = st if pi_model else S.teacher
+        tea_target = S.student if pi_model else S.teacher
         with torch.no_grad():
-            l0 = dl.forward(ux0, tea, S.layers, frozen=True)
-            l1 = dl.forward(ux1, tea, S.layers, frozen=True) if mode == 'mix' else None
+            l0 = run(ux0, tea, tea_target)
+            l1 = run(ux1, tea, tea_target) if mode == 'mix' else None
         kw = dict(loss_fn=loss_fn, conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, ramp_val=ramp_val,
                   rampup=rampup, cons_weight=cons_weight)
         if mode == 'mix':
-            l_stu = dl.forward(L.paste(ux0, ux1, masks), st, S.layers, frozen=True)
+            l_stu = run(L.paste(ux0, ux1, masks), st, S.student)
             r = L.mix_mode_loss(l_stu, l0, l1, masks, um0, um1, **kw)
         else:
-            l_stu = dl.forward(ux0 * masks, st, S.layers, frozen=True)
+            l_stu = run(ux0 * masks, st, S.student)
             r = L.cut_mode_loss(l_stu, l0, masks, um0, **kw)
         total = total + r['unsup_loss']
         closs, rate = r['consistency_loss'], r['conf_rate']

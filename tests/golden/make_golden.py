@@ -658,8 +658,53 @@ def gen_checkpoint():
     print('wrote checkpoint_meta.json (loaded {} of {} keys, kept {})'.format(len(loaded), len(after), kept))
 
 
+# ----------------------------------------------------------------------------------------------------------
+# 12. rotate / scale crop: the affine matrices of SegCVTransformRandomCropRotateScale.transform_single
+#     (datapipe/seg_transforms_cv.py:331-358). The transform class itself imports cv2 (absent) at module level; the
+#     matrix arithmetic lives in datapipe/affine.py, which imports cleanly: this section runs THAT code on seeded
+#     parameter draws made in the transform's order, so the fixture pins draws -> centre -> local_xf (float32).
+# ----------------------------------------------------------------------------------------------------------
+def gen_affine():
+    import math
+    from datapipe import affine                         # reference
+    assert affine.__file__.startswith(REF)
+    cases = []
+    for seed, crop, img, rot_mag, max_scale, uniform in (
+            (1, (321, 321), (375, 500), 30.0, 1.5, True), (2, (256, 512), (1024, 2048), 10.0, 2.0, False),
+            (3, (224, 224), (200, 180), 45.0, 1.25, True), (4, (65, 97), (300, 300), 0.0, 1.5, True),
+            (5, (129, 129), (140, 400), 90.0, 1.0, False)):
+        rng = np.random.RandomState(seed)
+        crop_arr = np.array(crop)
+        log_max_scale, rot_rad = np.log(max_scale), math.radians(rot_mag)
+        for _ in range(3):
+            # (the statements of transform_single, :331-358, with the class attributes spelled out)
+            if uniform:
+                sf = np.exp(rng.uniform(-log_max_scale, log_max_scale, size=(1,)))
+                sf = np.repeat(sf, 2, axis=0)
+            else:
+                sf = np.exp(rng.uniform(-log_max_scale, log_max_scale, size=(2,)))
+            theta = rng.uniform(-rot_rad, rot_rad, size=(1,))
+            sc_size = crop_arr / sf
+            img_size = np.array(img)
+            extra = np.maximum(img_size - sc_size, 0.0)
+            centre = extra * rng.uniform(0.0, 1.0, size=(2,)) + np.minimum(sc_size, img_size) * 0.5
+            local_xf = affine.cat_nx2x3(
+                affine.translation_matrices(crop_arr[None, ::-1] * 0.5),
+                affine.rotation_matrices(theta),
+                affine.scale_matrices(sf[None, ::-1]),
+                affine.translation_matrices(-centre[None, ::-1]),
+            )
+            interp = int(rng.choice([0, 1]))            # rng.choice([cv2.INTER_NEAREST, cv2.INTER_LINEAR]) (:354), values 0 / 1
+            cases.append(dict(seed=seed, crop=list(crop), img=list(img), rot_mag=rot_mag, max_scale=max_scale,
+                              uniform=uniform, sf=sf.tolist(), theta=float(theta[0]), centre=centre.tolist(),
+                              xf=local_xf[0].astype(np.float64).tolist(), xf_dtype=str(local_xf.dtype), interp=interp))
+    with open(os.path.join(HERE, 'affine_rotate_scale.json'), 'w') as f:
+        json.dump(cases, f)
+    print('wrote affine_rotate_scale.json ({} cases)'.format(len(cases)))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['boxmask', 'ema', 'evaluation', 'lr', 'losses', 'deeplab2', 'optim', 'step', 'cli', 'cli_vat',
-                             'checkpoint']
+                             'checkpoint', 'affine']
     for w in which:
         globals()['gen_' + w]()

@@ -47,8 +47,9 @@ def test_device_staging_vs_numpy_oracle(cfg):
     for i in range(N):
         pivot = None
         if cfg.get('strong_colour') and params[i, 12]:
-            img0, _, _, _ = oaug.augment_sample(src[i].numpy(), None, params[i] * np.array([1] * 7 + [1, 1, 1, 0, 0, 0, 0, 0, 0]),
-                                                crop, np.zeros(3), np.ones(3))
+            geo_only = np.ones(params.shape[1])
+            geo_only[10:15] = 0                                   # no hue / greyscale / jitter: the geometric transform alone
+            img0, _, _, _ = oaug.augment_sample(src[i].numpy(), None, params[i] * geo_only, crop, np.zeros(3), np.ones(3))
             luma = float((img0.transpose(1, 2, 0) @ oaug.GREY).mean())
             order = int(params[i, 13])
             ops_ = [(order >> s) & 3 for s in (6, 4, 2, 0)]
@@ -67,6 +68,49 @@ def test_device_staging_vs_numpy_oracle(cfg):
         assert any(params[:, 12] != 0)
 
 
+@pytest.mark.parametrize('cfg', [dict(rot_mag=30.0, max_scale=1.5), dict(rot_mag=10.0, max_scale=2.0, scale_non_uniform=True, hflip=True),
+                                 dict(rot_mag=45.0, max_scale=1.25, strong_colour=True, vflip=True), dict(rot_mag=0.0, max_scale=1.5)],
+                         ids=['rot30_scale1.5', 'nonuniform_hflip', 'colour_vflip', 'scale_only'])
+@pytest.mark.parametrize('with_labels', [True, False], ids=['sup', 'unsup'])
+def test_rotate_scale_crop_vs_numpy_oracle(cfg, with_labels):
+    """SegCVTransformRandomCropRotateScale.transform_single (datapipe/seg_transforms_cv.py:331-362) on the device: image
+    warped with the reflected border (nearest for labelled samples, the drawn interpolation otherwise), labels nearest with
+    255 outside, validity mask zero outside -- against the exact-arithmetic numpy restatement for the same parameter rows.
+    The kernel evaluates the source coordinates in fp32: a pixel whose coordinate lands within 1e-4 of a rounding boundary
+    may pick the neighbour (cv2's own 1/1024 fixed point moves far more of them) -- bounded, not ignored."""
+    from cutmix_semisup_seg_amd.device_pipeline import DeviceAugmenter
+    from oracle import augment as oaug
+    crop = (48, 64)
+    g = torch.Generator().manual_seed(5)
+    N, Hs, Ws = 6, 60, 90                          # smaller than some scaled crops: the reflected border is exercised
+    src = torch.randint(0, 256, (N, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    lab = torch.randint(0, 5, (N, Hs, Ws), generator=g).to(torch.uint8) if with_labels else None
+    aug = DeviceAugmenter(crop, MEAN, STD, out_dtype=torch.float32, rng=np.random.RandomState(21),
+                          colour_rng=np.random.RandomState(22), **cfg)
+    assert aug.warp
+    params = aug.draw_params(N, (Hs, Ws), with_labels=with_labels)
+    assert (params[:, 15] == 1).all()
+    if with_labels:
+        assert (params[:, 22] == 0).all()                          # labelled samples: nearest, no draw (:353-354)
+    out = aug(src.to(DEV), None if lab is None else lab.to(DEV), params=params)
+    bad_px = tot_px = 0
+    for i in range(N):
+        i0, _, lb, al = oaug.augment_sample(src[i].numpy(), None if lab is None else lab[i].numpy(), params[i], crop, MEAN, STD)
+        got = out['image'][i].cpu().double().numpy()
+        wrong = (np.abs(got - i0) > 2e-3).any(axis=0)               # a whole-pixel disagreement = a flipped rounding
+        bad_px += int(wrong.sum())
+        tot_px += wrong.size
+        gm = out['mask'][i, 0].cpu().double().numpy()
+        assert (np.abs(gm - al) > 2e-3).mean() <= 2e-3
+        if with_labels:
+            assert (out['labels'][i, 0].cpu().numpy() != lb).mean() <= 2e-3
+            assert (lb == 255).any() or params[i, 16] > 0.99        # scaled-down crops reach past the image: 255 outside
+    assert bad_px <= 2e-3 * tot_px, (bad_px, tot_px)
+    assert float(out['mask'].min()) >= 0.0 and float(out['mask'].max()) <= 1.0 + 1e-6
+    if cfg.get('strong_colour'):
+        assert 'image_stu' in out and torch.isfinite(out['image_stu']).all()
+
+
 def test_trainer_cli_with_device_side_staging(tmp_path, monkeypatch):
     """The reference's augmentation options on the command line, served by the device-side staging."""
     from click.testing import CliRunner
@@ -79,3 +123,9 @@ def test_trainer_cli_with_device_side_staging(tmp_path, monkeypatch):
     assert res.exit_code == 0, res.output
     log = open(tmp_path / 'results' / 'train_seg_semisup_mask_mt' / 'log_aug.txt').read()
     assert 'Epoch 1' in log
+    # --aug_rot_mag / --aug_max_scale select the rotate + scale crop (train_seg_semisup_mask_mt.py:153-155)
+    args2 = ['--job_desc', 'rot', '--synthetic', '--synthetic_source_size', '90,120', '--arch', 'resnet101_deeplab_imagenet',
+             '--freeze_bn', '--batch_size', '2', '--crop_size', '65,65', '--aug_rot_mag', '20', '--aug_max_scale', '1.5',
+             '--aug_hflip', '--num_epochs', '1', '--iters_per_epoch', '2', '--synthetic_val_batches', '1']
+    res = CliRunner().invoke(trainer.experiment, args2, catch_exceptions=False)
+    assert res.exit_code == 0, res.output

@@ -1,0 +1,110 @@
+"""
+GPU: DeepLab v2 WITHOUT --freeze_bn -- the reference CLI's default (train_seg_semisup_mask_mt.py:587): every BatchNorm
+normalises with batch statistics and moves its running statistics, in the student AND in the train-mode teacher (Q4), while
+its affine parameters stay frozen (deeplab2.py:72-84, Q3). One whole CutMix mean-teacher iteration on the hand-written
+kernels (engine_kind = 'hip': every convolution on csrc/conv_f32.hip incl. the 7 x 7 stem as tap chunks, the strided
+1 x 1s and the class-wide head; every BatchNorm on csrc/bn.hip; the `no_library_convolutions` context refuses anything else)
+against oracle/step.py with frozen_bn=False: losses, confidence rate, every gradient, student and teacher running statistics.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _setup(dtype, kind, C=5, layers=(1, 1, 1, 1)):
+    from architectures import deeplab2
+    from cutmix_semisup_seg_amd import optim as fo
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig
+    from oracle import deeplab2 as odl
+    import optim_weight_ema
+    layers = list(layers)
+    st = odl.closed_form_state(C, layers)
+    mk = lambda: deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
+    stu, tea = mk(), mk()
+    stu.load_state_dict(st)
+    stu, tea = stu.to(DEV), tea.to(DEV)
+    stu.compute_dtype = tea.compute_dtype = dtype
+    stu.engine_kind = tea.engine_kind = kind
+    opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=1e-4),
+                             dict(params=list(stu.new_parameters()), lr=1e-3)])
+    for p in tea.parameters():
+        p.requires_grad = False
+    ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
+    ema.fuse_into(opt)
+    stu.train(); tea.train()                          # NO freeze_batchnorm(): batch statistics everywhere
+    step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=0.2, compute_dtype=dtype))
+    return st, stu, tea, opt, step
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def test_batch_statistics_iteration_on_the_hand_written_kernels_matches_the_oracle(no_library_convolutions):
+    from cutmix_semisup_seg_amd import ops
+    from cutmix_semisup_seg_amd.step import UnsupBatch
+    from oracle import step as ostep, boxmask as obox
+    import mask_gen
+    C, layers, N, H, W = 5, [1, 1, 1, 1], 3, 49, 65
+    st, stu, tea, opt, step = _setup(torch.float32, 'hip', C, layers)
+    assert not step._samples_independent() and not stu._use_hip_body()
+    g = torch.Generator().manual_seed(21)
+    x, ux0, ux1 = (torch.randn(N, 3, H, W, generator=g) for _ in range(3))
+    y = torch.randint(0, C, (N, 1, H, W), generator=g)
+    y[torch.rand(N, 1, H, W, generator=g) < 0.05] = 255
+    ranges = mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(N, (H, W), rng=np.random.RandomState(3))
+    m = torch.tensor(obox.rasterise(ranges, (H, W), True).astype(np.float32))
+    ones = torch.ones(N, 1, H, W)
+    S = ostep.StepState(st, C, layers, opt='adam', lr=1e-3, teacher_alpha=0.99)
+    grads = {}
+    ref = ostep.train_iteration(S, x, y, ux0, ux1, ones, ones, m, conf_thresh=0.2, frozen_bn=False, grads_out=grads)
+    tea_before = {k: v.clone() for k, v in tea.state_dict().items()}
+    with no_library_convolutions:
+        res = step(x.to(DEV), y.to(torch.uint8).to(DEV), [UnsupBatch(ux0.to(DEV), ops.ranges_to_device(ranges, DEV),
+                                                                    x1_tea=ux1.to(DEV))])
+    got = {k: float(v) for k, v in res.items()}
+    assert no_library_convolutions.refused == 0
+    eng = stu._hip_engine
+    assert eng is not None and eng.strict and eng.dtype == torch.float32 and eng.library_convs == 0
+    assert abs(got['sup_loss'] - ref['sup_loss']) <= 1e-4 * abs(ref['sup_loss'])
+    assert abs(got['consistency_loss'] - ref['consistency_loss']) <= 2e-3 * abs(ref['consistency_loss']) + 1e-9
+    assert abs(got['conf_rate'] - ref['conf_rate']) <= 2e-3
+    rels = {k: _rel(p.grad, grads[k]) for k, p in stu.named_parameters() if grads.get(k) is not None}
+    assert len(rels) >= 15
+    worst = sorted(rels.items(), key=lambda kv: -kv[1])[:4]
+    print('\nPARITY DeepLab v2 batch-statistics iteration (fp32, hand-written kernels) vs oracle: got {} ref {} gradients max '
+          '{:.2e} mean {:.2e} worst {}'.format(got, ref, max(rels.values()), float(np.mean(list(rels.values()))), worst))
+    assert max(rels.values()) <= 5e-3 and float(np.mean(list(rels.values()))) <= 1e-3, worst
+    # running statistics: the student saw two passes; the teacher two passes and then the EMA blend with the student's
+    sd_s, sd_t = stu.state_dict(), tea.state_dict()
+    for k in sd_s:
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            assert float((sd_s[k].cpu() - S.student[k]).abs().max()) <= 1e-4 * float(S.student[k].abs().max()) + 1e-6, k
+            assert float((sd_t[k].cpu() - S.teacher[k]).abs().max()) <= 1e-4 * float(S.teacher[k].abs().max()) + 1e-6, k
+            assert float((sd_t[k].cpu() - tea_before[k].cpu()).abs().max()) > 0, k
+    assert int(sd_s['bn1.num_batches_tracked']) == 2
+
+
+def test_bf16_batch_statistics_iteration_runs_on_the_mfma_engine():
+    """The default ('auto') engine in bf16: eligible convolutions on csrc/conv.hip, BatchNorm on csrc/bn.hip; the loss falls."""
+    from cutmix_semisup_seg_amd import ops
+    from cutmix_semisup_seg_amd.step import UnsupBatch
+    from cutmix_semisup_seg_amd.architectures.deeplab3plus import HipConvEngine
+    import mask_gen
+    C, N, H, W = 5, 4, 97, 97
+    st, stu, tea, opt, step = _setup(torch.bfloat16, 'auto', C, (1, 1, 2, 1))
+    for gp in opt.param_groups:
+        gp['lr'] *= 30
+    g = torch.Generator(device=DEV).manual_seed(1)
+    y = (torch.rand(N, 1, H, W, generator=g, device=DEV) * C).long().clamp_(0, C - 1).to(torch.uint8)
+    x = (torch.randn(N, 3, H, W, generator=g, device=DEV) + 0.5 * y.float()).bfloat16()
+    im = lambda: torch.randn(N, 3, H, W, generator=g, device=DEV).bfloat16()
+    ranges = ops.ranges_to_device(mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(
+        N, (H, W), rng=np.random.RandomState(0)), DEV)
+    losses = [float(step(x, y, [UnsupBatch(im(), ranges, x1_tea=im())])['sup_loss']) for _ in range(8)]
+    print('\nbf16 batch-statistics DeepLab v2 losses:', [round(v, 4) for v in losses])
+    assert isinstance(stu._hip_engine, HipConvEngine) and not stu._hip_engine.strict
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
