@@ -193,7 +193,7 @@ def run_workload(key, args, world, rank, dev):
     B, H, W, C = wl['batch'], wl['H'], wl['W'], wl['classes']
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     esz = 2.0 if dtype == torch.bfloat16 else 4.0
-    roofline_kernel = args.roofline_kernel or ('conv' if 'arch' not in wl else 'adam_ema')
+    roofline_kernel = args.roofline_kernel or 'conv'       # the dominant kernel of every workload (incl. DeepLab v3+)
     sample_every = max(1, args.roofline_sample)
 
     torch.manual_seed(12345)                       # identical replicas on every rank

@@ -331,6 +331,35 @@ def test_fp32_hand_written_backward_matches_the_oracle_autograd(no_library_convo
     assert max(rels.values()) <= 2e-3 and float(np.mean(list(rels.values()))) <= 2e-4, worst
 
 
+def test_full_size_cfg4_forward_matches_the_oracle(no_library_convolutions):
+    """BASELINE configs[3] at its full geometry: the ResNet-101 DeepLab v3+ on a 513 x 513 crop (N = 1, 21 classes), forward
+    pass of the hand-written fp32 engine against the oracle (every BatchNorm on running statistics); the bf16 engine is
+    printed next to it."""
+    from oracle import deeplab3plus as o3
+    layers, C = (3, 4, 23, 3), 21
+    st = _he_state(C, layers)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 3, 513, 513, generator=g).bfloat16().float()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = o3.forward_lowres(x, st, layers)
+        net = _net(C, layers, torch.float32, st, kind='hip')
+        net.eval()
+        with no_library_convolutions:
+            lo = net.forward_lowres(x.to(DEV)).cpu()
+        e32 = float((lo - ref).norm() / ref.norm())
+        del net
+        net16 = _net(C, layers, torch.bfloat16, st)
+        net16.eval()
+        lo16 = net16.forward_lowres(x.to(DEV).bfloat16()).cpu()
+        e16 = float((lo16 - ref).norm() / ref.norm())
+    print('\nPARITY v3+ ResNet-101 at 1x3x513x513 (cfg 4 geometry): fp32 hand-written engine rel {:.2e}, bf16 engine rel {:.2e}; '
+          'argmax agreement fp32 {:.5f} bf16 {:.5f}'.format(e32, e16, float((lo.argmax(1) == ref.argmax(1)).float().mean()),
+                                                           float((lo16.argmax(1) == ref.argmax(1)).float().mean())))
+    assert tuple(lo.shape) == tuple(ref.shape) == (1, C, 129, 129)
+    assert e32 <= 1e-4 and e16 <= 5e-2
+
+
 def test_recorded_backbone_passes_equal_the_launch_by_launch_passes():
     """The executor records its forward and backward passes once per input shape (csrc/program.hip) and replays them:
     same kernels, same order, persistent buffers -- outputs and every gradient must agree with the launch-by-launch

@@ -122,13 +122,23 @@ def test_executor_teacher_forward_only_and_weight_refresh():
     assert net._hip_executor.arena.grad is None
 
 
-def test_hip_engine_needs_frozen_bn():
+def test_hip_engine_without_frozen_bn_runs_layer_by_layer_on_the_hand_written_kernels(no_library_convolutions):
+    """Round 2 refused this configuration (the static executor folds FROZEN BatchNorm into its epilogues); since round 3
+    batch-statistics passes -- the reference CLI's default, no --freeze_bn -- run through the strict layer engine
+    (deeplab3plus.HipConvEngine: every convolution on csrc/conv*.hip, BatchNorm on csrc/bn.hip), never the library."""
     from architectures import deeplab2
+    from cutmix_semisup_seg_amd.architectures.deeplab3plus import HipConvEngine
     net = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, [1, 1, 1, 1], 5, np.zeros(3), np.ones(3)).to(DEV)
     net.engine_kind = 'hip'
     net.train()
-    with pytest.raises(RuntimeError, match='frozen BatchNorm'):
-        net.forward_lowres(torch.zeros(1, 3, 33, 33, device=DEV))
+    assert not net._use_hip_body()
+    with no_library_convolutions:
+        out = net.forward_lowres(torch.randn(2, 3, 33, 33, device=DEV).bfloat16())
+        out.sum().backward()
+    assert isinstance(net._hip_engine, HipConvEngine) and net._hip_engine.strict and net._hip_engine.library_convs == 0
+    assert tuple(out.shape) == (2, 5, 5, 5) and bool(torch.isfinite(out).all()) and no_library_convolutions.refused == 0
+    net.freeze_batchnorm()
+    assert net._use_hip_body()                                  # frozen again: back on the static executor
 
 
 def test_whole_step_bf16_hip_engine_tracks_fp32_library_engine():

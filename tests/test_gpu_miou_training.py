@@ -149,3 +149,86 @@ def test_trained_miou_matches_the_oracle_within_0p2_points():
     # land in a different order every run) was 0.807 .. 0.861 over the validation runs of round 2 against the oracle's
     # 0.8295, so the trajectory is held to a 6-point band; the 0.2-point statement above is the evaluation parity.
     assert abs(miou_32 - miou_ref) <= 0.06 and abs(miou_16 - miou_ref) <= 0.06, (miou_32, miou_16, miou_ref)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# N1 on a real-depth network: ResNet-[3, 4, 6, 3] DeepLab v2, 300 iterations, several seeds, the device
+# in both configurations against ORACLE-TRAINED runs (tests/golden/n1_oracle_runs.json, made by
+# tests/golden/make_n1_oracle_runs.py on the CPU of the build container: ~3 minutes per seed, too long to repeat here).
+# ----------------------------------------------------------------------------------------------------------------------
+_LAST = {}
+
+
+def _device_run_seed(seed, dtype, T):
+    from architectures import deeplab2
+    import evaluation
+    import optim_weight_ema
+    from cutmix_semisup_seg_amd import ops, optim as fo
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
+    train, val = T.data(seed)
+    mk = lambda: deeplab2.ResNetDeepLab(deeplab2.Bottleneck, T.LAYERS, T.C, np.zeros(3), np.ones(3))
+    stu, tea = mk(), mk()
+    stu.load_state_dict(T.init_state(seed))
+    stu, tea = stu.to(DEV), tea.to(DEV)
+    stu.compute_dtype = tea.compute_dtype = dtype
+    stu.engine_kind = tea.engine_kind = 'hip'
+    opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=T.LR * 0.1),
+                             dict(params=list(stu.new_parameters()), lr=T.LR)])
+    for p in tea.parameters():
+        p.requires_grad = False
+    ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, T.ALPHA)
+    ema.fuse_into(opt)
+    stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()
+    step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=T.TAU, compute_dtype=dtype, deterministic=True))
+    cu = lambda t: t.to(DEV).to(dtype)
+    log = []
+    for x, y, u0, u1, ranges in train:
+        r = step(cu(x), y.to(torch.uint8).to(DEV), [UnsupBatch(cu(u0), ops.ranges_to_device(ranges, DEV), x1_tea=cu(u1))])
+        log.append(r['sup_loss'])
+    log = [float(v) for v in log]
+    tea.eval()
+    ev = evaluation.EvaluatorIoU(T.C)
+    with torch.no_grad():
+        for x, y in val:
+            ev.sample_logits(tea.forward_lowres(cu(x)), y.to(torch.uint8).to(DEV), (T.H, T.W), ignore_value=255,
+                             align_corners=True)
+    ops.set_deterministic_wgrad(False)
+    return float(ev.score().mean()), log
+
+
+def test_device_trained_miou_vs_oracle_trained_over_seeds():
+    """Means over the seeds of the device-trained teacher mIoU (fp32 parity configuration, bf16 throughput configuration)
+    against the mean of the oracle-trained runs; and -- with the deterministic weight-gradient combine -- two device runs of
+    the same seed agree BIT FOR BIT (loss log and mIoU): the run-to-run spread of round 2 (5 pt on the toy task) is gone."""
+    import json
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import n1_task as T
+    ref = json.load(open(os.path.join(GOLDEN, 'n1_oracle_runs.json')))
+    seeds = [s for s in T.SEEDS if str(s) in ref]
+    assert len(seeds) >= 3
+    rows = []
+    for s in seeds:
+        m32, l32 = _device_run_seed(s, torch.float32, T)
+        m16, l16 = _device_run_seed(s, torch.bfloat16, T)
+        if s == seeds[0]:
+            _LAST['l16_0'] = l16
+        rows.append((s, ref[str(s)]['miou'], m32, m16, ref[str(s)]['sup_loss'][-1], l32[-1], l16[-1]))
+        assert ref[str(s)]['sup_loss'][0] == pytest.approx(l32[0], rel=1e-3)          # same initial weights, same data
+    m16b, l16b = _device_run_seed(seeds[0], torch.bfloat16, T)
+    mo, m32, m16 = (float(np.mean([r[i] for r in rows])) for i in (1, 2, 3))
+    so, s32, s16 = (float(np.std([r[i] for r in rows])) for i in (1, 2, 3))
+    print('\nN1 [3,4,6,3] x {} iterations, per seed (oracle, device fp32, device bf16 mIoU; last sup loss x3): {}'.format(
+        T.ITERS, [tuple(round(v, 4) if isinstance(v, float) else v for v in r) for r in rows]))
+    print('N1 means over {} seeds: oracle {:.4f} (std {:.4f})  device fp32 {:.4f} (std {:.4f})  device bf16 {:.4f} (std {:.4f}); '
+          'repeat of seed {} in bf16: mIoU {:.6f} vs {:.6f}, identical loss log: {}'.format(
+              len(seeds), mo, so, m32, s32, m16, s16, seeds[0], m16b, rows[0][3], l16b == _LAST.get('l16_0')))
+    assert m16b == rows[0][3] and l16b == _LAST['l16_0']                # bit-reproducible training run
+    assert min(r[1] for r in rows) > 0.8                                 # the task was learnt (oracle)
+    # measured on MI355X (profiles/r03f_*): oracle 0.9497 / 0.9522 / 0.9555, device fp32 0.9497 / 0.9523 / 0.9556, device bf16
+    # 0.9502 / 0.9524 / 0.9555 -- means 0.9524 / 0.9525 / 0.9527: within 0.03 pt. Asserted at the north star's 0.2 pt (means)
+    # and 0.5 pt (any single seed)
+    assert abs(m32 - mo) <= 0.002 and abs(m16 - mo) <= 0.002, (mo, m32, m16)
+    assert all(abs(r[2] - r[1]) <= 0.005 and abs(r[3] - r[1]) <= 0.005 for r in rows), rows
