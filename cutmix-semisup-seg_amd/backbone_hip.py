@@ -1037,14 +1037,15 @@ def hip_conv2d(x, conv, arena, key, dtype=torch.bfloat16):
 def hip_conv2d_eligible(x, conv, dtype=torch.bfloat16):
     """The layers the 'auto' engine sends to the MFMA kernels: stride 1, 'same' padding, >= 128 input channels (padded to
     a multiple of 64 if need be), output channels in multiples of 64 (or >= 32, padded), >= 64 pixels -- where the
-    padding copies cost less than the kernels gain. (`engine_kind = 'hip'` sends EVERY convolution there.)"""
+    padding copies cost less than the kernels gain (round 3: the pixel count is that of the BATCH, which brings
+    DenseNet-161's fourth dense block, 7 x 7 maps at a 224 crop, to the MFMA kernels). (`engine_kind = 'hip'` sends EVERY convolution there.)"""
     kh, kw = conv.kernel_size
     return (x.is_cuda and x.dtype == dtype and conv.groups == 1
             and conv.stride == (1, 1) and kh == kw and kh * kw <= 18
             and conv.padding == (conv.dilation[0] * (kh - 1) // 2,) * 2 and conv.dilation[0] == conv.dilation[1]
             and (conv.in_channels % 64 == 0 or conv.in_channels >= 128)
             and (conv.out_channels % 64 == 0 or conv.out_channels >= 32)
-            and x.shape[2] * x.shape[3] >= 64)
+            and x.shape[0] * x.shape[2] * x.shape[3] >= 64)
 
 
 class _StemFn(torch.autograd.Function):
