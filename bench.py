@@ -207,7 +207,9 @@ def run_workload(key, args, world, rank, dev):
         p.requires_grad = False
     ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
     ema.fuse_into(opt)
-    stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()      # --freeze_bn
+    stu.train(); tea.train()
+    if not args.no_freeze_bn:
+        stu.freeze_batchnorm(); tea.freeze_batchnorm()      # --freeze_bn (run_*_experiments.sh)
     cfg = StepConfig(mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.97, conf_per_pixel=False,
                      fuse_batches=not args.no_fuse_batches, compute_dtype=dtype,
                      overlap_teacher=not args.no_overlap, allreduce_dtype=args.allreduce_dtype,
@@ -607,6 +609,9 @@ def main():
                     help='roofline.traffic: measure it now with two rocprofv3 --pmc passes of this script (single GPU, '
                          'workload pascal; ~1.5 min), or leave it null')
     ap.add_argument('--no_fuse_batches', action='store_true')
+    ap.add_argument('--no_freeze_bn', action='store_true',
+                    help='BatchNorm on batch statistics (the reference CLI default; its experiment scripts pass --freeze_bn): '
+                         'the passes run layer by layer through the conv engine instead of the static executor')
     ap.add_argument('--allreduce_dtype', choices=['fp32', 'bf16'], default='fp32',
                     help='data-parallel gradient exchange: the fp32 arena (177 MB per step) or a bf16 staging copy (86 MB)')
     ap.add_argument('--deterministic', action='store_true',

@@ -76,6 +76,15 @@ class WgradDesc(C.Structure):
                 ('dw_cout', c_int), ('workspace', c_void_p), ('workspace_bytes', C.c_longlong)]
 
 
+class BnOp(C.Structure):
+    _fields_ = [('what', c_int), ('dtype', c_int), ('c', c_int), ('relu', c_int),
+                ('x', c_void_p), ('res', c_void_p), ('y', c_void_p), ('dy', c_void_p), ('dx', c_void_p), ('dres', c_void_p),
+                ('sums', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('mean', c_void_p), ('rstd', c_void_p),
+                ('scale', c_void_p), ('shift', c_void_p), ('running_mean', c_void_p), ('running_var', c_void_p),
+                ('counter', c_void_p), ('clear_a', c_void_p), ('clear_b', c_void_p), ('count', C.c_double), ('n_pixels', C.c_ulonglong), ('eps', c_float),
+                ('momentum', c_float)]
+
+
 class AugmentDesc(C.Structure):
     _fields_ = [('src', c_void_p), ('src_labels', c_void_p), ('out0', c_void_p), ('out1', c_void_p),
                 ('out_labels', c_void_p), ('out_mask', c_void_p), ('params', c_void_p),
@@ -139,6 +148,8 @@ PROTOTYPES = {
                               c_void_p]),
     'cms_bn_finalize': (c_int, [c_void_p, C.c_double, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'cms_bn_finalize_ex': (c_int, [c_void_p, C.c_double, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cms_bn_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_size_t, c_int, c_void_p]),
     'cms_bn_bwd_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, C.c_double, c_size_t, c_int, c_void_p]),
@@ -168,6 +179,7 @@ PROTOTYPES = {
                                             c_int, c_int, c_int, c_int, c_int, c_int]),
     'cms_program_add_aspp_spread': (c_int, [c_void_p, c_void_p, c_void_p, c_int, _P(c_int), _P(c_int), c_int, c_int, c_int,
                                             c_int, c_int, c_int, c_int, c_int]),
+    'cms_program_add_bn': (c_int, [c_void_p, _P(BnOp), c_int, c_int]),
     'cms_program_size': (c_int, [c_void_p]),
     'cms_program_run': (c_int, [c_void_p, c_int, c_int, _P(c_void_p), c_int]),
     'cms_program_run_pair': (c_int, [c_void_p, _P(c_void_p), c_int, c_void_p, _P(c_void_p), c_int]),

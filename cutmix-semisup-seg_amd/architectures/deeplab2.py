@@ -245,16 +245,28 @@ class ResNetDeepLab(nn.Module):
         from .deeplab3plus import _engine_of
         return _engine_of(self, x)
 
+    def _frozen_bn(self):
+        return all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+
     def _use_hip_body(self):
-        """True: the static MFMA executor (backbone_hip.DeepLabHipExecutor) runs stem, body and head -- whenever every
-        BatchNorm is frozen (running statistics fold into the convolution epilogues)."""
+        """True: the static MFMA executor (backbone_hip.DeepLabHipExecutor) runs the body and the head. With every BatchNorm
+        frozen the running statistics fold into the convolution epilogues (and the stem runs on csrc/stem.hip); with
+        BatchNorm on batch statistics (round 3) every unit is  conv -> csrc/bn.hip  inside the same recorded programs, the stem
+        goes through the layer engine. Under torch.distributed the batch-statistics passes stay on the layer engine, whose
+        BatchNorm all-reduces its statistics between the two passes (SyncBN); `batchstat_executor = False` forces that."""
         if self.engine_kind == 'torch' or self.engine is not None:
             return False
-        frozen = all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
-        if frozen and self.engine_kind == 'hip' and (self.compute_dtype not in (torch.bfloat16, torch.float32)
-                                                     or self.num_classes > 32):
-            raise RuntimeError('the MFMA executor needs bf16 or fp32 compute and <= 32 classes')
-        return frozen and self.compute_dtype in (torch.bfloat16, torch.float32) and self.num_classes <= 32
+        ok = self.compute_dtype in (torch.bfloat16, torch.float32) and self.num_classes <= 32
+        if self._frozen_bn():
+            if self.engine_kind == 'hip' and not ok:
+                raise RuntimeError('the MFMA executor needs bf16 or fp32 compute and <= 32 classes')
+            return ok
+        if not ok or not self.__dict__.get('batchstat_executor', True):
+            return False
+        if self.compute_dtype == torch.float32 and self.engine_kind != 'hip':
+            return False                       # 'auto' in fp32: the library comparison engine, as for the other networks
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
     def hip_executor(self):
         # one executor per compute dtype (bf16: throughput configuration; fp32: parity configuration on the f32-input
@@ -268,9 +280,16 @@ class ResNetDeepLab(nn.Module):
 
     def stem_nhwc(self, x):
         """conv1 + bn1 + ReLU + max-pool (:183-186) -> NHWC, the input of the MFMA executor."""
-        if self.stem_kind == 'hip' and self._use_hip_body():
+        if self.stem_kind == 'hip' and self._use_hip_body() and self._frozen_bn():
             return self.hip_executor().stem(x)                 # csrc/stem.hip, no library convolution in the pass
-        eng = self._engine(x)
+        if self.stem_kind == 'hip' and self._use_hip_body() and self.engine_kind == 'auto':
+            # batch-statistics pass on the executor: the 7 x 7 / stride 2 stem on the hand-written kernels as well (tap
+            # chunks, 3 -> 64 channel padding): the library's weight gradient for this layer takes 36 ms per call at
+            # 20 x 321 x 321 (profiles/r03r_*), twice the whole frozen-BatchNorm step
+            from .deeplab3plus import _engine_of
+            eng = _engine_of(self, x, strict=True)
+        else:
+            eng = self._engine(x)
         x = eng.prepare_input(x)
         x = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         x = eng.maxpool(x)

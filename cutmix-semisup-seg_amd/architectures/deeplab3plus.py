@@ -256,22 +256,23 @@ class HipConvEngine(TorchEngine):
         return hip_classifier(x, conv, self.arena, key, key[:-len('weight')] + 'bias', self.dtype)
 
 
-def _engine_of(net, x):
+def _engine_of(net, x, strict=None):
     """Engine selection shared by DeepLabv3Wrapper and the U-Nets (`EngineNetMixin`): an explicit `net.engine`, the
-    library engine for engine_kind 'torch', otherwise the HipConvEngine of (compute dtype, strictness)."""
-    if net.engine is not None:
+    library engine for engine_kind 'torch', otherwise the HipConvEngine of (compute dtype, strictness). `strict=True`
+    asks for the all-hand-written engine whatever `engine_kind` says."""
+    if net.engine is not None and strict is None:
         return net.engine
     if not x.is_cuda:
         raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
                            'fallback'.format(x.device))
     if net.compute_dtype not in (torch.bfloat16, torch.float32):
         raise TypeError('compute_dtype must be torch.bfloat16 or torch.float32')
-    if net.engine_kind == 'torch':
+    if net.engine_kind == 'torch' and strict is None:
         key = ('torch', net.compute_dtype)
         if key not in _ENGINES:
             _ENGINES[key] = TorchEngine(net.compute_dtype)
         return _ENGINES[key]
-    strict = net.engine_kind == 'hip'
+    strict = (net.engine_kind == 'hip') if strict is None else bool(strict)
     # 'auto' in fp32 keeps the library (comparison runs of the bf16 'auto' engine against fp32 library kernels); the
     # hand-written fp32 path is asked for by name
     if not strict and net.compute_dtype == torch.float32:

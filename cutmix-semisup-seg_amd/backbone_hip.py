@@ -17,8 +17,10 @@ Per bottleneck (frozen BatchNorm folded into scale/bias, deeplab2.py:92-107):
     are accumulated straight into the fp32 gradient arena. dgrad is the forward kernel on the transposed weights
     (BN scale folded, cms_conv_pack_transpose) with negated tap offsets.
 
-Only valid with frozen BatchNorm (`--freeze_bn`; BN layers in eval mode) -- with batch statistics the networks run on
-the library engine instead (architectures/deeplab2.py: TorchEngine).
+With frozen BatchNorm (`--freeze_bn`; BN layers in eval mode) the statistics fold into scale / bias as above. Round 3:
+BatchNorm on BATCH statistics (the reference CLI's default, train_seg_semisup_mask_mt.py:587; deeplab2.py:72-84) runs on
+the executor too -- every unit becomes  u = conv(x);  y = relu(bn_batch(u) (+ res))  with the csrc/bn.hip launches recorded
+into the same programs (cms_program_add_bn), see `_fwd_unit_bn` / `_bwd_unit_bn` below.
 """
 import torch
 
@@ -37,7 +39,7 @@ def executors_of(module):
 
 class _Conv(object):
     __slots__ = ('wkey', 'bn', 'taps', 'ntaps', 'neg_taps', 'stride', 'cin', 'cout', 'scale', 'bias', 'wT', 'ksize',
-                 'pad', 'dil', 'wdot', 'dbeta')
+                 'pad', 'dil', 'wdot', 'dbeta', 'wT_raw')
 
     def __init__(self, wkey, bn, conv):
         self.wkey, self.bn = wkey, bn
@@ -48,6 +50,7 @@ class _Conv(object):
         self.stride = conv.stride[0]
         self.cin, self.cout = conv.in_channels, conv.out_channels
         self.scale = self.bias = self.wT = None
+        self.wT_raw = None                 # dgrad operand WITHOUT a folded BatchNorm scale (batch-statistics passes)
         self.wdot = self.dbeta = None      # side outputs of the weight gradient when the BN affine trains
 
 
@@ -266,11 +269,14 @@ class DeepLabHipExecutor(object):
     def fwd_begin(self, x, save):
         """x: bf16 NHWC (N, h, w, 64) = stem + max-pool output. The forward pass in three pieces (begin / one call per
         bottleneck / end) so that a caller can interleave the launches of two networks on two streams (`_BodyPairFn`)."""
-        if not self._affine_ready:
+        bn = self.batch_statistics()
+        if not bn and not self._affine_ready:
             self._refresh_affine()
-        return {'cur': x, 'saved': [] if save else None}
+        return {'cur': x, 'saved': [] if save else None, 'bn': bn}
 
     def fwd_block(self, st, bi):
+        if st.get('bn'):
+            return self._fwd_block_bn(st, bi)
         b, cur = self.blocks[bi], st['cur']
         a1 = self._fwd(cur, b.c1, True)
         a2 = self._fwd(a1, b.c2, True)
@@ -293,6 +299,147 @@ class DeepLabHipExecutor(object):
             saved.append(cur)
         return logits, saved
 
+    # ------------------------------------------------------------------------------------------ batch-statistics passes
+    def batch_statistics(self):
+        """True when the network's BatchNorm layers are in training mode (no --freeze_bn): the passes normalise with batch
+        statistics and move the running statistics (momentum), in the student and in the train-mode teacher alike (Q3, Q4)."""
+        return any(self._bn_module(c).training for c in self._all_convs())      # (the executor's own layers: DeepLab v3+ keeps
+                                                                                # its HEAD on batch statistics, not the backbone)
+
+    def _bn_module(self, c):
+        mods = self.__dict__.setdefault('_bn_modules', {})
+        m = mods.get(c.bn)
+        if m is None:
+            m = mods[c.bn] = self.net.get_submodule(c.bn)
+        return m
+
+    def _fwd_unit_bn(self, x, c, relu, res=None, save=True):
+        """y = relu(batch_norm(conv(x)) (+ res)) as FOUR launches on persistent buffers: raw convolution, statistics (reduce
+        -> finalize, which also moves the running statistics, counts the batch and leaves the unit's sum buffers zeroed for
+        their next use), normalise + residual + ReLU. -> (y, saved), saved = (u, y, mean, rstd, backward sums) for
+        `_bwd_unit_bn`."""
+        n, h, w, _ = x.shape
+        ho, wo = self._out_hw(h, w, c.stride)
+        u = ops.conv_igemm(x, self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), tile=self._tile(c.cout))
+        a, bn, C = self.arena, self._bn_module(c), c.cout
+        npix = n * ho * wo
+        dev = x.device
+        stats = torch.zeros(2 * C, dtype=torch.float64, device=dev)         # zero now, and again after every finalize
+        bsums = torch.zeros(2 * C, dtype=torch.float64, device=dev) if save else None
+        mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+        ops.bn_op('reduce', c=C, dtype=self.dtype, n_pixels=npix, x=u, sums=stats)
+        ops.bn_op('finalize', c=C, count=npix, eps=bn.eps, momentum=bn.momentum, sums=stats, gamma=a.view(c.bn + '.weight'),
+                  beta=a.view(c.bn + '.bias'), mean=mean, rstd=rstd, scale=scale, shift=shift,
+                  running_mean=a.view(c.bn + '.running_mean'), running_var=a.view(c.bn + '.running_var'),
+                  clear_a=stats, clear_b=bsums, counter=bn.num_batches_tracked)
+        y = torch.empty_like(u)
+        ops.bn_op('apply', c=C, dtype=self.dtype, n_pixels=npix, relu=relu, x=u, res=res, y=y, scale=scale, shift=shift)
+        return y, (u, y if relu else None, mean, rstd, bsums)
+
+    def _bwd_unit_bn(self, dy, saved, c, want_res):
+        """Backward of the normalisation of one unit: dy (gradient wrt y) -> (du = gradient wrt the convolution output,
+        dres = gradient wrt the residual input or None). The ReLU mask comes from the stored y."""
+        u, y, mean, rstd, sums = saved          # `sums`: zeroed by the forward pass's finalize launch
+        C = c.cout
+        npix = u.numel() // C
+        ops.bn_op('reduce_bwd', c=C, dtype=self.dtype, n_pixels=npix, x=u, dy=dy, y=y, mean=mean, rstd=rstd, sums=sums)
+        du = torch.empty_like(u)
+        dres = torch.empty_like(u) if want_res else None
+        ops.bn_op('bwd_apply', c=C, dtype=self.dtype, n_pixels=npix, count=npix, x=u, dy=dy, y=y, dx=du, dres=dres, mean=mean,
+                  rstd=rstd, gamma=self.arena.view(c.bn + '.weight'), sums=sums)
+        return du, dres
+
+    def _fwd_block_bn(self, st, bi):
+        b, cur = self.blocks[bi], st['cur']
+        save = st['saved'] is not None
+        a1, s1 = self._fwd_unit_bn(cur, b.c1, True, save=save)
+        a2, s2 = self._fwd_unit_bn(a1, b.c2, True, save=save)
+        sd = None
+        if b.cd is None:
+            res = cur
+        else:
+            res, sd = self._fwd_unit_bn(cur, b.cd, False, save=save)
+        out, s3 = self._fwd_unit_bn(a2, b.c3, True, res=res, save=save)
+        st['cur'] = out
+        if st['saved'] is not None:
+            st['saved'].append((cur, a1, a2, s1, s2, s3, sd))
+
+    def _refresh_backward_weights_bn(self):
+        """dgrad operands wT[tap][ci][co] = w^T (NO BatchNorm scale: the normalisation has its own backward) of all body
+        convolutions + the head: one launch."""
+        if self.__dict__.get('_pack_plan_bn') is None:
+            triples = []
+            for c in self._all_convs():
+                w = self._w(c)
+                c.wT_raw = torch.empty((w.shape[0], w.shape[2], w.shape[1]), dtype=self.dtype, device=w.device)
+                triples.append((w, c.wT_raw, None))
+            triples.append((self.aspp_wall, self.aspp_wallT, None))
+            self._pack_plan_bn = ops.PackTransposePlan(triples)
+        self._pack_plan_bn.run()
+
+    def _dgrad_raw(self, du, c, res=None, in_hw=None):
+        n, ho, wo, _ = du.shape
+        if c.stride == 1:
+            return ops.conv_igemm(du, c.wT_raw, c.neg_taps, res=res, mode=1, tile=self._tile(c.cin))
+        return ops.conv_igemm(du, c.wT_raw, c.neg_taps, res=res, mode=1, out_hw=(ho, wo), out_stride=c.stride,
+                              out_full_hw=in_hw, tile=self._tile(c.cin))
+
+    def _wgrad_raw(self, du, x, c):
+        ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride)
+
+    def _backward_chain_bn(self, saved, dlg, want_w, sides, hook, box=None):
+        """The launches of the backward pass with BatchNorm on batch statistics (recordable): head, then per bottleneck
+        bn3 -> conv3 -> bn2 -> conv2 -> bn1 -> conv1 (+ the downsample branch). -> (dx, dwall or None)"""
+        x4 = saved[-1]
+        main = torch.cuda.current_stream()
+        d = ops.aspp_spread_bwd(dlg, self.aspp_taps, self.aspp_zc, self.dtype)
+        dwall = None
+        if want_w:
+            dwall = torch.empty((1, self.aspp_zc, 2048), dtype=torch.float32, device=d.device)
+            ops.memset_zero(dwall)
+            ops.conv_wgrad(d, x4, [(0, 0)], dwall)
+            if box is not None:
+                box['dwall'] = dwall
+        dOut = ops.conv_igemm(d, self.aspp_wallT, [(0, 0)], mode=1)        # gradient wrt the block OUTPUT: bn3 applies its mask
+        keep = []
+        closes = set(self.bucket_starts())
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            b = self.blocks[bi]
+            xin, a1, a2, s1, s2, s3, sd = saved[bi]
+            in_hw = (xin.shape[1], xin.shape[2])
+            du3, dres = self._bwd_unit_bn(dOut, s3, b.c3, True)
+            da2 = self._dgrad_raw(du3, b.c3)
+            du2, _ = self._bwd_unit_bn(da2, s2, b.c2, False)
+            da1 = self._dgrad_raw(du2, b.c2)
+            du1, _ = self._bwd_unit_bn(da1, s1, b.c1, False)
+            dud = None
+            if b.cd is not None:
+                dud, _ = self._bwd_unit_bn(dres, sd, b.cd, False)
+            if want_w:
+                jobs = [(du3, a2, b.c3), (du2, a1, b.c2)] + ([(dud, xin, b.cd)] if b.cd is not None else []) + [(du1, xin, b.c1)]
+                if sides:
+                    for sd_ in sides:
+                        ops.stream_wait(sd_, main)
+                    keep.append((du3, du2, du1, dud))
+                    for ji, (du_, x_, c_) in enumerate(jobs):
+                        with torch.cuda.stream(sides[ji % len(sides)]):
+                            self._wgrad_raw(du_, x_, c_)
+                    if len(sides) > 1 and bi in closes:
+                        for sd_ in sides[1:]:
+                            ops.stream_wait(sides[0], sd_)
+                    with torch.cuda.stream(sides[0]):
+                        hook(bi)
+                else:
+                    for du_, x_, c_ in jobs:
+                        self._wgrad_raw(du_, x_, c_)
+                    hook(bi)
+            dx = dres if b.cd is None else self._dgrad_raw(dud, b.cd, in_hw=in_hw)
+            dOut = self._dgrad_raw(du1, b.c1, res=dx, in_hw=in_hw)
+        for sd_ in sides:
+            ops.stream_wait(main, sd_)
+        del keep
+        return dOut, dwall
+
     # ------------------------------------------------------------------------------------------ stem
     def _stem_prepare(self):
         if not self._affine_ready:
@@ -309,7 +456,7 @@ class DeepLabHipExecutor(object):
 
     def _prepare_forward(self):
         """Operand tables a forward pass reads (torch ops on the current stream, only when stale)."""
-        if not self._affine_ready:
+        if not self._affine_ready and not self.batch_statistics():
             self._refresh_affine()
         self._refresh_aspp_fwd()
 
@@ -337,7 +484,7 @@ class DeepLabHipExecutor(object):
         synchronising, evicting and re-recording on almost every image, and pins no activation sets in HBM."""
         if save:
             return False
-        key = (kind, tuple(int(v) for v in shape), False, self._tile_key())
+        key = (kind, tuple(int(v) for v in shape), False, self._tile_key()) + ((self.batch_statistics(),) if kind == 'fwd' else ())
         if key in self._programs:
             return False
         seen = self.__dict__.setdefault('_seen_shapes', {})
@@ -350,7 +497,7 @@ class DeepLabHipExecutor(object):
     def forward_program(self, shape, save):
         """The recorded forward pass for an input of `shape` (N, h, w, 64) -- recorded on first use, on the CURRENT
         stream (its stream 0). Attributes: x_in (persistent input buffer), logits, saved."""
-        key = ('fwd', tuple(int(v) for v in shape), bool(save), self._tile_key())
+        key = ('fwd', tuple(int(v) for v in shape), bool(save), self._tile_key(), self.batch_statistics())
         prog = self._program_lookup(key)
         if prog is None:
             self._prepare_forward()
@@ -364,6 +511,7 @@ class DeepLabHipExecutor(object):
                 prog.group = len(self.blocks)
                 logits, saved = self.fwd_end(st)
             prog.x_in, prog.logits, prog.saved = x_in, logits, saved
+            prog.bn = key[-1]
             prog.bwd = {}
             prog.generation = -1
             self._programs[key] = prog
@@ -519,7 +667,16 @@ class DeepLabHipExecutor(object):
     def backward(self, token, dlogits):
         """dlogits fp32 (N,C,h,w); `token` from `forward(.., save=True)`. Accumulates weight gradients into the arena;
         returns d loss / d x (NHWC, the executor's dtype)."""
-        self._refresh_for_backward()
+        bn = (token[0].bn if self.use_programs and isinstance(token, tuple) and isinstance(token[0], ops.Program)
+              else len(token[0]) == 7)
+        chain = self._backward_chain_bn if bn else self._backward_chain
+        if bn:
+            if self.__dict__.get('_wT_raw_version', -1) != self.version or self.blocks[0].c1.wT_raw is None:
+                self._refresh_aspp_fwd()
+                self._refresh_backward_weights_bn()
+                self._wT_raw_version = self.version
+        else:
+            self._refresh_for_backward()
         want_w = self._want_w()
         if want_w and self._grad_sentinel().grad is None:        # somebody called module.zero_grad(): re-home the views
             self.arena.ensure_grads_attached()
@@ -539,7 +696,7 @@ class DeepLabHipExecutor(object):
                 if self.grad_hook is not None:
                     self.grad_hook(bi)
             # the chain creates dwall before its first hook call: hand it over through the box
-            dx, dwall = self._backward_chain(token, dlogits, want_w, sides, hook, box)
+            dx, dwall = chain(token, dlogits, want_w, sides, hook, box)
             if dwall is not None and 'done' not in box:
                 self._head_weight_grads(dwall)
             return dx
@@ -555,7 +712,7 @@ class DeepLabHipExecutor(object):
             dlg = torch.empty(tuple(dlogits.shape), dtype=torch.float32, device=dlogits.device)   # persistent input
             streams = [main] + sides
             with ops.recording(prog, streams):
-                dx, dwall = self._backward_chain(fprog.saved, dlg, want_w, sides, prog.mark)
+                dx, dwall = chain(fprog.saved, dlg, want_w, sides, prog.mark)
             prog.dlg, prog.dx, prog.dwall = dlg, dx, dwall
             fprog.bwd[key] = prog
         prog.dlg.copy_(dlogits)

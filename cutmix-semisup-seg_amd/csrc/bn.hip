@@ -19,6 +19,7 @@
 // vectors, coalesced along the channel axis); the per-channel reduction over pixels is per-thread accumulation, then a
 // cross-lane tree (__shfl_xor over the lanes of a wave that hold the same channel group) and LDS across waves.
 #include <algorithm>
+#include <cstdlib>
 #include "common.hpp"
 
 namespace cms {
@@ -77,17 +78,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
             load8(rstd + cg * 8, rs);
         }
         if (active) {
-            for (size_t p = (size_t)blockIdx.x * slots + slot; p < P; p += (size_t)gridDim.x * slots) {
-                const size_t o = p * (size_t)pitch + (size_t)cg * 8;
-                float xv[8];
-                load8(x + o, xv);
+            // four pixels per iteration: four independent 16-byte loads per tensor in flight per thread (one was latency-bound:
+            // 1 TB/s on the 34 MB activations of layer3, profiles/r03r_*)
+            const size_t stride = (size_t)gridDim.x * slots;
+            auto accumulate = [&](const float (&xv)[8], const float (&dv)[8], const float (&yv)[8]) {
                 if (MODE == 0) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] = fmaf(xv[e], xv[e], a1[e]); }
                 } else {
-                    float dv[8], yv[8];
-                    load8(dy + o, dv);
-                    if (y) load8(y + o, yv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float d = (y == nullptr || yv[e] > 0.0f) ? dv[e] : 0.0f;
@@ -95,6 +93,31 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
                         a1[e] = fmaf(d, (xv[e] - mu[e]) * rs[e], a1[e]);
                     }
                 }
+            };
+            size_t p = (size_t)blockIdx.x * slots + slot;
+            for (; p + 3 * stride < P; p += 4 * stride) {
+                float xv[4][8], dv[4][8], yv[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const size_t o = (p + u * stride) * (size_t)pitch + (size_t)cg * 8;
+                    load8(x + o, xv[u]);
+                    if (MODE == 1) {
+                        load8(dy + o, dv[u]);
+                        if (y) load8(y + o, yv[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) accumulate(xv[u], dv[u], yv[u]);
+            }
+            for (; p < P; p += stride) {
+                const size_t o = p * (size_t)pitch + (size_t)cg * 8;
+                float xv[8], dv[8], yv[8];
+                load8(x + o, xv);
+                if (MODE == 1) {
+                    load8(dy + o, dv);
+                    if (y) load8(y + o, yv);
+                }
+                accumulate(xv, dv, yv);
             }
         }
         // lanes of a wave that hold the same channel group: CG divides 64 -> tree over the lane bits above log2(CG)
@@ -132,8 +155,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ mean,
                                    float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, int C) {
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, int C,
+                                   double* __restrict__ clear_a, double* __restrict__ clear_b, long long* __restrict__ counter) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && counter) *counter += 1;             // nn.BatchNorm2d.num_batches_tracked
     if (c >= C) return;
     const double m = sums[c] / count;
     double var = sums[C + c] / count - m * m;
@@ -149,6 +174,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
         running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
+    // recorded passes (cms_program_add_bn): leave the sum buffers of this unit zeroed for their next use -- the forward sums
+    // just consumed (every thread has read its own two entries above) and the sums of the unit's backward pass
+    if (clear_a) { clear_a[c] = 0.0; clear_a[C + c] = 0.0; }
+    if (clear_b) { clear_b[c] = 0.0; clear_b[C + c] = 0.0; }
 }
 
 template <class T>
@@ -229,7 +258,16 @@ extern "C" int cms_bn_reduce(const void* x, const void* dy, const void* y, int d
         const int CG = cs / 8;
         const int slots = CG >= 256 ? 1 : 256 / CG;
         size_t want = (n_pixels + slots - 1) / slots;
-        if (want > 1024) want = 1024;
+        // every block ends with 2 * C fp64 atomics on the SAME 2 * C addresses: the adds of an address serialise, so that phase
+        // grows with the grid (1024 blocks: ~15 us of a 32 us launch; 2048: 52 us in total, profiles/r03t_*). Step time of the
+        // batch-statistics DeepLab v2 against the cap (profiles/r03v_*): 128 -> 46.1 ms, 256 -> 45.7, 384 -> 46.8, 512 -> 48.9,
+        // 768 -> 52.6: one block per CU with 4-pixel-unrolled loads.
+        static int env_cap = -1;                    // CMS_BN_GRID: A/B switch, read once
+        if (env_cap < 0) {
+            const char* e = getenv("CMS_BN_GRID");
+            env_cap = e ? atoi(e) : 256;
+        }
+        if (want > (size_t)env_cap) want = (size_t)env_cap;
         const dim3 grid((unsigned)want);
         const size_t lds = (size_t)slots * CG * 16 * sizeof(float);
         const char* xs = (const char*)x + (size_t)c0 * esz;
@@ -245,13 +283,21 @@ extern "C" int cms_bn_reduce(const void* x, const void* dy, const void* y, int d
     return launch_status("cms_bn_reduce");
 }
 
+extern "C" int cms_bn_finalize_ex(const double* sums, double count, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* mean, float* rstd, float* scale, float* shift, float* running_mean,
+                                  float* running_var, int c, double* clear_a, double* clear_b, long long* counter,
+                                  void* stream) {
+    CMS_REQUIRE(sums && mean && rstd && scale && shift && c > 0 && count > 0, "bn_finalize: NULL pointer / bad geometry");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, gamma, beta,
+                       eps, momentum, mean, rstd, scale, shift, running_mean, running_var, c, clear_a, clear_b, counter);
+    return launch_status("cms_bn_finalize");
+}
+
 extern "C" int cms_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
                                float momentum, float* mean, float* rstd, float* scale, float* shift, float* running_mean,
                                float* running_var, int c, void* stream) {
-    CMS_REQUIRE(sums && mean && rstd && scale && shift && c > 0 && count > 0, "bn_finalize: NULL pointer / bad geometry");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, gamma, beta,
-                       eps, momentum, mean, rstd, scale, shift, running_mean, running_var, c);
-    return launch_status("cms_bn_finalize");
+    return cms_bn_finalize_ex(sums, count, gamma, beta, eps, momentum, mean, rstd, scale, shift, running_mean, running_var, c,
+                              nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int cms_bn_apply(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,

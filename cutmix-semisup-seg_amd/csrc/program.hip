@@ -17,7 +17,7 @@
 
 namespace cms {
 
-enum OpKind { OP_CONV = 0, OP_WGRAD = 1, OP_MEMSET = 2, OP_SYNC = 3, OP_ASPP_GATHER = 4, OP_ASPP_SPREAD = 5 };
+enum OpKind { OP_CONV = 0, OP_WGRAD = 1, OP_MEMSET = 2, OP_SYNC = 3, OP_ASPP_GATHER = 4, OP_ASPP_SPREAD = 5, OP_BN = 6 };
 
 struct AsppOp {            // arguments of cms_aspp_gather_fwd / cms_aspp_spread_bwd
     const float* src;      // z / dlogits
@@ -37,6 +37,7 @@ struct Op {
     cms_conv_desc conv;
     cms_wgrad_desc wg;
     AsppOp aspp;
+    cms_bn_op bn;
     void* ptr;
     size_t bytes;
     hipEvent_t ev;     // OP_SYNC
@@ -113,6 +114,21 @@ static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
     }
     case OP_WGRAD:
         return o.f32 ? cms_conv_wgrad_f32(&o.wg, s) : cms_conv_wgrad(&o.wg, s);
+    case OP_BN: {
+        const cms_bn_op& b = o.bn;
+        switch (b.what) {
+        case 0: return cms_bn_reduce(b.x, nullptr, nullptr, b.dtype, nullptr, nullptr, b.sums, (size_t)b.n_pixels, b.c, 0, s);
+        case 1: return cms_bn_finalize_ex(b.sums, b.count, b.gamma, b.beta, b.eps, b.momentum, b.mean, b.rstd, b.scale, b.shift,
+                                          b.running_mean, b.running_var, b.c, b.clear_a, b.clear_b, b.counter, s);
+        case 2: return cms_bn_apply(b.x, b.res, b.y, b.dtype, b.scale, b.shift, b.relu, (size_t)b.n_pixels, b.c, s);
+        case 3: return cms_bn_reduce(b.x, b.dy, b.y, b.dtype, b.mean, b.rstd, b.sums, (size_t)b.n_pixels, b.c, 1, s);
+        case 4: return cms_bn_bwd_apply(b.x, b.dy, b.y, b.dx, b.dres, b.dtype, b.mean, b.rstd, b.gamma, b.sums, b.count,
+                                        (size_t)b.n_pixels, b.c, s);
+        case 5: return cms_increment_counter((int64_t*)b.counter, s);
+        }
+        set_error("program: unknown BatchNorm op %d", b.what);
+        return CMS_EINVAL;
+    }
     case OP_MEMSET:
         if (hipMemsetAsync(o.ptr, 0, o.bytes, s) != hipSuccess) {
             set_error("program: hipMemsetAsync failed");
@@ -224,6 +240,16 @@ extern "C" int cms_program_add_aspp_spread(cms_program* p, const float* dlogits,
                                            int group) {
     return add_aspp(p, OP_ASPP_SPREAD, dlogits, nullptr, d_nhwc, d_dtype, tap_dy, tap_dx, n_taps, n, c, zc, h, w, stream_idx,
                     group);
+}
+
+extern "C" int cms_program_add_bn(cms_program* p, const cms_bn_op* op, int stream_idx, int group) {
+    CMS_REQUIRE(p && op, "program_add_bn: NULL pointer");
+    CMS_REQUIRE(op->what >= 0 && op->what <= 5, "program_add_bn: unknown op %d", op->what);
+    CMS_REQUIRE(stream_idx >= 0 && stream_idx < CMS_PROGRAM_MAX_STREAMS, "program_add_bn: stream index %d", stream_idx);
+    Op o = {};
+    o.kind = OP_BN; o.stream = stream_idx; o.group = group;
+    o.bn = *op;
+    return push(p, o);
 }
 
 extern "C" int cms_program_size(const cms_program* p) { return p ? (int)p->ops.size() : 0; }

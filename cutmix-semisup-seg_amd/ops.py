@@ -449,6 +449,50 @@ def batch_norm_act(x_nhwc, gamma, beta, running_mean, running_var, momentum=0.1,
     return _BatchNormActFn.apply(x_nhwc, gamma, beta, res, running_mean, running_var, momentum, eps, relu, group)
 
 
+_BN_WHAT = {'reduce': 0, 'finalize': 1, 'apply': 2, 'reduce_bwd': 3, 'bwd_apply': 4, 'count': 5}
+
+
+def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, momentum=0.1, **t):
+    """One launch of the batch-statistics BatchNorm protocol (csrc/bn.hip) on caller-owned buffers -- issued now, or appended
+    to the program being recorded (cms_program_add_bn): the executor's batch-statistics passes (backbone_hip.py) are made of
+    these. `what`: reduce | finalize | apply | reduce_bwd | bwd_apply | count; tensors by keyword (x, res, y, dy, dx, dres,
+    sums, gamma, beta, mean, rstd, scale, shift, running_mean, running_var, counter, clear_a, clear_b)."""
+    _need_cuda(*t.values())
+    d = _lib.BnOp()
+    d.what = _BN_WHAT[what]
+    d.dtype = _lib.F32 if dtype == torch.float32 else _lib.BF16
+    d.c, d.relu = int(c), int(bool(relu))
+    for k, v in t.items():
+        setattr(d, k, None if v is None else v.data_ptr())
+    d.count, d.n_pixels = float(count), int(n_pixels)
+    d.eps, d.momentum = float(eps), float(momentum)
+    if _REC is not None:
+        prog = _REC[0]
+        idx = fn['cms_program_add_bn'](prog.h, C.byref(d), _rec_stream_index(), prog.group)
+        if idx < 0:
+            check(idx, 'cms_program_add_bn')
+        prog.keep += [v for v in t.values() if v is not None]
+        return
+    g = lambda k: _ptr(t.get(k))
+    if what == 'reduce':
+        check(fn['cms_bn_reduce'](g('x'), None, None, d.dtype, None, None, g('sums'), d.n_pixels, d.c, 0, _stream()), 'cms_bn_reduce')
+    elif what == 'finalize':
+        check(fn['cms_bn_finalize_ex'](g('sums'), d.count, g('gamma'), g('beta'), d.eps, d.momentum, g('mean'), g('rstd'),
+                                       g('scale'), g('shift'), g('running_mean'), g('running_var'), d.c, g('clear_a'),
+                                       g('clear_b'), g('counter'), _stream()), 'cms_bn_finalize_ex')
+    elif what == 'apply':
+        check(fn['cms_bn_apply'](g('x'), g('res'), g('y'), d.dtype, g('scale'), g('shift'), d.relu, d.n_pixels, d.c, _stream()),
+              'cms_bn_apply')
+    elif what == 'reduce_bwd':
+        check(fn['cms_bn_reduce'](g('x'), g('dy'), g('y'), d.dtype, g('mean'), g('rstd'), g('sums'), d.n_pixels, d.c, 1, _stream()),
+              'cms_bn_reduce')
+    elif what == 'bwd_apply':
+        check(fn['cms_bn_bwd_apply'](g('x'), g('dy'), g('y'), g('dx'), g('dres'), d.dtype, g('mean'), g('rstd'), g('gamma'),
+                                     g('sums'), d.count, d.n_pixels, d.c, _stream()), 'cms_bn_bwd_apply')
+    else:
+        check(fn['cms_increment_counter'](g('counter'), _stream()), 'cms_increment_counter')
+
+
 # ---------------------------------------------------------------------------------------------- stem
 def stem_out_hw(h, w):
     """-> (ho, wo, hp, wp): sizes after the 7x7/2 convolution and after the ceil-mode 3x3/2 max-pool."""

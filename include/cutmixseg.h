@@ -386,6 +386,12 @@ int cms_bn_reduce(const void* x, const void* dy, const void* y, int dtype, const
 int cms_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
                     float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var, int c,
                     void* stream);
+/* The same, plus what a REPLAYED pass needs from this launch (cms_program_add_bn): `clear_a` / `clear_b` (double[2*c] each, or
+ * NULL) are zeroed after the statistics were read -- normally the forward sums themselves and the sums of the unit's backward
+ * pass -- and `counter` (nn.BatchNorm2d.num_batches_tracked, or NULL) is incremented: three tiny launches fewer per layer. */
+int cms_bn_finalize_ex(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
+                       float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var, int c,
+                       double* clear_a, double* clear_b, long long* counter, void* stream);
 int cms_bn_apply(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
                  size_t n_pixels, int c, void* stream);
 int cms_bn_bwd_apply(const void* x, const void* dy, const void* y, void* dx, void* dres, int dtype, const float* mean,
@@ -457,6 +463,35 @@ int cms_program_add_aspp_spread(cms_program* p, const float* dlogits, void* d_nh
                                 const int* tap_dx, int n_taps, int n, int c, int zc, int h, int w, int stream_idx, int group);
 /* work enqueued so far on `from_stream` must finish before anything enqueued later on `to_stream` starts */
 int cms_program_add_sync(cms_program* p, int from_stream, int to_stream, int group);
+/* Batch-statistics BatchNorm launches inside a program (round 3: DeepLab v2 WITHOUT --freeze_bn on the executor,
+ * architectures/deeplab2.py:72-84 / train_seg_semisup_mask_mt.py:587). `what`: 0 = cms_bn_reduce(mode 0), 1 = cms_bn_finalize,
+ * 2 = cms_bn_apply, 3 = cms_bn_reduce(mode 1), 4 = cms_bn_bwd_apply, 5 = cms_increment_counter(counter); unused pointers NULL.
+ * All buffers are the caller's and persistent (a program is replayed many times). */
+typedef struct cms_bn_op {
+    int what, dtype, c, relu;
+    const void* x;             /* conv output u, NHWC                                                          */
+    const void* res;           /* apply: residual or NULL                                                      */
+    void* y;                   /* apply: output; reduce(mode 1) / bwd_apply: the stored output (ReLU mask) or NULL */
+    const void* dy;            /* backward: incoming gradient                                                  */
+    void* dx;                  /* bwd_apply: gradient wrt x                                                    */
+    void* dres;                /* bwd_apply: gradient wrt the residual (= masked dy) or NULL                   */
+    double* sums;              /* double[2*c] (+1): forward / backward sums                                    */
+    const float* gamma;
+    const float* beta;
+    float* mean;
+    float* rstd;
+    float* scale;
+    float* shift;
+    float* running_mean;
+    float* running_var;
+    long long* counter;        /* what 1 (optional) / what 5: num_batches_tracked                              */
+    double* clear_a;           /* what 1: zeroed after the statistics were read (cms_bn_finalize_ex), or NULL  */
+    double* clear_b;
+    double count;              /* pixels the statistics run over                                               */
+    unsigned long long n_pixels;
+    float eps, momentum;
+} cms_bn_op;
+int cms_program_add_bn(cms_program* p, const cms_bn_op* op, int stream_idx, int group);
 int cms_program_size(const cms_program* p);
 /* enqueue ops [first, last) (last < 0: to the end); never synchronises the host */
 int cms_program_run(cms_program* p, int first, int last, void* const* streams, int n_streams);

@@ -45,6 +45,7 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu\n", sizeof(cms_conv_desc), sizeof(cms_wgrad_desc), sizeof(cms_pack_item),
          offsetof(cms_conv_desc, zeros), offsetof(cms_wgrad_desc, stride));
   printf("%zu\n", offsetof(cms_wgrad_desc, dbeta));
+  printf("%zu %zu %zu %zu\n", sizeof(cms_bn_op), offsetof(cms_bn_op, count), offsetof(cms_bn_op, eps), sizeof(cms_augment_desc));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -67,6 +68,8 @@ int main(void) {
     assert sizes[10] == _lib.ConvDesc.zeros.offset
     assert sizes[11] == _lib.WgradDesc.stride.offset
     assert sizes[12] == _lib.WgradDesc.dbeta.offset
+    assert sizes[13] == ctypes.sizeof(_lib.BnOp) and sizes[14] == _lib.BnOp.count.offset and sizes[15] == _lib.BnOp.eps.offset
+    assert sizes[16] == ctypes.sizeof(_lib.AugmentDesc)
 
 
 def test_bad_arguments_come_back_as_error_codes_not_crashes():

@@ -2,9 +2,13 @@
 GPU: DeepLab v2 WITHOUT --freeze_bn -- the reference CLI's default (train_seg_semisup_mask_mt.py:587): every BatchNorm
 normalises with batch statistics and moves its running statistics, in the student AND in the train-mode teacher (Q4), while
 its affine parameters stay frozen (deeplab2.py:72-84, Q3). One whole CutMix mean-teacher iteration on the hand-written
-kernels (engine_kind = 'hip': every convolution on csrc/conv_f32.hip incl. the 7 x 7 stem as tap chunks, the strided
-1 x 1s and the class-wide head; every BatchNorm on csrc/bn.hip; the `no_library_convolutions` context refuses anything else)
-against oracle/step.py with frozen_bn=False: losses, confidence rate, every gradient, student and teacher running statistics.
+kernels against oracle/step.py with frozen_bn=False: losses, confidence rate, every gradient, student and teacher running
+statistics -- on BOTH routes of this build:
+  * 'executor': body and head on the static executor, every unit = convolution + csrc/bn.hip launches recorded into the
+    same programs (cms_program_add_bn); the stem through the strict layer engine (7 x 7 as tap chunks);
+  * 'layers': everything through the strict layer engine (what runs under torch.distributed, where BatchNorm all-reduces
+    its statistics between its two passes).
+The `no_library_convolutions` context refuses any library convolution / BatchNorm call in either.
 """
 import numpy as np
 import pytest
@@ -59,14 +63,17 @@ def _rel(a, b):
     return float((a.double().cpu() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-def test_batch_statistics_iteration_on_the_hand_written_kernels_matches_the_oracle(no_library_convolutions):
+@pytest.mark.parametrize('route', ['executor', 'layers'])
+def test_batch_statistics_iteration_on_the_hand_written_kernels_matches_the_oracle(no_library_convolutions, route):
     from cutmix_semisup_seg_amd import ops
     from cutmix_semisup_seg_amd.step import UnsupBatch
     from oracle import step as ostep, boxmask as obox
     import mask_gen
     C, layers, N, H, W = 5, [1, 1, 1, 1], 3, 49, 65
     st, stu, tea, opt, step = _setup(torch.float32, 'hip', C, layers)
-    assert not step._samples_independent() and not stu._use_hip_body()
+    if route == 'layers':
+        stu.batchstat_executor = tea.batchstat_executor = False
+    assert not step._samples_independent() and stu._use_hip_body() == (route == 'executor')
     g = torch.Generator().manual_seed(21)
     x, ux0, ux1 = (torch.randn(N, 3, H, W, generator=g) for _ in range(3))
     y = torch.randint(0, C, (N, 1, H, W), generator=g)
@@ -85,6 +92,12 @@ def test_batch_statistics_iteration_on_the_hand_written_kernels_matches_the_orac
     assert no_library_convolutions.refused == 0
     eng = stu._hip_engine
     assert eng is not None and eng.strict and eng.dtype == torch.float32 and eng.library_convs == 0
+    if route == 'executor':
+        progs = stu._hip_executor.programs()
+        assert stu._hip_executor.dtype == torch.float32 and len(progs) >= 2 and all(getattr(p, 'bn', True) for p in progs if hasattr(p, 'bn'))
+        assert tea._hip_executor is not None
+    else:
+        assert stu._hip_executor is None
     assert abs(got['sup_loss'] - ref['sup_loss']) <= 1e-4 * abs(ref['sup_loss'])
     assert abs(got['consistency_loss'] - ref['consistency_loss']) <= 2e-3 * abs(ref['consistency_loss']) + 1e-9
     assert abs(got['conf_rate'] - ref['conf_rate']) <= 2e-3
@@ -130,5 +143,6 @@ def test_bf16_batch_statistics_iteration_runs_on_the_mfma_engine():
         N, (H, W), rng=np.random.RandomState(0)), DEV)
     losses = [float(step(x, y, [UnsupBatch(im(), ranges, x1_tea=im())])['sup_loss']) for _ in range(20)]
     print('\nbf16 batch-statistics DeepLab v2 losses:', [round(v, 4) for v in losses])
-    assert isinstance(stu._hip_engine, HipConvEngine) and not stu._hip_engine.strict
+    assert isinstance(stu._hip_engine, HipConvEngine)            # (the stem's layer engine; body + head on the executor)
+    assert stu._hip_executor is not None and stu._hip_executor.batch_statistics()
     assert all(np.isfinite(losses)) and min(losses[-5:]) < losses[0]
