@@ -134,7 +134,8 @@ __device__ __forceinline__ void buf_load_lds16(const buf_rsrc_t& r, const unsign
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "s"(lds_addr_of(lds)), "v"(voff), "s"(r.w), "s"(soff)
+                 : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr_of(lds))), "v"(voff), "s"(r.w),
+                   "s"(__builtin_amdgcn_readfirstlane((int)soff))
                  : "memory");
 }
 // four of them: LDS destinations lds + k * step (k = 0..3)
@@ -1126,6 +1127,30 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
                      : ((d->variant == 4 || d->variant == 6 || d->variant == 7) ? 2
                         : (d->variant == 5 ? 3 : ((small && d->variant != 43) ? 4 : 1)));      // 43: flat addresses (round-1 loader)
     const int tile = d->tile;   // 0 = auto
+    if (d->variant >= 60 && d->variant <= 75) {
+        // Round 3 experiment: the stage rings on WIDE tiles with buffer-addressed asm loads (the wide rings 10..14 of round 2
+        // used the builtin loads the compiler drains): 60..63 = 128 (co) x 256 (pixels) on 8 waves; 70..73 = 256 x 256 on 8
+        // waves (each wave 128 co x 64 pixels: 6 fragment reads per 8 MFMAs, 64 KB staged per 4x the work of the default tile)
+        CMS_REQUIRE(d->zeros != nullptr && small, "conv: variants 60..75 need the zero run and tensors below 2 GB");
+        if (d->variant < 70) {
+            CMS_REQUIRE(d->cout % 128 == 0, "conv: variants 60..63 need Cout %% 128 == 0");
+            switch (d->variant) {
+            case 60: conv_launch_ring<2, 4, 2, 2, 1, 64, 2, true>(a, s); break;
+            case 61: conv_launch_ring<2, 4, 2, 2, 2, 64, 1, true>(a, s); break;
+            case 62: conv_launch_ring<2, 4, 2, 2, 3, 32, 2, true>(a, s); break;
+            default: conv_launch_ring<2, 4, 2, 2, 4, 32, 1, true>(a, s); break;
+            }
+        } else {
+            CMS_REQUIRE(d->cout % 256 == 0, "conv: variants 70..73 need Cout %% 256 == 0");
+            switch (d->variant) {
+            case 70: conv_launch_ring<2, 4, 4, 2, 1, 64, 1, true>(a, s); break;
+            case 71: conv_launch_ring<2, 4, 4, 2, 2, 64, 1, true>(a, s); break;
+            case 72: conv_launch_ring<2, 4, 4, 2, 3, 32, 1, true>(a, s); break;
+            default: conv_launch_ring<2, 4, 4, 2, 4, 32, 1, true>(a, s); break;
+            }
+        }
+        return launch_status("cms_conv_igemm");
+    }
     if (d->variant >= 50 && d->variant <= 54) {
         // 50..54: the stage rings 10..14 of the 128 x 128 tile with buffer addressing
         CMS_REQUIRE(d->zeros != nullptr && small && d->cout % 128 == 0 && (tile == 0 || tile == 128),

@@ -122,23 +122,34 @@ def test_executor_teacher_forward_only_and_weight_refresh():
     assert net._hip_executor.arena.grad is None
 
 
-def test_hip_engine_without_frozen_bn_runs_layer_by_layer_on_the_hand_written_kernels(no_library_convolutions):
-    """Round 2 refused this configuration (the static executor folds FROZEN BatchNorm into its epilogues); since round 3
-    batch-statistics passes -- the reference CLI's default, no --freeze_bn -- run through the strict layer engine
-    (deeplab3plus.HipConvEngine: every convolution on csrc/conv*.hip, BatchNorm on csrc/bn.hip), never the library."""
+@pytest.mark.parametrize('route', ['executor', 'layers'])
+def test_hip_engine_without_frozen_bn_stays_on_the_hand_written_kernels(no_library_convolutions, route):
+    """Round 2 refused this configuration (the static executor folded FROZEN BatchNorm into its epilogues). Since round 3
+    batch-statistics passes -- the reference CLI's default, no --freeze_bn -- run on the executor with csrc/bn.hip launches
+    recorded into its programs (stem through the strict layer engine), or, with `batchstat_executor = False` (and always
+    under torch.distributed), layer by layer through the strict engine. Never the library."""
     from architectures import deeplab2
     from cutmix_semisup_seg_amd.architectures.deeplab3plus import HipConvEngine
     net = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, [1, 1, 1, 1], 5, np.zeros(3), np.ones(3)).to(DEV)
     net.engine_kind = 'hip'
+    if route == 'layers':
+        net.batchstat_executor = False
     net.train()
-    assert not net._use_hip_body()
+    assert net._use_hip_body() == (route == 'executor')
     with no_library_convolutions:
         out = net.forward_lowres(torch.randn(2, 3, 33, 33, device=DEV).bfloat16())
         out.sum().backward()
     assert isinstance(net._hip_engine, HipConvEngine) and net._hip_engine.strict and net._hip_engine.library_convs == 0
     assert tuple(out.shape) == (2, 5, 5, 5) and bool(torch.isfinite(out).all()) and no_library_convolutions.refused == 0
+    if route == 'executor':
+        assert net._hip_executor is not None and net._hip_executor.batch_statistics() and len(net._hip_executor.programs()) >= 2
+    else:
+        assert net._hip_executor is None
+    assert int(net.bn1.num_batches_tracked) == 1 and int(net.layer3[0].bn2.num_batches_tracked) == 1
+    assert all(p.grad is not None and float(p.grad.abs().max()) > 0 for k, p in net.named_parameters()
+               if p.requires_grad and 'conv2d_list.2' not in k and 'conv2d_list.3' not in k)
     net.freeze_batchnorm()
-    assert net._use_hip_body()                                  # frozen again: back on the static executor
+    assert net._use_hip_body() and not net._hip_executors[net.compute_dtype].batch_statistics() if route == 'executor' else True
 
 
 def test_whole_step_bf16_hip_engine_tracks_fp32_library_engine():
