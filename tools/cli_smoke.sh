@@ -1,0 +1,15 @@
+#!/bin/bash
+# End-to-end runs of the two trainers' command lines on synthetic data (GPU box): the reference's DEFAULT flags (no
+# --freeze_bn: BatchNorm on batch statistics, on the executor), the experiment scripts' flags (--freeze_bn), deterministic
+# mode, the rotate + scale crop, the VAT trainer. Each prints its last log lines.
+set -e
+cd "$(dirname "$0")/.."
+W=$(mktemp -d /tmp/cli_smoke.XXXX)
+run() { name=$1; shift; echo "== $name: $*"; ( cd $W && python $OLDPWD/"$@" > $name.out 2>&1 ) || { tail -20 $W/$name.out; exit 1; }; tail -3 $W/$name.out | cut -c1-200; }
+COMMON="--synthetic --arch resnet101_deeplab_imagenet --batch_size 4 --crop_size 129,129 --learning_rate 3e-5 --num_epochs 1 --iters_per_epoch 4 --synthetic_val_batches 1"
+run default_cli train_seg_semisup_mask_mt.py --job_desc d $COMMON
+run freeze_bn train_seg_semisup_mask_mt.py --job_desc f $COMMON --freeze_bn
+run deterministic train_seg_semisup_mask_mt.py --job_desc det $COMMON --freeze_bn --deterministic
+run rot_scale train_seg_semisup_mask_mt.py --job_desc r $COMMON --freeze_bn --synthetic_source_size 160,200 --aug_rot_mag 20 --aug_max_scale 1.5 --aug_hflip --aug_strong_colour
+run vat train_seg_semisup_vat_mt.py --job_desc v --synthetic --arch resnet101_deeplab_imagenet --freeze_bn --batch_size 2 --crop_size 65,65 --num_epochs 1 --iters_per_epoch 2 --synthetic_val_batches 1
+echo "cli_smoke OK"
