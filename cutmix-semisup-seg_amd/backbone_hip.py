@@ -314,35 +314,33 @@ class DeepLabHipExecutor(object):
         return m
 
     def _fwd_unit_bn(self, x, c, relu, res=None, save=True):
-        """y = relu(batch_norm(conv(x)) (+ res)) as FOUR launches on persistent buffers: raw convolution, statistics (reduce
-        -> finalize, which also moves the running statistics, counts the batch and leaves the unit's sum buffers zeroed for
-        their next use), normalise + residual + ReLU. -> (y, saved), saved = (u, y, mean, rstd, backward sums) for
-        `_bwd_unit_bn`."""
+        """y = relu(batch_norm(conv(x)) (+ res)) as THREE launches on persistent buffers: raw convolution, statistics (one
+        atomics-free reduction whose last blocks also finalise: scale / shift, running statistics, batch counter), normalise +
+        residual + ReLU. -> (y, saved), saved = (u, y, mean, rstd, backward sums, workspace) for `_bwd_unit_bn`."""
         n, h, w, _ = x.shape
         ho, wo = self._out_hw(h, w, c.stride)
         u = ops.conv_igemm(x, self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), tile=self._tile(c.cout))
         a, bn, C = self.arena, self._bn_module(c), c.cout
         npix = n * ho * wo
         dev = x.device
-        stats = torch.zeros(2 * C, dtype=torch.float64, device=dev)         # zero now, and again after every finalize
-        bsums = torch.zeros(2 * C, dtype=torch.float64, device=dev) if save else None
+        bsums = torch.empty(2 * C, dtype=torch.float64, device=dev) if save else None
         mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
-        ops.bn_op('reduce', c=C, dtype=self.dtype, n_pixels=npix, x=u, sums=stats)
-        ops.bn_op('finalize', c=C, count=npix, eps=bn.eps, momentum=bn.momentum, sums=stats, gamma=a.view(c.bn + '.weight'),
-                  beta=a.view(c.bn + '.bias'), mean=mean, rstd=rstd, scale=scale, shift=shift,
+        ws = ops.bn_workspace(npix, C, dev)         # this unit's: tile counters + partial sums (forward, then backward)
+        ops.bn_op('stats', c=C, dtype=self.dtype, n_pixels=npix, eps=bn.eps, momentum=bn.momentum, x=u, ws=ws,
+                  gamma=a.view(c.bn + '.weight'), beta=a.view(c.bn + '.bias'), mean=mean, rstd=rstd, scale=scale, shift=shift,
                   running_mean=a.view(c.bn + '.running_mean'), running_var=a.view(c.bn + '.running_var'),
-                  clear_a=stats, clear_b=bsums, counter=bn.num_batches_tracked)
+                  counter=bn.num_batches_tracked)
         y = torch.empty_like(u)
         ops.bn_op('apply', c=C, dtype=self.dtype, n_pixels=npix, relu=relu, x=u, res=res, y=y, scale=scale, shift=shift)
-        return y, (u, y if relu else None, mean, rstd, bsums)
+        return y, (u, y if relu else None, mean, rstd, bsums, ws)
 
     def _bwd_unit_bn(self, dy, saved, c, want_res):
         """Backward of the normalisation of one unit: dy (gradient wrt y) -> (du = gradient wrt the convolution output,
         dres = gradient wrt the residual input or None). The ReLU mask comes from the stored y."""
-        u, y, mean, rstd, sums = saved          # `sums`: zeroed by the forward pass's finalize launch
+        u, y, mean, rstd, sums, ws = saved      # `sums` is overwritten by the reduction; `ws`: the unit's workspace
         C = c.cout
         npix = u.numel() // C
-        ops.bn_op('reduce_bwd', c=C, dtype=self.dtype, n_pixels=npix, x=u, dy=dy, y=y, mean=mean, rstd=rstd, sums=sums)
+        ops.bn_op('reduce_bwd', c=C, dtype=self.dtype, n_pixels=npix, x=u, dy=dy, y=y, mean=mean, rstd=rstd, sums=sums, ws=ws)
         du = torch.empty_like(u)
         dres = torch.empty_like(u) if want_res else None
         ops.bn_op('bwd_apply', c=C, dtype=self.dtype, n_pixels=npix, count=npix, x=u, dy=dy, y=y, dx=du, dres=dres, mean=mean,

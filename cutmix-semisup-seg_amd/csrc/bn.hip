@@ -150,6 +150,167 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x,
     }
 }
 
+// what one channel's statistics turn into (shared by bn_finalize_kernel and the fused tail of bn_reduce_tiled_kernel)
+struct BnFin {
+    const float* gamma;
+    const float* beta;
+    float* mean;
+    float* rstd;
+    float* scale;
+    float* shift;
+    float* running_mean;
+    float* running_var;
+    long long* counter;
+    double count;
+    float eps, momentum;
+};
+
+__device__ __forceinline__ void bn_finalize_channel(const BnFin& f, int c, double s0, double s1) {
+    const double m = s0 / f.count;
+    double var = s1 / f.count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)f.eps));
+    f.mean[c] = (float)m;
+    f.rstd[c] = r;
+    const float g = f.gamma ? f.gamma[c] : 1.0f, b = f.beta ? f.beta[c] : 0.0f;
+    f.scale[c] = g * r;
+    f.shift[c] = b - (float)m * g * r;
+    if (f.running_mean) f.running_mean[c] = (1.0f - f.momentum) * f.running_mean[c] + f.momentum * (float)m;
+    if (f.running_var) {
+        const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+        f.running_var[c] = (1.0f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+    }
+}
+
+// Round 3: the reduction WITHOUT data atomics. bn_reduce_kernel ends every block with 2 C fp64 atomics; the memory-side
+// atomic units retire ~11 G of them per second whatever the addresses (tools/atomic_probe.hip), so a C = 1024 layer on 256
+// blocks spends ~48 us there against ~8 us of loads (profiles/r03t_*: 52 / 58 us per launch, 37 % of the batch-statistics
+// step). Here a block owns a CHANNEL TILE of 64 channels (one 128-byte line per pixel row in bf16) and one of S pixel
+// splits, stores its 128 partial sums with plain stores, and the LAST block of a tile to arrive (one counter atomic per
+// block, self-resetting) adds the S partials in fixed order in fp64 -- bit-reproducible -- and either writes sums[] (the
+// data-parallel protocol all-reduces them) or, FIN, finalises its 64 channels on the spot (no bn_finalize launch).
+//   ws: unsigned counters[tiles] (zero before the first use) padded to 256 bytes, then float part[tiles][S][2][64]
+constexpr int BN_CT = 64;            // channels per tile
+
+template <class T, int MODE, bool FIN>
+__global__ __launch_bounds__(256) void bn_reduce_tiled_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                              const T* __restrict__ y, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, double* __restrict__ sums,
+                                                              unsigned* counters, float* part,
+                                                              size_t P, int C, int tiles, int S, BnFin fin) {
+    __shared__ float red[4][2 * BN_CT];
+    __shared__ double redd[256];
+    __shared__ int last_flag;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+    const int cgl = tid & 7, slot = tid >> 3;          // 8 channel groups of 8 channels x 32 pixel rows side by side
+    const int c0 = tile * BN_CT + cgl * 8;
+    const bool active = c0 < C;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.0f;
+    if (active) {
+        float mu[8], rs[8];
+        if (MODE == 1) {
+            load8(mean + c0, mu);
+            load8(rstd + c0, rs);
+        }
+        auto accumulate = [&](const float (&xv)[8], const float (&dv)[8], const float (&yv)[8]) {
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] = fmaf(xv[e], xv[e], a1[e]); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (y == nullptr || yv[e] > 0.0f) ? dv[e] : 0.0f;
+                    a0[e] += d;
+                    a1[e] = fmaf(d, (xv[e] - mu[e]) * rs[e], a1[e]);
+                }
+            }
+        };
+        const size_t stride = (size_t)S * 32;
+        size_t p = (size_t)split * 32 + slot;
+        for (; p + 3 * stride < P; p += 4 * stride) {
+            float xv[4][8], dv[4][8], yv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t o = (p + u * stride) * (size_t)C + (size_t)c0;
+                load8(x + o, xv[u]);
+                if (MODE == 1) {
+                    load8(dy + o, dv[u]);
+                    if (y) load8(y + o, yv[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accumulate(xv[u], dv[u], yv[u]);
+        }
+        for (; p < P; p += stride) {
+            const size_t o = p * (size_t)C + (size_t)c0;
+            float xv[8], dv[8], yv[8];
+            load8(x + o, xv);
+            if (MODE == 1) {
+                load8(dy + o, dv);
+                if (y) load8(y + o, yv);
+            }
+            accumulate(xv, dv, yv);
+        }
+    }
+    // the 8 pixel rows of a wave that share a channel group (lane bits 3..5), then the 4 waves through LDS
+#pragma unroll
+    for (int off = 32; off >= 8; off >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a0[e] += __shfl_xor(a0[e], off, 64);
+            a1[e] += __shfl_xor(a1[e], off, 64);
+        }
+    }
+    if ((tid & 63) < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[tid >> 6][cgl * 8 + e] = a0[e];
+            red[tid >> 6][BN_CT + cgl * 8 + e] = a1[e];
+        }
+    }
+    __syncthreads();
+    float* mine = part + ((size_t)tile * S + split) * (2 * BN_CT);
+    if (tid < 2 * BN_CT) mine[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    // release the partials, count this block in; the block that completes the tile reads all S of them
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned prev = atomicAdd(counters + tile, 1u);
+        last_flag = prev == (unsigned)(S - 1);
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();
+    {
+        const float* pp = part + (size_t)tile * S * (2 * BN_CT) + (tid & 127);
+        double acc = 0.0;
+        int s = tid >> 7;
+        for (; s + 6 < S; s += 8) {
+            const float v0 = pp[(size_t)s * 128], v1 = pp[(size_t)(s + 2) * 128], v2 = pp[(size_t)(s + 4) * 128],
+                        v3 = pp[(size_t)(s + 6) * 128];
+            acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+        }
+        for (; s < S; s += 2) acc += (double)pp[(size_t)s * 128];
+        redd[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < BN_CT) {
+        const int c = tile * BN_CT + tid;
+        if (c < C) {
+            const double s0 = redd[tid] + redd[128 + tid], s1 = redd[BN_CT + tid] + redd[128 + BN_CT + tid];
+            if (sums) { sums[c] = s0; sums[C + c] = s1; }
+            if (FIN) bn_finalize_channel(fin, c, s0, s1);
+        }
+    }
+    if (tid == 0) {
+        counters[tile] = 0;                            // ready for the next launch on this workspace
+        if (FIN && tile == 0 && fin.counter) *fin.counter += 1;
+    }
+}
+
 // sums (sum x, sum x^2) over `count` pixels -> mean, rstd, scale, shift; running statistics like nn.BatchNorm2d (momentum,
 // unbiased variance)
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
@@ -213,6 +374,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            double count, size_t P, int C) {
     const int CG = C / 8;
     const size_t total = P * CG;
+    const double inv_count = 1.0 / count;       // (two fp64 DIVISIONS per element made this kernel ALU-bound: 52 us where its
+                                                // 4-5 tensors of traffic take 25, profiles/r03t_*)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int cg = (int)(i % CG);
         const size_t o = i * 8;
@@ -227,7 +390,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             const int c = cg * 8 + e;
             const float d = (y == nullptr || yv[e] > 0.0f) ? dv[e] : 0.0f;
             const float xh = (xv[e] - mu[e]) * rs[e];
-            const float m1 = (float)(sums[c] / count), m2 = (float)(sums[C + c] / count);
+            const float m1 = (float)(sums[c] * inv_count), m2 = (float)(sums[C + c] * inv_count);
             const float g = gamma ? gamma[c] : 1.0f;
             out[e] = g * rs[e] * (d - m1 - xh * m2);
             dr[e] = d;
@@ -281,6 +444,73 @@ extern "C" int cms_bn_reduce(const void* x, const void* dy, const void* y, int d
 #undef CMS_BN_RED
     }
     return launch_status("cms_bn_reduce");
+}
+
+// ---- atomics-free reduction (bn_reduce_tiled_kernel) ----------------------------------------------------------------------
+static void bn_tiling(size_t n_pixels, int c, int* tiles, int* splits) {
+    static int target = -1;                         // CMS_BN_BLOCKS: blocks per launch aimed at (A/B switch, read once)
+    if (target < 0) {
+        const char* e = getenv("CMS_BN_BLOCKS");
+        target = e ? std::max(1, atoi(e)) : 1024;
+    }
+    const int t = (c + BN_CT - 1) / BN_CT;
+    size_t s = (size_t)std::max(1, target / t);
+    s = std::min<size_t>(s, 256);
+    s = std::min<size_t>(s, (n_pixels + 127) / 128);       // >= 4 rounds of 32 pixel rows per block
+    *tiles = t;
+    *splits = (int)std::max<size_t>(s, 1);
+}
+
+static size_t bn_counter_bytes(int tiles) { return ((size_t)tiles * sizeof(unsigned) + 255) / 256 * 256; }
+
+extern "C" size_t cms_bn_workspace_bytes(size_t n_pixels, int c) {
+    if (n_pixels == 0 || c <= 0) return 0;
+    int tiles, S;
+    bn_tiling(n_pixels, c, &tiles, &S);
+    return bn_counter_bytes(tiles) + (size_t)tiles * S * 2 * BN_CT * sizeof(float);
+}
+
+static int bn_reduce_tiled(const void* x, const void* dy, const void* y, int dtype, const float* mean, const float* rstd,
+                           double* sums, size_t n_pixels, int c, int mode, void* ws, const BnFin* fin, hipStream_t s) {
+    int tiles, S;
+    bn_tiling(n_pixels, c, &tiles, &S);
+    unsigned* counters = (unsigned*)ws;
+    float* part = (float*)((char*)ws + bn_counter_bytes(tiles));
+    const dim3 grid((unsigned)(tiles * S));
+    BnFin f = fin ? *fin : BnFin{};
+#define CMS_BN_TILED(T, M, F) hipLaunchKernelGGL((bn_reduce_tiled_kernel<T, M, F>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, sums, counters, part, n_pixels, c, tiles, S, f)
+    if (dtype == CMS_F32) {
+        if (mode == 1) CMS_BN_TILED(float, 1, false);
+        else if (fin) CMS_BN_TILED(float, 0, true);
+        else CMS_BN_TILED(float, 0, false);
+    } else {
+        if (mode == 1) CMS_BN_TILED(uint16_t, 1, false);
+        else if (fin) CMS_BN_TILED(uint16_t, 0, true);
+        else CMS_BN_TILED(uint16_t, 0, false);
+    }
+#undef CMS_BN_TILED
+    return 0;
+}
+
+extern "C" int cms_bn_reduce_ws(const void* x, const void* dy, const void* y, int dtype, const float* mean, const float* rstd,
+                                double* sums, size_t n_pixels, int c, int mode, void* ws, void* stream) {
+    CMS_REQUIRE(x && sums && ws, "bn_reduce_ws: NULL pointer");
+    CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_reduce_ws: bad dtype");
+    CMS_REQUIRE(bn_geo_ok(n_pixels, c), "bn_reduce_ws: bad geometry (channels %% 8 == 0)");
+    CMS_REQUIRE(mode == 0 || (mode == 1 && dy && mean && rstd), "bn_reduce_ws: mode 1 needs dy, mean, rstd");
+    bn_reduce_tiled(x, dy, y, dtype, mean, rstd, sums, n_pixels, c, mode, ws, nullptr, (hipStream_t)stream);
+    return launch_status("cms_bn_reduce_ws");
+}
+
+extern "C" int cms_bn_stats(const void* x, int dtype, size_t n_pixels, int c, const float* gamma, const float* beta, float eps,
+                            float momentum, float* mean, float* rstd, float* scale, float* shift, float* running_mean,
+                            float* running_var, long long* counter, double* sums, void* ws, void* stream) {
+    CMS_REQUIRE(x && ws && mean && rstd && scale && shift, "bn_stats: NULL pointer");
+    CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_stats: bad dtype");
+    CMS_REQUIRE(bn_geo_ok(n_pixels, c), "bn_stats: bad geometry (channels %% 8 == 0)");
+    BnFin f{gamma, beta, mean, rstd, scale, shift, running_mean, running_var, counter, (double)n_pixels, eps, momentum};
+    bn_reduce_tiled(x, nullptr, nullptr, dtype, nullptr, nullptr, sums, n_pixels, c, 0, ws, &f, (hipStream_t)stream);
+    return launch_status("cms_bn_stats");
 }
 
 extern "C" int cms_bn_finalize_ex(const double* sums, double count, const float* gamma, const float* beta, float eps,

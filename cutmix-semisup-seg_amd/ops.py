@@ -390,40 +390,41 @@ class _BatchNormActFn(torch.autograd.Function):
         n_pix = x.numel() // x.shape[-1]
         c = int(x.shape[-1])
         dev = x.device
-        stats = torch.zeros(2 * c + 1, dtype=torch.float64, device=dev)
-        # (fill_, not `stats[2 * c] = n_pix`: the element assignment is a host-to-device copy of a pageable scalar, which
-        # on this runtime waits for the stream -- 1.7 ms per BatchNorm, 63 ms per DeepLab v3+ step)
-        stats[2 * c:].fill_(float(n_pix))
-        check(fn['cms_bn_reduce'](_ptr(x), None, None, _dtype_code(x), None, None, _ptr(stats), n_pix, c, 0, _stream()),
-              'cms_bn_reduce')
+        mean, rstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+        ws = bn_workspace(n_pix, c, dev)
         world = _world(group)
         if world > 1:
+            stats = torch.empty(2 * c, dtype=torch.float64, device=dev)
+            check(fn['cms_bn_reduce_ws'](_ptr(x), None, None, _dtype_code(x), None, None, _ptr(stats), n_pix, c, 0, _ptr(ws),
+                                         _stream()), 'cms_bn_reduce_ws')
             _allreduce_sum(stats, group)
             count = float(n_pix) * world       # (equal shards: the per-GPU batch is fixed under weak scaling)
-        else:
+            check(fn['cms_bn_finalize'](_ptr(stats), count, _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(mean),
+                                        _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var), c,
+                                        _stream()), 'cms_bn_finalize')
+        else:                                  # statistics and their finalisation in ONE launch
             count = float(n_pix)
-        mean, rstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
-        check(fn['cms_bn_finalize'](_ptr(stats), count, _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(mean),
-                                    _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var), c,
-                                    _stream()), 'cms_bn_finalize')
+            check(fn['cms_bn_stats'](_ptr(x), _dtype_code(x), n_pix, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+                                     _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var),
+                                     None, None, _ptr(ws), _stream()), 'cms_bn_stats')
         y = torch.empty_like(x)
         check(fn['cms_bn_apply'](_ptr(x), _ptr(res), _ptr(y), _dtype_code(x), _ptr(scale), _ptr(shift), int(bool(relu)), n_pix,
                                  c, _stream()), 'cms_bn_apply')
-        ctx.save_for_backward(x, y if relu else None, mean, rstd, gamma)
+        ctx.save_for_backward(x, y if relu else None, mean, rstd, gamma, ws)
         ctx.meta = (n_pix, c, count, group, res is not None, gamma is not None and gamma.requires_grad,
                     beta is not None and beta.requires_grad)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, rstd, gamma = ctx.saved_tensors
+        x, y, mean, rstd, gamma, ws = ctx.saved_tensors
         n_pix, c, count, group, has_res, want_g, want_b = ctx.meta
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        sums = torch.zeros(2 * c, dtype=torch.float64, device=x.device)
-        check(fn['cms_bn_reduce'](_ptr(x), _ptr(dy), _ptr(y), _dtype_code(x), _ptr(mean), _ptr(rstd), _ptr(sums), n_pix, c, 1,
-                                  _stream()), 'cms_bn_reduce')
+        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        check(fn['cms_bn_reduce_ws'](_ptr(x), _ptr(dy), _ptr(y), _dtype_code(x), _ptr(mean), _ptr(rstd), _ptr(sums), n_pix, c, 1,
+                                     _ptr(ws), _stream()), 'cms_bn_reduce_ws')
         local = sums
         if _world(group) > 1:
             local = sums.clone()                 # parameter gradients stay local (the arena all-reduce sums them)
@@ -449,14 +450,22 @@ def batch_norm_act(x_nhwc, gamma, beta, running_mean, running_var, momentum=0.1,
     return _BatchNormActFn.apply(x_nhwc, gamma, beta, res, running_mean, running_var, momentum, eps, relu, group)
 
 
-_BN_WHAT = {'reduce': 0, 'finalize': 1, 'apply': 2, 'reduce_bwd': 3, 'bwd_apply': 4, 'count': 5}
+def bn_workspace(n_pixels, c, device):
+    """Zero-filled workspace of one call site of the atomics-free BatchNorm reductions (cms_bn_workspace_bytes): tile counters
+    + partial sums; the kernels leave it ready for their next launch, launches on different streams must not share it."""
+    n = int(fn['cms_bn_workspace_bytes'](int(n_pixels), int(c)))
+    return torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
+
+
+_BN_WHAT = {'reduce': 0, 'finalize': 1, 'apply': 2, 'reduce_bwd': 3, 'bwd_apply': 4, 'count': 5, 'stats': 6}
 
 
 def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, momentum=0.1, **t):
     """One launch of the batch-statistics BatchNorm protocol (csrc/bn.hip) on caller-owned buffers -- issued now, or appended
     to the program being recorded (cms_program_add_bn): the executor's batch-statistics passes (backbone_hip.py) are made of
-    these. `what`: reduce | finalize | apply | reduce_bwd | bwd_apply | count; tensors by keyword (x, res, y, dy, dx, dres,
-    sums, gamma, beta, mean, rstd, scale, shift, running_mean, running_var, counter, clear_a, clear_b)."""
+    these. `what`: reduce | finalize | apply | reduce_bwd | bwd_apply | count | stats (= reduce + finalize in one launch);
+    tensors by keyword (x, res, y, dy, dx, dres, sums, gamma, beta, mean, rstd, scale, shift, running_mean, running_var,
+    counter, clear_a, clear_b, ws). With `ws` (bn_workspace) the reductions take the atomics-free kernels."""
     _need_cuda(*t.values())
     d = _lib.BnOp()
     d.what = _BN_WHAT[what]
@@ -474,8 +483,15 @@ def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, mo
         prog.keep += [v for v in t.values() if v is not None]
         return
     g = lambda k: _ptr(t.get(k))
-    if what == 'reduce':
+    if what == 'reduce' and t.get('ws') is not None:
+        check(fn['cms_bn_reduce_ws'](g('x'), None, None, d.dtype, None, None, g('sums'), d.n_pixels, d.c, 0, g('ws'), _stream()),
+              'cms_bn_reduce_ws')
+    elif what == 'reduce':
         check(fn['cms_bn_reduce'](g('x'), None, None, d.dtype, None, None, g('sums'), d.n_pixels, d.c, 0, _stream()), 'cms_bn_reduce')
+    elif what == 'stats':
+        check(fn['cms_bn_stats'](g('x'), d.dtype, d.n_pixels, d.c, g('gamma'), g('beta'), d.eps, d.momentum, g('mean'), g('rstd'),
+                                 g('scale'), g('shift'), g('running_mean'), g('running_var'), g('counter'), g('sums'), g('ws'),
+                                 _stream()), 'cms_bn_stats')
     elif what == 'finalize':
         check(fn['cms_bn_finalize_ex'](g('sums'), d.count, g('gamma'), g('beta'), d.eps, d.momentum, g('mean'), g('rstd'),
                                        g('scale'), g('shift'), g('running_mean'), g('running_var'), d.c, g('clear_a'),
@@ -483,6 +499,9 @@ def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, mo
     elif what == 'apply':
         check(fn['cms_bn_apply'](g('x'), g('res'), g('y'), d.dtype, g('scale'), g('shift'), d.relu, d.n_pixels, d.c, _stream()),
               'cms_bn_apply')
+    elif what == 'reduce_bwd' and t.get('ws') is not None:
+        check(fn['cms_bn_reduce_ws'](g('x'), g('dy'), g('y'), d.dtype, g('mean'), g('rstd'), g('sums'), d.n_pixels, d.c, 1, g('ws'),
+                                     _stream()), 'cms_bn_reduce_ws')
     elif what == 'reduce_bwd':
         check(fn['cms_bn_reduce'](g('x'), g('dy'), g('y'), d.dtype, g('mean'), g('rstd'), g('sums'), d.n_pixels, d.c, 1, _stream()),
               'cms_bn_reduce')

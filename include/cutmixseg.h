@@ -392,6 +392,20 @@ int cms_bn_finalize(const double* sums, double count, const float* gamma, const 
 int cms_bn_finalize_ex(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
                        float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var, int c,
                        double* clear_a, double* clear_b, long long* counter, void* stream);
+/* Round 3: the reductions without data atomics (the memory-side atomic units retire ~11 G adds per second: 2*C*blocks of them
+ * were 80 % of cms_bn_reduce's time). Blocks own 64-channel tiles, store partial sums into `ws` and the last block of a tile
+ * adds them in fixed order in fp64: bit-reproducible; `sums` (double[2*c]) is OVERWRITTEN, not accumulated. `ws`:
+ * cms_bn_workspace_bytes(n_pixels, c) bytes, zero-filled once by the caller, owned by one call site (launches on different
+ * streams must not share it); it is left ready for the next launch.
+ *   cms_bn_reduce_ws : cms_bn_reduce's contract (mode 0 / 1) -- the data-parallel protocol all-reduces `sums` after it.
+ *   cms_bn_stats     : forward statistics AND cms_bn_finalize_ex's work (count = n_pixels; `counter` incremented) in the one
+ *                      launch, for single-process callers; `sums` optional (NULL: not written). */
+size_t cms_bn_workspace_bytes(size_t n_pixels, int c);
+int cms_bn_reduce_ws(const void* x, const void* dy, const void* y, int dtype, const float* mean, const float* rstd, double* sums,
+                     size_t n_pixels, int c, int mode, void* ws, void* stream);
+int cms_bn_stats(const void* x, int dtype, size_t n_pixels, int c, const float* gamma, const float* beta, float eps,
+                 float momentum, float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var,
+                 long long* counter, double* sums, void* ws, void* stream);
 int cms_bn_apply(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
                  size_t n_pixels, int c, void* stream);
 int cms_bn_bwd_apply(const void* x, const void* dy, const void* y, void* dx, void* dres, int dtype, const float* mean,
@@ -465,7 +479,8 @@ int cms_program_add_aspp_spread(cms_program* p, const float* dlogits, void* d_nh
 int cms_program_add_sync(cms_program* p, int from_stream, int to_stream, int group);
 /* Batch-statistics BatchNorm launches inside a program (round 3: DeepLab v2 WITHOUT --freeze_bn on the executor,
  * architectures/deeplab2.py:72-84 / train_seg_semisup_mask_mt.py:587). `what`: 0 = cms_bn_reduce(mode 0), 1 = cms_bn_finalize,
- * 2 = cms_bn_apply, 3 = cms_bn_reduce(mode 1), 4 = cms_bn_bwd_apply, 5 = cms_increment_counter(counter); unused pointers NULL.
+ * 2 = cms_bn_apply, 3 = cms_bn_reduce(mode 1), 4 = cms_bn_bwd_apply, 5 = cms_increment_counter(counter), 6 = cms_bn_stats; unused pointers NULL. With `ws` set, what 0 / 3
+ * run cms_bn_reduce_ws.
  * All buffers are the caller's and persistent (a program is replayed many times). */
 typedef struct cms_bn_op {
     int what, dtype, c, relu;
@@ -487,6 +502,7 @@ typedef struct cms_bn_op {
     long long* counter;        /* what 1 (optional) / what 5: num_batches_tracked                              */
     double* clear_a;           /* what 1: zeroed after the statistics were read (cms_bn_finalize_ex), or NULL  */
     double* clear_b;
+    void* ws;                  /* what 0 / 3 (optional), 6: cms_bn_workspace_bytes(n_pixels, c) bytes          */
     double count;              /* pixels the statistics run over                                               */
     unsigned long long n_pixels;
     float eps, momentum;
