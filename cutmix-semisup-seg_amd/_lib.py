@@ -82,7 +82,7 @@ class BnOp(C.Structure):
                 ('sums', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('mean', c_void_p), ('rstd', c_void_p),
                 ('scale', c_void_p), ('shift', c_void_p), ('running_mean', c_void_p), ('running_var', c_void_p),
                 ('counter', c_void_p), ('clear_a', c_void_p), ('clear_b', c_void_p), ('ws', c_void_p), ('count', C.c_double), ('n_pixels', C.c_ulonglong), ('eps', c_float),
-                ('momentum', c_float)]
+                ('momentum', c_float), ('groups', c_int), ('reserved', c_int)]
 
 
 class AugmentDesc(C.Structure):
@@ -150,11 +150,15 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'cms_bn_finalize_ex': (c_int, [c_void_p, C.c_double, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'cms_bn_workspace_bytes': (c_size_t, [c_size_t, c_int]),
+    'cms_bn_workspace_bytes': (c_size_t, [c_size_t, c_int, c_int]),
     'cms_bn_reduce_ws': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
-                                 c_void_p, c_void_p]),
-    'cms_bn_stats': (c_int, [c_void_p, c_int, c_size_t, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
+                                 c_int, c_void_p, c_void_p]),
+    'cms_bn_stats': (c_int, [c_void_p, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cms_bn_apply_groups': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_size_t, c_int, c_int,
+                                    c_void_p]),
+    'cms_bn_bwd_apply_groups': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, C.c_double, c_size_t, c_int, c_int, c_void_p]),
     'cms_bn_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_size_t, c_int, c_void_p]),
     'cms_bn_bwd_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, C.c_double, c_size_t, c_int, c_void_p]),

@@ -131,12 +131,15 @@ class TorchEngine(object):
                     if residual is not None:
                         rh = residual.permute(0, 2, 3, 1)
                         rh = rh if rh.is_contiguous() else rh.contiguous()
+                    groups = int(getattr(self, 'bn_groups', 1))    # sample groups normalised apart (step.py, grouped passes)
                     out = ops.batch_norm_act(yh, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                             relu=relu, res=rh)
+                                             relu=relu, res=rh, groups=groups)
                     if bn.num_batches_tracked is not None:
-                        bn.num_batches_tracked += 1
+                        bn.num_batches_tracked += groups
                     return out.permute(0, 3, 1, 2)
                 # (odd channel counts / non-channels-last inputs: the library, in fp32)
+                if int(getattr(self, 'bn_groups', 1)) != 1:
+                    raise RuntimeError('grouped batch statistics need the csrc/bn.hip path (channels-last, channels % 8 == 0)')
                 y = F.batch_norm(y.float(), bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum,
                                  bn.eps).to(y.dtype)
                 if bn.num_batches_tracked is not None:
@@ -291,12 +294,33 @@ class ResNetDeepLab(nn.Module):
         else:
             eng = self._engine(x)
         x = eng.prepare_input(x)
-        x = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        eng.bn_groups = self.sample_groups()
+        try:
+            x = eng.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        finally:
+            eng.bn_groups = 1
         x = eng.maxpool(x)
         return x.permute(0, 2, 3, 1).contiguous()
 
+    def sample_groups(self):
+        """Number of equal runs of samples the NEXT batch-statistics pass normalises separately (set by the training step
+        around a pass over [supervised batch; mixed batch], see `supports_sample_groups`); 1 otherwise."""
+        return int(self.__dict__.get('_bn_groups', 1))
+
+    def set_sample_groups(self, groups):
+        self.__dict__['_bn_groups'] = int(groups)
+
+    def supports_sample_groups(self):
+        """True when a batch-statistics pass of this network runs entirely on BatchNorm kernels that keep sample groups apart
+        (the executor's units and the stem's csrc/bn.hip layer): the training step may then push the reference's separate
+        forward passes (train_seg_semisup_mask_mt.py:296-358) through the network as ONE batch."""
+        return (not self._frozen_bn()) and self._use_hip_body()
+
     def forward_lowres(self, x):
         """(N,3,H,W) -> (N,C,h,w) fp32 head output (the reference's `x` just before its interpolate, :193)."""
+        if not x.is_cuda:
+            raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
+                               'fallback'.format(x.device))
         if self._use_hip_body():
             from ..backbone_hip import run_body
             return run_body(self.hip_executor(), self.stem_nhwc(x))

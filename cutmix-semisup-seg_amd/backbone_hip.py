@@ -272,7 +272,10 @@ class DeepLabHipExecutor(object):
         bn = self.batch_statistics()
         if not bn and not self._affine_ready:
             self._refresh_affine()
-        return {'cur': x, 'saved': [] if save else None, 'bn': bn}
+        groups = self.bn_groups() if bn else 1
+        if x.shape[0] % groups != 0:
+            raise ValueError('{} sample groups do not divide a batch of {}'.format(groups, x.shape[0]))
+        return {'cur': x, 'saved': [] if save else None, 'bn': bn, 'groups': groups}
 
     def fwd_block(self, st, bi):
         if st.get('bn'):
@@ -306,6 +309,12 @@ class DeepLabHipExecutor(object):
         return any(self._bn_module(c).training for c in self._all_convs())      # (the executor's own layers: DeepLab v3+ keeps
                                                                                 # its HEAD on batch statistics, not the backbone)
 
+    def bn_groups(self):
+        """Sample groups of the next batch-statistics pass (architectures/deeplab2.py:set_sample_groups): the batch is that
+        many equal runs of samples, each normalised with its own statistics."""
+        fn = getattr(self.net, 'sample_groups', None)
+        return 1 if fn is None else int(fn())
+
     def _bn_module(self, c):
         mods = self.__dict__.setdefault('_bn_modules', {})
         m = mods.get(c.bn)
@@ -313,7 +322,7 @@ class DeepLabHipExecutor(object):
             m = mods[c.bn] = self.net.get_submodule(c.bn)
         return m
 
-    def _fwd_unit_bn(self, x, c, relu, res=None, save=True):
+    def _fwd_unit_bn(self, x, c, relu, res=None, save=True, groups=1):
         """y = relu(batch_norm(conv(x)) (+ res)) as THREE launches on persistent buffers: raw convolution, statistics (one
         atomics-free reduction whose last blocks also finalise: scale / shift, running statistics, batch counter), normalise +
         residual + ReLU. -> (y, saved), saved = (u, y, mean, rstd, backward sums, workspace) for `_bwd_unit_bn`."""
@@ -323,41 +332,45 @@ class DeepLabHipExecutor(object):
         a, bn, C = self.arena, self._bn_module(c), c.cout
         npix = n * ho * wo
         dev = x.device
-        bsums = torch.empty(2 * C, dtype=torch.float64, device=dev) if save else None
-        mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
-        ws = ops.bn_workspace(npix, C, dev)         # this unit's: tile counters + partial sums (forward, then backward)
-        ops.bn_op('stats', c=C, dtype=self.dtype, n_pixels=npix, eps=bn.eps, momentum=bn.momentum, x=u, ws=ws,
+        G = int(groups)
+        bsums = torch.empty(G * 2 * C, dtype=torch.float64, device=dev) if save else None
+        mean, rstd, scale, shift = (torch.empty(G * C, dtype=torch.float32, device=dev) for _ in range(4))
+        ws = ops.bn_workspace(npix, C, dev, G)      # this unit's: tile counters + partial sums (forward, then backward)
+        ops.bn_op('stats', c=C, dtype=self.dtype, n_pixels=npix, groups=G, eps=bn.eps, momentum=bn.momentum, x=u, ws=ws,
                   gamma=a.view(c.bn + '.weight'), beta=a.view(c.bn + '.bias'), mean=mean, rstd=rstd, scale=scale, shift=shift,
                   running_mean=a.view(c.bn + '.running_mean'), running_var=a.view(c.bn + '.running_var'),
                   counter=bn.num_batches_tracked)
         y = torch.empty_like(u)
-        ops.bn_op('apply', c=C, dtype=self.dtype, n_pixels=npix, relu=relu, x=u, res=res, y=y, scale=scale, shift=shift)
-        return y, (u, y if relu else None, mean, rstd, bsums, ws)
+        ops.bn_op('apply', c=C, dtype=self.dtype, n_pixels=npix, groups=G, relu=relu, x=u, res=res, y=y, scale=scale,
+                  shift=shift)
+        return y, (u, y if relu else None, mean, rstd, bsums, ws, G)
 
     def _bwd_unit_bn(self, dy, saved, c, want_res):
         """Backward of the normalisation of one unit: dy (gradient wrt y) -> (du = gradient wrt the convolution output,
         dres = gradient wrt the residual input or None). The ReLU mask comes from the stored y."""
-        u, y, mean, rstd, sums, ws = saved      # `sums` is overwritten by the reduction; `ws`: the unit's workspace
+        u, y, mean, rstd, sums, ws, G = saved   # `sums` is overwritten by the reduction; `ws`: the unit's workspace
         C = c.cout
         npix = u.numel() // C
-        ops.bn_op('reduce_bwd', c=C, dtype=self.dtype, n_pixels=npix, x=u, dy=dy, y=y, mean=mean, rstd=rstd, sums=sums, ws=ws)
+        ops.bn_op('reduce_bwd', c=C, dtype=self.dtype, n_pixels=npix, groups=G, x=u, dy=dy, y=y, mean=mean, rstd=rstd, sums=sums,
+                  ws=ws)
         du = torch.empty_like(u)
         dres = torch.empty_like(u) if want_res else None
-        ops.bn_op('bwd_apply', c=C, dtype=self.dtype, n_pixels=npix, count=npix, x=u, dy=dy, y=y, dx=du, dres=dres, mean=mean,
+        ops.bn_op('bwd_apply', c=C, dtype=self.dtype, n_pixels=npix, groups=G, count=npix // G, x=u, dy=dy, y=y, dx=du, dres=dres,
+                  mean=mean,
                   rstd=rstd, gamma=self.arena.view(c.bn + '.weight'), sums=sums)
         return du, dres
 
     def _fwd_block_bn(self, st, bi):
         b, cur = self.blocks[bi], st['cur']
-        save = st['saved'] is not None
-        a1, s1 = self._fwd_unit_bn(cur, b.c1, True, save=save)
-        a2, s2 = self._fwd_unit_bn(a1, b.c2, True, save=save)
+        save, G = st['saved'] is not None, st.get('groups', 1)
+        a1, s1 = self._fwd_unit_bn(cur, b.c1, True, save=save, groups=G)
+        a2, s2 = self._fwd_unit_bn(a1, b.c2, True, save=save, groups=G)
         sd = None
         if b.cd is None:
             res = cur
         else:
-            res, sd = self._fwd_unit_bn(cur, b.cd, False, save=save)
-        out, s3 = self._fwd_unit_bn(a2, b.c3, True, res=res, save=save)
+            res, sd = self._fwd_unit_bn(cur, b.cd, False, save=save, groups=G)
+        out, s3 = self._fwd_unit_bn(a2, b.c3, True, res=res, save=save, groups=G)
         st['cur'] = out
         if st['saved'] is not None:
             st['saved'].append((cur, a1, a2, s1, s2, s3, sd))
@@ -458,6 +471,10 @@ class DeepLabHipExecutor(object):
             self._refresh_affine()
         self._refresh_aspp_fwd()
 
+    def _bn_key(self):
+        """0 = frozen statistics (folded affine), else the number of sample groups of a batch-statistics pass."""
+        return self.bn_groups() if self.batch_statistics() else 0
+
     def _tile_key(self):
         return (self.conv_tile, tuple(sorted(self.tile_rules.items())))
 
@@ -482,7 +499,7 @@ class DeepLabHipExecutor(object):
         synchronising, evicting and re-recording on almost every image, and pins no activation sets in HBM."""
         if save:
             return False
-        key = (kind, tuple(int(v) for v in shape), False, self._tile_key()) + ((self.batch_statistics(),) if kind == 'fwd' else ())
+        key = (kind, tuple(int(v) for v in shape), False, self._tile_key()) + ((self._bn_key(),) if kind == 'fwd' else ())
         if key in self._programs:
             return False
         seen = self.__dict__.setdefault('_seen_shapes', {})
@@ -495,7 +512,7 @@ class DeepLabHipExecutor(object):
     def forward_program(self, shape, save):
         """The recorded forward pass for an input of `shape` (N, h, w, 64) -- recorded on first use, on the CURRENT
         stream (its stream 0). Attributes: x_in (persistent input buffer), logits, saved."""
-        key = ('fwd', tuple(int(v) for v in shape), bool(save), self._tile_key(), self.batch_statistics())
+        key = ('fwd', tuple(int(v) for v in shape), bool(save), self._tile_key(), self._bn_key())
         prog = self._program_lookup(key)
         if prog is None:
             self._prepare_forward()
@@ -509,7 +526,7 @@ class DeepLabHipExecutor(object):
                 prog.group = len(self.blocks)
                 logits, saved = self.fwd_end(st)
             prog.x_in, prog.logits, prog.saved = x_in, logits, saved
-            prog.bn = key[-1]
+            prog.bn = bool(key[-1])
             prog.bwd = {}
             prog.generation = -1
             self._programs[key] = prog

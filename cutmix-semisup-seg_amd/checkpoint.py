@@ -22,7 +22,7 @@ import torch
 
 # attributes of this build's runtime that must not travel in a pickle
 RUNTIME_ATTRS = ('_hip_executor', '_hip_executors', '_cms_arena', '_hip_engine', '_hip_engines', '_hip_engine_hooked', 'engine',
-                 '_sentinel', '_data_grad_only')
+                 '_sentinel', '_data_grad_only', '_bn_groups')
 
 
 def export_module(net):

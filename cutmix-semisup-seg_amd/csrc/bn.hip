@@ -182,27 +182,40 @@ __device__ __forceinline__ void bn_finalize_channel(const BnFin& f, int c, doubl
     }
 }
 
-// Round 3: the reduction WITHOUT data atomics. bn_reduce_kernel ends every block with 2 C fp64 atomics; the memory-side
-// atomic units retire ~11 G of them per second whatever the addresses (tools/atomic_probe.hip), so a C = 1024 layer on 256
-// blocks spends ~48 us there against ~8 us of loads (profiles/r03t_*: 52 / 58 us per launch, 37 % of the batch-statistics
-// step). Here a block owns a CHANNEL TILE of 64 channels (one 128-byte line per pixel row in bf16) and one of S pixel
-// splits, stores its 128 partial sums with plain stores, and the LAST block of a tile to arrive (one counter atomic per
-// block, self-resetting) adds the S partials in fixed order in fp64 -- bit-reproducible -- and either writes sums[] (the
-// data-parallel protocol all-reduces them) or, FIN, finalises its 64 channels on the spot (no bn_finalize launch).
-//   ws: unsigned counters[tiles] (zero before the first use) padded to 256 bytes, then float part[tiles][S][2][64]
+// Round 3: the reduction WITHOUT data atomics. bn_reduce_kernel ends every block with 2 C fp64 atomics; inside the training
+// step they queue behind the weight gradients' 2.5 GB of fp32 atomics in the memory-side atomic units (52 / 58 us per launch in
+// the step against 10-22 us alone, profiles/r03t_*, r03bn_*). Here a block owns a CHANNEL TILE of 64 channels (one 128-byte line
+// per pixel row in bf16), one sample GROUP and one of S pixel splits of that group, stores its 128 partial sums, and the LAST
+// block of a tile to arrive (one counter atomic per block, self-resetting) adds the partials of every group in fixed order in
+// fp64 -- bit-reproducible -- and either writes sums[] (the data-parallel protocol all-reduces them) or, FIN, finalises its 64
+// channels on the spot (no bn_finalize launch).
+//   GROUPS (gridDim.y): the pixel rows are G equal runs of consecutive samples whose statistics are kept APART -- one launch
+//   normalises the supervised and the mixed batch of the student (or the teacher's two batches) exactly as the reference's
+//   separate forward passes do (train_seg_semisup_mask_mt.py:296-358), the running statistics moving once per group, in order.
+//   Layouts: mean / rstd / scale / shift [G][C], sums [G][2][C].
+//   ws: unsigned counters[tiles] (zero before the first use) padded to 256 bytes, then float part[tiles][G][S][2][64]
 constexpr int BN_CT = 64;            // channels per tile
+
+// 16-byte agent-coherent load (global_load_dwordx4 sc1: served past the non-coherent L2 lines of other XCDs)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 load_sc1_x4(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 
 template <class T, int MODE, bool FIN>
 __global__ __launch_bounds__(256) void bn_reduce_tiled_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                               const T* __restrict__ y, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, double* __restrict__ sums,
                                                               unsigned* counters, float* part,
-                                                              size_t P, int C, int tiles, int S, BnFin fin) {
+                                                              size_t Pg, int C, int tiles, int S, BnFin fin) {
     __shared__ float red[4][2 * BN_CT];
-    __shared__ double redd[256];
+    __shared__ double redd[8][2 * BN_CT];
     __shared__ int last_flag;
     const int tid = threadIdx.x;
     const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+    const int G = gridDim.y, grp = blockIdx.y;
     const int cgl = tid & 7, slot = tid >> 3;          // 8 channel groups of 8 channels x 32 pixel rows side by side
     const int c0 = tile * BN_CT + cgl * 8;
     const bool active = c0 < C;
@@ -212,8 +225,8 @@ __global__ __launch_bounds__(256) void bn_reduce_tiled_kernel(const T* __restric
     if (active) {
         float mu[8], rs[8];
         if (MODE == 1) {
-            load8(mean + c0, mu);
-            load8(rstd + c0, rs);
+            load8(mean + (size_t)grp * C + c0, mu);
+            load8(rstd + (size_t)grp * C + c0, rs);
         }
         auto accumulate = [&](const float (&xv)[8], const float (&dv)[8], const float (&yv)[8]) {
             if (MODE == 0) {
@@ -228,13 +241,14 @@ __global__ __launch_bounds__(256) void bn_reduce_tiled_kernel(const T* __restric
                 }
             }
         };
+        const size_t base = (size_t)grp * Pg * (size_t)C + (size_t)c0;
         const size_t stride = (size_t)S * 32;
         size_t p = (size_t)split * 32 + slot;
-        for (; p + 3 * stride < P; p += 4 * stride) {
+        for (; p + 3 * stride < Pg; p += 4 * stride) {
             float xv[4][8], dv[4][8], yv[4][8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const size_t o = (p + u * stride) * (size_t)C + (size_t)c0;
+                const size_t o = base + (p + u * stride) * (size_t)C;
                 load8(x + o, xv[u]);
                 if (MODE == 1) {
                     load8(dy + o, dv[u]);
@@ -244,8 +258,8 @@ __global__ __launch_bounds__(256) void bn_reduce_tiled_kernel(const T* __restric
 #pragma unroll
             for (int u = 0; u < 4; ++u) accumulate(xv[u], dv[u], yv[u]);
         }
-        for (; p < P; p += stride) {
-            const size_t o = p * (size_t)C + (size_t)c0;
+        for (; p < Pg; p += stride) {
+            const size_t o = base + p * (size_t)C;
             float xv[8], dv[8], yv[8];
             load8(x + o, xv);
             if (MODE == 1) {
@@ -272,42 +286,68 @@ __global__ __launch_bounds__(256) void bn_reduce_tiled_kernel(const T* __restric
         }
     }
     __syncthreads();
-    float* mine = part + ((size_t)tile * S + split) * (2 * BN_CT);
-    if (tid < 2 * BN_CT) mine[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    // release the partials, count this block in; the block that completes the tile reads all S of them
-    __threadfence();
+    // The partials travel through AGENT-SCOPE relaxed atomic stores / `sc1` loads (write-through, L2-bypassing accesses): no
+    // __threadfence(), whose release / acquire halves are a writeback / invalidate of the whole XCD L2 on this part -- with
+    // them the kernel took 26-93 us alone where the loads need 5-20 (tools/bn_bench.py, profiles/r03bn_*). An explicit
+    // s_waitcnt vmcnt(0) (the write-through stores have been acknowledged; a workgroup-scope release fence emits nothing on
+    // this target) and the barrier order them before the counter add.
+    float* mine = part + (((size_t)tile * G + grp) * S + split) * (2 * BN_CT);
+    if (tid < 2 * BN_CT)
+        __hip_atomic_store(mine + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        const unsigned prev = atomicAdd(counters + tile, 1u);
-        last_flag = prev == (unsigned)(S - 1);
+        const unsigned prev = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = prev == (unsigned)(G * S - 1);
     }
     __syncthreads();
     if (!last_flag) return;
-    __threadfence();
-    {
-        const float* pp = part + (size_t)tile * S * (2 * BN_CT) + (tid & 127);
-        double acc = 0.0;
-        int s = tid >> 7;
-        for (; s + 6 < S; s += 8) {
-            const float v0 = pp[(size_t)s * 128], v1 = pp[(size_t)(s + 2) * 128], v2 = pp[(size_t)(s + 4) * 128],
-                        v3 = pp[(size_t)(s + 6) * 128];
-            acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+    // the tile is complete: per group, S rows of 128 floats; 32 lanes x 16 bytes cover a row, 8 rows side by side, up to 8 loads
+    // in flight per thread; fixed order: rows rg, rg + 8, ... per thread, then the 8 row groups
+    const int q = tid & 31, rg = tid >> 5;
+    for (int g = 0; g < G; ++g) {
+        const float* pp = part + ((size_t)tile * G + g) * S * (2 * BN_CT) + q * 4;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        int r = rg;
+        for (; r + 56 < S; r += 64) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = load_sc1_x4(pp + (size_t)(r + 8 * u) * (2 * BN_CT));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]),
+                         "+v"(v[7]) :: "memory");
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc[0] += (double)v[u].x; acc[1] += (double)v[u].y; acc[2] += (double)v[u].z; acc[3] += (double)v[u].w;
+            }
         }
-        for (; s < S; s += 2) acc += (double)pp[(size_t)s * 128];
-        redd[tid] = acc;
-    }
-    __syncthreads();
-    if (tid < BN_CT) {
-        const int c = tile * BN_CT + tid;
-        if (c < C) {
-            const double s0 = redd[tid] + redd[128 + tid], s1 = redd[BN_CT + tid] + redd[128 + BN_CT + tid];
-            if (sums) { sums[c] = s0; sums[C + c] = s1; }
-            if (FIN) bn_finalize_channel(fin, c, s0, s1);
+        for (; r < S; r += 8) {
+            f32x4 v = load_sc1_x4(pp + (size_t)r * (2 * BN_CT));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory");
+            acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
+        }
+        __syncthreads();                                // (previous group's readers of redd are done)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) redd[rg][q * 4 + e] = acc[e];
+        __syncthreads();
+        if (tid < BN_CT) {
+            const int c = tile * BN_CT + tid;
+            if (c < C) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s0 += redd[k][tid]; s1 += redd[k][BN_CT + tid]; }
+                if (sums) { sums[(size_t)g * 2 * C + c] = s0; sums[(size_t)g * 2 * C + C + c] = s1; }
+                if (FIN) {
+                    BnFin f = fin;                      // this group's outputs; the running statistics move once per group, in order
+                    f.mean += (size_t)g * C; f.rstd += (size_t)g * C; f.scale += (size_t)g * C; f.shift += (size_t)g * C;
+                    bn_finalize_channel(f, c, s0, s1);
+                }
+            }
         }
     }
     if (tid == 0) {
-        counters[tile] = 0;                            // ready for the next launch on this workspace
-        if (FIN && tile == 0 && fin.counter) *fin.counter += 1;
+        __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        if (FIN && tile == 0 && fin.counter) *fin.counter += G;
     }
 }
 
@@ -341,15 +381,19 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
     if (clear_b) { clear_b[c] = 0.0; clear_b[C + c] = 0.0; }
 }
 
+// gridDim.y = sample groups (scale / shift / mean / rstd [G][C], sums [G][2][C]); P = pixel rows of ONE group
 template <class T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        int relu, size_t P, int C) {
     const int CG = C / 8;
     const size_t total = P * CG;
+    const size_t gbase = (size_t)blockIdx.y * total * 8;
+    scale += (size_t)blockIdx.y * C;
+    shift += (size_t)blockIdx.y * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int cg = (int)(i % CG);
-        const size_t o = i * 8;
+        const size_t o = gbase + i * 8;
         float xv[8], sc[8], sh[8], rv[8];
         load8(x + o, xv);
         load8(scale + cg * 8, sc);
@@ -366,6 +410,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 }
 
 // dx = gamma * rstd * (dy' - sum_dy / n - xhat * sum_dyxhat / n); dres = dy' (gradient of the residual branch, optional)
+// The host picks a grid whose thread count is a multiple of C / 8, so a thread keeps ITS channel group over the whole loop and
+// loads the per-channel coefficients once: the per-element version fetched sums[c] as 16 scattered 8-byte loads per 16-byte
+// vector -- 64 cache lines per wave instruction against the 24 lines of x, dy, y -- and ran at 1.7-1.9 TB/s where bn_apply
+// reaches 5.3-6 (tools/bn_bench.py, profiles/r03bn_*: 160 -> 56 us on 16810 x 2048).
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const T* __restrict__ y, T* __restrict__ dx, T* __restrict__ dres,
@@ -374,29 +422,51 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            double count, size_t P, int C) {
     const int CG = C / 8;
     const size_t total = P * CG;
-    const double inv_count = 1.0 / count;       // (two fp64 DIVISIONS per element made this kernel ALU-bound: 52 us where its
-                                                // 4-5 tensors of traffic take 25, profiles/r03t_*)
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        const size_t o = i * 8;
-        float xv[8], dv[8], yv[8], mu[8], rs[8], out[8], dr[8];
-        load8(x + o, xv);
-        load8(dy + o, dv);
-        if (y) load8(y + o, yv);
+    const size_t gbase = (size_t)blockIdx.y * total * 8;
+    mean += (size_t)blockIdx.y * C;
+    rstd += (size_t)blockIdx.y * C;
+    sums += (size_t)blockIdx.y * 2 * C;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;          // multiple of CG (cms_bn_bwd_apply)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cg = (int)(i % CG);
+    float mu[8], rs[8], grs[8], m1[8], m2[8];
+    {
+        const double inv_count = 1.0 / count;
         load8(mean + cg * 8, mu);
         load8(rstd + cg * 8, rs);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = cg * 8 + e;
+            m1[e] = (float)(sums[c] * inv_count);
+            m2[e] = (float)(sums[C + c] * inv_count);
+            grs[e] = (gamma ? gamma[c] : 1.0f) * rs[e];
+        }
+    }
+    auto one = [&](const float (&xv)[8], const float (&dv)[8], const float (&yv)[8], size_t o) {
+        float out[8], dr[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
             const float d = (y == nullptr || yv[e] > 0.0f) ? dv[e] : 0.0f;
             const float xh = (xv[e] - mu[e]) * rs[e];
-            const float m1 = (float)(sums[c] * inv_count), m2 = (float)(sums[C + c] * inv_count);
-            const float g = gamma ? gamma[c] : 1.0f;
-            out[e] = g * rs[e] * (d - m1 - xh * m2);
+            out[e] = grs[e] * (d - m1[e] - xh * m2[e]);
             dr[e] = d;
         }
         store8(dx + o, out);
         if (dres) store8(dres + o, dr);
+    };
+    for (; i + stride < total; i += 2 * stride) {                  // two vectors in flight per thread
+        float xa[8], da[8], ya[8], xb[8], db[8], yb[8];
+        const size_t oa = gbase + i * 8, ob = gbase + (i + stride) * 8;
+        load8(x + oa, xa); load8(dy + oa, da); if (y) load8(y + oa, ya);
+        load8(x + ob, xb); load8(dy + ob, db); if (y) load8(y + ob, yb);
+        one(xa, da, ya, oa);
+        one(xb, db, yb, ob);
+    }
+    if (i < total) {
+        float xa[8], da[8], ya[8];
+        const size_t oa = gbase + i * 8;
+        load8(x + oa, xa); load8(dy + oa, da); if (y) load8(y + oa, ya);
+        one(xa, da, ya, oa);
     }
 }
 
@@ -447,38 +517,43 @@ extern "C" int cms_bn_reduce(const void* x, const void* dy, const void* y, int d
 }
 
 // ---- atomics-free reduction (bn_reduce_tiled_kernel) ----------------------------------------------------------------------
-static void bn_tiling(size_t n_pixels, int c, int* tiles, int* splits) {
+static int bn_groups_ok(size_t n_pixels, int groups) { return groups >= 1 && n_pixels % (size_t)groups == 0; }
+
+static void bn_tiling(size_t n_pixels, int c, int groups, int* tiles, int* splits) {
     static int target = -1;                         // CMS_BN_BLOCKS: blocks per launch aimed at (A/B switch, read once)
     if (target < 0) {
         const char* e = getenv("CMS_BN_BLOCKS");
-        target = e ? std::max(1, atoi(e)) : 1024;
+        target = e ? std::max(1, atoi(e)) : 512;
     }
     const int t = (c + BN_CT - 1) / BN_CT;
-    size_t s = (size_t)std::max(1, target / t);
-    s = std::min<size_t>(s, 256);
-    s = std::min<size_t>(s, (n_pixels + 127) / 128);       // >= 4 rounds of 32 pixel rows per block
+    const size_t pg = n_pixels / (size_t)groups;
+    size_t s = (size_t)std::max(1, target / (t * groups));
+    s = std::min<size_t>(s, (size_t)std::max(1, 128 / groups));     // <= 128 partial rows per tile for its last block to add
+    s = std::min<size_t>(s, (pg + 127) / 128);                      // >= 4 rounds of 32 pixel rows per block
     *tiles = t;
     *splits = (int)std::max<size_t>(s, 1);
 }
 
 static size_t bn_counter_bytes(int tiles) { return ((size_t)tiles * sizeof(unsigned) + 255) / 256 * 256; }
 
-extern "C" size_t cms_bn_workspace_bytes(size_t n_pixels, int c) {
-    if (n_pixels == 0 || c <= 0) return 0;
+extern "C" size_t cms_bn_workspace_bytes(size_t n_pixels, int c, int groups) {
+    if (n_pixels == 0 || c <= 0 || !bn_groups_ok(n_pixels, groups)) return 0;
     int tiles, S;
-    bn_tiling(n_pixels, c, &tiles, &S);
-    return bn_counter_bytes(tiles) + (size_t)tiles * S * 2 * BN_CT * sizeof(float);
+    bn_tiling(n_pixels, c, groups, &tiles, &S);
+    return bn_counter_bytes(tiles) + (size_t)tiles * groups * S * 2 * BN_CT * sizeof(float);
 }
 
 static int bn_reduce_tiled(const void* x, const void* dy, const void* y, int dtype, const float* mean, const float* rstd,
-                           double* sums, size_t n_pixels, int c, int mode, void* ws, const BnFin* fin, hipStream_t s) {
+                           double* sums, size_t n_pixels, int c, int groups, int mode, void* ws, const BnFin* fin,
+                           hipStream_t s) {
     int tiles, S;
-    bn_tiling(n_pixels, c, &tiles, &S);
+    bn_tiling(n_pixels, c, groups, &tiles, &S);
     unsigned* counters = (unsigned*)ws;
     float* part = (float*)((char*)ws + bn_counter_bytes(tiles));
-    const dim3 grid((unsigned)(tiles * S));
+    const dim3 grid((unsigned)(tiles * S), (unsigned)groups);
+    const size_t pg = n_pixels / (size_t)groups;
     BnFin f = fin ? *fin : BnFin{};
-#define CMS_BN_TILED(T, M, F) hipLaunchKernelGGL((bn_reduce_tiled_kernel<T, M, F>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, sums, counters, part, n_pixels, c, tiles, S, f)
+#define CMS_BN_TILED(T, M, F) hipLaunchKernelGGL((bn_reduce_tiled_kernel<T, M, F>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, sums, counters, part, pg, c, tiles, S, f)
     if (dtype == CMS_F32) {
         if (mode == 1) CMS_BN_TILED(float, 1, false);
         else if (fin) CMS_BN_TILED(float, 0, true);
@@ -493,23 +568,26 @@ static int bn_reduce_tiled(const void* x, const void* dy, const void* y, int dty
 }
 
 extern "C" int cms_bn_reduce_ws(const void* x, const void* dy, const void* y, int dtype, const float* mean, const float* rstd,
-                                double* sums, size_t n_pixels, int c, int mode, void* ws, void* stream) {
+                                double* sums, size_t n_pixels, int c, int groups, int mode, void* ws, void* stream) {
     CMS_REQUIRE(x && sums && ws, "bn_reduce_ws: NULL pointer");
     CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_reduce_ws: bad dtype");
     CMS_REQUIRE(bn_geo_ok(n_pixels, c), "bn_reduce_ws: bad geometry (channels %% 8 == 0)");
+    CMS_REQUIRE(bn_groups_ok(n_pixels, groups), "bn_reduce_ws: %d groups do not divide %zu pixel rows", groups, n_pixels);
     CMS_REQUIRE(mode == 0 || (mode == 1 && dy && mean && rstd), "bn_reduce_ws: mode 1 needs dy, mean, rstd");
-    bn_reduce_tiled(x, dy, y, dtype, mean, rstd, sums, n_pixels, c, mode, ws, nullptr, (hipStream_t)stream);
+    bn_reduce_tiled(x, dy, y, dtype, mean, rstd, sums, n_pixels, c, groups, mode, ws, nullptr, (hipStream_t)stream);
     return launch_status("cms_bn_reduce_ws");
 }
 
-extern "C" int cms_bn_stats(const void* x, int dtype, size_t n_pixels, int c, const float* gamma, const float* beta, float eps,
-                            float momentum, float* mean, float* rstd, float* scale, float* shift, float* running_mean,
-                            float* running_var, long long* counter, double* sums, void* ws, void* stream) {
+extern "C" int cms_bn_stats(const void* x, int dtype, size_t n_pixels, int c, int groups, const float* gamma, const float* beta,
+                            float eps, float momentum, float* mean, float* rstd, float* scale, float* shift,
+                            float* running_mean, float* running_var, long long* counter, double* sums, void* ws, void* stream) {
     CMS_REQUIRE(x && ws && mean && rstd && scale && shift, "bn_stats: NULL pointer");
     CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_stats: bad dtype");
     CMS_REQUIRE(bn_geo_ok(n_pixels, c), "bn_stats: bad geometry (channels %% 8 == 0)");
-    BnFin f{gamma, beta, mean, rstd, scale, shift, running_mean, running_var, counter, (double)n_pixels, eps, momentum};
-    bn_reduce_tiled(x, nullptr, nullptr, dtype, nullptr, nullptr, sums, n_pixels, c, 0, ws, &f, (hipStream_t)stream);
+    CMS_REQUIRE(bn_groups_ok(n_pixels, groups), "bn_stats: %d groups do not divide %zu pixel rows", groups, n_pixels);
+    BnFin f{gamma, beta, mean, rstd, scale, shift, running_mean, running_var, counter, (double)(n_pixels / (size_t)groups), eps,
+            momentum};
+    bn_reduce_tiled(x, nullptr, nullptr, dtype, nullptr, nullptr, sums, n_pixels, c, groups, 0, ws, &f, (hipStream_t)stream);
     return launch_status("cms_bn_stats");
 }
 
@@ -530,37 +608,64 @@ extern "C" int cms_bn_finalize(const double* sums, double count, const float* ga
                               nullptr, nullptr, nullptr, stream);
 }
 
-extern "C" int cms_bn_apply(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
-                            size_t n_pixels, int c, void* stream) {
+extern "C" int cms_bn_apply_groups(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift,
+                                   int relu, size_t n_pixels, int c, int groups, void* stream) {
     CMS_REQUIRE(x && y && scale && shift, "bn_apply: NULL pointer");
     CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_apply: bad dtype");
     CMS_REQUIRE(bn_geo_ok(n_pixels, c), "bn_apply: bad geometry (channels %% 8 == 0)");
-    const size_t total = n_pixels * (c / 8);
+    CMS_REQUIRE(bn_groups_ok(n_pixels, groups), "bn_apply: %d groups do not divide %zu pixel rows", groups, n_pixels);
+    const size_t pg = n_pixels / (size_t)groups;
+    const size_t total = pg * (c / 8);
     hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)grid_for(total, 256, std::max(1, 256 * 16 / groups)), (unsigned)groups);
     if (dtype == CMS_F32)
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, (const float*)x,
-                           (const float*)res, (float*)y, scale, shift, relu, n_pixels, c);
+        hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)res, (float*)y, scale,
+                           shift, relu, pg, c);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<uint16_t>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, (const uint16_t*)x,
-                           (const uint16_t*)res, (uint16_t*)y, scale, shift, relu, n_pixels, c);
+        hipLaunchKernelGGL(bn_apply_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)res,
+                           (uint16_t*)y, scale, shift, relu, pg, c);
     return launch_status("cms_bn_apply");
+}
+
+extern "C" int cms_bn_apply(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
+                            size_t n_pixels, int c, void* stream) {
+    return cms_bn_apply_groups(x, res, y, dtype, scale, shift, relu, n_pixels, c, 1, stream);
+}
+
+extern "C" int cms_bn_bwd_apply_groups(const void* x, const void* dy, const void* y, void* dx, void* dres, int dtype,
+                                       const float* mean, const float* rstd, const float* gamma, const double* sums, double count,
+                                       size_t n_pixels, int c, int groups, void* stream) {
+    CMS_REQUIRE(x && dy && dx && mean && rstd && sums, "bn_bwd_apply: NULL pointer");
+    CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_bwd_apply: bad dtype");
+    CMS_REQUIRE(bn_geo_ok(n_pixels, c) && count > 0, "bn_bwd_apply: bad geometry (channels %% 8 == 0)");
+    CMS_REQUIRE(bn_groups_ok(n_pixels, groups), "bn_bwd_apply: %d groups do not divide %zu pixel rows", groups, n_pixels);
+    const size_t pg = n_pixels / (size_t)groups;
+    const size_t total = pg * (c / 8);
+    hipStream_t s = (hipStream_t)stream;
+    // thread count = multiple of the channel groups (a thread keeps its group): blocks in units of CG / gcd(CG, 256)
+    const int CG = c / 8;
+    int a = CG, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const unsigned unit = (unsigned)(CG / a);
+    static int cap = -1;                            // CMS_BN_APPLY_BLOCKS (A/B switch, read once)
+    if (cap < 0) {
+        const char* e = getenv("CMS_BN_APPLY_BLOCKS");
+        cap = e ? std::max(1, atoi(e)) : 1024;
+    }
+    unsigned want = (unsigned)std::min<size_t>((total + 255) / 256, (size_t)std::max(1, cap / groups));
+    want = std::max(unit, want / unit * unit);
+    const dim3 grid(want, (unsigned)groups);
+    if (dtype == CMS_F32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y,
+                           (float*)dx, (float*)dres, mean, rstd, gamma, sums, count, pg, c);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)dy,
+                           (const uint16_t*)y, (uint16_t*)dx, (uint16_t*)dres, mean, rstd, gamma, sums, count, pg, c);
+    return launch_status("cms_bn_bwd_apply");
 }
 
 extern "C" int cms_bn_bwd_apply(const void* x, const void* dy, const void* y, void* dx, void* dres, int dtype, const float* mean,
                                 const float* rstd, const float* gamma, const double* sums, double count, size_t n_pixels, int c,
                                 void* stream) {
-    CMS_REQUIRE(x && dy && dx && mean && rstd && sums, "bn_bwd_apply: NULL pointer");
-    CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_bwd_apply: bad dtype");
-    CMS_REQUIRE(bn_geo_ok(n_pixels, c) && count > 0, "bn_bwd_apply: bad geometry (channels %% 8 == 0)");
-    const size_t total = n_pixels * (c / 8);
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == CMS_F32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, (const float*)x,
-                           (const float*)dy, (const float*)y, (float*)dx, (float*)dres, mean, rstd, gamma, sums, count,
-                           n_pixels, c);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<uint16_t>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s,
-                           (const uint16_t*)x, (const uint16_t*)dy, (const uint16_t*)y, (uint16_t*)dx, (uint16_t*)dres, mean,
-                           rstd, gamma, sums, count, n_pixels, c);
-    return launch_status("cms_bn_bwd_apply");
+    return cms_bn_bwd_apply_groups(x, dy, y, dx, dres, dtype, mean, rstd, gamma, sums, count, n_pixels, c, 1, stream);
 }

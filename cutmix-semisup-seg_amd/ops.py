@@ -383,19 +383,22 @@ def _world(group):
 
 class _BatchNormActFn(torch.autograd.Function):
     """relu(batch_norm(x) (+ res)) on NHWC tensors with batch statistics (csrc/bn.hip); under torch.distributed the
-    statistics are all-reduced between the two passes of either direction (SyncBN)."""
+    statistics are all-reduced between the two passes of either direction (SyncBN). `groups`: the batch
+    is that many equal runs of samples normalised separately (one launch for what the reference does in separate passes)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, res, running_mean, running_var, momentum, eps, relu, group):
+    def forward(ctx, x, gamma, beta, res, running_mean, running_var, momentum, eps, relu, group, groups):
         n_pix = x.numel() // x.shape[-1]
         c = int(x.shape[-1])
         dev = x.device
-        mean, rstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
-        ws = bn_workspace(n_pix, c, dev)
+        mean, rstd, scale, shift = (torch.empty(groups * c, dtype=torch.float32, device=dev) for _ in range(4))
+        ws = bn_workspace(n_pix, c, dev, groups)
         world = _world(group)
         if world > 1:
+            if groups != 1:
+                raise ValueError('batch_norm_act: sample groups are a single-process feature')
             stats = torch.empty(2 * c, dtype=torch.float64, device=dev)
-            check(fn['cms_bn_reduce_ws'](_ptr(x), None, None, _dtype_code(x), None, None, _ptr(stats), n_pix, c, 0, _ptr(ws),
+            check(fn['cms_bn_reduce_ws'](_ptr(x), None, None, _dtype_code(x), None, None, _ptr(stats), n_pix, c, 1, 0, _ptr(ws),
                                          _stream()), 'cms_bn_reduce_ws')
             _allreduce_sum(stats, group)
             count = float(n_pix) * world       # (equal shards: the per-GPU batch is fixed under weak scaling)
@@ -403,78 +406,89 @@ class _BatchNormActFn(torch.autograd.Function):
                                         _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var), c,
                                         _stream()), 'cms_bn_finalize')
         else:                                  # statistics and their finalisation in ONE launch
-            count = float(n_pix)
-            check(fn['cms_bn_stats'](_ptr(x), _dtype_code(x), n_pix, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
-                                     _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var),
-                                     None, None, _ptr(ws), _stream()), 'cms_bn_stats')
+            count = float(n_pix // groups)
+            check(fn['cms_bn_stats'](_ptr(x), _dtype_code(x), n_pix, c, groups, _ptr(gamma), _ptr(beta), float(eps),
+                                     float(momentum), _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean),
+                                     _ptr(running_var), None, None, _ptr(ws), _stream()), 'cms_bn_stats')
         y = torch.empty_like(x)
-        check(fn['cms_bn_apply'](_ptr(x), _ptr(res), _ptr(y), _dtype_code(x), _ptr(scale), _ptr(shift), int(bool(relu)), n_pix,
-                                 c, _stream()), 'cms_bn_apply')
+        check(fn['cms_bn_apply_groups'](_ptr(x), _ptr(res), _ptr(y), _dtype_code(x), _ptr(scale), _ptr(shift), int(bool(relu)),
+                                        n_pix, c, groups, _stream()), 'cms_bn_apply')
         ctx.save_for_backward(x, y if relu else None, mean, rstd, gamma, ws)
         ctx.meta = (n_pix, c, count, group, res is not None, gamma is not None and gamma.requires_grad,
-                    beta is not None and beta.requires_grad)
+                    beta is not None and beta.requires_grad, groups)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, mean, rstd, gamma, ws = ctx.saved_tensors
-        n_pix, c, count, group, has_res, want_g, want_b = ctx.meta
+        n_pix, c, count, group, has_res, want_g, want_b, groups = ctx.meta
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
-        check(fn['cms_bn_reduce_ws'](_ptr(x), _ptr(dy), _ptr(y), _dtype_code(x), _ptr(mean), _ptr(rstd), _ptr(sums), n_pix, c, 1,
-                                     _ptr(ws), _stream()), 'cms_bn_reduce_ws')
+        sums = torch.empty(groups * 2 * c, dtype=torch.float64, device=x.device)
+        check(fn['cms_bn_reduce_ws'](_ptr(x), _ptr(dy), _ptr(y), _dtype_code(x), _ptr(mean), _ptr(rstd), _ptr(sums), n_pix, c,
+                                     groups, 1, _ptr(ws), _stream()), 'cms_bn_reduce_ws')
         local = sums
         if _world(group) > 1:
             local = sums.clone()                 # parameter gradients stay local (the arena all-reduce sums them)
             _allreduce_sum(sums, group)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        check(fn['cms_bn_bwd_apply'](_ptr(x), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dres), _dtype_code(x), _ptr(mean), _ptr(rstd),
-                                     _ptr(gamma), _ptr(sums), count, n_pix, c, _stream()), 'cms_bn_bwd_apply')
-        dgamma = local[c:2 * c].float() if want_g else None
-        dbeta = local[0:c].float() if want_b else None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+        check(fn['cms_bn_bwd_apply_groups'](_ptr(x), _ptr(dy), _ptr(y), _ptr(dx), _ptr(dres), _dtype_code(x), _ptr(mean),
+                                            _ptr(rstd), _ptr(gamma), _ptr(sums), count, n_pix, c, groups, _stream()),
+              'cms_bn_bwd_apply')
+        local = local.view(groups, 2, c).sum(0)    # the groups' passes add into the same parameter gradients
+        dgamma = local[1].float() if want_g else None
+        dbeta = local[0].float() if want_b else None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x_nhwc, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=False, res=None,
-                   group=None):
+                   group=None, groups=1):
     """nn.BatchNorm2d in training mode (+ residual add, + ReLU) on a contiguous NHWC tensor (channels %% 8 == 0).
-    Updates the running statistics in place like the module does."""
+    Updates the running statistics in place like the module does (once per sample group, in order)."""
     _need_cuda(x_nhwc, gamma, beta, running_mean, running_var, res)
     if not x_nhwc.is_contiguous() or x_nhwc.shape[-1] % 8 != 0 or x_nhwc.dtype not in (torch.bfloat16, torch.float32):
         raise ValueError('batch_norm_act: contiguous NHWC bf16 / fp32 tensor with channels % 8 == 0 required')
     if res is not None and (res.shape != x_nhwc.shape or res.dtype != x_nhwc.dtype or not res.is_contiguous()):
         raise ValueError('batch_norm_act: residual must match the input')
-    return _BatchNormActFn.apply(x_nhwc, gamma, beta, res, running_mean, running_var, momentum, eps, relu, group)
+    groups = int(groups)
+    if groups < 1 or x_nhwc.shape[0] % groups != 0:
+        raise ValueError('batch_norm_act: {} sample groups do not divide a batch of {}'.format(groups, x_nhwc.shape[0]))
+    return _BatchNormActFn.apply(x_nhwc, gamma, beta, res, running_mean, running_var, momentum, eps, relu, group, groups)
 
 
-def bn_workspace(n_pixels, c, device):
+def bn_workspace(n_pixels, c, device, groups=1):
     """Zero-filled workspace of one call site of the atomics-free BatchNorm reductions (cms_bn_workspace_bytes): tile counters
     + partial sums; the kernels leave it ready for their next launch, launches on different streams must not share it."""
-    n = int(fn['cms_bn_workspace_bytes'](int(n_pixels), int(c)))
+    n = int(fn['cms_bn_workspace_bytes'](int(n_pixels), int(c), int(groups)))
+    if n == 0:
+        raise ValueError('bn_workspace: bad geometry ({} pixel rows, {} channels, {} groups)'.format(n_pixels, c, groups))
     return torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
 
 
 _BN_WHAT = {'reduce': 0, 'finalize': 1, 'apply': 2, 'reduce_bwd': 3, 'bwd_apply': 4, 'count': 5, 'stats': 6}
 
 
-def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, momentum=0.1, **t):
+def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, momentum=0.1, groups=1, **t):
     """One launch of the batch-statistics BatchNorm protocol (csrc/bn.hip) on caller-owned buffers -- issued now, or appended
     to the program being recorded (cms_program_add_bn): the executor's batch-statistics passes (backbone_hip.py) are made of
     these. `what`: reduce | finalize | apply | reduce_bwd | bwd_apply | count | stats (= reduce + finalize in one launch);
     tensors by keyword (x, res, y, dy, dx, dres, sums, gamma, beta, mean, rstd, scale, shift, running_mean, running_var,
-    counter, clear_a, clear_b, ws). With `ws` (bn_workspace) the reductions take the atomics-free kernels."""
+    counter, clear_a, clear_b, ws). With `ws` (bn_workspace) the reductions take the atomics-free kernels; `groups` > 1
+    (sample groups normalised separately, include/cutmixseg.h) needs them. `count` = pixels of one group."""
     _need_cuda(*t.values())
     d = _lib.BnOp()
     d.what = _BN_WHAT[what]
     d.dtype = _lib.F32 if dtype == torch.float32 else _lib.BF16
-    d.c, d.relu = int(c), int(bool(relu))
+    d.c, d.relu, d.groups = int(c), int(bool(relu)), int(groups)
     for k, v in t.items():
         setattr(d, k, None if v is None else v.data_ptr())
     d.count, d.n_pixels = float(count), int(n_pixels)
     d.eps, d.momentum = float(eps), float(momentum)
+    has_ws = t.get('ws') is not None
+    if d.groups > 1 and what in ('reduce', 'reduce_bwd') and not has_ws:
+        raise ValueError('bn_op: grouped reductions need a workspace')
     if _REC is not None:
         prog = _REC[0]
         idx = fn['cms_program_add_bn'](prog.h, C.byref(d), _rec_stream_index(), prog.group)
@@ -483,31 +497,32 @@ def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, mo
         prog.keep += [v for v in t.values() if v is not None]
         return
     g = lambda k: _ptr(t.get(k))
-    if what == 'reduce' and t.get('ws') is not None:
-        check(fn['cms_bn_reduce_ws'](g('x'), None, None, d.dtype, None, None, g('sums'), d.n_pixels, d.c, 0, g('ws'), _stream()),
-              'cms_bn_reduce_ws')
+    G = max(1, d.groups)
+    if what == 'reduce' and has_ws:
+        check(fn['cms_bn_reduce_ws'](g('x'), None, None, d.dtype, None, None, g('sums'), d.n_pixels, d.c, G, 0, g('ws'),
+                                     _stream()), 'cms_bn_reduce_ws')
     elif what == 'reduce':
         check(fn['cms_bn_reduce'](g('x'), None, None, d.dtype, None, None, g('sums'), d.n_pixels, d.c, 0, _stream()), 'cms_bn_reduce')
     elif what == 'stats':
-        check(fn['cms_bn_stats'](g('x'), d.dtype, d.n_pixels, d.c, g('gamma'), g('beta'), d.eps, d.momentum, g('mean'), g('rstd'),
-                                 g('scale'), g('shift'), g('running_mean'), g('running_var'), g('counter'), g('sums'), g('ws'),
-                                 _stream()), 'cms_bn_stats')
+        check(fn['cms_bn_stats'](g('x'), d.dtype, d.n_pixels, d.c, G, g('gamma'), g('beta'), d.eps, d.momentum, g('mean'),
+                                 g('rstd'), g('scale'), g('shift'), g('running_mean'), g('running_var'), g('counter'), g('sums'),
+                                 g('ws'), _stream()), 'cms_bn_stats')
     elif what == 'finalize':
         check(fn['cms_bn_finalize_ex'](g('sums'), d.count, g('gamma'), g('beta'), d.eps, d.momentum, g('mean'), g('rstd'),
                                        g('scale'), g('shift'), g('running_mean'), g('running_var'), d.c, g('clear_a'),
                                        g('clear_b'), g('counter'), _stream()), 'cms_bn_finalize_ex')
     elif what == 'apply':
-        check(fn['cms_bn_apply'](g('x'), g('res'), g('y'), d.dtype, g('scale'), g('shift'), d.relu, d.n_pixels, d.c, _stream()),
-              'cms_bn_apply')
-    elif what == 'reduce_bwd' and t.get('ws') is not None:
-        check(fn['cms_bn_reduce_ws'](g('x'), g('dy'), g('y'), d.dtype, g('mean'), g('rstd'), g('sums'), d.n_pixels, d.c, 1, g('ws'),
-                                     _stream()), 'cms_bn_reduce_ws')
+        check(fn['cms_bn_apply_groups'](g('x'), g('res'), g('y'), d.dtype, g('scale'), g('shift'), d.relu, d.n_pixels, d.c, G,
+                                        _stream()), 'cms_bn_apply')
+    elif what == 'reduce_bwd' and has_ws:
+        check(fn['cms_bn_reduce_ws'](g('x'), g('dy'), g('y'), d.dtype, g('mean'), g('rstd'), g('sums'), d.n_pixels, d.c, G, 1,
+                                     g('ws'), _stream()), 'cms_bn_reduce_ws')
     elif what == 'reduce_bwd':
         check(fn['cms_bn_reduce'](g('x'), g('dy'), g('y'), d.dtype, g('mean'), g('rstd'), g('sums'), d.n_pixels, d.c, 1, _stream()),
               'cms_bn_reduce')
     elif what == 'bwd_apply':
-        check(fn['cms_bn_bwd_apply'](g('x'), g('dy'), g('y'), g('dx'), g('dres'), d.dtype, g('mean'), g('rstd'), g('gamma'),
-                                     g('sums'), d.count, d.n_pixels, d.c, _stream()), 'cms_bn_bwd_apply')
+        check(fn['cms_bn_bwd_apply_groups'](g('x'), g('dy'), g('y'), g('dx'), g('dres'), d.dtype, g('mean'), g('rstd'),
+                                            g('gamma'), g('sums'), d.count, d.n_pixels, d.c, G, _stream()), 'cms_bn_bwd_apply')
     else:
         check(fn['cms_increment_counter'](g('counter'), _stream()), 'cms_increment_counter')
 

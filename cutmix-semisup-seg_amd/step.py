@@ -17,7 +17,10 @@ Reference order (per iteration):                                        here
 (*) With frozen BatchNorm (`--freeze_bn`, the configuration of the reference's run_*_experiments.sh) and no dropout
 every sample goes through the networks independently, so concatenating batches and summing the two losses before a
 single backward is the same computation with half the kernel launches and twice the GEMM M dimension. With
-batch-statistics BN the passes are kept separate and in the reference's order (`fuse_batches=False`).
+batch-statistics BN (the reference CLI's default) the batches still travel together when both networks run on the executor
+(single process): the BatchNorm kernels keep SAMPLE GROUPS apart -- each of the reference's forward passes is one group with
+its own statistics, and the running statistics move once per group in the reference's order (`_sample_groups`, csrc/bn.hip).
+Otherwise (DeepLab v3+ head, U-Nets, data parallel, Pi model) the passes are kept separate and in the reference's order.
 
 Data parallel: one process per GPU; gradients of the flat arena are summed with ONE all-reduce (RCCL) and scaled by
 1/world inside the optimizer kernel; the confidence count is all-reduced (8 bytes) so that the default
@@ -218,6 +221,30 @@ class CutMixMeanTeacherStep(object):
                     return False
         return True
 
+    def _sample_groups(self, n_sup, unsup_batches, use_unsup):
+        """Batch-statistics BatchNorm couples the samples of a batch -- but only WITHIN a forward pass of the reference. When both
+        networks run on kernels that keep sample groups apart (`supports_sample_groups`: DeepLab v2 on the executor,
+        single-process), the passes can still travel as one batch: [supervised; mixed_1; ...] through the student and
+        [x0_1; x1_1; ...] through the teacher, every group normalised with its own statistics and the running statistics moved
+        once per group in the reference's order. -> (student groups, teacher groups) or None. Needs equal group sizes, separate
+        student / teacher networks (the Pi model interleaves both kinds of passes through ONE set of running statistics) and
+        no active dropout."""
+        if self.world > 1 or (use_unsup and self.teacher is self.student):
+            return None
+        for net in (self.student, self.teacher) if use_unsup else (self.student,):
+            ok = getattr(net, 'supports_sample_groups', None)
+            if ok is None or not ok():
+                return None
+            for m in net.modules():
+                if m.training and 'Dropout' in type(m).__name__ and getattr(m, 'p', 0) > 0:
+                    return None
+        if not use_unsup:
+            return (1, 0)
+        if any(ub.x0_tea.shape[0] != n_sup or ub.x0_stu.shape[0] != n_sup for ub in unsup_batches):
+            return None
+        k = len(unsup_batches)
+        return (1 + k, (2 if self.cfg.mix else 1) * k)
+
     def _both_on_executor(self):
         for net in (self.student, self.teacher):
             use = getattr(net, '_use_hip_body', None)
@@ -266,7 +293,13 @@ class CutMixMeanTeacherStep(object):
         n_sup = sup_x.shape[0]
         ramp = ramp_val if cfg.rampup > 0 else 1.0
 
-        if cfg.fuse_batches and self._samples_independent():
+        independent = self._samples_independent()
+        groups = None if (independent or not cfg.fuse_batches) else self._sample_groups(n_sup, unsup_batches, use_unsup)
+        if cfg.fuse_batches and (independent or groups is not None):
+            if groups is not None:
+                self.student.set_sample_groups(groups[0])
+                if use_unsup:
+                    self.teacher.set_sample_groups(groups[1])
             stu_in = [sup_x]
             tea_in = []
             if use_unsup:
@@ -324,6 +357,10 @@ class CutMixMeanTeacherStep(object):
             finally:
                 if ex is not None:
                     ex.grad_hook = None
+                if groups is not None:
+                    self.student.set_sample_groups(1)
+                    if use_unsup:
+                        self.teacher.set_sample_groups(1)
         else:
             # reference order, separate passes (batch-statistics BN). The teacher's passes depend on nothing the student
             # does within the iteration (its weights only move in the EMA at the end), so they are issued FIRST, on

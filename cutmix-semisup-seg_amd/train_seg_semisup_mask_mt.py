@@ -136,7 +136,7 @@ def train_seg_semisup_mask_mt(submit_config, dataset, model, arch, freeze_bn,
     step_cfg = StepConfig(mask_mode=mask_mode, cons_loss_fn=cons_loss_fn, cons_weight=cons_weight,
                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, rampup=rampup,
                           unsup_batch_ratio=unsup_batch_ratio, invert=not boxmask_no_invert,
-                          fuse_batches=bool(freeze_bn) and not no_fuse_batches, compute_dtype=dtype,
+                          fuse_batches=not no_fuse_batches, compute_dtype=dtype,
                           deterministic=deterministic, allreduce_dtype=allreduce_dtype)
     step = CutMixMeanTeacherStep(student_net, teacher_net, student_optim, teacher_optim, step_cfg)
 

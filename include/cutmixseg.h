@@ -392,20 +392,30 @@ int cms_bn_finalize(const double* sums, double count, const float* gamma, const 
 int cms_bn_finalize_ex(const double* sums, double count, const float* gamma, const float* beta, float eps, float momentum,
                        float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var, int c,
                        double* clear_a, double* clear_b, long long* counter, void* stream);
-/* Round 3: the reductions without data atomics (the memory-side atomic units retire ~11 G adds per second: 2*C*blocks of them
- * were 80 % of cms_bn_reduce's time). Blocks own 64-channel tiles, store partial sums into `ws` and the last block of a tile
- * adds them in fixed order in fp64: bit-reproducible; `sums` (double[2*c]) is OVERWRITTEN, not accumulated. `ws`:
- * cms_bn_workspace_bytes(n_pixels, c) bytes, zero-filled once by the caller, owned by one call site (launches on different
- * streams must not share it); it is left ready for the next launch.
+/* Round 3: the reductions without data atomics (inside the step the fp64 adds of cms_bn_reduce queue behind the weight
+ * gradients' fp32 atomics in the memory-side units: 52 us per launch in the step against 10-22 alone). Blocks own 64-channel
+ * tiles, store partial sums into `ws` and the last block of a tile adds them in fixed order in fp64: bit-reproducible; `sums` is
+ * OVERWRITTEN, not accumulated. `ws`: cms_bn_workspace_bytes(n_pixels, c, groups) bytes, zero-filled once by the caller, owned
+ * by one call site (launches on different streams must not share it); it is left ready for the next launch.
+ * `groups` (>= 1, dividing n_pixels): the pixel rows are `groups` equal runs of consecutive samples whose statistics are kept
+ * apart -- ONE launch over [supervised batch; mixed batch] normalises each exactly as the reference's separate forward passes
+ * do (train_seg_semisup_mask_mt.py:296-358); the running statistics move once per group, in group order, `counter` by `groups`.
+ * Layouts with groups: mean / rstd / scale / shift float[groups][c], sums double[groups][2][c]; `count` = pixels of ONE group.
  *   cms_bn_reduce_ws : cms_bn_reduce's contract (mode 0 / 1) -- the data-parallel protocol all-reduces `sums` after it.
- *   cms_bn_stats     : forward statistics AND cms_bn_finalize_ex's work (count = n_pixels; `counter` incremented) in the one
- *                      launch, for single-process callers; `sums` optional (NULL: not written). */
-size_t cms_bn_workspace_bytes(size_t n_pixels, int c);
+ *   cms_bn_stats     : forward statistics AND cms_bn_finalize_ex's work (count = n_pixels / groups) in the one launch, for
+ *                      single-process callers; `sums` optional (NULL: not written).
+ *   cms_bn_apply_groups / cms_bn_bwd_apply_groups : the element-wise passes with per-group coefficients. */
+size_t cms_bn_workspace_bytes(size_t n_pixels, int c, int groups);
 int cms_bn_reduce_ws(const void* x, const void* dy, const void* y, int dtype, const float* mean, const float* rstd, double* sums,
-                     size_t n_pixels, int c, int mode, void* ws, void* stream);
-int cms_bn_stats(const void* x, int dtype, size_t n_pixels, int c, const float* gamma, const float* beta, float eps,
+                     size_t n_pixels, int c, int groups, int mode, void* ws, void* stream);
+int cms_bn_stats(const void* x, int dtype, size_t n_pixels, int c, int groups, const float* gamma, const float* beta, float eps,
                  float momentum, float* mean, float* rstd, float* scale, float* shift, float* running_mean, float* running_var,
                  long long* counter, double* sums, void* ws, void* stream);
+int cms_bn_apply_groups(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
+                        size_t n_pixels, int c, int groups, void* stream);
+int cms_bn_bwd_apply_groups(const void* x, const void* dy, const void* y, void* dx, void* dres, int dtype, const float* mean,
+                            const float* rstd, const float* gamma, const double* sums, double count, size_t n_pixels, int c,
+                            int groups, void* stream);
 int cms_bn_apply(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
                  size_t n_pixels, int c, void* stream);
 int cms_bn_bwd_apply(const void* x, const void* dy, const void* y, void* dx, void* dres, int dtype, const float* mean,
@@ -502,10 +512,12 @@ typedef struct cms_bn_op {
     long long* counter;        /* what 1 (optional) / what 5: num_batches_tracked                              */
     double* clear_a;           /* what 1: zeroed after the statistics were read (cms_bn_finalize_ex), or NULL  */
     double* clear_b;
-    void* ws;                  /* what 0 / 3 (optional), 6: cms_bn_workspace_bytes(n_pixels, c) bytes          */
+    void* ws;                  /* what 0 / 3 (optional), 6: cms_bn_workspace_bytes(n_pixels, c, groups) bytes  */
     double count;              /* pixels the statistics run over                                               */
     unsigned long long n_pixels;
     float eps, momentum;
+    int groups;                /* sample groups (0 / 1: one); needs `ws` for what 0 / 3                       */
+    int reserved;
 } cms_bn_op;
 int cms_program_add_bn(cms_program* p, const cms_bn_op* op, int stream_idx, int group);
 int cms_program_size(const cms_program* p);

@@ -150,3 +150,97 @@ def test_sync_batchnorm_two_ranks_equals_single_process_on_the_whole_batch():
     for r in res:                                                       # every rank holds the GLOBAL running statistics
         np.testing.assert_allclose(r[4], want[1].float().numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(r[5], want[2].float().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('shape', [(2, 41, 41, 1024), (3, 81, 81, 64), (1, 33, 65, 2208), (10, 41, 41, 256)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['fp32', 'bf16'])
+def test_atomics_free_reductions_match_fp64_sums_and_repeat_bit_for_bit(shape, dtype):
+    """cms_bn_reduce_ws (mode 0 and 1) and cms_bn_stats on multi-split geometries of the networks: sums against fp64 on the
+    host, the fused finalisation against cms_bn_finalize on the same sums, the same workspace used over and over (the last
+    block of a tile resets its counter), and two launches agreeing bit for bit (fixed summation order; the atomics kernel
+    cms_bn_reduce is held to the same sums at its own rounding)."""
+    from cutmix_semisup_seg_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[-1]
+    x = (torch.randn(*shape, generator=g) * 1.3 + 0.4).to(dtype)
+    dy = torch.randn(*shape, generator=g).to(dtype)
+    y = torch.relu(torch.randn(*shape, generator=g)).to(dtype)
+    npix = x.numel() // C
+    xd, dyd = x.double().reshape(npix, C), dy.double().reshape(npix, C)
+    want0 = torch.cat([xd.sum(0), (xd * xd).sum(0)])
+    mean = (want0[:C] / npix).float()
+    rstd = (1.0 / torch.sqrt(want0[C:] / npix - (want0[:C] / npix) ** 2 + 1e-5)).float()
+    dm = dyd * (y.double().reshape(npix, C) > 0)
+    want1 = torch.cat([dm.sum(0), (dm * ((xd - mean.double()) * rstd.double())).sum(0)])
+    xg, dyg, yg, mg, rg = (t.to(DEV) for t in (x, dy, y, mean, rstd))
+    ws = ops.bn_workspace(npix, C, DEV)
+    tol = dict(rtol=2e-5, atol=2e-3 * (npix ** 0.5) * 1e-2)
+
+    def reduce(mode):
+        out = torch.full((2 * C,), float('nan'), dtype=torch.float64, device=DEV)     # overwritten, not accumulated
+        if mode == 0:
+            ops.bn_op('reduce', c=C, dtype=dtype, n_pixels=npix, x=xg, sums=out, ws=ws)
+        else:
+            ops.bn_op('reduce_bwd', c=C, dtype=dtype, n_pixels=npix, x=xg, dy=dyg, y=yg, mean=mg, rstd=rg, sums=out, ws=ws)
+        return out.cpu()
+
+    a0, a1, b0, b1 = reduce(0), reduce(1), reduce(0), reduce(1)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    torch.testing.assert_close(a0, want0, **tol)
+    torch.testing.assert_close(a1, want1, **tol)
+    old = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    ops.bn_op('reduce', c=C, dtype=dtype, n_pixels=npix, x=xg, sums=old)
+    torch.testing.assert_close(old.cpu(), want0, **tol)
+
+    # fused statistics + finalisation == finalize on the same sums
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV)
+    outs = []
+    for fused in (True, False):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        cnt = torch.zeros((), dtype=torch.int64, device=DEV)
+        m, r, sc, sh = (torch.empty(C, device=DEV) for _ in range(4))
+        sums = torch.empty(2 * C, dtype=torch.float64, device=DEV)
+        kw = dict(c=C, eps=1e-5, momentum=0.1, gamma=gamma, beta=beta, mean=m, rstd=r, scale=sc, shift=sh, running_mean=rm,
+                  running_var=rv, counter=cnt)
+        if fused:
+            ops.bn_op('stats', dtype=dtype, n_pixels=npix, x=xg, sums=sums, ws=ws, **kw)
+        else:
+            ops.bn_op('reduce', c=C, dtype=dtype, n_pixels=npix, x=xg, sums=sums, ws=ws)
+            ops.bn_op('finalize', count=npix, sums=sums, **kw)
+        outs.append([t.cpu() for t in (m, r, sc, sh, rm, rv, cnt, sums)])
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    assert int(outs[0][6]) == 1
+    torch.testing.assert_close(outs[0][0].double(), want0[:C] / npix, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('C,dtype', [(64, torch.float32), (256, torch.bfloat16), (2208, torch.float32)])
+def test_sample_groups_equal_separate_passes(C, dtype):
+    """batch_norm_act(groups=3) over [a; b; c] == three calls in that order: outputs, running statistics (moved once per group,
+    in order) and every gradient (the parameter gradients of the groups add up)."""
+    from cutmix_semisup_seg_amd import ops
+    g = torch.Generator().manual_seed(C)
+    G, N, H, W = 3, 2, 9, 7
+    x = (torch.randn(G * N, H, W, C, generator=g) * torch.tensor([1.0, 2.0, 0.5]).repeat_interleave(N).view(-1, 1, 1, 1) + 0.2).to(dtype)
+    res = torch.randn(G * N, H, W, C, generator=g).to(dtype)
+    dy = torch.randn(G * N, H, W, C, generator=g).to(dtype)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+
+    def run(groups):
+        xg, rg = x.to(DEV).requires_grad_(True), res.to(DEV).requires_grad_(True)
+        gg, bg = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        if groups == 1:
+            ys = [ops.batch_norm_act(xg[i * N:(i + 1) * N], gg, bg, rm, rv, 0.1, 1e-5, relu=True, res=rg[i * N:(i + 1) * N])
+                  for i in range(G)]
+            y = torch.cat(ys, 0)
+        else:
+            y = ops.batch_norm_act(xg, gg, bg, rm, rv, 0.1, 1e-5, relu=True, res=rg, groups=G)
+        y.backward(dy.to(DEV))
+        return [t.detach().float().cpu() for t in (y, rm, rv, xg.grad, rg.grad, gg.grad, bg.grad)]
+
+    a, b = run(1), run(G)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for name, u, v in zip(('y', 'running_mean', 'running_var', 'dx', 'dres', 'dgamma', 'dbeta'), a, b):
+        torch.testing.assert_close(u, v, rtol=tol, atol=tol, msg=lambda m, name=name: name + ': ' + m)

@@ -63,7 +63,7 @@ def _rel(a, b):
     return float((a.double().cpu() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-@pytest.mark.parametrize('route', ['executor', 'layers'])
+@pytest.mark.parametrize('route', ['executor', 'executor_separate_passes', 'layers'])
 def test_batch_statistics_iteration_on_the_hand_written_kernels_matches_the_oracle(no_library_convolutions, route):
     from cutmix_semisup_seg_amd import ops
     from cutmix_semisup_seg_amd.step import UnsupBatch
@@ -73,7 +73,12 @@ def test_batch_statistics_iteration_on_the_hand_written_kernels_matches_the_orac
     st, stu, tea, opt, step = _setup(torch.float32, 'hip', C, layers)
     if route == 'layers':
         stu.batchstat_executor = tea.batchstat_executor = False
-    assert not step._samples_independent() and stu._use_hip_body() == (route == 'executor')
+    if route == 'executor_separate_passes':
+        step.cfg.fuse_batches = False
+    assert not step._samples_independent() and stu._use_hip_body() == (route != 'layers')
+    # 'executor': the four forward passes of the reference travel as two grouped batches ([sup; mixed] through the student,
+    # [x0; x1] through the teacher), the BatchNorm kernels keeping the groups' statistics apart (step._sample_groups)
+    assert (step._sample_groups(N, [None], False) is not None) == (route != 'layers')
     g = torch.Generator().manual_seed(21)
     x, ux0, ux1 = (torch.randn(N, 3, H, W, generator=g) for _ in range(3))
     y = torch.randint(0, C, (N, 1, H, W), generator=g)
@@ -92,8 +97,10 @@ def test_batch_statistics_iteration_on_the_hand_written_kernels_matches_the_orac
     assert no_library_convolutions.refused == 0
     eng = stu._hip_engine
     assert eng is not None and eng.strict and eng.dtype == torch.float32 and eng.library_convs == 0
-    if route == 'executor':
+    if route != 'layers':
         progs = stu._hip_executor.programs()
+        shapes = sorted(int(p.x_in.shape[0]) for p in progs if hasattr(p, 'x_in'))
+        assert shapes == ([2 * N] if route == 'executor' else [N]), shapes
         assert stu._hip_executor.dtype == torch.float32 and len(progs) >= 2 and all(getattr(p, 'bn', True) for p in progs if hasattr(p, 'bn'))
         assert tea._hip_executor is not None
     else:
