@@ -162,6 +162,11 @@ PROTOTYPES = {
     'cms_bn_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_size_t, c_int, c_void_p]),
     'cms_bn_bwd_apply': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, C.c_double, c_size_t, c_int, c_void_p]),
+    'cms_channel_copy': (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_int, c_int, c_size_t, c_void_p]),
+    'cms_add_n': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    'cms_rows_reduce': (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_float, c_void_p]),
+    'cms_upsample_nhwc': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p]),
     'cms_aspp_gather_fwd': (c_int, [c_void_p, c_void_p, c_void_p, _P(c_int), _P(c_int), c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_void_p]),
     'cms_aspp_spread_bwd': (c_int, [c_void_p, c_void_p, c_int, _P(c_int), _P(c_int), c_int, c_int, c_int, c_int, c_int,

@@ -124,16 +124,39 @@ class ASPP(nn.Module):
                                      nn.BatchNorm2d(out_channels), nn.ReLU(), nn.Dropout(0.5))
 
     def forward(self, x, eng):
-        br = [eng.conv_bn_act(x, m[0], m[1], relu=True) for m in list(self.convs)[:-1]]
-        pool = self.convs[-1]
-        g = x.float().mean(dim=(2, 3), keepdim=True).to(x.dtype)
+        convs = list(self.convs)
+        xh = _as_nhwc(x)
+        if xh is not None:
+            # hand-written data movement (csrc/nhwc.hip): the five consumers' gradients are summed by one launch, the pooled
+            # branch is a row reduction, the concat writes channel slices (the pooled branch broadcast in the same pass)
+            xs = [a.permute(0, 3, 1, 2) for a in ops.fanout(xh, len(convs))]
+        else:
+            xs = [x] * len(convs)
+        br = [eng.conv_bn_act(xi, m[0], m[1], relu=True) for xi, m in zip(xs, convs[:-1])]
+        pool = convs[-1]
+        if xh is not None:
+            g = ops.global_avg_pool(xs[-1].permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+        else:
+            g = x.float().mean(dim=(2, 3), keepdim=True).to(x.dtype)
         g = eng.conv_bn_act(g, pool[1], pool[2], relu=True)
-        # bilinear upsampling of a 1 x 1 map is a broadcast (torchvision's F.interpolate call computes the same values);
-        # the library's channels-last bilinear BACKWARD funnels H*W atomics into one pixel here: 190 ms per call
-        br.append(g.expand(-1, -1, x.shape[2], x.shape[3]))
-        y = eng.conv_bn_act(torch.cat(br, dim=1), self.project[0], self.project[1], relu=True)
+        brh = [_as_nhwc(b) for b in br]
+        if xh is not None and all(b is not None for b in brh) and g.is_cuda and g.shape[1] % 8 == 0 and g.dtype == br[0].dtype:
+            cat = ops.concat_channels(brh + [g.permute(0, 2, 3, 1)]).permute(0, 3, 1, 2)
+        else:
+            # bilinear upsampling of a 1 x 1 map is a broadcast (torchvision's F.interpolate call computes the same values);
+            # the library's channels-last bilinear BACKWARD funnels H*W atomics into one pixel here: 190 ms per call
+            cat = torch.cat(br + [g.expand(-1, -1, x.shape[2], x.shape[3])], dim=1)
+        y = eng.conv_bn_act(cat, self.project[0], self.project[1], relu=True)
         drop = self.project[3]
         return F.dropout(y, drop.p, drop.training)
+
+
+def _as_nhwc(t):
+    """NHWC view of a channels-last (N,C,H,W) CUDA tensor that csrc/nhwc.hip can take, else None."""
+    if not (t.is_cuda and t.dim() == 4 and t.dtype in (torch.bfloat16, torch.float32) and t.shape[1] % 8 == 0):
+        return None
+    v = t.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else None
 
 
 class DeepLabHeadV3Plus(nn.Module):
@@ -156,9 +179,14 @@ class DeepLabHeadV3Plus(nn.Module):
     def forward(self, feature, eng):
         low = eng.conv_bn_act(feature['low_level'], self.project[0], self.project[1], relu=True)
         out = self.aspp(feature['out'], eng)
-        # (NCHW-contiguous detour: the library's channels-last bilinear backward is ~100x slower than its NCHW one)
-        out = F.interpolate(out.contiguous(), size=low.shape[2:4], mode='bilinear', align_corners=False)
-        y = torch.cat([low, _ToChannelsLast.apply(out)], dim=1)
+        lh, oh = _as_nhwc(low), _as_nhwc(out)
+        if lh is not None and oh is not None and lh.dtype == oh.dtype:
+            # upsample written straight into its channel slice of the concat buffer, gather-form adjoint (csrc/nhwc.hip)
+            y = ops.upsample_concat(lh, oh, align_corners=False).permute(0, 3, 1, 2)
+        else:
+            # (NCHW-contiguous detour: the library's channels-last bilinear backward is ~100x slower than its NCHW one)
+            out = F.interpolate(out.contiguous(), size=low.shape[2:4], mode='bilinear', align_corners=False)
+            y = torch.cat([low, _ToChannelsLast.apply(out)], dim=1)
         y = eng.conv_bn_act(y, self.classifier[0], self.classifier[1], relu=True)
         y = eng.conv_bn_act(y, self.classifier[3], self.classifier[4], relu=True)
         last = self.classifier[6]
@@ -375,14 +403,34 @@ class DeepLabv3Wrapper(nn.Module):
         """(N,3,H,W) -> fp32 (N,C,h,w) logits at the low-level feature size (the reference's tensor just before its
         final interpolate, deeplab3plus.py:76)."""
         eng = self._engine(x)
-        if x.is_cuda and self._use_hip_backbone():
-            from ..backbone_hip import run_v3_body
-            ex = self.hip_executor()
-            low, out = run_v3_body(ex, ex.stem(x))              # stem on csrc/stem.hip (floor-mode pool, trainable BN affine)
-            feats = {'low_level': low.permute(0, 3, 1, 2), 'out': out.permute(0, 3, 1, 2)}    # channels-last views
-        else:
-            feats = self.deeplab.backbone(eng.prepare_input(x), eng)
-        return self.deeplab.classifier(feats, eng)
+        eng.bn_groups = self.sample_groups()        # batch-statistics layers normalise each sample group apart (step.py)
+        try:
+            if x.is_cuda and self._use_hip_backbone():
+                from ..backbone_hip import run_v3_body
+                ex = self.hip_executor()
+                low, out = run_v3_body(ex, ex.stem(x))          # stem on csrc/stem.hip (floor-mode pool, trainable BN affine)
+                feats = {'low_level': low.permute(0, 3, 1, 2), 'out': out.permute(0, 3, 1, 2)}    # channels-last views
+            else:
+                feats = self.deeplab.backbone(eng.prepare_input(x), eng)
+            return self.deeplab.classifier(feats, eng)
+        finally:
+            eng.bn_groups = 1
+
+    def sample_groups(self):
+        """Equal runs of samples the next pass normalises separately in its batch-statistics layers (see
+        architectures/deeplab2.py:set_sample_groups); 1 otherwise."""
+        return int(self.__dict__.get('_bn_groups', 1))
+
+    def set_sample_groups(self, groups):
+        self.__dict__['_bn_groups'] = int(groups)
+
+    def supports_sample_groups(self):
+        """True when every BatchNorm that runs on batch statistics (the head always: deeplab3plus.py:120-121; the backbone
+        too without --freeze_bn) takes csrc/bn.hip, whose kernels keep sample groups apart: the training step may then send
+        [supervised; mixed] through the network as one batch. (Dropout draws per element and couples nothing.)"""
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.training]
+        return (len(bns) > 0 and self.engine is None
+                and all(m.num_features % 8 == 0 and m.momentum is not None and m.running_mean is not None for m in bns))
 
     def forward(self, x, feature_maps=False, use_dropout=False):
         lo = self.forward_lowres(x)

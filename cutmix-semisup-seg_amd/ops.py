@@ -309,6 +309,170 @@ def upsample_bilinear(x, size, align_corners=True):
     return _UpsampleFn.apply(x, tuple(size), align_corners)
 
 
+# ---------------------------------------------------------------------------------------------- NHWC data movement (v3+ head)
+def _nhwc_ok(*ts):
+    """contiguous NHWC bf16 / fp32 CUDA tensors with channels %% 8 == 0: what csrc/nhwc.hip takes."""
+    for t in ts:
+        if not (t.is_cuda and t.dim() == 4 and t.is_contiguous() and t.dtype in (torch.bfloat16, torch.float32)
+                and t.shape[-1] % 8 == 0):
+            return False
+    return len({t.dtype for t in ts}) == 1
+
+
+def _channel_copy(src, src_off, src_pitch, dst, dst_off, dst_pitch, rows, channels, row_div=1):
+    es = src.element_size()
+    check(fn['cms_channel_copy'](src.data_ptr() + src_off * es, int(src_pitch), dst.data_ptr() + dst_off * es, int(dst_pitch),
+                                 int(rows), int(channels), _dtype_code(src), int(row_div), _stream()), 'cms_channel_copy')
+
+
+class _ConcatChannelsFn(torch.autograd.Function):
+    """torch.cat(dim = channels) of NHWC tensors; inputs of shape (N, 1, 1, C) are broadcast over the map (the pooled ASPP
+    branch, deeplab3plus.py's F.interpolate of a 1 x 1 map). Backward: slice copies, pixel sums for the broadcast inputs."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        big = next(x for x in xs if x.shape[1] * x.shape[2] > 1 or len(xs) == 1)
+        n, h, w = (int(v) for v in big.shape[:3])
+        ctot = sum(int(x.shape[3]) for x in xs)
+        out = torch.empty((n, h, w, ctot), dtype=big.dtype, device=big.device)
+        off, meta = 0, []
+        for x in xs:
+            c = int(x.shape[3])
+            bc = tuple(x.shape[1:3]) == (1, 1) and (h, w) != (1, 1)
+            _channel_copy(x, 0, c, out, off, ctot, n * h * w, c, row_div=h * w if bc else 1)
+            meta.append((off, c, bc))
+            off += c
+        ctx.meta, ctx.geo = meta, (n, h, w, ctot)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, ctot = ctx.geo
+        g = g.contiguous()
+        outs = []
+        for i, (off, c, bc) in enumerate(ctx.meta):
+            if not ctx.needs_input_grad[i]:
+                outs.append(None)
+            elif bc:
+                acc = torch.empty((n, c), dtype=torch.float32, device=g.device)
+                check(fn['cms_rows_reduce'](g.data_ptr() + off * g.element_size(), ctot, n, h * w, c, _dtype_code(g), _ptr(acc),
+                                            1.0, _stream()), 'cms_rows_reduce')
+                outs.append(acc.to(g.dtype).view(n, 1, 1, c))
+            else:
+                d = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+                _channel_copy(g, off, ctot, d, 0, c, n * h * w, c)
+                outs.append(d)
+        return tuple(outs)
+
+
+def concat_channels(xs):
+    """NHWC tensors (N,H,W,Ci) [or (N,1,1,Ci): broadcast] -> (N,H,W,sum Ci) on csrc/nhwc.hip."""
+    xs = [x if x.is_contiguous() else x.contiguous() for x in xs]
+    if not _nhwc_ok(*xs):
+        raise ValueError('concat_channels: contiguous NHWC bf16 / fp32 CUDA tensors with channels % 8 == 0 required')
+    return _ConcatChannelsFn.apply(*xs)
+
+
+class _UpsampleConcatFn(torch.autograd.Function):
+    """cat([low, bilinear_upsample(x -> low's size)], channels) in one buffer (deeplab3plus.py:54-55 of the reference:
+    F.interpolate(..., mode='bilinear', align_corners=False) then torch.cat) -- NHWC, the upsample written straight into its
+    channel slice; backward = slice copy + the gather-form adjoint of the interpolation."""
+
+    @staticmethod
+    def forward(ctx, low, x, align_corners):
+        n, H, W, cl = (int(v) for v in low.shape)
+        _, h, w, cx = (int(v) for v in x.shape)
+        out = torch.empty((n, H, W, cl + cx), dtype=low.dtype, device=low.device)
+        _channel_copy(low, 0, cl, out, 0, cl + cx, n * H * W, cl)
+        check(fn['cms_upsample_nhwc'](_ptr(x), out.data_ptr() + cl * out.element_size(), cl + cx, n, h, w, H, W, cx,
+                                      _dtype_code(x), int(bool(align_corners)), 0, _stream()), 'cms_upsample_nhwc')
+        ctx.geo = (n, H, W, cl, h, w, cx, bool(align_corners))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, H, W, cl, h, w, cx, align = ctx.geo
+        g = g.contiguous()
+        dlow = dx = None
+        if ctx.needs_input_grad[0]:
+            dlow = torch.empty((n, H, W, cl), dtype=g.dtype, device=g.device)
+            _channel_copy(g, 0, cl + cx, dlow, 0, cl, n * H * W, cl)
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty((n, h, w, cx), dtype=g.dtype, device=g.device)
+            check(fn['cms_upsample_nhwc'](g.data_ptr() + cl * g.element_size(), _ptr(dx), cl + cx, n, h, w, H, W, cx,
+                                          _dtype_code(g), int(align), 1, _stream()), 'cms_upsample_nhwc')
+        return dlow, dx, None
+
+
+def upsample_concat(low, x, align_corners=False):
+    low = low if low.is_contiguous() else low.contiguous()
+    x = x if x.is_contiguous() else x.contiguous()
+    if not _nhwc_ok(low, x) or low.shape[0] != x.shape[0]:
+        raise ValueError('upsample_concat: contiguous NHWC bf16 / fp32 CUDA tensors with channels % 8 == 0 required')
+    return _UpsampleConcatFn.apply(low, x, align_corners)
+
+
+class _GlobalAvgPoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(1) on NHWC: (N,H,W,C) -> (N,1,1,C), fp32 accumulation."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n, h, w, c = (int(v) for v in x.shape)
+        acc = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        check(fn['cms_rows_reduce'](_ptr(x), c, n, h * w, c, _dtype_code(x), _ptr(acc), 1.0 / float(h * w), _stream()),
+              'cms_rows_reduce')
+        ctx.geo = (n, h, w, c)
+        return acc.to(x.dtype).view(n, 1, 1, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c = ctx.geo
+        row = (g.reshape(n, c).float() * (1.0 / float(h * w))).to(g.dtype).contiguous()
+        dx = torch.empty((n, h, w, c), dtype=g.dtype, device=g.device)
+        _channel_copy(row, 0, c, dx, 0, c, n * h * w, c, row_div=h * w)
+        return dx
+
+
+def global_avg_pool(x):
+    x = x if x.is_contiguous() else x.contiguous()
+    if not _nhwc_ok(x):
+        raise ValueError('global_avg_pool: contiguous NHWC bf16 / fp32 CUDA tensor with channels % 8 == 0 required')
+    return _GlobalAvgPoolFn.apply(x)
+
+
+class _FanoutFn(torch.autograd.Function):
+    """k aliases of one tensor whose gradients are summed by ONE launch (cms_add_n) instead of autograd's k - 1 pairwise adds
+    (the ASPP input feeds five branches: four 346 MB bf16 adds per cfg 4 pass)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k = k
+        return tuple(x.view(x.shape) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g if g.is_contiguous() else g.contiguous() for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        g0 = live[0]
+        if not (g0.is_cuda and g0.dtype in (torch.bfloat16, torch.float32) and g0.numel() % 8 == 0 and len(live) <= 6
+                and all(g.dtype == g0.dtype and g.shape == g0.shape for g in live)):
+            out = live[0]
+            for g in live[1:]:
+                out = out + g
+            return out, None
+        out = torch.empty_like(g0)
+        ptrs = (C.c_void_p * len(live))(*[g.data_ptr() for g in live])
+        check(fn['cms_add_n'](ptrs, len(live), _ptr(out), g0.numel(), _dtype_code(g0), _stream()), 'cms_add_n')
+        return out, None
+
+
+def fanout(x, k):
+    return _FanoutFn.apply(x, int(k))
+
+
 # ---------------------------------------------------------------------------------------------- EMA
 def ema_flat(tgt, src, alpha, tgt_bf16=None):
     """tgt = tgt*alpha + src*(1-alpha) over flat fp32 CUDA buffers, reference rounding (optim_weight_ema.py:21-25)."""

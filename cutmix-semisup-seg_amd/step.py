@@ -226,18 +226,15 @@ class CutMixMeanTeacherStep(object):
         networks run on kernels that keep sample groups apart (`supports_sample_groups`: DeepLab v2 on the executor,
         single-process), the passes can still travel as one batch: [supervised; mixed_1; ...] through the student and
         [x0_1; x1_1; ...] through the teacher, every group normalised with its own statistics and the running statistics moved
-        once per group in the reference's order. -> (student groups, teacher groups) or None. Needs equal group sizes, separate
-        student / teacher networks (the Pi model interleaves both kinds of passes through ONE set of running statistics) and
-        no active dropout."""
+        once per group in the reference's order. -> (student groups, teacher groups) or None. Needs equal group sizes and
+        separate student / teacher networks (the Pi model interleaves both kinds of passes through ONE set of running
+        statistics). Dropout (DeepLab v3+'s head) draws per element and couples nothing."""
         if self.world > 1 or (use_unsup and self.teacher is self.student):
             return None
         for net in (self.student, self.teacher) if use_unsup else (self.student,):
             ok = getattr(net, 'supports_sample_groups', None)
             if ok is None or not ok():
                 return None
-            for m in net.modules():
-                if m.training and 'Dropout' in type(m).__name__ and getattr(m, 'p', 0) > 0:
-                    return None
         if not use_unsup:
             return (1, 0)
         if any(ub.x0_tea.shape[0] != n_sup or ub.x0_stu.shape[0] != n_sup for ub in unsup_batches):

@@ -423,6 +423,25 @@ int cms_bn_bwd_apply(const void* x, const void* dy, const void* y, void* dx, voi
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * NHWC data movement of the DeepLab v3+ head (csrc/nhwc.hip; reference: architectures/deeplab3plus.py:40-55 -- torch.cat of
+ * the ASPP branches, the pooled branch broadcast over the map, F.interpolate(bilinear, align_corners=False) + torch.cat with
+ * the low-level features -- and autograd's sum of the gradients that meet at the ASPP input). Pixel rows may sit in wider
+ * rows of a concat buffer: `*_pitch` = elements per row of that buffer; rows, pitches and pointers are multiples of 16 bytes.
+ *   cms_channel_copy : dst[r][0:channels] = src[r / row_div][0:channels]   (row_div > 1 broadcasts one row per sample)
+ *   cms_add_n        : dst = src_0 + ... + src_{k-1}, k <= 6, fp32 accumulation, dense tensors of n elements (n % 8 == 0)
+ *   cms_rows_reduce  : dst[n][c] (fp32) = scale * sum_p src[n][p][c]        (global average pool; adjoint of the broadcast)
+ *   cms_upsample_nhwc: backward == 0: dst[N,H,W, pitch] <- bilinear(src[N,h,w,C]); backward != 0: the adjoint in gather form,
+ *                      src = d(dst) in rows of dst_pitch, dst = d(src) dense (N,h,w,C). No atomics, fixed summation order.
+ * ------------------------------------------------------------------------------------------------------------ */
+int cms_channel_copy(const void* src, size_t src_pitch, void* dst, size_t dst_pitch, size_t rows, int channels, int dtype,
+                     size_t row_div, void* stream);
+int cms_add_n(const void* const* srcs, int k, void* dst, size_t n, int dtype, void* stream);
+int cms_rows_reduce(const void* src, size_t pitch, int n, size_t rows_per_sample, int channels, int dtype, float* dst,
+                    float scale, void* stream);
+int cms_upsample_nhwc(const void* src, void* dst, size_t dst_pitch, int n, int h, int w, int H, int W, int channels, int dtype,
+                      int align_corners, int backward, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * ASPP head (architectures/deeplab2.py:112-128) with the 2048-channel activation read ONCE (csrc/aspp.hip):
  *   forward   Z = X . Wall^T as a 1x1 cms_conv_igemm (rows of Wall: tap*C + class, fp32 NCHW output), then
  *             logits[n][c][y][x] = bias[c] + sum_t Z[n][t*C + c][y + dy_t][x + dx_t]            (cms_aspp_gather_fwd)

@@ -89,8 +89,11 @@ def test_forward_matches_the_oracle_eval_and_train_mode(no_library_convolutions)
     assert float((lo16 - ref).abs().max()) <= 0.15 * float(ref.abs().max())
 
 
-def test_training_iteration_matches_the_oracle_step(no_library_convolutions):
-    """Non-fused passes in the reference's order (batch-statistics head), fused loss kernels, fused Adam + EMA.
+@pytest.mark.parametrize('fuse', [True, False], ids=['grouped_batches', 'separate_passes'])
+def test_training_iteration_matches_the_oracle_step(no_library_convolutions, fuse):
+    """The reference's passes (batch-statistics head) -- as two sample-grouped batches ([sup; mixed] through the student,
+    [x0; x1] through the teacher: the head's BatchNorm kernels keep the groups' statistics apart) or as the four separate
+    passes in the reference's order --, fused loss kernels, fused Adam + EMA.
     Losses, gradients and running statistics are compared with the oracle; the first Adam update moves every weight
     by ~lr * sign(g), which turns noise-level gradient components into O(lr) differences, so the update itself is
     checked for sign / size against the device gradients and the EMA against its own formula (both have bit-level
@@ -109,10 +112,10 @@ def test_training_iteration_matches_the_oracle_step(no_library_convolutions):
     ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
     ema.fuse_into(opt)
     stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()
-    cfg = StepConfig(mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.0, fuse_batches=True,
+    cfg = StepConfig(mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.0, fuse_batches=fuse,
                      compute_dtype=torch.float32)
     step = CutMixMeanTeacherStep(stu, tea, opt, ema, cfg)
-    assert not step._samples_independent()              # fuse_batches is overridden for this network
+    assert not step._samples_independent() and stu.supports_sample_groups() and tea.supports_sample_groups()
 
     S = sv.StepStateV3Plus(st, C, layers, lr=lr)
     g = torch.Generator().manual_seed(11)
