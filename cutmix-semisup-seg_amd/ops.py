@@ -628,7 +628,9 @@ def bn_workspace(n_pixels, c, device, groups=1):
     n = int(fn['cms_bn_workspace_bytes'](int(n_pixels), int(c), int(groups)))
     if n == 0:
         raise ValueError('bn_workspace: bad geometry ({} pixel rows, {} channels, {} groups)'.format(n_pixels, c, groups))
-    return torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
+    ws = torch.empty((n + 3) // 4, dtype=torch.int32, device=device)
+    ws[:min(ws.numel(), 1024)].zero_()          # the tile counters (<= 4 KB: one per 64 channels) lead the workspace
+    return ws
 
 
 _BN_WHAT = {'reduce': 0, 'finalize': 1, 'apply': 2, 'reduce_bwd': 3, 'bwd_apply': 4, 'count': 5, 'stats': 6}
