@@ -629,6 +629,9 @@ def main():
     ap.add_argument('--roofline_sample', type=int, default=5,
                     help='bracket every k-th launch of the conv kernel with events (1 = all; the brackets cost ~3 %% '
                          'of the step when every launch carries them)')
+    ap.add_argument('--no_also', action='store_true',
+                    help='default run (--workload both, one GPU): skip the two extra short runs reported under "also" '
+                         '(DeepLab v3+ at configs[3]; configs[1] without --freeze_bn)')
     ap.add_argument('--dry_launch', action='store_true',
                     help='launch-path check without a GPU: gloo group, count the ranks, print the JSON skeleton')
     args = ap.parse_args()
@@ -661,6 +664,28 @@ def main():
 
     keys = ['pascal', 'cityscapes'] if args.workload == 'both' else [args.workload]
     results = [run_workload(k, args, world, rank, dev) for k in keys]
+    also = []
+    if args.workload == 'both' and world == 1 and not args.no_also:
+        # Two more configurations in the SAME driver-run line (short runs, never the headline `value`): BASELINE configs[3]
+        # (DeepLab v3+ at 10x3x513x513) and configs[1] under the reference CLI's default BatchNorm mode (no --freeze_bn:
+        # batch statistics). A failure here is reported in the entry and does not touch the main result.
+        import argparse as _ap
+        for name, key, over in (('pascal_v3plus (BASELINE configs[3])', 'pascal_v3plus', {}),
+                                ('pascal without --freeze_bn (reference CLI default: batch-statistics BatchNorm)', 'pascal',
+                                 {'no_freeze_bn': True})):
+            a2 = _ap.Namespace(**vars(args))
+            a2.steps, a2.warmup = min(args.steps, 10 if key == 'pascal_v3plus' else 20), min(args.warmup, 3)
+            a2.no_cpu_baseline, a2.traffic, a2.timed_only = True, 'omit', True
+            for k, v in over.items():
+                setattr(a2, k, v)
+            try:
+                r = run_workload(key, a2, world, rank, dev)
+                also.append({'name': name, 'value': r['value'], 'unit': 'images/sec', 'ms_per_step': r['ms_per_step'],
+                             'steps': a2.steps, 'warmup': a2.warmup, 'config': r['config'],
+                             'roofline': {k: r['roofline'].get(k) for k in ('kernel', 'frac', 'avg_launch_ms', 'step_mfma')}})
+            except Exception as e:                  # noqa: BLE001 -- reported, the headline line still goes out
+                also.append({'name': name, 'error': '{}: {}'.format(type(e).__name__, e)})
+                torch.cuda.empty_cache()
     if rank == 0:
         head = results[0]
         out = {
@@ -690,6 +715,8 @@ def main():
             if r['workload'] == 'cityscapes':
                 out['value_512x1024'] = r['value']
         out['configs'] = results
+        if also:
+            out['also'] = also
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
