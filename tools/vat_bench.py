@@ -12,6 +12,7 @@ from architectures import network_architectures
 import optim_weight_ema
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'deeplab'
+engine_kind = sys.argv[2] if len(sys.argv) > 2 else None      # 'hip': every convolution on the hand-written kernels
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 if which == 'denseunet':
@@ -27,6 +28,8 @@ else:
     stu, tea = Net(C, pretrained=False).to(dev), Net(C, pretrained=False).to(dev)
     opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=3e-6), dict(params=list(stu.new_parameters()), lr=3e-5)])
     cfg = vat.VATConfig(cons_loss_fn='kld', conf_thresh=0.97)
+if engine_kind:
+    stu.engine_kind = tea.engine_kind = engine_kind
 for p in tea.parameters():
     p.requires_grad = False
 ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
@@ -48,8 +51,8 @@ for _ in range(K):
     r = step(x, y, [vat.VATUnsupBatch(xt)])
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print('VAT step [{}]: {:.1f} ms, {:.1f} img/s (sup loss {:.3f}, cons loss {:.5f})'.format(
-    which, dt * 1e3, B / dt, float(r['sup_loss']), float(r['consistency_loss'])))
+print('VAT step [{}{}]: {:.1f} ms, {:.1f} img/s (sup loss {:.3f}, cons loss {:.5f})'.format(
+    which, ' engine_kind=' + engine_kind if engine_kind else '', dt * 1e3, B / dt, float(r['sup_loss']), float(r['consistency_loss'])))
 if os.environ.get('CMS_HOST_PROFILE'):         # where the host time of an iteration goes
     import cProfile, pstats
     ts = []
