@@ -629,7 +629,8 @@ def bn_workspace(n_pixels, c, device, groups=1):
     if n == 0:
         raise ValueError('bn_workspace: bad geometry ({} pixel rows, {} channels, {} groups)'.format(n_pixels, c, groups))
     ws = torch.empty((n + 3) // 4, dtype=torch.int32, device=device)
-    ws[:min(ws.numel(), 1024)].zero_()          # the tile counters (<= 4 KB: one per 64 channels) lead the workspace
+    counters = ((int(c) + 63) // 64 * 4 + 255) // 256 * 64      # int32 words: one counter per 64-channel tile, padded to 256 B
+    ws[:min(ws.numel(), counters)].zero_()      # only the counters need a defined start; the partial sums are written first
     return ws
 
 
