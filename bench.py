@@ -390,10 +390,10 @@ def run_workload(key, args, world, rank, dev):
         return tot
 
     def issued():
-        tot = dict(flops=0.0, conv_launches=0, conv_bytes=0.0, head_launches=0, head_bytes=0.0)
+        tot = dict(flops=0.0, conv_launches=0, conv_bytes=0.0, head_launches=0, head_bytes=0.0, floor_s=0.0)
         for e in executors():
             for kk in tot:
-                tot[kk] += e.issued[kk]
+                tot[kk] += e.issued.get(kk, 0.0)
         return tot
 
     def one_step(i):
@@ -557,6 +557,16 @@ def run_workload(key, args, world, rank, dev):
                 out['roofline']['traffic_source'] = 'not measured in this run (--traffic measure, single GPU, workload pascal)'
         if isolated is not None:
             out['roofline']['isolated'] = isolated
+        if prog_i.get('floor_s', 0.0) > 0:
+            # the MIXED roofline beside the MFMA-only fraction. Per recorded convolution / weight-gradient launch
+            # max(algorithmic bytes / 8 TB/s, FLOPs / 2.5 PFLOP/s), summed over the step: the time the step's convolution work
+            # would take if every launch ran alone at whichever roof binds it
+            out['roofline']['mixed'] = {
+                'floor_ms_per_step': prog_i['floor_s'] / args.steps * 1e3,
+                'step_ms': elapsed / args.steps * 1e3,
+                'frac': prog_i['floor_s'] / elapsed,
+                'basis': 'sum over the recorded convolution, ASPP-head and weight-gradient launches of max(bytes / 8 TB/s, '
+                         'FLOPs / 2.5 PFLOP/s), over the step time'}
         if timed['flops'] > 0:
             # all MFMA work of the step (forward, data-gradient AND weight-gradient convolutions) over the step time
             out['roofline']['step_mfma'] = {
@@ -682,7 +692,7 @@ def main():
                 r = run_workload(key, a2, world, rank, dev)
                 also.append({'name': name, 'value': r['value'], 'unit': 'images/sec', 'ms_per_step': r['ms_per_step'],
                              'steps': a2.steps, 'warmup': a2.warmup, 'config': r['config'],
-                             'roofline': {k: r['roofline'].get(k) for k in ('kernel', 'frac', 'avg_launch_ms', 'step_mfma')}})
+                             'roofline': {k: r['roofline'].get(k) for k in ('kernel', 'frac', 'avg_launch_ms', 'step_mfma', 'mixed')}})
             except Exception as e:                  # noqa: BLE001 -- reported, the headline line still goes out
                 also.append({'name': name, 'error': '{}: {}'.format(type(e).__name__, e)})
                 torch.cuda.empty_cache()

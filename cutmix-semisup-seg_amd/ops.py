@@ -791,6 +791,9 @@ def stem_dgrad(ds, w147, scale, x_shape):
 
 
 # ---------------------------------------------------------------------------------------------- launch programs
+HBM_PEAK_BPS, MFMA_PEAK_FLOPS = 8.0e12, 2.5e15       # MI355X_MICROARCH.md: HBM3E, dense bf16 MFMA
+
+
 class Program(object):
     """A recorded network pass (csrc/program.hip): launch descriptors over persistent buffers, replayed from C++ with
     one call. Record with `with recording(prog, [main_stream, side_stream, ...]):` around ordinary calls of
@@ -808,6 +811,8 @@ class Program(object):
         self.conv_launches = 0
         self.conv_bytes = 0.0   # algorithmic HBM bytes of the convolution launches (operands once, output once)
         self.head_bytes = 0.0   # ... of the ASPP head launches among them (fp32 NCHW logits)
+        self.floor_s = 0.0      # sum over the convolution / weight-gradient launches of max(bytes / 8 TB/s, FLOPs / 2.5 PFLOP/s):
+                                # the mixed HBM / MFMA roofline of one replay (bench.py: roofline.mixed)
         self.head_launches = 0
         self.n_streams = 1
 
@@ -1052,6 +1057,7 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
         nbytes = esz * (x.numel() + w_packed.numel()) + float(n * ho * wo) * (
             (4.0 * d.cout_real if out_f32_nchw is not None else esz * cout)
             + (esz * cout if res is not None else 0.0) + (esz * cout if mask_src is not None else 0.0))
+        prog.floor_s += max(nbytes / HBM_PEAK_BPS, 2.0 * n * ho * wo * cout * cin * ntaps / MFMA_PEAK_FLOPS)
         if out_f32_nchw is not None:
             prog.head_launches += 1
             prog.head_bytes += nbytes
@@ -1205,6 +1211,8 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
             check(idx, 'cms_program_add_wgrad')
         prog.keep += [t for t in (du, x, dw, scale, w_bf16, wdot, dbeta, ws) if t is not None]
         prog.flops += 2.0 * n * ho * wo * cout * cin * len(taps)
+        prog.floor_s += max((du.element_size() * (du.numel() + x.numel()) + 4.0 * dw.numel()) / HBM_PEAK_BPS,
+                            2.0 * n * ho * wo * cout * cin * len(taps) / MFMA_PEAK_FLOPS)
         return dw
     name = 'cms_conv_wgrad_f32' if f32 else 'cms_conv_wgrad'
     check(fn[name](C.byref(d), _stream()), name)
