@@ -1067,8 +1067,12 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
     if (d_in->variant == 0 && conv_default_variant() != 0) {
         const int v = conv_default_variant();
         // ring variants exist for the 128-channel tile of the bf16 output only
-        const bool ring = (v >= 10 && v <= 14) || (v >= 50 && v <= 54);
-        if (!ring || (d_in->cout % 128 == 0 && (d_in->tile == 0 || d_in->tile == 128) && d_in->zeros != nullptr)) {
+        const bool ring = (v >= 10 && v <= 14) || (v >= 50 && v <= 54) || (v >= 60 && v <= 75);
+        const int need = (v >= 70 && v <= 75) ? 256 : 128;
+        const bool small_ok = (size_t)d_in->n * d_in->h * d_in->w_in * d_in->cin * 2 < (1ull << 31) &&
+                              (size_t)d_in->ntaps * d_in->cout * d_in->cin * 2 < (1ull << 31);
+        if (!ring || (d_in->cout % need == 0 && (d_in->tile == 0 || d_in->tile == 128) && d_in->zeros != nullptr && small_ok &&
+                      d_in->y != nullptr && (d_in->ksplit <= 1))) {
             d_copy = *d_in;
             d_copy.variant = v;
             d = &d_copy;
