@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _one_iteration(deterministic, seed=3):
+def _one_iteration(deterministic, seed=3, freeze_bn=True):
     from cutmix_semisup_seg_amd import ops, optim as fo
     from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
     from architectures import deeplab2
@@ -30,7 +30,9 @@ def _one_iteration(deterministic, seed=3):
         p.requires_grad = False
     ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
     ema.fuse_into(opt)
-    stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()
+    stu.train(); tea.train()
+    if freeze_bn:
+        stu.freeze_batchnorm(); tea.freeze_batchnorm()
     stu.engine_kind = tea.engine_kind = 'hip'
     step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=0.2, deterministic=deterministic))
     g = torch.Generator(device=DEV).manual_seed(11)
@@ -59,3 +61,16 @@ def test_deterministic_mode_gives_bit_identical_gradients_run_to_run():
     rel = max(float((ga[k] - gc[k]).norm() / (ga[k].norm() + 1e-30)) for k in ga)
     print('atomics mode: {} of {} tensors differ run to run; deterministic vs atomics max rel {:.2e}'.format(n_diff, len(gc), rel))
     assert rel <= 1e-4
+
+
+def test_deterministic_mode_with_batch_statistics_is_bit_reproducible_too():
+    """The reference CLI's default BatchNorm mode (no --freeze_bn): the statistics reductions of csrc/bn.hip add their partial
+    sums in a fixed order (no data atomics since round 3), so with the deterministic weight gradients the whole grouped
+    iteration -- losses, every gradient, the updated weights, the running statistics -- repeats bit for bit."""
+    ra, ga, wa = _one_iteration(True, freeze_bn=False)
+    rb, gb, wb = _one_iteration(True, freeze_bn=False)
+    assert ra == rb
+    differing = [k for k in ga if not torch.equal(ga[k], gb[k])]
+    print('\nbatch-statistics, deterministic mode: {} of {} gradient tensors differ between two runs: {}'.format(
+        len(differing), len(ga), differing[:8]))
+    assert not differing and torch.equal(wa, wb)
