@@ -11,5 +11,9 @@ run default_cli train_seg_semisup_mask_mt.py --job_desc d $COMMON
 run freeze_bn train_seg_semisup_mask_mt.py --job_desc f $COMMON --freeze_bn
 run deterministic train_seg_semisup_mask_mt.py --job_desc det $COMMON --freeze_bn --deterministic
 run rot_scale train_seg_semisup_mask_mt.py --job_desc r $COMMON --freeze_bn --synthetic_source_size 160,200 --aug_rot_mag 20 --aug_max_scale 1.5 --aug_hflip --aug_strong_colour
+V3="--synthetic --arch resnet101_deeplabv3plus_imagenet --batch_size 4 --crop_size 129,129 --learning_rate 3e-5 --num_epochs 1 --iters_per_epoch 3 --synthetic_val_batches 1"
+run v3plus_freeze_bn train_seg_semisup_mask_mt.py --job_desc v3f $V3 --freeze_bn
+run v3plus_default_cli train_seg_semisup_mask_mt.py --job_desc v3d $V3
+run cut_mode_default_cli train_seg_semisup_mask_mt.py --job_desc cut $COMMON --mask_mode zero
 run vat train_seg_semisup_vat_mt.py --job_desc v --synthetic --arch resnet101_deeplab_imagenet --freeze_bn --batch_size 2 --crop_size 65,65 --num_epochs 1 --iters_per_epoch 2 --synthetic_val_batches 1
 echo "cli_smoke OK"
