@@ -286,12 +286,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
     stamp(13);                                             // tables written (before the barrier)
     // BN affine of the tile's channels: fetched here, so that the epilogue has no global load of its own in front of
     // its arithmetic (tools/conv_trace.py: the per-element float4 loads cost ~10k cycles per workgroup)
-    static_assert(BN <= NT && (BN == 32 || 2 * BN / 64 <= NW), "scale / bias staging");
+    static_assert(BN <= NT, "scale / bias staging");
     const bool use_scale = a.scale && a.mode == 0, use_bias = a.bias && a.mode == 0 && split == 0;   // (1, 0) in the dgrad epilogue
     if constexpr (GLDS && BN >= 64) {
         // asynchronously (4-byte direct-to-LDS loads, 64 floats per wave instruction): they land with the first stage
-        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        if (wave_u < 2 * BN / 64) {                                  // wave-uniform
+        for (int wave_u = __builtin_amdgcn_readfirstlane(wave); wave_u < 2 * BN / 64; wave_u += NW) {      // wave-uniform
             const int e = wave_u * 64 + lane;                        // element of [scale BN | bias BN]
             const bool is_scale = e < BN;
             if ((is_scale && use_scale) || (!is_scale && use_bias)) {
@@ -1067,8 +1066,8 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
     if (d_in->variant == 0 && conv_default_variant() != 0) {
         const int v = conv_default_variant();
         // ring variants exist for the 128-channel tile of the bf16 output only
-        const bool ring = (v >= 10 && v <= 14) || (v >= 50 && v <= 54) || (v >= 60 && v <= 75);
-        const int need = (v >= 70 && v <= 75) ? 256 : 128;
+        const bool ring = (v >= 10 && v <= 14) || (v >= 50 && v <= 54) || (v >= 60 && v <= 85);
+        const int need = (v >= 70 && v <= 85) ? 256 : 128;
         const bool small_ok = (size_t)d_in->n * d_in->h * d_in->w_in * d_in->cin * 2 < (1ull << 31) &&
                               (size_t)d_in->ntaps * d_in->cout * d_in->cin * 2 < (1ull << 31);
         if (!ring || (d_in->cout % need == 0 && (d_in->tile == 0 || d_in->tile == 128) && d_in->zeros != nullptr && small_ok &&
@@ -1131,6 +1130,20 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
                      : ((d->variant == 4 || d->variant == 6 || d->variant == 7) ? 2
                         : (d->variant == 5 ? 3 : ((small && d->variant != 43) ? 4 : 1)));      // 43: flat addresses (round-1 loader)
     const int tile = d->tile;   // 0 = auto
+    if (d->variant >= 80 && d->variant <= 85) {
+        // Round 3 experiment: 256 (co) x 128 (pixels) on FOUR waves (each 128 co x 64 pixels): 48 KB staged and 96 KB of fragment
+        // reads per 2x the MFMA work of the default tile, one workgroup per CU for layers of ~263 pixel tiles
+        CMS_REQUIRE(d->zeros != nullptr && small && d->cout % 256 == 0, "conv: variants 80..85 need the zero run, tensors below 2 GB, Cout %% 256 == 0");
+        switch (d->variant) {
+        case 80: conv_launch_ring<2, 2, 4, 2, 1, 64, 1, true>(a, s); break;
+        case 81: conv_launch_ring<2, 2, 4, 2, 2, 64, 1, true>(a, s); break;
+        case 82: conv_launch_ring<2, 2, 4, 2, 3, 64, 1, true>(a, s); break;
+        case 83: conv_launch_ring<2, 2, 4, 2, 3, 32, 1, true>(a, s); break;
+        case 84: conv_launch_ring<2, 2, 4, 2, 4, 32, 1, true>(a, s); break;
+        default: conv_launch_ring<2, 2, 4, 2, 2, 64, 2, true>(a, s); break;
+        }
+        return launch_status("cms_conv_igemm");
+    }
     if (d->variant >= 60 && d->variant <= 75) {
         // Round 3 experiment: the stage rings on WIDE tiles with buffer-addressed asm loads (the wide rings 10..14 of round 2
         // used the builtin loads the compiler drains): 60..63 = 128 (co) x 256 (pixels) on 8 waves; 70..73 = 256 x 256 on 8
