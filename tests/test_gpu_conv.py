@@ -1,8 +1,10 @@
 """
-GPU parity of the MFMA implicit-GEMM convolution (csrc/conv.hip, through the C ABI) against a plain PyTorch fp32
-reference of the same op on identical bf16-rounded inputs (F.conv2d in fp32 on the device + folded-BN affine +
-residual + ReLU; autograd for the data gradient). Tolerance: bf16 output rounding (2^-8 relative) on top of fp32
-accumulation-order differences.
+GPU parity of the MFMA implicit-GEMM convolution (csrc/conv.hip, through the C ABI) against the same op in FP64 ON THE HOST
+on identical bf16-rounded inputs (F.conv2d + folded-BN affine + residual + ReLU; autograd for the gradients) -- no library
+convolution of the device is involved in the main forward / data-gradient / weight-gradient comparisons. What
+separates the kernel from that reference is ONE bf16 rounding of the output (half an ulp: 2^-8 relative) plus fp32
+accumulation noise, and the tolerances say exactly that; the weight gradient (fp32 output, exact bf16 products) is held to
+fp32 summation noise.
 """
 import numpy as np
 import pytest
@@ -21,6 +23,13 @@ def ops():
 
 def _mk(shape, gen, scale=1.0):
     return (torch.randn(shape, generator=gen, device=DEV) * scale).bfloat16()
+
+
+def _d(t):             # device tensor -> fp64 on the host
+    return t.detach().double().cpu()
+
+
+BF16_HALF_ULP = 2.0 ** -8
 
 
 def _pack(w):          # (Cout, Cin, kh, kw) bf16 -> (taps, Cout, Cin)
@@ -56,19 +65,19 @@ def test_conv_forward(ops, case, epi):
     relu = epi != 'plain'
     y = ops.conv_igemm(x, _pack(w), ops.conv_taps(k, k, dil, pad), stride=stride, out_hw=(Ho, Wo), scale=scale,
                        bias=bias, res=res, relu=relu)
-    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, stride, pad, dil)
+    ref = F.conv2d(_d(x).permute(0, 3, 1, 2), _d(w), None, stride, pad, dil)
     if scale is not None:
-        ref = ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+        ref = ref * _d(scale).view(1, -1, 1, 1) + _d(bias).view(1, -1, 1, 1)
     if res is not None:
-        ref = ref + res.float().permute(0, 3, 1, 2)
+        ref = ref + _d(res).permute(0, 3, 1, 2)
     if relu:
         ref = F.relu(ref)
     ref = ref.permute(0, 2, 3, 1)
     assert y.shape == ref.shape
-    err = (y.float() - ref).abs()
-    tol = 1e-2 * ref.abs() + 2e-2
+    err = (_d(y) - ref).abs()
+    tol = 1.02 * BF16_HALF_ULP * ref.abs() + 1e-5 * float(ref.abs().max())
     assert bool((err <= tol).all()), 'max err {} at scale {}'.format(float(err.max()), float(ref.abs().max()))
-    assert float(err.mean()) <= 4e-3 * float(ref.abs().mean() + 1e-6) + 1e-4
+    assert float(err.mean()) <= 0.5 * BF16_HALF_ULP * float(ref.abs().mean()) + 1e-6
 
 
 @pytest.mark.parametrize('variant', [0, 1, 4, 5], ids=['direct_to_lds', 'register_staged', 'direct_to_lds_2stage',
@@ -125,13 +134,15 @@ def test_conv_dgrad_with_relu_mask(ops, case):
     wT = ops.conv_pack_transpose(_pack(w), scale=scale, flip=True)      # (taps, Cin, Cout)
     assert wT.shape == (k * k, Cin, Cout)
     dx = ops.conv_igemm(dU, wT, ops.conv_taps(k, k, dil, pad), res=add, mode=1, mask_src=x)
-    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
-    y = F.conv2d(xr, w.float(), None, 1, pad, dil) * scale.view(1, -1, 1, 1)
-    y.backward(dU.float().permute(0, 3, 1, 2))
-    ref = (xr.grad + add.float().permute(0, 3, 1, 2)) * (x.float().permute(0, 3, 1, 2) > 0)
+    xr = _d(x).permute(0, 3, 1, 2).requires_grad_(True)
+    # (the kernel's operand is bf16(w * scale), rounded once by the pack kernel: the reference differentiates that product)
+    ws = (w.float() * scale.view(-1, 1, 1, 1)).bfloat16()
+    y = F.conv2d(xr, _d(ws), None, 1, pad, dil)
+    y.backward(_d(dU).permute(0, 3, 1, 2))
+    ref = (xr.grad + _d(add).permute(0, 3, 1, 2)) * (_d(x).permute(0, 3, 1, 2) > 0)
     ref = ref.permute(0, 2, 3, 1)
-    err = (dx.float() - ref).abs()
-    assert bool((err <= 1.5e-2 * ref.abs() + 3e-2 * float(ref.abs().mean())).all()), float(err.max())
+    err = (_d(dx) - ref).abs()
+    assert bool((err <= 1.02 * BF16_HALF_ULP * ref.abs() + 1e-5 * float(ref.abs().max())).all()), float(err.max())
 
 
 def test_conv_dgrad_stride2_scatter(ops):
@@ -171,15 +182,16 @@ def test_conv_wgrad(ops, case):
     scale = torch.rand(Cout, generator=g, device=DEV) + 0.5
     dw = torch.zeros(k * k, Cout, Cin, device=DEV)
     ops.conv_wgrad(dU, x, ops.conv_taps(k, k, dil, pad), dw, stride=stride, scale=scale)
-    w = torch.zeros(Cout, Cin, k, k, device=DEV, requires_grad=True)
-    y = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, stride, pad, dil) * scale.view(1, -1, 1, 1)
-    y.backward(dU.float().permute(0, 3, 1, 2))
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(_d(x).permute(0, 3, 1, 2), w, None, stride, pad, dil) * _d(scale).view(1, -1, 1, 1)
+    y.backward(_d(dU).permute(0, 3, 1, 2))
     ref = w.grad.permute(2, 3, 0, 1).reshape(k * k, Cout, Cin)
-    err = (dw - ref).abs()
-    assert float(err.max()) <= 2e-3 * float(ref.abs().max()) + 1e-3, (float(err.max()), float(ref.abs().max()))
+    err = (_d(dw) - ref).abs()
+    # fp32 output, exact bf16 x bf16 products: what is left is fp32 summation noise over N * Ho * Wo pixels
+    assert float(err.max()) <= 2e-5 * float(ref.abs().max()), (float(err.max()), float(ref.abs().max()))
     # accumulation semantics: a second call adds
     ops.conv_wgrad(dU, x, ops.conv_taps(k, k, dil, pad), dw, stride=stride, scale=scale, ksplit=3)
-    assert float((dw - 2 * ref).abs().max()) <= 4e-3 * float(ref.abs().max()) + 2e-3
+    assert float((_d(dw) - 2 * ref).abs().max()) <= 4e-5 * float(ref.abs().max())
 
 
 def test_aspp_wgrad_padded_classes(ops):
