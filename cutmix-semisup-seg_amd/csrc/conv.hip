@@ -1310,27 +1310,50 @@ struct WgradArgs {
     short tap_dy[CMS_CONV_MAX_TAPS], tap_dx[CMS_CONV_MAX_TAPS];
 };
 
-// dw[tap][co][ci] += sum over slices of slab[s][tap][co][ci], co < cout_real (4 floats per thread)
+// dw[tap][co][ci] += sum over slices of slab[s][tap][co][ci], co < cout_real. 64 float4 outputs per block, the slices dealt
+// over 4 thread groups with 4 independent loads in flight each, combined through LDS in a FIXED order (round 3: one thread
+// per output walking all slices serially made this launch 35 us for the 64 KB gradients of layer1, whose 2-9 tiles are cut
+// into ~190 slices -- the whole in-step cost of the deterministic mode, profiles/r03s_*).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int ksplit,
                                                             size_t slab_stride, int ntaps, int Cout, int Cin, int cout_real,
                                                             int dw_cout) {
-    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;          // float4 index over [ntaps][cout_real][Cin / 4]
+    __shared__ float4 part[3][64];
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t q = (size_t)blockIdx.x * 64 + j;                      // float4 index over [ntaps][cout_real][Cin / 4]
     const int c4 = Cin >> 2;
     const size_t total = (size_t)ntaps * cout_real * c4;
-    if (q >= total) return;
-    const int ci = (int)(q % c4) * 4;
-    const size_t r = q / c4;
-    const int co = (int)(r % cout_real), tap = (int)(r / cout_real);
-    const float* src = slab + ((size_t)tap * Cout + co) * Cin + ci;
-    float4 acc = *reinterpret_cast<const float4*>(src);
-    for (int s = 1; s < ksplit; ++s) {
-        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)s * slab_stride);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    const bool valid = q < total;
+    float4 acc = float4{0.f, 0.f, 0.f, 0.f};
+    int ci = 0, co = 0, tap = 0;
+    if (valid) {
+        ci = (int)(q % c4) * 4;
+        const size_t r = q / c4;
+        co = (int)(r % cout_real);
+        tap = (int)(r / cout_real);
+        const float* src = slab + ((size_t)tap * Cout + co) * Cin + ci;
+        const float4 zero = float4{0.f, 0.f, 0.f, 0.f};
+        for (int s = g; s < ksplit; s += 16) {
+            const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab_stride);
+            const float4 v1 = s + 4 < ksplit ? *reinterpret_cast<const float4*>(src + (size_t)(s + 4) * slab_stride) : zero;
+            const float4 v2 = s + 8 < ksplit ? *reinterpret_cast<const float4*>(src + (size_t)(s + 8) * slab_stride) : zero;
+            const float4 v3 = s + 12 < ksplit ? *reinterpret_cast<const float4*>(src + (size_t)(s + 12) * slab_stride) : zero;
+            acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+            acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
     }
-    float4* dst = reinterpret_cast<float4*>(dw + ((size_t)tap * dw_cout + co) * Cin + ci);
-    float4 o = *dst;
-    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
-    *dst = o;
+    if (g > 0) part[g - 1][j] = acc;
+    __syncthreads();
+    if (g == 0 && valid) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 v = part[k][j];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(dw + ((size_t)tap * dw_cout + co) * Cin + ci);
+        float4 o = *dst;
+        o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+        *dst = o;
+    }
 }
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -1941,7 +1964,7 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
 #undef CMS_WGRAD_LAUNCH2
     if (use_slab) {
         const size_t total4 = (size_t)d->ntaps * a.cout_real * (d->cin / 4);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, a.slab, d->dw, ksplit,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, a.slab, d->dw, ksplit,
                            slice_elems, d->ntaps, d->cout, d->cin, a.cout_real, a.dw_cout);
     }
     return launch_status("cms_conv_wgrad");

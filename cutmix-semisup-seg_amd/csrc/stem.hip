@@ -486,11 +486,24 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_mfma_kernel(const uint16_t*
 
 // dw[i] += sum over blocks of slab[b][i], in block order (the deterministic combine of the two kernels above)
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nblocks) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 49 * STEM_CO * 3) return;
+    // 64 outputs per block, the slabs dealt over 4 thread groups (4 loads in flight each), fixed combine order
+    __shared__ float part[3][64];
+    constexpr int TOTAL = 49 * STEM_CO * 3;
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + j;
     float s = 0.0f;
-    for (int b = 0; b < nblocks; ++b) s += slab[(size_t)b * (49 * STEM_CO * 3) + i];
-    dw[i] += s;
+    if (i < TOTAL) {
+        for (int b = g; b < nblocks; b += 16) {
+            const float v0 = slab[(size_t)b * TOTAL + i];
+            const float v1 = b + 4 < nblocks ? slab[(size_t)(b + 4) * TOTAL + i] : 0.0f;
+            const float v2 = b + 8 < nblocks ? slab[(size_t)(b + 8) * TOTAL + i] : 0.0f;
+            const float v3 = b + 12 < nblocks ? slab[(size_t)(b + 12) * TOTAL + i] : 0.0f;
+            s += (v0 + v1) + (v2 + v3);
+        }
+    }
+    if (g > 0) part[g - 1][j] = s;
+    __syncthreads();
+    if (g == 0 && i < TOTAL) dw[i] += ((s + part[0][j]) + part[1][j]) + part[2][j];
 }
 
 // ---- gradient wrt the image: dx[n,c,iy,ix] = sum_{ky,kx,co} dS[n,(iy+3-ky)/2,(ix+3-kx)/2,co] * scale[co]-folded w
@@ -691,7 +704,7 @@ extern "C" int cms_stem_wgrad_ws(const void* x_nchw, int x_dtype, const void* ds
 #undef CMS_STEM_WG
     }
     if (slab)
-        hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((49 * STEM_CO * 3 + 255) / 256), dim3(256), 0, s, slab, dw_khkwcoci, nblk);
+        hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((49 * STEM_CO * 3 + 63) / 64), dim3(256), 0, s, slab, dw_khkwcoci, nblk);
     return launch_status("cms_stem_wgrad");
 }
 

@@ -1133,7 +1133,9 @@ class PackTransposePlan(object):
 # atomics). Off by default: inside the two-stream step the atomics are 1.5-2 % faster (profiles/r03a_*). Switch on with
 # `set_deterministic_wgrad(True)` (StepConfig.deterministic, the trainers' --deterministic) or CMS_WGRAD_SLAB=1.
 import os as _os
-_WGRAD_DETERMINISTIC = _os.environ.get('CMS_WGRAD_SLAB', '0') not in ('', '0')
+_WGRAD_DETERMINISTIC = _os.environ.get('CMS_WGRAD_SLAB', '0') not in ('', '0', '2')
+# CMS_WGRAD_SLAB=2 (experiment): slabs only for the large layers (|dW| >= 256 k elements: layer3 / layer4), atomics for the rest
+_WGRAD_SLAB_LARGE = _os.environ.get('CMS_WGRAD_SLAB', '0') == '2'
 _WGRAD_WS = {}            # (device index, stream handle) -> uint8 scratch of eagerly issued launches
 
 
@@ -1200,7 +1202,7 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
     d.dbeta = dbeta.data_ptr() if dbeta is not None else None
     d.dw_cout = 0 if dw_cout is None else int(dw_cout)
     ws = None
-    if not f32 and _WGRAD_DETERMINISTIC:
+    if not f32 and (_WGRAD_DETERMINISTIC or (_WGRAD_SLAB_LARGE and len(taps) * cout * cin >= 262144)):
         ws = _wgrad_workspace(d, du.device, _REC is not None)
         if ws is not None:
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
