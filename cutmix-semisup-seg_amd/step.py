@@ -327,13 +327,15 @@ class CutMixMeanTeacherStep(object):
                     with torch.cuda.stream(side), torch.no_grad():
                         tea_lo = self.teacher.forward_lowres(x_tea)
                 stu_lo = self.student.forward_lowres(x_stu)
-            if use_unsup and side is not main:
-                main.wait_stream(side)
             # dense NCHW scratch for the loss kernels (stu_lo itself may be channels-last strided)
             grad_lo = torch.zeros(stu_lo.shape, dtype=torch.float32, device=stu_lo.device)
             lo_det = stu_lo.detach()
+            # the supervised loss needs nothing from the teacher: its kernels are issued BEFORE the join and overlap the tail
+            # of the teacher's pass on the other stream
             ce_sc, ce_ctx = ops.ce_forward(lo_det[:n_sup], sup_y, out_size, 255, self.align_corners, group=self.group)
             ops.ce_backward(ce_ctx, ce_sc, grad_lo[:n_sup])
+            if use_unsup and side is not main:
+                main.wait_stream(side)
             cons_vals = []
             if use_unsup:
                 s_off, t_off = n_sup, 0
