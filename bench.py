@@ -213,7 +213,7 @@ def run_workload(key, args, world, rank, dev):
     cfg = StepConfig(mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.97, conf_per_pixel=False,
                      fuse_batches=not args.no_fuse_batches, compute_dtype=dtype,
                      overlap_teacher=not args.no_overlap, allreduce_dtype=args.allreduce_dtype,
-                     deterministic=args.deterministic)
+                     deterministic=args.deterministic, early_optimizer=args.early_optimizer)
     step = CutMixMeanTeacherStep(stu, tea, opt, ema, cfg)
     step.time_buckets = world > 1            # (bytes, issue-to-wait) of every gradient bucket of the LAST timed step
     has_ex = hasattr(stu, 'hip_executor')
@@ -639,6 +639,8 @@ def main():
     ap.add_argument('--roofline_sample', type=int, default=5,
                     help='bracket every k-th launch of the conv kernel with events (1 = all; the brackets cost ~3 %% '
                          'of the step when every launch carries them)')
+    ap.add_argument('--early_optimizer', action='store_true',
+                    help='A/B: optimizer + EMA launches per finished gradient slice during the backward pass (third stream)')
     ap.add_argument('--no_also', action='store_true',
                     help='default run (--workload both, one GPU): skip the two extra short runs reported under "also" '
                          '(DeepLab v3+ at configs[3]; configs[1] without --freeze_bn)')

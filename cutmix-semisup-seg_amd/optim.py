@@ -72,6 +72,14 @@ class _FusedOptimizer(object):
         self._chunk_seg = torch.from_numpy(cs.view(np.int32)).to(dev)
         self._chunk_off = torch.from_numpy(co.view(np.int32)).to(dev)
         self._n_chunks = int(cs.shape[0])
+        # first chunk of the segment that starts at a given arena element (+ the end of the arena): ranged launches
+        self._chunk_at = {}
+        c0 = 0
+        for s in a.segments:
+            self._chunk_at[int(s.offset)] = c0
+            c0 += (int(s.count) + _lib.OPT_CHUNK - 1) // _lib.OPT_CHUNK
+        self._chunk_at[int(a.flat.numel())] = c0
+        self._early = None                  # chunk ranges already updated in this step (begin_ranged / step_range)
         self.slot0 = torch.zeros_like(a.flat)
         self.slot1 = torch.zeros_like(a.flat) if self.KIND == 'adam' else None
         # learning rates travel host -> device through a RING of pinned slots, each guarded by an event: the trainer
@@ -161,13 +169,46 @@ class _FusedOptimizer(object):
                 raise ValueError('{}: parameter groups differ in `{}` ({}); only `lr` may differ per group'.format(
                     type(self).__name__, name, vals))
 
-    def step(self):
-        self._upload_lrs()
+    def _launch(self, first_chunk, n_chunks):
+        if n_chunks <= 0:
+            return
         d = self._desc()
         self._fill(d)
+        d.chunk_seg = self._chunk_seg.data_ptr() + 4 * first_chunk
+        d.chunk_off = self._chunk_off.data_ptr() + 4 * first_chunk
+        d.n_chunks = int(n_chunks)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(fn['cms_adam_ema_step' if self.KIND == 'adam' else 'cms_sgd_ema_step'](C.byref(d), stream),
               'cms_{}_ema_step'.format(self.KIND))
+
+    # -- ranged launches: parts of the step issued EARLY, as soon as their gradients are final (step.py: the backward pass
+    # finishes the arena from the end towards the start, the update of [layer4 + head] can run while layer1's gradients are
+    # still being computed). `begin_ranged()` on the stream the backward pass starts from (learning rates uploaded there),
+    # `step_range(lo, hi)` for arena elements [lo, hi) (segment-aligned) on the stream that holds their final gradients,
+    # `step()` then updates what is left and closes the step (one step-counter increment for all of it).
+    def begin_ranged(self):
+        self._upload_lrs()
+        self._early = []
+
+    def step_range(self, lo, hi):
+        if self._early is None:
+            raise RuntimeError('step_range() outside begin_ranged() .. step()')
+        c0, c1 = self._chunk_at[int(lo)], self._chunk_at[int(hi)]
+        for a0, a1 in self._early:
+            if c0 < a1 and a0 < c1:
+                raise RuntimeError('step_range: elements updated twice in one step')
+        self._launch(c0, c1 - c0)
+        self._early.append((c0, c1))
+
+    def step(self):
+        self._upload_lrs()
+        done = sorted(self._early or [])
+        self._early = None
+        pos = 0
+        for c0, c1 in done + [(self._n_chunks, self._n_chunks)]:       # the complement of the early ranges
+            self._launch(pos, c0 - pos)
+            pos = max(pos, c1)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(fn['cms_increment_counter'](C.c_void_p(self.step_count.data_ptr()), stream), 'cms_increment_counter')
         from .backbone_hip import executors_of
         for ex in executors_of(self.module):

@@ -34,7 +34,8 @@ from . import ops
 class StepConfig(object):
     def __init__(self, mask_mode='mix', cons_loss_fn='var', cons_weight=1.0, conf_thresh=0.97, conf_per_pixel=False,
                  rampup=-1, unsup_batch_ratio=1, invert=True, fuse_batches=True, compute_dtype=torch.bfloat16,
-                 overlap_teacher=True, bucketed_allreduce=True, allreduce_dtype='fp32', deterministic=False):
+                 overlap_teacher=True, bucketed_allreduce=True, allreduce_dtype='fp32', deterministic=False,
+                 early_optimizer=False):
         if mask_mode not in ('mix', 'zero', 'cut'):
             raise ValueError('Unknown mask_mode {}'.format(mask_mode))
         self.mix = mask_mode == 'mix'
@@ -52,6 +53,10 @@ class StepConfig(object):
         self.allreduce_dtype = allreduce_dtype
         # run-to-run deterministic weight gradients (ops.set_deterministic_wgrad): 1.5-2 % slower inside the step
         self.deterministic = bool(deterministic)
+        # single process: optimizer + EMA launches per finished gradient slice during the backward pass (_arm_early_optimizer);
+        # measured: no gain (507 / 509 vs 507 / 505 img/s, profiles/r03eo_*) -- the 0.28 ms HBM-bound update only trades bandwidth
+        # with the convolutions it overlaps -- so it is off by default
+        self.early_optimizer = bool(early_optimizer)
         self.compute_dtype = compute_dtype
         self.cons = ops.ConsistencyConfig(mode='mix' if self.mix else 'cut', loss_fn=cons_loss_fn,
                                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, invert=invert)
@@ -210,6 +215,39 @@ class CutMixMeanTeacherStep(object):
         ex.grad_hook = self._buckets.on_block
         return ex
 
+    def _arm_early_optimizer(self):
+        """Single process: the fused optimizer + EMA kernel for a slice of the arena is issued on the weight-gradient stream
+        as soon as that slice's gradients are final -- [layer4 + head], the two halves of layer3, [layer1 - layer2], at the
+        bottlenecks the data-parallel buckets close at -- instead of one 0.28 ms launch after the whole backward pass; the
+        stem's slice follows in `student_optim.step()`. Same arithmetic per element, so the results are bit-identical."""
+        if self.world > 1 or not getattr(self.cfg, 'early_optimizer', False) or not hasattr(self.student_optim, 'step_range'):
+            return None
+        use_hip = getattr(self.student, '_use_hip_body', None)
+        if use_hip is None or not use_hip() or not hasattr(self.student.hip_executor(), 'block_grad_offsets'):
+            return None
+        ex = self.student.hip_executor()
+        if not ex.use_programs or not ex._want_w():
+            return None
+        opt = self.student_optim
+        offs, starts = ex.block_grad_offsets(), set(ex.bucket_starts())
+        state = {'hi': int(opt.arena.flat.numel())}
+        opt.begin_ranged()
+        if self.__dict__.get('_opt_stream') is None:
+            self._opt_stream = torch.cuda.Stream(device=opt.arena.device)
+        side = self._opt_stream
+
+        def on_block(bi):
+            # (called on the weight-gradient stream right after the slice's last weight gradient was enqueued there: the
+            # update runs on a THIRD stream behind that point, next to the weight gradients of the earlier layers)
+            if bi in starts and offs[bi] < state['hi']:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    opt.step_range(offs[bi], state['hi'])
+                state['hi'] = int(offs[bi])
+        ex.grad_hook = on_block
+        self._early_armed = True
+        return ex
+
     def _samples_independent(self):
         """Batches may only be concatenated when no layer couples the samples of a batch: every BatchNorm frozen and
         no active dropout, in BOTH networks (DeepLab v3+ keeps batch statistics and dropout in its head even under
@@ -350,7 +388,7 @@ class CutMixMeanTeacherStep(object):
                     ops.consistency_backward(cctx, sc, grad_lo[s_off:s_off + n])
                     s_off += n
                     cons_vals.append(sc)
-            ex = self._arm_buckets()
+            ex = self._arm_buckets() or self._arm_early_optimizer()
             try:
                 stu_lo.backward(grad_lo.to(stu_lo.dtype))
             finally:
@@ -398,6 +436,8 @@ class CutMixMeanTeacherStep(object):
                     cons_vals.append(sc)
 
         self._allreduce_grads()
+        if self.__dict__.pop('_early_armed', False):
+            torch.cuda.current_stream().wait_stream(self._opt_stream)       # the early slices of this step's update
         self.student_optim.step()
         if self.teacher_optim is not None:
             self.teacher_optim.step()

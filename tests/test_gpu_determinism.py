@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _one_iteration(deterministic, seed=3, freeze_bn=True):
+def _one_iteration(deterministic, seed=3, freeze_bn=True, early_optimizer=True, iters=1):
     from cutmix_semisup_seg_amd import ops, optim as fo
     from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
     from architectures import deeplab2
@@ -34,13 +34,17 @@ def _one_iteration(deterministic, seed=3, freeze_bn=True):
     if freeze_bn:
         stu.freeze_batchnorm(); tea.freeze_batchnorm()
     stu.engine_kind = tea.engine_kind = 'hip'
-    step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=0.2, deterministic=deterministic))
+    step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=0.2, deterministic=deterministic,
+                                                              early_optimizer=early_optimizer))
     g = torch.Generator(device=DEV).manual_seed(11)
     im = lambda: torch.randn(N, 3, H, W, generator=g, device=DEV).bfloat16()
     y = torch.randint(0, C, (N, 1, H, W), generator=g, device=DEV).to(torch.uint8)
     r = mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(N, (H, W), rng=np.random.RandomState(5))
-    res = step(im(), y, [UnsupBatch(im(), ops.ranges_to_device(r, DEV), x1_tea=im())])
+    for _ in range(iters):
+        res = step(im(), y, [UnsupBatch(im(), ops.ranges_to_device(r, DEV), x1_tea=im())])
     torch.cuda.synchronize()
+    _one_iteration.last_state = ({k: v.clone() for k, v in stu.state_dict().items()},
+                                 {k: v.clone() for k, v in tea.state_dict().items()}, int(opt.step_count.item()))
     grads = {k: p.grad.detach().clone() for k, p in stu.named_parameters() if p.grad is not None}
     ops.set_deterministic_wgrad(False)
     return {k: float(v) for k, v in res.items()}, grads, stu.state_dict()['layer3.1.conv2.weight'].clone()
@@ -74,3 +78,16 @@ def test_deterministic_mode_with_batch_statistics_is_bit_reproducible_too():
     print('\nbatch-statistics, deterministic mode: {} of {} gradient tensors differ between two runs: {}'.format(
         len(differing), len(ga), differing[:8]))
     assert not differing and torch.equal(wa, wb)
+
+
+def test_early_optimizer_launches_change_nothing():
+    """The optimizer + EMA kernel issued per finished gradient slice during the backward pass (StepConfig.early_optimizer, the
+    default) against ONE launch after it: in deterministic mode student, teacher and step counter agree bit for bit after
+    three iterations."""
+    _one_iteration(True, iters=3, early_optimizer=True)
+    sa, ta, na = _one_iteration.last_state
+    _one_iteration(True, iters=3, early_optimizer=False)
+    sb, tb, nb = _one_iteration.last_state
+    assert na == nb == 3
+    bad = [k for k in sa if not torch.equal(sa[k], sb[k])] + ['teacher.' + k for k in ta if not torch.equal(ta[k], tb[k])]
+    assert not bad, bad[:8]
