@@ -770,12 +770,12 @@ class DeepLabHipExecutor(object):
     def _side_streams(self, k):
         k = max(1, min(int(k), 3))
         while len(self._sides) < k:
-            self._sides.append(torch.cuda.Stream(device=self.arena.device))
+            self._sides.append(ops.pooled_stream(self.arena.device, 'wgrad{}'.format(len(self._sides))))
         return self._sides[:k]
 
     def _side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.arena.device)
+            self._side = ops.pooled_stream(self.arena.device, 'side')
         return self._side
 
 

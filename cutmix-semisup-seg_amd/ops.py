@@ -309,6 +309,26 @@ def upsample_bilinear(x, size, align_corners=True):
     return _UpsampleFn.apply(x, tuple(size), align_corners)
 
 
+# ---------------------------------------------------------------------------------------------- stream pool
+_STREAM_POOL = {}
+
+
+def pooled_stream(device, role):
+    """A process-wide side stream per (device, role): roles 'teacher', 'wgrad0..2', 'side', 'optimizer'. HIP multiplexes its
+    streams onto a handful of hardware queues; a process that keeps creating streams (bench.py runs four workloads, a
+    notebook rebuilds its step object) ends up with its 'concurrent' streams on ONE queue and loses the overlap the step is
+    built on (configs[1] without --freeze_bn as the fourth workload of one process: 277 img/s against 312 alone,
+    profiles/r03also_*). Objects that need a side stream take it from here instead of creating their own."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    key = (dev.index, str(role))
+    st = _STREAM_POOL.get(key)
+    if st is None:
+        st = _STREAM_POOL[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 # ---------------------------------------------------------------------------------------------- NHWC data movement (v3+ head)
 def _nhwc_ok(*ts):
     """contiguous NHWC bf16 / fp32 CUDA tensors with channels %% 8 == 0: what csrc/nhwc.hip takes."""

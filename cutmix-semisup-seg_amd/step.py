@@ -233,7 +233,7 @@ class CutMixMeanTeacherStep(object):
         state = {'hi': int(opt.arena.flat.numel())}
         opt.begin_ranged()
         if self.__dict__.get('_opt_stream') is None:
-            self._opt_stream = torch.cuda.Stream(device=opt.arena.device)
+            self._opt_stream = ops.pooled_stream(opt.arena.device, 'optimizer')
         side = self._opt_stream
 
         def on_block(bi):
@@ -289,7 +289,7 @@ class CutMixMeanTeacherStep(object):
 
     def _teacher_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            self._side = ops.pooled_stream(torch.cuda.current_device(), 'teacher')
         return self._side
 
     def nan_detected(self):
