@@ -325,7 +325,12 @@ def pooled_stream(device, role):
     key = (dev.index, str(role))
     st = _STREAM_POOL.get(key)
     if st is None:
-        st = _STREAM_POOL[key] = torch.cuda.Stream(device=dev)
+        # CMS_STREAM_PRIO="wgrad=-1+teacher=-1" (experiment, read at creation): -1 = high priority for roles with that prefix
+        prio = 0
+        for item in _os.environ.get('CMS_STREAM_PRIO', '').split('+'):
+            if '=' in item and str(role).startswith(item.split('=')[0]):
+                prio = int(item.split('=')[1])
+        st = _STREAM_POOL[key] = torch.cuda.Stream(device=dev, priority=prio)
     return st
 
 
