@@ -303,6 +303,46 @@ def test_step_fuses_batches_only_when_samples_are_independent():
     assert step3._samples_independent()
 
 
+def test_step_groups_batches_under_batch_statistics_only_where_the_kernels_keep_groups_apart():
+    """Batch-statistics BatchNorm: the passes may still travel as [sup; mixed] / [x0; x1] when both networks normalise SAMPLE
+    GROUPS apart (step._sample_groups): DeepLab v2 on the executor and DeepLab v3+, equal batch sizes, separate student /
+    teacher objects, one process -- decided on the host, checked here without a GPU."""
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
+    from cutmix_semisup_seg_amd.architectures import deeplab3plus as d3
+    v2 = lambda: deeplab2.ResNetDeepLab(deeplab2.Bottleneck, [1, 1, 1, 1], 3, np.zeros(3), np.ones(3))
+    stu, tea = v2(), v2()
+    stu.train(); tea.train()
+    step = CutMixMeanTeacherStep(stu, tea, None, None, StepConfig())
+    ub = lambda n: UnsupBatch(torch.zeros(n, 3, 9, 9), None, x1_tea=torch.zeros(n, 3, 9, 9))
+    assert stu.supports_sample_groups() and stu.sample_groups() == 1
+    assert step._sample_groups(4, [ub(4)], True) == (2, 2)
+    assert step._sample_groups(4, [ub(4), ub(4)], True) == (3, 4)
+    assert step._sample_groups(4, [], False) == (1, 0)
+    assert step._sample_groups(4, [ub(3)], True) is None                    # unequal group sizes
+    step.cfg.mix = False
+    assert step._sample_groups(4, [ub(4)], True) == (2, 1)                  # cut mode: one teacher pass
+    step.cfg.mix = True
+    tea.batchstat_executor = False                                          # teacher on the layer engine: no grouped kernels there
+    assert step._sample_groups(4, [ub(4)], True) is None
+    tea.batchstat_executor = True
+    pi = CutMixMeanTeacherStep(stu, stu, None, None, StepConfig())          # Pi model: ONE set of running statistics
+    assert pi._sample_groups(4, [ub(4)], True) is None
+    stu.freeze_batchnorm()
+    assert not stu.supports_sample_groups()                                 # frozen statistics: nothing to group (plain fusion)
+    stu.set_sample_groups(3)
+    assert stu.sample_groups() == 3
+    from cutmix_semisup_seg_amd import checkpoint
+    assert '_bn_groups' not in checkpoint.export_module(stu).__dict__       # runtime state stays out of checkpoints
+    stu.set_sample_groups(1)
+    w, wt = (d3.DeepLabv3Wrapper(d3._deeplabv3plus(3, 8, (1, 1, 1, 1))) for _ in range(2))
+    for n in (w, wt):
+        n.train(); n.freeze_batchnorm()
+    s3 = CutMixMeanTeacherStep(w, wt, None, None, StepConfig())
+    assert w.supports_sample_groups() and s3._sample_groups(2, [ub(2)], True) == (2, 2)      # head BatchNorms, dropout active
+    w.eval()
+    assert not w.supports_sample_groups()
+
+
 def test_which_convolutions_of_the_v3plus_head_are_routed_to_the_mfma_kernels():
     from cutmix_semisup_seg_amd.backbone_hip import hip_conv2d_eligible
     from cutmix_semisup_seg_amd.architectures import deeplab3plus as d3
