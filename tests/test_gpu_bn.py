@@ -244,3 +244,31 @@ def test_sample_groups_equal_separate_passes(C, dtype):
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     for name, u, v in zip(('y', 'running_mean', 'running_var', 'dx', 'dres', 'dgamma', 'dbeta'), a, b):
         torch.testing.assert_close(u, v, rtol=tol, atol=tol, msg=lambda m, name=name: name + ': ' + m)
+
+
+def test_last_block_protocol_never_reads_a_stale_partial():
+    """The reductions pass their partial sums through write-through stores and sc1 loads without fences (csrc/bn.hip): launches
+    alternating between two inputs on ONE workspace, with convolutions on another stream keeping the L2s busy, must reproduce
+    each input's first result bit for bit (a stale partial would be the other input's). tools/bn_stress.py is the long version."""
+    from cutmix_semisup_seg_amd import ops
+    torch.manual_seed(0)
+    P, C, G = 16810, 1024, 2
+    xs = [(torch.randn(P, C, device=DEV) * (1.0 + i) + i).bfloat16() for i in range(2)]
+    ws = ops.bn_workspace(P, C, DEV, G)
+    side = torch.cuda.Stream()
+    xc = torch.randn(8, 41, 41, 256, device=DEV).bfloat16()
+    wc = (torch.randn(9, 256, 256, device=DEV) * 0.05).bfloat16()
+    taps = ops.conv_taps(3, 3, 2, 2)
+    ref, outs = {}, []
+    for it in range(400):
+        if it % 40 == 0:
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    ops.conv_igemm(xc, wc, taps)
+        out = torch.empty(G * 2 * C, dtype=torch.float64, device=DEV)
+        ops.bn_op('reduce', c=C, dtype=torch.bfloat16, n_pixels=P, groups=G, x=xs[it & 1], sums=out, ws=ws)
+        outs.append((it & 1, out))
+    torch.cuda.synchronize()
+    for i, o in outs:
+        assert torch.equal(ref.setdefault(i, o), o)
+    assert not torch.equal(ref[0], ref[1])
