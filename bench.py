@@ -195,6 +195,9 @@ def run_workload(key, args, world, rank, dev):
 
     wl = WORKLOADS[key]
     B, H, W, C = wl['batch'], wl['H'], wl['W'], wl['classes']
+    if os.environ.get('CMS_BENCH_HW_' + key.upper()):       # EXPERIMENT ONLY (tile-fit studies): another crop size, e.g. 313x313
+        H, W = (int(v) for v in os.environ['CMS_BENCH_HW_' + key.upper()].split('x'))
+        wl = dict(wl, H=H, W=W, name=wl['name'] + ' [EXPERIMENT: crop {}x{}]'.format(H, W))
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     esz = 2.0 if dtype == torch.bfloat16 else 4.0
     roofline_kernel = args.roofline_kernel or 'conv'       # the dominant kernel of every workload (incl. DeepLab v3+)

@@ -65,7 +65,8 @@ class ConvDesc(C.Structure):
                 ('ho', c_int), ('wo', c_int), ('cout', c_int), ('cout_real', c_int), ('ntaps', c_int),
                 ('tap_dy', c_int * 18), ('tap_dx', c_int * 18), ('stride', c_int),
                 ('out_h', c_int), ('out_w', c_int), ('out_stride', c_int), ('relu', c_int), ('mode', c_int),
-                ('tile', c_int), ('ksplit', c_int), ('zeros', c_void_p), ('variant', c_int), ('zeros_bytes', c_int)]
+                ('tile', c_int), ('ksplit', c_int), ('zeros', c_void_p), ('variant', c_int), ('zeros_bytes', c_int),
+                ('workspace', c_void_p), ('workspace_bytes', C.c_longlong)]
 
 
 class WgradDesc(C.Structure):
@@ -137,6 +138,7 @@ PROTOTYPES = {
                                      c_int, c_void_p, c_void_p, c_void_p]),
     'cms_confusion': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
     'cms_conv_igemm': (c_int, [_P(ConvDesc), c_void_p]),
+    'cms_conv_igemm_workspace_bytes': (C.c_longlong, []),
     'cms_conv_set_trace': (c_int, [c_void_p, c_int]),
     'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_wgrad_workspace_bytes': (C.c_longlong, [_P(WgradDesc)]),

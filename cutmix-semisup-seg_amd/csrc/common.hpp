@@ -57,6 +57,11 @@ __device__ __forceinline__ void block_sum(float (&v)[K], float* smem /* >= K*16 
     }
 }
 
+// csrc/conv8.hip: the eight-phase 256 x 256 convolution (mode 0: one whole tile per workgroup, 1: persistent + stream-K)
+size_t conv8_workspace_bytes(int n_cu);
+bool conv8_supported(const cms_conv_desc* d);
+int conv8_launch(const cms_conv_desc* d, hipStream_t s, int mode, int grid_cap, void* trace, int trace_wgs);
+
 inline int grid_for(size_t work_items, int block, int max_blocks = 256 * 8) {
     size_t b = (work_items + block - 1) / block;
     if (b > (size_t)max_blocks) b = max_blocks;

@@ -1058,9 +1058,47 @@ static int conv_default_variant() {
     return v;
 }
 
+// The eight-phase 256 x 256 kernel (csrc/conv8.hip) takes the wide, K-deep layers. CMS_CONV8 (read once): 0 = never,
+// 1 = one whole tile per workgroup (default: +3.5 / +5 % on the two-stream step at 321 x 321 / 512 x 1024, profiles/r04d_*),
+// 2 = persistent launch with a stream-K round where the descriptor carries a workspace (slower: the 256 KB partial tiles
+// move at the ~10 B/clk a CU gets from memory), CMS_CONV8_MIN_KT = fewest 64-deep K tiles per output tile it is used for
+// (default 16), CMS_CONV8_GRID = workgroup cap of mode 2, CMS_CONV8_PASSES = bit 0 forward / bit 1 data-gradient launches.
+static int conv8_env(int which) {
+    static int mode = -1, min_kt = 0, grid = 0, passes = 3;
+    if (mode < 0) {
+        const char* e = getenv("CMS_CONV8");
+        const char* k = getenv("CMS_CONV8_MIN_KT");
+        const char* g = getenv("CMS_CONV8_GRID");
+        const char* p = getenv("CMS_CONV8_PASSES");            // bit 0: forward epilogue launches, bit 1: data gradients
+        min_kt = k ? atoi(k) : 16;
+        grid = g ? atoi(g) : 0;
+        passes = p ? atoi(p) : 3;
+        mode = e ? atoi(e) : 1;
+    }
+    return which == 0 ? mode : (which == 1 ? min_kt : (which == 2 ? grid : passes));
+}
+
+extern "C" long long cms_conv_igemm_workspace_bytes(void) {
+    int n_cu = 0;
+    if (cms_device_info(&n_cu, nullptr, 0) != CMS_OK || n_cu <= 0) n_cu = 256;
+    return (long long)cms::conv8_workspace_bytes(n_cu);
+}
+
 extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
     int rc = conv_check(d_in);
     if (rc) return rc;
+    if (d_in->variant >= 90 && d_in->variant <= 93)     // 92 / 93: 90 / 91 with cycle stamps into the cms_conv_set_trace buffer
+        return cms::conv8_launch(d_in, (hipStream_t)stream, (d_in->variant - 90) & 1, conv8_env(2),
+                                 d_in->variant >= 92 ? g_conv_trace : nullptr, g_conv_trace_wgs);
+    cms_conv_desc d_no8;
+    if (d_in->variant == 99) {                 // the 128 x 128 family, whatever CMS_CONV8 says (reference of the conv8 tests)
+        d_no8 = *d_in;
+        d_no8.variant = 0;
+        d_in = &d_no8;
+    } else if (d_in->variant == 0 && d_in->tile == 0 && conv8_env(0) > 0 && cms::conv8_supported(d_in) &&
+        d_in->ntaps * (d_in->cin / 64) >= conv8_env(1) && conv_default_variant() == 0 &&
+        ((conv8_env(3) >> (d_in->mode == 0 ? 0 : 1)) & 1))
+        return cms::conv8_launch(d_in, (hipStream_t)stream, conv8_env(0) - 1, conv8_env(2), nullptr, 0);
     cms_conv_desc d_copy;
     const cms_conv_desc* d = d_in;
     if (d_in->variant == 0 && conv_default_variant() != 0) {

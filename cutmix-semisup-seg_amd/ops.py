@@ -1009,6 +1009,28 @@ def _zero_page(device):
     return z
 
 
+_CONV8_WS = {}
+
+
+def conv8_workspace(device):
+    """Scratch of the eight-phase 256 x 256 convolution (csrc/conv8.hip: arrival counters + stream-K slabs,
+    cms_conv_igemm_workspace_bytes). Launches that may overlap must not share it: a recorded program owns one per stream
+    it records on (student / teacher passes and the two streams of a backward pass replay concurrently); eager launches
+    share one per (device, stream). The counters (first 64 KB) start at zero and every launch leaves them zero."""
+    if _REC is not None:
+        prog = _REC[0]
+        store, key = prog.__dict__.setdefault('conv8_ws', {}), _rec_stream_index()
+    else:
+        store, key = _CONV8_WS, (device.index, int(torch.cuda.current_stream().cuda_stream))
+    ws = store.get(key)
+    if ws is None:
+        n = int(fn['cms_conv_igemm_workspace_bytes']())
+        ws = torch.empty(n, dtype=torch.uint8, device=device)
+        ws[:65536].zero_()
+        store[key] = ws
+    return ws
+
+
 def conv_taps(kh, kw, dilation, padding):
     """(dy, dx) input offsets of the kh*kw taps in [ky][kx] order."""
     return [(ky * dilation - padding, kx * dilation - padding) for ky in range(kh) for kx in range(kw)]
@@ -1071,6 +1093,10 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     zp = _zero_page(x.device)
     d.zeros, d.zeros_bytes = zp.data_ptr(), zp.numel() * 2
     d.variant = int(variant)
+    if not f32 and out_f32_nchw is None and cout % 256 == 0 and cin % 64 == 0 and ksplit <= 1 \
+            and ((int(variant) == 0 and ntaps * (cin // 64) >= 8) or int(variant) in (91, 93)):
+        ws = conv8_workspace(x.device)       # wide, K-deep layer: the library may take the eight-phase kernel (csrc/conv8.hip)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     if _REC is not None:
         prog = _REC[0]
         idx = fn['cms_program_add_conv'](prog.h, C.byref(d), int(f32), _rec_stream_index(), prog.group)

@@ -249,11 +249,23 @@ typedef struct cms_conv_desc {
                               two stages, 5 = two stages of 32 K-elements; 2 / 3 = ablation switches (no MFMA / no
                               loads) of variant 0, 6 / 7 = the same of variant 4 (tools/conv_ablate*.py); 10..14 = stage
                               rings, 20..25 = K rotation / staggered starts, 30 = cycle trace (all measured, none
-                              faster: DESIGN.md section 4.1)                                                     */
+                              faster: DESIGN.md section 4.1); 90 = the eight-phase 256 x 256 kernel, one whole tile
+                              per workgroup; 91 = the same, persistent with a stream-K round (needs `workspace`);
+                              99 = never the eight-phase kernel                                                 */
     int zeros_bytes;       /* length of the `zeros` run (checked against 2 * cin + 128)                          */
+    void* workspace;       /* optional scratch of the eight-phase 256 x 256 kernel (csrc/conv8.hip; variant 90 / 91 or
+                              the automatic choice for Cout % 256 == 0 layers with >= 8 K tiles), at least
+                              cms_conv_igemm_workspace_bytes() long: 64 KB of arrival counters -- ZERO before the first
+                              launch that uses the buffer, left zero by every launch -- followed by the fp32 slabs of
+                              the stream-K round (tiles whose K loop is cut across workgroups so that the launch fills
+                              every CU; the last arriver of a tile adds the pieces in a fixed order). Launches that may
+                              overlap (different streams) need different workspaces. NULL: whole tiles only.        */
+    long long workspace_bytes;
 } cms_conv_desc;
 
 int cms_conv_igemm(const cms_conv_desc* d, void* stream);
+/* bytes of cms_conv_desc.workspace that every launch on this device is satisfied with */
+long long cms_conv_igemm_workspace_bytes(void);
 
 /* Diagnostic (tools/conv_trace.py): launches with variant 30 stamp s_memtime at every phase of the K loop of wave 0
  * (own loads landed / barrier / MFMAs issued / barrier / next stage issued) into `buf`: 512 dwords per workgroup for
