@@ -266,6 +266,14 @@ class ResNetDeepLab(nn.Module):
             return ok
         if not ok or not self.__dict__.get('batchstat_executor', True):
             return False
+        if any(p.requires_grad for m in self.modules() if isinstance(m, nn.BatchNorm2d) for p in m.parameters(recurse=False)):
+            # the executor's batch-statistics backward computes sum(dy) / sum(dy * xhat) for the data gradient only and does not
+            # accumulate them into the gradients of a TRAINABLE BatchNorm affine (the reference freezes it: deeplab2.py:76-84);
+            # a network with a trainable affine goes through the layer engine, whose autograd function returns dgamma / dbeta
+            if self.engine_kind == 'hip':
+                raise RuntimeError('batch-statistics passes on the executor need the BatchNorm affine frozen (requires_grad = '
+                                   'False, as the reference has it); use engine_kind = "auto" for a trainable affine')
+            return False
         if self.compute_dtype == torch.float32 and self.engine_kind != 'hip':
             return False                       # 'auto' in fp32: the library comparison engine, as for the other networks
         import torch.distributed as dist

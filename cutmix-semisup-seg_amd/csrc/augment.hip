@@ -81,6 +81,73 @@ __device__ __forceinline__ void warp_src(const float* p, int cx, int cy, float& 
     sy = fmaf(p[19], (float)cx, fmaf(p[20], (float)cy, p[21]));
 }
 
+// The geometric half of the transform for ONE (flip-undone) output pixel (cx, cy) of sample `img`: interpolated source colour
+// (0..255), validity weight `alpha`, `img_alpha` = factor of the mean in the standardisation (window mode: zero padding),
+// (ny, nx) = nearest source pixel for the labels. Shared by the image kernel and the luminance pre-pass, so that the contrast
+// pivot is the mean of exactly the pixels the image kernel produces (same taps, same weights).
+__device__ __forceinline__ void sample_source(const AugArgs& a, const float* p, const uint8_t* img, int cx, int cy, float (&rgb)[3],
+                                              float& alpha, float& img_alpha, int& ny, int& nx) {
+    const float y0 = p[0], x0 = p[1], sh = p[2], sw = p[3];
+    const bool warp = p[15] != 0.0f;
+    rgb[0] = rgb[1] = rgb[2] = 0.0f;
+    alpha = 0.0f;
+    img_alpha = 1.0f;
+    ny = nx = 0;
+    if (warp) {
+        // datapipe/seg_transforms_cv.py:344-362: cv2.warpAffine(image, local_xf, crop, flags=interp, BORDER_REFLECT_101),
+        // labels INTER_NEAREST / constant 255, mask constant 0
+        float sx, sy;
+        warp_src(p, cx, cy, sx, sy);
+        nx = (int)floorf(sx + 0.5f);
+        ny = (int)floorf(sy + 0.5f);
+        if (p[22] == 0.0f) {
+            const uint8_t* q = img + ((size_t)reflect101(ny, a.Hs) * a.Ws + reflect101(nx, a.Ws)) * 3;
+            rgb[0] = (float)q[0]; rgb[1] = (float)q[1]; rgb[2] = (float)q[2];
+            alpha = ((unsigned)ny < (unsigned)a.Hs && (unsigned)nx < (unsigned)a.Ws) ? 1.0f : 0.0f;
+        } else {
+            const int ix0 = (int)floorf(sx), iy0 = (int)floorf(sy);
+            const float wx = sx - (float)ix0, wy = sy - (float)iy0;
+            auto wtap = [&](int Y, int X, float w) {
+                const uint8_t* q = img + ((size_t)reflect101(Y, a.Hs) * a.Ws + reflect101(X, a.Ws)) * 3;
+                rgb[0] += w * (float)q[0];
+                rgb[1] += w * (float)q[1];
+                rgb[2] += w * (float)q[2];
+                if ((unsigned)Y < (unsigned)a.Hs && (unsigned)X < (unsigned)a.Ws) alpha += w;
+            };
+            wtap(iy0, ix0, (1.0f - wy) * (1.0f - wx));
+            wtap(iy0, ix0 + 1, (1.0f - wy) * wx);
+            wtap(iy0 + 1, ix0, wy * (1.0f - wx));
+            wtap(iy0 + 1, ix0 + 1, wy * wx);
+        }
+    } else {
+        // bilinear tap positions inside the source window (cv2.INTER_LINEAR: half-pixel centres, border replicated)
+        float fy = ((float)cy + 0.5f) * (sh / (float)a.H) - 0.5f, fx = ((float)cx + 0.5f) * (sw / (float)a.W) - 0.5f;
+        fy = fminf(fmaxf(fy, 0.0f), sh - 1.0f);
+        fx = fminf(fmaxf(fx, 0.0f), sw - 1.0f);
+        const int iy0 = (int)floorf(fy), ix0 = (int)floorf(fx);
+        const float wy = fy - (float)iy0, wx = fx - (float)ix0;
+        const int iy1 = min(iy0 + 1, (int)sh - 1), ix1 = min(ix0 + 1, (int)sw - 1);
+        const int Y0 = iy0 + (int)y0, Y1 = iy1 + (int)y0, X0 = ix0 + (int)x0, X1 = ix1 + (int)x0;
+        auto tap = [&](int Y, int X, float w) {
+            if (w != 0.0f && (unsigned)Y < (unsigned)a.Hs && (unsigned)X < (unsigned)a.Ws) {
+                const uint8_t* q = img + ((size_t)Y * a.Ws + X) * 3;
+                rgb[0] += w * (float)q[0];
+                rgb[1] += w * (float)q[1];
+                rgb[2] += w * (float)q[2];
+                alpha += w;
+            }
+        };
+        tap(Y0, X0, (1.0f - wy) * (1.0f - wx));
+        tap(Y0, X1, (1.0f - wy) * wx);
+        tap(Y1, X0, wy * (1.0f - wx));
+        tap(Y1, X1, wy * wx);
+        img_alpha = alpha;
+        // cv2.INTER_NEAREST: floor(dst * scale)
+        ny = min((int)((float)cy * (sh / (float)a.H)), (int)sh - 1) + (int)y0;
+        nx = min((int)((float)cx * (sw / (float)a.W)), (int)sw - 1) + (int)x0;
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
     const size_t total = (size_t)a.N * a.H * a.W;
@@ -96,66 +163,10 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
         if (p[6] != 0.0f) { const int t = cy; cy = cx; cx = t; }
         if (p[5] != 0.0f) cy = a.H - 1 - cy;
         if (p[4] != 0.0f) cx = a.W - 1 - cx;
-        const float y0 = p[0], x0 = p[1], sh = p[2], sw = p[3];
-        const bool warp = p[15] != 0.0f;
-        float rgb[3] = {0.0f, 0.0f, 0.0f};
-        float alpha = 0.0f;
-        const uint8_t* img = a.src + (size_t)n * a.Hs * a.Ws * 3;
-        float img_alpha = 1.0f;                 // factor of the mean in the standardisation (window mode: zero padding)
-        int ny = 0, nx = 0;                     // nearest source pixel for the labels
-        if (warp) {
-            // datapipe/seg_transforms_cv.py:344-362: cv2.warpAffine(image, local_xf, crop, flags=interp, BORDER_REFLECT_101),
-            // labels INTER_NEAREST / constant 255, mask constant 0
-            float sx, sy;
-            warp_src(p, cx, cy, sx, sy);
-            nx = (int)floorf(sx + 0.5f);
-            ny = (int)floorf(sy + 0.5f);
-            if (p[22] == 0.0f) {
-                const uint8_t* q = img + ((size_t)reflect101(ny, a.Hs) * a.Ws + reflect101(nx, a.Ws)) * 3;
-                rgb[0] = (float)q[0]; rgb[1] = (float)q[1]; rgb[2] = (float)q[2];
-                alpha = ((unsigned)ny < (unsigned)a.Hs && (unsigned)nx < (unsigned)a.Ws) ? 1.0f : 0.0f;
-            } else {
-                const int ix0 = (int)floorf(sx), iy0 = (int)floorf(sy);
-                const float wx = sx - (float)ix0, wy = sy - (float)iy0;
-                auto wtap = [&](int Y, int X, float w) {
-                    const uint8_t* q = img + ((size_t)reflect101(Y, a.Hs) * a.Ws + reflect101(X, a.Ws)) * 3;
-                    rgb[0] += w * (float)q[0];
-                    rgb[1] += w * (float)q[1];
-                    rgb[2] += w * (float)q[2];
-                    if ((unsigned)Y < (unsigned)a.Hs && (unsigned)X < (unsigned)a.Ws) alpha += w;
-                };
-                wtap(iy0, ix0, (1.0f - wy) * (1.0f - wx));
-                wtap(iy0, ix0 + 1, (1.0f - wy) * wx);
-                wtap(iy0 + 1, ix0, wy * (1.0f - wx));
-                wtap(iy0 + 1, ix0 + 1, wy * wx);
-            }
-        } else {
-            // bilinear tap positions inside the source window (cv2.INTER_LINEAR: half-pixel centres, border replicated)
-            float fy = ((float)cy + 0.5f) * (sh / (float)a.H) - 0.5f, fx = ((float)cx + 0.5f) * (sw / (float)a.W) - 0.5f;
-            fy = fminf(fmaxf(fy, 0.0f), sh - 1.0f);
-            fx = fminf(fmaxf(fx, 0.0f), sw - 1.0f);
-            const int iy0 = (int)floorf(fy), ix0 = (int)floorf(fx);
-            const float wy = fy - (float)iy0, wx = fx - (float)ix0;
-            const int iy1 = min(iy0 + 1, (int)sh - 1), ix1 = min(ix0 + 1, (int)sw - 1);
-            const int Y0 = iy0 + (int)y0, Y1 = iy1 + (int)y0, X0 = ix0 + (int)x0, X1 = ix1 + (int)x0;
-            auto tap = [&](int Y, int X, float w) {
-                if (w != 0.0f && (unsigned)Y < (unsigned)a.Hs && (unsigned)X < (unsigned)a.Ws) {
-                    const uint8_t* q = img + ((size_t)Y * a.Ws + X) * 3;
-                    rgb[0] += w * (float)q[0];
-                    rgb[1] += w * (float)q[1];
-                    rgb[2] += w * (float)q[2];
-                    alpha += w;
-                }
-            };
-            tap(Y0, X0, (1.0f - wy) * (1.0f - wx));
-            tap(Y0, X1, (1.0f - wy) * wx);
-            tap(Y1, X0, wy * (1.0f - wx));
-            tap(Y1, X1, wy * wx);
-            img_alpha = alpha;
-            // cv2.INTER_NEAREST: floor(dst * scale)
-            ny = min((int)((float)cy * (sh / (float)a.H)), (int)sh - 1) + (int)y0;
-            nx = min((int)((float)cx * (sw / (float)a.W)), (int)sw - 1) + (int)x0;
-        }
+        float rgb[3];
+        float alpha, img_alpha;
+        int ny, nx;
+        sample_source(a, p, a.src + (size_t)n * a.Hs * a.Ws * 3, cx, cy, rgb, alpha, img_alpha, ny, nx);
         float r = rgb[0] * (1.0f / 255.0f), g = rgb[1] * (1.0f / 255.0f), b = rgb[2] * (1.0f / 255.0f);
         const size_t o = (size_t)n * 3 * plane + (size_t)oy * a.W + ox;
         if (a.out0) {
@@ -209,27 +220,14 @@ __global__ __launch_bounds__(256) void augment_luma_kernel(AugArgs a, float* __r
     __shared__ float red[16];
     const int n = blockIdx.x;
     const float* p = a.params + (size_t)n * CMS_AUG_PARAMS;
-    const float y0 = p[0], x0 = p[1], sh = p[2], sw = p[3];
     const uint8_t* img = a.src + (size_t)n * a.Hs * a.Ws * 3;
     float acc = 0.0f;
     for (int i = threadIdx.x; i < a.H * a.W; i += blockDim.x) {
         const int cy = i / a.W, cx = i % a.W;           // (flips do not change the mean)
-        if (p[15] != 0.0f) {                            // affine warp: nearest tap, reflected border
-            float sx, sy;
-            warp_src(p, cx, cy, sx, sy);
-            const uint8_t* q = img + ((size_t)reflect101((int)floorf(sy + 0.5f), a.Hs) * a.Ws +
-                                      reflect101((int)floorf(sx + 0.5f), a.Ws)) * 3;
-            acc += gray_of((float)q[0], (float)q[1], (float)q[2]) * (1.0f / 255.0f);
-            continue;
-        }
-        float fy = ((float)cy + 0.5f) * (sh / (float)a.H) - 0.5f, fx = ((float)cx + 0.5f) * (sw / (float)a.W) - 0.5f;
-        fy = fminf(fmaxf(fy, 0.0f), sh - 1.0f);
-        fx = fminf(fmaxf(fx, 0.0f), sw - 1.0f);
-        const int Y = (int)(fy + 0.5f) + (int)y0, X = (int)(fx + 0.5f) + (int)x0;     // nearest tap is enough for a mean
-        if ((unsigned)Y < (unsigned)a.Hs && (unsigned)X < (unsigned)a.Ws) {
-            const uint8_t* q = img + ((size_t)Y * a.Ws + X) * 3;
-            acc += gray_of((float)q[0], (float)q[1], (float)q[2]) * (1.0f / 255.0f);
-        }
+        float rgb[3], alpha, img_alpha;
+        int ny, nx;
+        sample_source(a, p, img, cx, cy, rgb, alpha, img_alpha, ny, nx);      // the image kernel's own taps and weights
+        acc += gray_of(rgb[0], rgb[1], rgb[2]) * (1.0f / 255.0f);
     }
     float v[1] = {acc};
     block_sum<1>(v, red);

@@ -197,6 +197,9 @@ __device__ __forceinline__ void bn_finalize_channel(const BnFin& f, int c, doubl
 constexpr int BN_CT = 64;            // channels per tile
 
 // 16-byte agent-coherent load (global_load_dwordx4 sc1: served past the non-coherent L2 lines of other XCDs)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "bn_reduce_tiled_kernel's write-through / sc1 hand-off is written for gfx942 / gfx950 (sc1 cache-policy bit); build with --offload-arch=gfx950"
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 load_sc1_x4(const float* p) {
     f32x4 v;
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void bn_reduce_tiled_kernel(const T* __restric
                                                               const T* __restrict__ y, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, double* __restrict__ sums,
                                                               unsigned* counters, float* part,
-                                                              size_t Pg, int C, int tiles, int S, BnFin fin) {
+                                                              size_t Pg, int C, int tiles, int S, BnFin fin, int fenced) {
     __shared__ float red[4][2 * BN_CT];
     __shared__ double redd[8][2 * BN_CT];
     __shared__ int last_flag;
@@ -298,8 +301,18 @@ __global__ __launch_bounds__(256) void bn_reduce_tiled_kernel(const T* __restric
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
+        // `fenced` (CMS_BN_FENCE=1): the textbook release / acquire pair of the HIP memory model on top of the write-through
+        // protocol -- an agent-scope release before the ticket (a writeback of the XCD's L2: 26-93 us per launch alone,
+        // profiles/r03bn_fenced_variant.log), an agent-scope acquire in the last block. The default relies on what
+        // cdna_hip_programming.md (Guideline 16, R1) documents for this part: sc1 stores + drained vmcnt + relaxed agent
+        // ticket, sc1 loads on the reading side. tools/bn_stress.py and tests/test_gpu_bn.py run both.
+        if (fenced) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const unsigned prev = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = prev == (unsigned)(G * S - 1);
+        if (fenced && last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     if (!last_flag) return;
@@ -500,6 +513,7 @@ extern "C" int cms_bn_reduce(const void* x, const void* dy, const void* y, int d
             const char* e = getenv("CMS_BN_GRID");
             env_cap = e ? atoi(e) : 256;
         }
+        if (env_cap < 1) env_cap = 1;               // (CMS_BN_GRID=0 would ask for an empty grid)
         if (want > (size_t)env_cap) want = (size_t)env_cap;
         const dim3 grid((unsigned)want);
         const size_t lds = (size_t)slots * CG * 16 * sizeof(float);
@@ -517,6 +531,13 @@ extern "C" int cms_bn_reduce(const void* x, const void* dy, const void* y, int d
 }
 
 // ---- atomics-free reduction (bn_reduce_tiled_kernel) ----------------------------------------------------------------------
+// CMS_BN_FENCE=1: the fenced (release / acquire) variant of the last-block hand-off. Read at every launch (a getenv), so that
+// one process can run both variants (tests/test_gpu_bn.py, tools/bn_stress.py).
+static int bn_fenced() {
+    const char* e = getenv("CMS_BN_FENCE");
+    return (e && atoi(e) != 0) ? 1 : 0;
+}
+
 static int bn_groups_ok(size_t n_pixels, int groups) { return groups >= 1 && n_pixels % (size_t)groups == 0; }
 
 static void bn_tiling(size_t n_pixels, int c, int groups, int* tiles, int* splits) {
@@ -553,7 +574,7 @@ static int bn_reduce_tiled(const void* x, const void* dy, const void* y, int dty
     const dim3 grid((unsigned)(tiles * S), (unsigned)groups);
     const size_t pg = n_pixels / (size_t)groups;
     BnFin f = fin ? *fin : BnFin{};
-#define CMS_BN_TILED(T, M, F) hipLaunchKernelGGL((bn_reduce_tiled_kernel<T, M, F>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, sums, counters, part, pg, c, tiles, S, f)
+#define CMS_BN_TILED(T, M, F) hipLaunchKernelGGL((bn_reduce_tiled_kernel<T, M, F>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, sums, counters, part, pg, c, tiles, S, f, bn_fenced())
     if (dtype == CMS_F32) {
         if (mode == 1) CMS_BN_TILED(float, 1, false);
         else if (fin) CMS_BN_TILED(float, 0, true);

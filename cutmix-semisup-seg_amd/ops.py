@@ -356,7 +356,8 @@ class _ConcatChannelsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, *xs):
-        big = next(x for x in xs if x.shape[1] * x.shape[2] > 1 or len(xs) == 1)
+        # (every input 1 x 1 -- a feature map of one pixel: all of them share that geometry)
+        big = next((x for x in xs if x.shape[1] * x.shape[2] > 1 or len(xs) == 1), xs[0])
         n, h, w = (int(v) for v in big.shape[:3])
         ctot = sum(int(x.shape[3]) for x in xs)
         out = torch.empty((n, h, w, ctot), dtype=big.dtype, device=big.device)

@@ -335,6 +335,18 @@ class CutMixMeanTeacherStep(object):
                 self.student.set_sample_groups(groups[0])
                 if use_unsup:
                     self.teacher.set_sample_groups(groups[1])
+            self.__dict__['_groups_armed'] = groups is not None      # restored by _fused_iteration_done, whatever raises
+        try:
+            return self._train_step_body(sup_x, sup_y, unsup_batches, ramp_val, groups, independent, use_unsup, n_sup, ramp,
+                                         out_size)
+        finally:
+            if self.__dict__.pop('_groups_armed', False):
+                self.student.set_sample_groups(1)
+                self.teacher.set_sample_groups(1)
+
+    def _train_step_body(self, sup_x, sup_y, unsup_batches, ramp_val, groups, independent, use_unsup, n_sup, ramp, out_size):
+        cfg = self.cfg
+        if cfg.fuse_batches and (independent or groups is not None):
             stu_in = [sup_x]
             tea_in = []
             if use_unsup:
@@ -394,10 +406,6 @@ class CutMixMeanTeacherStep(object):
             finally:
                 if ex is not None:
                     ex.grad_hook = None
-                if groups is not None:
-                    self.student.set_sample_groups(1)
-                    if use_unsup:
-                        self.teacher.set_sample_groups(1)
         else:
             # reference order, separate passes (batch-statistics BN). The teacher's passes depend on nothing the student
             # does within the iteration (its weights only move in the EMA at the end), so they are issued FIRST, on

@@ -59,8 +59,9 @@ def test_device_staging_vs_numpy_oracle(cfg):
         torch.testing.assert_close(out['mask'][i, 0].cpu().double(), torch.from_numpy(np.ascontiguousarray(al)), rtol=1e-5, atol=1e-5)
         assert np.array_equal(out['labels'][i, 0].cpu().numpy(), lb)
         if cfg.get('strong_colour'):
-            # (nearest-tap luminance pre-pass on the device vs the bilinear mean here: the pivot differs in the 3rd digit)
-            torch.testing.assert_close(out['image_stu'][i].cpu().double(), torch.from_numpy(i1), rtol=2e-2, atol=2e-2)
+            # (round 4: the luminance pre-pass uses the image kernel's own taps and weights, so the contrast pivot is the mean
+            # of the very pixels that are jittered: fp32 reduction noise only; it used a nearest tap and a 2e-2 bound)
+            torch.testing.assert_close(out['image_stu'][i].cpu().double(), torch.from_numpy(i1), rtol=2e-3, atol=2e-3)
     if cfg.get('strong_colour'):
         same = [i for i in range(N) if not params[i, 12] and not params[i, 11]]
         for i in same:                                           # jitter not drawn: the student view IS the teacher view

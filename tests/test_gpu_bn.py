@@ -246,11 +246,15 @@ def test_sample_groups_equal_separate_passes(C, dtype):
         torch.testing.assert_close(u, v, rtol=tol, atol=tol, msg=lambda m, name=name: name + ': ' + m)
 
 
-def test_last_block_protocol_never_reads_a_stale_partial():
+@pytest.mark.parametrize('fenced', [0, 1], ids=['write_through', 'release_acquire_fences'])
+def test_last_block_protocol_never_reads_a_stale_partial(fenced, monkeypatch):
     """The reductions pass their partial sums through write-through stores and sc1 loads without fences (csrc/bn.hip): launches
     alternating between two inputs on ONE workspace, with convolutions on another stream keeping the L2s busy, must reproduce
-    each input's first result bit for bit (a stale partial would be the other input's). tools/bn_stress.py is the long version."""
+    each input's first result bit for bit (a stale partial would be the other input's). tools/bn_stress.py is the long version.
+    CMS_BN_FENCE=1 (read at every launch) adds the release / acquire fences of the HIP memory model: the fallback a user can
+    switch on, held to the same test -- and to the same bits as the default."""
     from cutmix_semisup_seg_amd import ops
+    monkeypatch.setenv('CMS_BN_FENCE', str(fenced))
     torch.manual_seed(0)
     P, C, G = 16810, 1024, 2
     xs = [(torch.randn(P, C, device=DEV) * (1.0 + i) + i).bfloat16() for i in range(2)]

@@ -1,7 +1,8 @@
 """Stress test of the last-block protocol of bn_reduce_tiled_kernel (csrc/bn.hip): partial sums travel through write-through
 stores + an explicit s_waitcnt, a counter atomic, and sc1 loads in the last block -- no fences. Thousands of launches alternate
 between two inputs on ONE workspace while another stream keeps the L2s busy with convolutions; every result must equal,
-bit for bit, the first result computed for that input (a stale partial would be the other input's)."""
+bit for bit, the first result computed for that input (a stale partial would be the other input's).
+CMS_BN_FENCE=1 python tools/bn_stress.py runs the fenced (release / acquire) variant of the same kernel."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
