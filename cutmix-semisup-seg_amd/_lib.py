@@ -142,6 +142,10 @@ PROTOTYPES = {
     'cms_conv_set_trace': (c_int, [c_void_p, c_int]),
     'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_wgrad_workspace_bytes': (C.c_longlong, [_P(WgradDesc)]),
+    'cms_conv_wgrad_group_kind': (c_int, [_P(WgradDesc)]),
+    'cms_conv_wgrad_group_bytes': (C.c_longlong, [c_int]),
+    'cms_conv_wgrad_group_pack': (c_int, [_P(WgradDesc), c_int, c_int, c_void_p, C.c_longlong, _P(c_int)]),
+    'cms_conv_wgrad_group_run': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'cms_conv_pack_transpose_batch': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'cms_augment_batch': (c_int, [_P(AugmentDesc), c_void_p]),
@@ -189,6 +193,7 @@ PROTOTYPES = {
     'cms_program_destroy': (c_int, [c_void_p]),
     'cms_program_add_conv': (c_int, [c_void_p, _P(ConvDesc), c_int, c_int, c_int]),
     'cms_program_add_wgrad': (c_int, [c_void_p, _P(WgradDesc), c_int, c_int, c_int]),
+    'cms_program_add_wgrad_group': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     'cms_program_add_memset': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int]),
     'cms_program_add_sync': (c_int, [c_void_p, c_int, c_int, c_int]),
     'cms_program_add_aspp_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _P(c_int), _P(c_int), c_int, c_int,

@@ -25,6 +25,7 @@ MI355X-first:
   * weights are read from the bf16 copy the fused optimizer maintains in the parameter arena when present
 """
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -249,7 +250,13 @@ class ResNetDeepLab(nn.Module):
         return _engine_of(self, x)
 
     def _frozen_bn(self):
-        return all(not m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        # (asked several times per iteration: the list of BatchNorm modules is built once -- the module tree is static --
+        # instead of walking ~300 modules each time, which cost 0.4 ms of host time per call at the head of every
+        # iteration, where the GPU waits for the host: profiles/r04m_host_profile.txt)
+        bns = self.__dict__.get('_bn_list')
+        if bns is None:
+            bns = self.__dict__['_bn_list'] = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        return all(not m.training for m in bns)
 
     def _use_hip_body(self):
         """True: the static MFMA executor (backbone_hip.DeepLabHipExecutor) runs the body and the head. With every BatchNorm
@@ -266,7 +273,7 @@ class ResNetDeepLab(nn.Module):
             return ok
         if not ok or not self.__dict__.get('batchstat_executor', True):
             return False
-        if any(p.requires_grad for m in self.modules() if isinstance(m, nn.BatchNorm2d) for p in m.parameters(recurse=False)):
+        if any(p.requires_grad for m in self.__dict__['_bn_list'] for p in m.parameters(recurse=False)):
             # the executor's batch-statistics backward computes sum(dy) / sum(dy * xhat) for the data gradient only and does not
             # accumulate them into the gradients of a TRAINABLE BatchNorm affine (the reference freezes it: deeplab2.py:76-84);
             # a network with a trainable affine goes through the layer engine, whose autograd function returns dgamma / dbeta

@@ -22,6 +22,7 @@ BatchNorm on BATCH statistics (the reference CLI's default, train_seg_semisup_ma
 the executor too -- every unit becomes  u = conv(x);  y = relu(bn_batch(u) (+ res))  with the csrc/bn.hip launches recorded
 into the same programs (cms_program_add_bn), see `_fwd_unit_bn` / `_bwd_unit_bn` below.
 """
+import os
 import torch
 
 from . import ops
@@ -111,6 +112,10 @@ class DeepLabHipExecutor(object):
         # of ~1.5 workgroups per CU each). Measured on cfg 2 (profiles/r02f_wgrad_streams.txt): 1 -> 443-445 img/s,
         # 2 -> 433, 3 -> 443: one stream beside the data-gradient chain already keeps the machine busy
         self.wgrad_streams = 1
+        # Weight gradients of this many consecutive bottlenecks go out as ONE grouped launch per kind (ops.conv_wgrad_group)
+        # on the weight-gradient stream, behind the data-gradient chain of the stretch; 0 = one launch per layer (round 1-3).
+        # CMS_WGRAD_GROUP sets it (A/B switch, read once).
+        self.wgrad_group_blocks = int(os.environ.get('CMS_WGRAD_GROUP', '0'))
         self._sides = []
         self.conv_tile = 0         # experiment knob: force a tile shape on the 128-multiple layers (tools, bench)
         self.tile_rules = {}       # output channels -> tile code (per-layer choice against the workgroup-count staircase)
@@ -463,7 +468,10 @@ class DeepLabHipExecutor(object):
         """(N, 3, H, W) image batch -> NHWC (N, hp, wp, 64) input of the body: 7x7/2 convolution + frozen BatchNorm +
         ReLU + max-pool (deeplab2.py:183-186) on csrc/stem.hip, with its own backward pass (weight gradient into the
         arena; image gradient only when the input asks for one: VAT)."""
-        return _StemFn.apply(x.contiguous(), dict(self.net.named_parameters())[self.stem_wkey], self)
+        w = self.__dict__.get('_stem_param')
+        if w is None:                     # (a walk over all named parameters: once, not per pass)
+            w = self.__dict__['_stem_param'] = dict(self.net.named_parameters())[self.stem_wkey]
+        return _StemFn.apply(x.contiguous(), w, self)
 
     def _prepare_forward(self):
         """Operand tables a forward pass reads (torch ops on the current stream, only when stale)."""
@@ -647,6 +655,7 @@ class DeepLabHipExecutor(object):
         capture = getattr(self, 'debug_capture', None)
         keep = []                 # tensors read on the side stream must outlive the python scope that made them
         closes = set(self.bucket_starts())
+        pending, pending_blocks = [], []
         for bi in range(len(self.blocks) - 1, -1, -1):
             if capture is not None:
                 capture[bi] = dC
@@ -657,6 +666,24 @@ class DeepLabHipExecutor(object):
             dU1 = self._dgrad(dU2, b.c2, mask=a1)
             if not want_w:
                 pass
+            elif sides and self.wgrad_group_blocks > 0 and self.dtype == torch.bfloat16:
+                # grouped: collect the launches of this bottleneck; the group goes out behind the data gradients of its LAST
+                # bottleneck (a gradient bucket closing here ends the group too)
+                keep.append((dC, dU2, dU1))
+                pending_blocks.append(bi)
+                pending += [(dC, a2, b.c3), (dU2, a1, b.c2)] + ([(dC, xin, b.cd)] if b.cd is not None else []) + [(dU1, xin, b.c1)]
+                if len(pending_blocks) >= self.wgrad_group_blocks or bi in closes or bi == 0:
+                    ops.stream_wait(sides[0], main)
+                    with torch.cuda.stream(sides[0]):
+                        grouped = [(du_, x_, c_.taps, self.arena.packed(c_.wkey, self.arena.grad), c_.stride, c_.scale)
+                                   for du_, x_, c_ in pending if c_.wdot is None]
+                        ops.conv_wgrad_group(grouped)
+                        for du_, x_, c_ in pending:
+                            if c_.wdot is not None:
+                                self._wgrad(du_, x_, c_)
+                        for pb in pending_blocks:
+                            hook(pb)
+                    pending, pending_blocks = [], []
             elif sides:
                 for sd in sides:
                     ops.stream_wait(sd, main)

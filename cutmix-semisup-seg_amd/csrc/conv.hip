@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include "common.hpp"
 
@@ -1410,8 +1411,10 @@ __device__ __forceinline__ uint32_t wg_off(int pix, int ch) {     // byte offset
 // PLAIN launches then advance a SCALAR offset per stage (no vector ALU in the loader at all); rows past the slice are
 // out-of-range offsets (hardware zero fill). tools/wgrad_trace.py: the register loader spent 1450..1900 of a
 // 3700..4100-cycle stage issuing its 8 loads (64-bit address arithmetic) and 750 waiting for them + ds_write.
+// (the body is a device function of the LOGICAL block id -- XCD-remapped by the caller -- so that a grouped launch can run the
+// weight gradients of many layers in one grid: conv_wgrad_group_kernel below)
 template <int TCO, int TCI, bool PLAIN, bool BETA, bool DMA = false, int DNS = 1>   // 32x32 MFMA tiles per wave along co / ci; waves are 2 x 2
-__global__ __launch_bounds__(256, DMA ? ((BETA || !PLAIN) ? 3 : 4) : 1) void conv_wgrad_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, int b) {
     constexpr int BCO = 2 * TCO * 32, BCI = 2 * TCI * 32;       // <= 128 each
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WG_STAGE = 2 * 64 * 256;        // one stage: dU tile + X tile (32 KB)
@@ -1434,12 +1437,6 @@ __global__ __launch_bounds__(256, DMA ? ((BETA || !PLAIN) ? 3 : 4) : 1) void con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wco = wave & 1, wci = wave >> 1;
     const int nco = a.Cout / BCO, nci = a.Cin / BCI;
-    int b = blockIdx.x;
-    {   // XCD-aware order: all (co, ci, tap) tiles of one pixel slice are consecutive logical ids and therefore run
-        // on one XCD, which then fetches that slice of dU / X from HBM once instead of once per XCD
-        const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = b % 8, idx = b / 8;
-        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     const int tco = b % nco; b /= nco;
     const int tci = b % nci; b /= nci;
     const int tap = b % a.ntaps; b /= a.ntaps;
@@ -1843,6 +1840,42 @@ __global__ __launch_bounds__(256, DMA ? ((BETA || !PLAIN) ? 3 : 4) : 1) void con
     }
 }
 
+// XCD-aware order: all (co, ci, tap) tiles of one pixel slice are consecutive logical ids and therefore run on one XCD, which
+// then fetches that slice of dU / X from HBM once instead of once per XCD
+__device__ __forceinline__ int xcd_logical_block() {
+    const int b = blockIdx.x, nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = b % 8, idx = b / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int TCO, int TCI, bool PLAIN, bool BETA, bool DMA = false, int DNS = 1>
+__global__ __launch_bounds__(256, DMA ? ((BETA || !PLAIN) ? 3 : 4) : 1) void conv_wgrad_kernel(WgradArgs a) {
+    wgrad_body<TCO, TCI, PLAIN, BETA, DMA, DNS>(a, xcd_logical_block());
+}
+
+// GROUPED launch: the weight gradients of MANY layers (the bottlenecks of a stretch of the backward pass) in one grid. A
+// per-layer launch has 16 ... 144 output tiles and needs 8 ... 21 pixel slices to put even 1.3 workgroups on a CU; each of
+// those workgroups then runs ~25 pixel stages and pays a 64 KB atomic epilogue (21-34 k cycles) for them. In a group the
+// tiles of all layers fill the machine together: 2-3 slices suffice, a workgroup runs ~200 stages per epilogue, and 3-4
+// workgroups per CU overlap each other's load and MFMA phases. The table is device-resident (built once per recorded pass):
+// item i owns logical blocks [first_block, first_block + blocks).
+struct WgradGroupItem {
+    WgradArgs a;
+    int first_block;
+    int pad_[3];
+};
+
+template <bool PLAIN>
+__global__ __launch_bounds__(256, PLAIN ? 4 : 3) void conv_wgrad_group_kernel(const WgradGroupItem* __restrict__ items, int n_items) {
+    const int b = xcd_logical_block();
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {                                   // last item with first_block <= b (block-uniform: scalar loads)
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const WgradArgs a = items[lo].a;
+    wgrad_body<2, 2, PLAIN, false, true, 1>(a, b - __builtin_amdgcn_readfirstlane(items[lo].first_block));
+}
 
 }  // namespace cms
 
@@ -1934,13 +1967,12 @@ extern "C" long long cms_conv_wgrad_workspace_bytes(const cms_wgrad_desc* d) {
     return ks > 1 ? (long long)ks * d->ntaps * d->cout * d->cin * (long long)sizeof(float) : 0;
 }
 
-extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
+static int wgrad_fill_args(const cms_wgrad_desc* d, WgradArgs& a) {
     CMS_REQUIRE(d && d->du && d->x && d->dw, "conv_wgrad: NULL pointer");
     CMS_REQUIRE(d->cin % 64 == 0 && d->cout % 64 == 0, "conv_wgrad: Cin (%d) and Cout (%d) must be multiples of 64", d->cin,
                 d->cout);
     CMS_REQUIRE(d->ntaps > 0 && d->ntaps <= CMS_CONV_MAX_TAPS, "conv_wgrad: 1..%d taps", CMS_CONV_MAX_TAPS);
     CMS_REQUIRE(d->n > 0 && d->h > 0 && d->w_in > 0 && d->ho > 0 && d->wo > 0 && d->stride >= 1, "conv_wgrad: bad geometry");
-    WgradArgs a;
     a.du = (const uint16_t*)d->du; a.x = (const uint16_t*)d->x; a.dw = d->dw; a.scale = d->scale;
     a.N = d->n; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
     a.ntaps = d->ntaps; a.stride = d->stride;
@@ -1954,10 +1986,23 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
         a.tap_dy[i] = (short)(i < d->ntaps ? d->tap_dy[i] : 0);
         a.tap_dx[i] = (short)(i < d->ntaps ? d->tap_dx[i] : 0);
     }
-    const int bco = d->cout % 128 == 0 ? 128 : 64, bci = d->cin % 128 == 0 ? 128 : 64;
-    const int tiles = (d->cout / bco) * (d->cin / bci) * d->ntaps;
     CMS_REQUIRE((size_t)d->n * d->h * d->w_in * d->cin < (1u << 31) && (size_t)d->n * d->ho * d->wo * d->cout < (1u << 31),
                 "conv_wgrad: tensors must have < 2^31 elements");
+    a.slab = nullptr; a.slab_stride = 0; a.trace = nullptr; a.trace_wgs = 0;
+    a.ksplit = 1; a.pix_per_split = 64;
+    return CMS_OK;
+}
+
+static bool wgrad_is_plain(const cms_wgrad_desc* d) {
+    return d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho && d->w_in == d->wo;
+}
+
+extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
+    WgradArgs a;
+    const int rc0 = wgrad_fill_args(d, a);
+    if (rc0) return rc0;
+    const int bco = d->cout % 128 == 0 ? 128 : 64, bci = d->cin % 128 == 0 ? 128 : 64;
+    const int tiles = (d->cout / bco) * (d->cin / bci) * d->ntaps;
     int per = 64, stages = 1;
     bool dma = false;
     int ksplit = wgrad_plan(d, &per, &dma, &stages);
@@ -2006,4 +2051,77 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
                            slice_elems, d->ntaps, d->cout, d->cin, a.cout_real, a.dw_cout);
     }
     return launch_status("cms_conv_wgrad");
+}
+
+// ---- grouped weight gradients ------------------------------------------------------------------------------------------
+// 0 = this launch cannot join a group; 1 = the group of pointwise (1 x 1, stride 1) launches; 2 = the group of launches with
+// taps / strides. Grouped launches take the 128 x 128 tile on the direct-to-LDS loader and combine their slices with fp32
+// atomics: no side outputs, no slab.
+extern "C" int cms_conv_wgrad_group_kind(const cms_wgrad_desc* d) {
+    if (!d || !d->du || !d->x || !d->dw || d->cin % 128 != 0 || d->cout % 128 != 0 || d->ntaps <= 0 || d->ntaps > CMS_CONV_MAX_TAPS ||
+        d->wdot || d->dbeta || d->w || d->workspace || d->stride < 1)
+        return 0;
+    if ((d->cout_real > 0 && d->cout_real != d->cout) || (d->dw_cout > 0 && d->dw_cout != d->cout)) return 0;
+    const size_t M = (size_t)d->n * d->ho * d->wo;
+    if (M * d->cout * 2 >= (1ull << 31) || (size_t)d->n * d->h * d->w_in * d->cin * 2 >= (1ull << 31)) return 0;
+    return wgrad_is_plain(d) ? 1 : 2;
+}
+
+extern "C" long long cms_conv_wgrad_group_bytes(int n_items) { return (long long)n_items * (long long)sizeof(WgradGroupItem); }
+
+// Fills the HOST image of the item table (the caller copies it to the device once and keeps it; cms_conv_wgrad_group_run reads
+// the device copy). All launches must be of one kind. `target_workgroups` (0 = default) is what the split of the pixel axis aims
+// at for the WHOLE group. -> total blocks of the grid in *total_blocks.
+extern "C" int cms_conv_wgrad_group_pack(const cms_wgrad_desc* descs, int n, int target_workgroups, void* host_table, long long bytes,
+                                         int* total_blocks) {
+    CMS_REQUIRE(descs && n > 0 && host_table && total_blocks, "conv_wgrad_group_pack: NULL pointer / empty group");
+    CMS_REQUIRE(bytes >= cms_conv_wgrad_group_bytes(n), "conv_wgrad_group_pack: table buffer too small");
+    const int kind = cms_conv_wgrad_group_kind(&descs[0]);
+    CMS_REQUIRE(kind != 0, "conv_wgrad_group_pack: launch 0 cannot be grouped");
+    long long tiles_all = 0;
+    for (int i = 0; i < n; ++i) {
+        CMS_REQUIRE(cms_conv_wgrad_group_kind(&descs[i]) == kind, "conv_wgrad_group_pack: launch %d is of another kind", i);
+        tiles_all += (long long)(descs[i].cout / 128) * (descs[i].cin / 128) * descs[i].ntaps;
+    }
+    static int env_target = -1;
+    if (env_target < 0) {
+        const char* e = getenv("CMS_WGRAD_GROUP_TARGET");
+        env_target = e ? atoi(e) : 0;
+    }
+    const long long target = target_workgroups > 0 ? target_workgroups : (env_target > 0 ? env_target : 2048);
+    WgradGroupItem* items = (WgradGroupItem*)host_table;
+    long long first = 0;
+    for (int i = 0; i < n; ++i) {
+        const cms_wgrad_desc* d = &descs[i];
+        WgradGroupItem& it = items[i];
+        memset(&it, 0, sizeof(it));
+        const int rc = wgrad_fill_args(d, it.a);
+        if (rc) return rc;
+        const int M = d->n * d->ho * d->wo;
+        const int tiles = (d->cout / 128) * (d->cin / 128) * d->ntaps;
+        // the group's slices: about target / (all tiles) per tile, at least 8 pixel stages each
+        int ks = (int)std::max<long long>(1, (target + tiles_all / 2) / tiles_all);
+        ks = std::min(ks, std::max(1, M / 512));
+        int per = ((M + ks - 1) / ks + 63) / 64 * 64;
+        if (per < 64) per = 64;
+        ks = (M + per - 1) / per;
+        it.a.ksplit = ks;
+        it.a.pix_per_split = per;
+        it.first_block = (int)first;
+        first += (long long)tiles * ks;
+        CMS_REQUIRE(first < (1ll << 30), "conv_wgrad_group_pack: too many blocks");
+    }
+    *total_blocks = (int)first;
+    return CMS_OK;
+}
+
+extern "C" int cms_conv_wgrad_group_run(const void* table_dev, int n_items, int total_blocks, int kind, void* stream) {
+    CMS_REQUIRE(table_dev && n_items > 0 && total_blocks > 0 && (kind == 1 || kind == 2), "conv_wgrad_group_run: bad arguments");
+    const size_t lds = 2 * 64 * 256 + 128 * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == 1)
+        hipLaunchKernelGGL(conv_wgrad_group_kernel<true>, dim3(total_blocks), dim3(256), lds, s, (const WgradGroupItem*)table_dev, n_items);
+    else
+        hipLaunchKernelGGL(conv_wgrad_group_kernel<false>, dim3(total_blocks), dim3(256), lds, s, (const WgradGroupItem*)table_dev, n_items);
+    return launch_status("cms_conv_wgrad_group_run");
 }

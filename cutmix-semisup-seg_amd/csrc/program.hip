@@ -17,7 +17,7 @@
 
 namespace cms {
 
-enum OpKind { OP_CONV = 0, OP_WGRAD = 1, OP_MEMSET = 2, OP_SYNC = 3, OP_ASPP_GATHER = 4, OP_ASPP_SPREAD = 5, OP_BN = 6 };
+enum OpKind { OP_CONV = 0, OP_WGRAD = 1, OP_MEMSET = 2, OP_SYNC = 3, OP_ASPP_GATHER = 4, OP_ASPP_SPREAD = 5, OP_BN = 6, OP_WGRAD_GROUP = 7 };
 
 struct AsppOp {            // arguments of cms_aspp_gather_fwd / cms_aspp_spread_bwd
     const float* src;      // z / dlogits
@@ -114,6 +114,8 @@ static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
     }
     case OP_WGRAD:
         return o.f32 ? cms_conv_wgrad_f32(&o.wg, s) : cms_conv_wgrad(&o.wg, s);
+    case OP_WGRAD_GROUP:        // ptr = the device-resident item table, bytes = items, from = grid size, f32 = kind
+        return cms_conv_wgrad_group_run(o.ptr, (int)o.bytes, o.from, o.f32, s);
     case OP_BN: {
         const cms_bn_op& b = o.bn;
         const int g = b.groups > 1 ? b.groups : 1;
@@ -199,6 +201,16 @@ extern "C" int cms_program_add_wgrad(cms_program* p, const cms_wgrad_desc* d, in
     o.kind = OP_WGRAD; o.stream = stream_idx; o.group = group; o.f32 = f32 ? 1 : 0;
     o.wg = *d;
     o.flops = 2.0 * (double)d->n * d->ho * d->wo * (double)d->cout * d->cin * d->ntaps;
+    return push(p, o);
+}
+
+extern "C" int cms_program_add_wgrad_group(cms_program* p, const void* table_dev, int n_items, int total_blocks, int kind, int stream_idx,
+                                           int group) {
+    CMS_REQUIRE(p && table_dev && n_items > 0 && total_blocks > 0 && (kind == 1 || kind == 2), "program_add_wgrad_group: bad arguments");
+    CMS_REQUIRE(stream_idx >= 0 && stream_idx < CMS_PROGRAM_MAX_STREAMS, "program_add_wgrad_group: stream index %d", stream_idx);
+    Op o = {};
+    o.kind = OP_WGRAD_GROUP; o.stream = stream_idx; o.group = group;
+    o.ptr = const_cast<void*>(table_dev); o.bytes = (size_t)n_items; o.from = total_blocks; o.f32 = kind;
     return push(p, o);
 }
 

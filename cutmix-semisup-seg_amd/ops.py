@@ -48,6 +48,12 @@ def ranges_to_device(ranges, device):
     """int32 (N, n_boxes, 4) numpy / tensor -> contiguous int32 CUDA tensor."""
     if isinstance(ranges, np.ndarray):
         ranges = torch.from_numpy(np.ascontiguousarray(ranges, dtype=np.int32))
+    if not ranges.is_cuda and torch.device(device).type == 'cuda':
+        # through PINNED memory: a "non_blocking" copy from pageable memory is a blocking one (the runtime stages it when the
+        # stream gets there), i.e. the host would wait for the whole previous iteration at the first line of every iteration
+        # and the GPU would then idle through the host's launch latencies (1 ms of a 19.9 ms step: profiles/r04k_*). The
+        # caching host allocator keeps the staging block alive until the copy has run.
+        ranges = ranges.to(torch.int32).contiguous().pin_memory()
     return ranges.to(device=device, dtype=torch.int32, non_blocking=True).contiguous()
 
 
@@ -1271,3 +1277,74 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
     name = 'cms_conv_wgrad_f32' if f32 else 'cms_conv_wgrad'
     check(fn[name](C.byref(d), _stream()), name)
     return dw
+
+
+def conv_wgrad_group(jobs, target_workgroups=0):
+    """The weight gradients of MANY layers as one grid per kind (cms_conv_wgrad_group_*): `jobs` = list of
+    (du, x, taps, dw, stride, scale) as for `conv_wgrad`. Launches that cannot join a group (channel counts that are not
+    multiples of 128, fp32, deterministic slabs) are issued one by one. Under recording the device-resident item tables belong to
+    the program. Returns the number of grouped launches."""
+    if not jobs:
+        return 0
+    singles, kinds = [], {1: [], 2: []}
+    for job in jobs:
+        du, x, taps, dw, stride, scale = job
+        _need_cuda(du, x, dw, scale)
+        ok = du.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32 and du.is_contiguous() \
+            and x.is_contiguous() and dw.is_contiguous() and not _WGRAD_DETERMINISTIC and not _WGRAD_SLAB_LARGE
+        d = None
+        if ok:
+            n, ho, wo, cout = (int(v) for v in du.shape)
+            n2, h, w_in, cin = (int(v) for v in x.shape)
+            if n2 != n or tuple(dw.shape) != (len(taps), cout, cin):
+                raise ValueError('conv_wgrad_group: shape mismatch')
+            d = _lib.WgradDesc()
+            d.du, d.x, d.dw = du.data_ptr(), x.data_ptr(), dw.data_ptr()
+            d.scale = scale.data_ptr() if scale is not None else None
+            d.n, d.h, d.w_in, d.cin, d.ho, d.wo, d.cout = n, h, w_in, cin, ho, wo, cout
+            d.ntaps = len(taps)
+            for i, (dy, dx) in enumerate(taps):
+                d.tap_dy[i], d.tap_dx[i] = int(dy), int(dx)
+            d.stride = int(stride)
+            kind = int(fn['cms_conv_wgrad_group_kind'](C.byref(d)))
+            if kind in kinds:
+                kinds[kind].append((d, job))
+                continue
+        singles.append(job)
+    launched = 0
+    for kind, items in kinds.items():
+        if len(items) == 1:                    # nothing to group with
+            singles.append(items[0][1])
+            continue
+        if not items:
+            continue
+        n_items = len(items)
+        arr = (_lib.WgradDesc * n_items)(*[d for d, _ in items])
+        nbytes = int(fn['cms_conv_wgrad_group_bytes'](n_items))
+        host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        total = C.c_int(0)
+        check(fn['cms_conv_wgrad_group_pack'](arr, n_items, int(target_workgroups), C.c_void_p(host.data_ptr()), nbytes, C.byref(total)),
+              'cms_conv_wgrad_group_pack')
+        dev = items[0][1][0].device
+        table = host.to(dev, non_blocking=True)
+        keep = [table, host] + [t for _, job in items for t in (job[0], job[1], job[3], job[5]) if t is not None]
+        if _REC is not None:
+            prog = _REC[0]
+            idx = fn['cms_program_add_wgrad_group'](prog.h, C.c_void_p(table.data_ptr()), n_items, int(total.value), kind,
+                                                   _rec_stream_index(), prog.group)
+            if idx < 0:
+                check(idx, 'cms_program_add_wgrad_group')
+            prog.keep += keep
+            for d, (du, x, taps, dw, stride, scale) in items:
+                fl = 2.0 * d.n * d.ho * d.wo * d.cout * d.cin * d.ntaps
+                prog.flops += fl
+                prog.floor_s += max((du.element_size() * (du.numel() + x.numel()) + 4.0 * dw.numel()) / HBM_PEAK_BPS,
+                                    fl / MFMA_PEAK_FLOPS)
+        else:
+            check(fn['cms_conv_wgrad_group_run'](C.c_void_p(table.data_ptr()), n_items, int(total.value), kind, _stream()),
+                  'cms_conv_wgrad_group_run')
+            table.record_stream(torch.cuda.current_stream())
+        launched += 1
+    for du, x, taps, dw, stride, scale in singles:
+        conv_wgrad(du, x, taps, dw, stride=stride, scale=scale)
+    return launched

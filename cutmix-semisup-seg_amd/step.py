@@ -26,6 +26,7 @@ Data parallel: one process per GPU; gradients of the flat arena are summed with 
 1/world inside the optimizer kernel; the confidence count is all-reduced (8 bytes) so that the default
 "scalar confidence rate" mode uses the global rate.
 """
+import os
 import torch
 
 from . import ops
@@ -252,11 +253,14 @@ class CutMixMeanTeacherStep(object):
         """Batches may only be concatenated when no layer couples the samples of a batch: every BatchNorm frozen and
         no active dropout, in BOTH networks (DeepLab v3+ keeps batch statistics and dropout in its head even under
         --freeze_bn, deeplab3plus.py:120-121 -> the reference's separate passes are kept for it)."""
-        for net in (self.student, self.teacher):
-            for m in net.modules():
-                name = type(m).__name__
-                if m.training and ('BatchNorm' in name or ('Dropout' in name and getattr(m, 'p', 0) > 0)):
-                    return False
+        mods = self.__dict__.get('_coupling_modules')
+        if mods is None:                  # (the module trees are static: collect the candidates once, test their flags per call)
+            mods = self.__dict__['_coupling_modules'] = [
+                m for net in (self.student, self.teacher) for m in net.modules()
+                if 'BatchNorm' in type(m).__name__ or 'Dropout' in type(m).__name__]
+        for m in mods:
+            if m.training and ('BatchNorm' in type(m).__name__ or getattr(m, 'p', 0) > 0):
+                return False
         return True
 
     def _sample_groups(self, n_sup, unsup_batches, use_unsup):

@@ -330,6 +330,22 @@ typedef struct cms_wgrad_desc {
 } cms_wgrad_desc;
 
 int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream);
+
+/* GROUPED weight gradients (round 4): the launches of MANY layers -- the bottlenecks of a stretch of the backward pass, autograd
+ * of architectures/deeplab2.py:89-109 -- as ONE grid. A per-layer launch has 16 ... 144 output tiles and needs 8 ... 21 pixel
+ * slices to occupy the machine; each slice workgroup then runs ~25 pixel stages per 64 KB atomic epilogue. In a group the tiles
+ * of all layers fill the machine together (2-3 slices, ~200 stages per epilogue, 3-4 workgroups per CU).
+ *   cms_conv_wgrad_group_kind   0 = this launch cannot join a group (channel counts not multiples of 128, side outputs, a
+ *                               workspace, padded class axis), 1 = group of pointwise launches, 2 = group of launches with taps
+ *   cms_conv_wgrad_group_bytes  size of the item table for n launches
+ *   cms_conv_wgrad_group_pack   fills the HOST image of the table for n launches of ONE kind; the caller copies it to the device
+ *                               (once per recorded pass) -- target_workgroups: 0 = default; -> grid size in *total_blocks
+ *   cms_conv_wgrad_group_run    the launch: table_dev = the device copy                                                        */
+int cms_conv_wgrad_group_kind(const cms_wgrad_desc* d);
+long long cms_conv_wgrad_group_bytes(int n_items);
+int cms_conv_wgrad_group_pack(const cms_wgrad_desc* descs, int n, int target_workgroups, void* host_table, long long bytes,
+                              int* total_blocks);
+int cms_conv_wgrad_group_run(const void* table_dev, int n_items, int total_blocks, int kind, void* stream);
 /* bytes of `workspace` that make the launch deterministic (0: it has a single pixel slice and already is) */
 long long cms_conv_wgrad_workspace_bytes(const cms_wgrad_desc* d);
 
@@ -511,6 +527,9 @@ int cms_program_create(cms_program** out);
 int cms_program_destroy(cms_program* p);
 int cms_program_add_conv(cms_program* p, const cms_conv_desc* d, int f32, int stream_idx, int group);
 int cms_program_add_wgrad(cms_program* p, const cms_wgrad_desc* d, int f32, int stream_idx, int group);
+/* a grouped weight-gradient launch (cms_conv_wgrad_group_run) as a program op */
+int cms_program_add_wgrad_group(cms_program* p, const void* table_dev, int n_items, int total_blocks, int kind, int stream_idx,
+                                int group);
 int cms_program_add_memset(cms_program* p, void* ptr, size_t bytes, int stream_idx, int group);
 int cms_program_add_aspp_gather(cms_program* p, const float* z, const float* bias, float* logits, const int* tap_dy,
                                 const int* tap_dx, int n_taps, int n, int c, int zc, int h, int w, int stream_idx, int group);

@@ -2,10 +2,13 @@
 Oracle (test infrastructure): the virtual-adversarial pieces of train_seg_semisup_vat_mt.py on PyTorch-CPU fp32
 (SURVEY.md 8(f) rank 2).
 
-PARITY UNPINNED: in the reference these are closures inside the 570-line trainer function (`t_dot`, `normalize_eps`,
+PINNED (round 4): in the reference these are closures inside the 570-line trainer function (`t_dot`, `normalize_eps`,
 `normalized_noise_like`, `vat_direction`, `vat_perburbation`, train_seg_semisup_vat_mt.py:213-301), which cannot be
-imported (the function is hard-wired to cuda:0 and to the dataset pipeline) and the reference holds no vectors for
-them. Restated from the reference text:
+imported. tests/golden/make_golden.py::gen_vat cuts their FunctionDef nodes out of the reference's source with `ast` at
+generation time, binds the trainer's free variables to a tiny reference DeepLab v2 and runs them; tests/golden/vat.npz holds
+the outputs (initial noise as drawn, direction, perturbation, teacher logits; 4 consistency functions x fixed / adaptive
+radius) and tests/test_oracle_golden.py::test_vat_direction_and_perturbation_vs_the_reference_closures holds this file to
+them. What the functions do:
 
   normalize_eps(x)          x / (||x||_2 per sample + 1e-12)                                            :216-219
   vat_direction(x, x_hat)   y = net_eval(x) (no grad); eps0 = normalised noise * 1e-6*H*W/1000;          :227-271

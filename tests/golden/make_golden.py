@@ -703,8 +703,75 @@ def gen_affine():
     print('wrote affine_rotate_scale.json ({} cases)'.format(len(cases)))
 
 
+# ----------------------------------------------------------------------------------------------------------
+# 13. virtual adversarial direction / perturbation (train_seg_semisup_vat_mt.py:213-301)
+# ----------------------------------------------------------------------------------------------------------
+def gen_vat():
+    """The VAT pieces are closures inside the reference's 570-line trainer function and cannot be imported. Here their
+    FunctionDef nodes are cut out of the reference's source with `ast` AT GENERATION TIME, compiled, and executed with the
+    trainer's free variables (vat_dir_net, cons_loss_fn, adaptive_vat_radius, vat_radius) bound to a tiny reference DeepLab v2
+    with closed-form weights: the arrays written below are outputs of the reference's own code. Nothing of its text is
+    stored; the initial noise (torch.randn in `normalized_noise_like`) is captured so that the oracle and the device start
+    from the same draw."""
+    import ast
+    import math
+    oracle_dl = _load_oracle('deeplab2')
+    src = open(os.path.join(REF, 'train_seg_semisup_vat_mt.py')).read()
+    tree = ast.parse(src)
+    wanted = ['t_dot', 'normalize_eps', 'normalized_noise_like', 'vat_direction', 'vat_perburbation']
+    found = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in wanted and node.name not in found:
+            found[node.name] = node
+    assert sorted(found) == sorted(wanted), sorted(found)
+    mod = ast.Module(body=[found[n] for n in wanted], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    mean = np.array([0.485, 0.456, 0.406])
+    std = np.array([0.229, 0.224, 0.225])
+    C = 5
+    net = ref_deeplab2.ResNetDeepLab(ref_deeplab2.Bottleneck, [1, 1, 1, 1], C, mean, std)
+    net.load_state_dict(oracle_dl.closed_form_state(C, [1, 1, 1, 1]))
+    net.train()
+    net.freeze_batchnorm()
+    out = {}
+    meta = dict(layers=[1, 1, 1, 1], num_classes=C, cases=[])
+    x = _closed_form_input(2, 33, 33, 0.7)
+    x_hat = x + 0.05 * _closed_form_input(2, 33, 33, 1.9)          # the colour-augmented view of the same crop
+    out['x'], out['x_hat'] = x.numpy(), x_hat.numpy()
+    for loss_fn in ('var', 'bce', 'kld', 'logits_var'):
+        for adaptive in (False, True):
+            ns = dict(torch=torch, F=F, math=math, network_architectures=network_architectures, vat_dir_net=net,
+                      cons_loss_fn=loss_fn, adaptive_vat_radius=adaptive, vat_radius=0.5)
+            exec(compile(mod, '<reference VAT closures>', 'exec'), ns)
+            ref_noise = ns['normalized_noise_like']
+            drawn = {}
+
+            def capture(xx, requires_grad=False, scale=1.0, _f=ref_noise, _d=drawn):
+                e = _f(xx, requires_grad=requires_grad, scale=scale)
+                _d['eps0'] = e.detach().clone()
+                return e
+            ns['normalized_noise_like'] = capture
+            torch.manual_seed(1234)
+            pert, y_logits, y_prob = ns['vat_perburbation'](x, x_hat, None)
+            torch.manual_seed(1234)
+            direction, _, _ = ns['vat_direction'](x, x_hat)
+            key = '{}__{}'.format(loss_fn, 'adaptive' if adaptive else 'fixed')
+            out[key + '__eps0'] = drawn['eps0'].numpy()
+            out[key + '__direction'] = direction.detach().numpy()
+            out[key + '__perturbation'] = pert.detach().numpy()
+            out[key + '__y_logits_sub4'] = y_logits.detach().numpy()[:, :, ::4, ::4].copy()
+            meta['cases'].append(dict(key=key, loss_fn=loss_fn, adaptive=adaptive, vat_radius=0.5,
+                                      pert_norm=[float(v) for v in pert.detach().reshape(2, -1).norm(dim=1)]))
+            assert not net.training, 'vat_direction leaves the direction network in eval mode (:237)'
+            net.train()
+            net.freeze_batchnorm()
+    save('vat', **out)
+    with open(os.path.join(HERE, 'vat_meta.json'), 'w') as f:
+        json.dump(meta, f, indent=0)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['boxmask', 'ema', 'evaluation', 'lr', 'losses', 'deeplab2', 'optim', 'step', 'cli', 'cli_vat',
-                             'checkpoint', 'affine']
+                             'checkpoint', 'affine', 'vat']
     for w in which:
         globals()['gen_' + w]()

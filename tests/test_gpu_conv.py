@@ -359,3 +359,33 @@ def test_conv_balanced_launch_equals_plain_tiles(ops, case):
             ref = ref + res.float()
         ref = ref.relu()
     torch.testing.assert_close(y_auto.float(), ref, rtol=2 ** -7, atol=2e-2)
+
+
+def test_grouped_weight_gradients_equal_the_per_layer_launches(ops):
+    """ops.conv_wgrad_group: the weight gradients of many layers as one grid per kind (pointwise / with taps) -- the same sums
+    as the per-layer launches (fp32 atomics: the order of the additions differs), including the launches it has to issue one by
+    one (64-channel layers, a single launch of its kind), accumulating INTO the gradient buffers."""
+    g = torch.Generator(device=DEV).manual_seed(21)
+    N, H, W = 3, 23, 19
+    specs = [(256, 128, 1, 1, 1), (128, 128, 3, 2, 1), (128, 512, 1, 1, 1), (512, 128, 1, 1, 1), (128, 128, 3, 1, 1),
+             (64, 128, 1, 1, 1), (256, 256, 3, 4, 1), (128, 256, 1, 1, 2)]
+    jobs, refs = [], []
+    for cin, cout, k, dil, stride in specs:
+        pad = dil * (k - 1) // 2
+        ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        x = _mk((N, H, W, cin), g)
+        du = _mk((N, ho, wo, cout), g)
+        scale = torch.rand(cout, generator=g, device=DEV) + 0.5
+        taps = ops.conv_taps(k, k, dil, pad)
+        init = torch.randn(k * k, cout, cin, generator=g, device=DEV)
+        ref = init.clone()
+        ops.conv_wgrad(du, x, taps, ref, stride=stride, scale=scale)
+        dw = init.clone()
+        jobs.append((du, x, taps, dw, stride, scale))
+        refs.append(ref)
+    launched = ops.conv_wgrad_group(jobs)
+    assert launched == 2                                   # one grid of pointwise launches, one of launches with taps / strides
+    torch.cuda.synchronize()
+    for (du, x, taps, dw, stride, scale), ref in zip(jobs, refs):
+        tol = 2e-5 * float(ref.abs().max())
+        assert float((dw - ref).abs().max()) <= tol, (tuple(dw.shape), float((dw - ref).abs().max()), tol)

@@ -1,6 +1,7 @@
 """
 GPU: the VAT mean-teacher iteration (vat.py; train_seg_semisup_vat_mt.py:213-301, 346-476)
-against oracle/vat.py (parity unpinned: the reference's VAT functions are closures of its trainer).
+against oracle/vat.py and -- round 4 -- against outputs of the reference's own VAT closures (tests/golden/vat.npz, made by
+tests/golden/make_golden.py::gen_vat: the closures cut out of the trainer with `ast` and run on a reference network).
 """
 import numpy as np
 import pytest
@@ -68,6 +69,37 @@ def test_vat_direction_matches_the_oracle(loss_fn, dtype):
     torch.testing.assert_close(got.reshape(2, -1).norm(dim=1), torch.ones(2), rtol=1e-4, atol=1e-4)
     # no weight gradient leaked into the network during the direction pass
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in net.parameters())
+
+
+@pytest.mark.parametrize('loss_fn', ['kld', 'var', 'logits_var', 'bce'])
+@pytest.mark.parametrize('adaptive', [False, True], ids=['fixed_radius', 'adaptive_radius'])
+def test_vat_perturbation_vs_the_reference_closures(loss_fn, adaptive):
+    """The device path (fp32 hand-written engine for the direction pass) against what the REFERENCE's closures computed for
+    the same network, images and initial noise (tests/golden/vat.npz)."""
+    import json
+    import os
+    from oracle import deeplab2 as odl
+    from cutmix_semisup_seg_amd import vat
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    g = np.load(os.path.join(here, 'vat.npz'))
+    meta = json.load(open(os.path.join(here, 'vat_meta.json')))
+    C, layers = meta['num_classes'], meta['layers']
+    from architectures import deeplab2
+    net = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225]))
+    net.load_state_dict(odl.closed_form_state(C, layers))
+    net = net.to(DEV)
+    net.compute_dtype = torch.float32
+    net.train()
+    net.freeze_batchnorm()
+    key = '{}__{}'.format(loss_fn, 'adaptive' if adaptive else 'fixed')
+    x, x_hat = torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['x_hat']).to(DEV)
+    eps0 = torch.from_numpy(g[key + '__eps0']).to(DEV)
+    pert, _ = vat.vat_perturbation(net, x, x_hat, vat_radius=0.5, adaptive=adaptive, cons_loss_fn=loss_fn, eps0=eps0)
+    want = torch.from_numpy(g[key + '__perturbation'])
+    got = pert.float().cpu()
+    cos = (got.reshape(2, -1) * want.reshape(2, -1)).sum(dim=1) / (got.reshape(2, -1).norm(dim=1) * want.reshape(2, -1).norm(dim=1))
+    assert float(cos.min()) >= 0.9995, cos
+    torch.testing.assert_close(got.reshape(2, -1).norm(dim=1), want.reshape(2, -1).norm(dim=1), rtol=2e-4, atol=0)     # the radius
 
 
 def test_vat_iteration_bf16_executor():

@@ -288,3 +288,37 @@ def test_whole_step(cfg_name, cfg):
         steps = [S.steps[k] for k in ('conv1.weight', 'layer1.0.conv1.weight', 'layer1.0.downsample.0.weight',
                                       'layer5.conv2d_list.0.weight')]
         assert steps == [int(v) for v in g[cfg_name + '__adam_steps']] == [3, 9, 12, 3]
+
+
+# ---------------------------------------------------------------------------------------------------------- VAT (round 4)
+_VM = load_golden_json('vat_meta')
+
+
+@pytest.mark.parametrize('case', _VM['cases'], ids=[c['key'] for c in _VM['cases']])
+def test_vat_direction_and_perturbation_vs_the_reference_closures(case):
+    """oracle/vat.py against outputs of the REFERENCE'S OWN closures (t_dot / normalize_eps / normalized_noise_like /
+    vat_direction / vat_perburbation, train_seg_semisup_vat_mt.py:213-301), which tests/golden/make_golden.py::gen_vat cuts out
+    of the trainer with `ast` and runs on a tiny reference DeepLab v2 with closed-form weights: the initial noise the
+    reference drew is part of the fixture, so direction (unit norm per sample), radius (fixed and adaptive) and the teacher
+    logits are compared value by value, for all four consistency functions."""
+    from oracle import vat as ov
+    g = load_golden('vat')
+    C, layers = _VM['num_classes'], _VM['layers']
+    st = odl.closed_form_state(C, layers)
+    x, x_hat = torch.from_numpy(g['x']), torch.from_numpy(g['x_hat'])
+    key = case['key']
+    eps0 = torch.from_numpy(g[key + '__eps0'])
+    # the reference's draw is already normalised and scaled (:222-226, 240-241)
+    np.testing.assert_allclose(eps0.reshape(2, -1).norm(dim=1).numpy(), [ov.noise_scale(x.shape)] * 2, rtol=1e-5)
+    fnet = lambda t: odl.forward(t, st, layers, frozen=True)
+    d, y_logits = ov.vat_direction(fnet, x, x_hat, eps0, case['loss_fn'])
+    want_d = torch.from_numpy(g[key + '__direction'])
+    cos = (d.reshape(2, -1) * want_d.reshape(2, -1)).sum(dim=1)
+    assert float(cos.min()) >= 1.0 - 1e-5, cos
+    np.testing.assert_allclose(d.numpy(), want_d.numpy(), rtol=0, atol=2e-3 * float(want_d.abs().max()))
+    np.testing.assert_allclose(y_logits.numpy()[:, :, ::4, ::4], g[key + '__y_logits_sub4'], rtol=2e-4, atol=2e-5)
+    pert, _ = ov.vat_perturbation(fnet, x, x_hat, eps0, vat_radius=case['vat_radius'], adaptive=case['adaptive'],
+                                  cons_loss_fn=case['loss_fn'])
+    want_p = torch.from_numpy(g[key + '__perturbation'])
+    np.testing.assert_allclose(pert.reshape(2, -1).norm(dim=1).numpy(), case['pert_norm'], rtol=1e-5)      # the radius
+    np.testing.assert_allclose(pert.numpy(), want_p.numpy(), rtol=0, atol=2e-3 * float(want_p.abs().max()))
