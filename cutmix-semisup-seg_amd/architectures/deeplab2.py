@@ -262,8 +262,9 @@ class ResNetDeepLab(nn.Module):
         """True: the static MFMA executor (backbone_hip.DeepLabHipExecutor) runs the body and the head. With every BatchNorm
         frozen the running statistics fold into the convolution epilogues (and the stem runs on csrc/stem.hip); with
         BatchNorm on batch statistics (round 3) every unit is  conv -> csrc/bn.hip  inside the same recorded programs, the stem
-        goes through the layer engine. Under torch.distributed the batch-statistics passes stay on the layer engine, whose
-        BatchNorm all-reduces its statistics between the two passes (SyncBN); `batchstat_executor = False` forces that."""
+        goes through the layer engine. Under torch.distributed the units all-reduce their per-group sums between the reduction
+        and the finalisation (SyncBN: a host op between two launches of the recorded pass); `batchstat_executor = False` forces
+        the layer engine."""
         if self.engine_kind == 'torch' or self.engine is not None:
             return False
         ok = self.compute_dtype in (torch.bfloat16, torch.float32) and self.num_classes <= 32
@@ -283,8 +284,7 @@ class ResNetDeepLab(nn.Module):
             return False
         if self.compute_dtype == torch.float32 and self.engine_kind != 'hip':
             return False                       # 'auto' in fp32: the library comparison engine, as for the other networks
-        import torch.distributed as dist
-        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        return True            # (round 4: under torch.distributed the executor's units all-reduce their statistics -- SyncBN)
 
     def hip_executor(self):
         # one executor per compute dtype (bf16: throughput configuration; fp32: parity configuration on the f32-input

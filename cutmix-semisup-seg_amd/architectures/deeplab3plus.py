@@ -254,6 +254,13 @@ class HipConvEngine(TorchEngine):
         if key is not None and hip_conv2d_eligible(x, conv, self.dtype):
             return hip_conv2d(x, conv, self.arena, key, self.dtype)
         self.library_convs += 1
+        seen = self.__dict__.setdefault('_library_warned', set())
+        if (key, tuple(x.shape)) not in seen:            # one line per layer and input shape, not per call
+            seen.add((key, tuple(x.shape)))
+            import warnings
+            warnings.warn('cutmix-semisup-seg_amd: convolution {} on input {} goes to the LIBRARY (MIOpen) -- engine_kind "auto" '
+                          'keeps the hand-written MFMA kernels for stride-1 / same-padding / wide layers; engine_kind = "hip" '
+                          'runs every convolution on them'.format(key or conv, tuple(x.shape)), RuntimeWarning, stacklevel=2)
         return super(HipConvEngine, self).conv2d(x, conv)
 
     def bn_act(self, y, bn, relu, residual=None):

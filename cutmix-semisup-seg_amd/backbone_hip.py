@@ -341,10 +341,26 @@ class DeepLabHipExecutor(object):
         bsums = torch.empty(G * 2 * C, dtype=torch.float64, device=dev) if save else None
         mean, rstd, scale, shift = (torch.empty(G * C, dtype=torch.float32, device=dev) for _ in range(4))
         ws = ops.bn_workspace(npix, C, dev, G)      # this unit's: tile counters + partial sums (forward, then backward)
-        ops.bn_op('stats', c=C, dtype=self.dtype, n_pixels=npix, groups=G, eps=bn.eps, momentum=bn.momentum, x=u, ws=ws,
-                  gamma=a.view(c.bn + '.weight'), beta=a.view(c.bn + '.bias'), mean=mean, rstd=rstd, scale=scale, shift=shift,
-                  running_mean=a.view(c.bn + '.running_mean'), running_var=a.view(c.bn + '.running_var'),
-                  counter=bn.num_batches_tracked)
+        world = ops._world(None)
+        if world > 1:
+            # SyncBN on the executor (round 4; SURVEY 8(e) "BN statistics"): per-group (sum x, sum x^2) -> ONE all-reduce of
+            # [G][2][C] doubles between two launches of the recorded pass (a host op of the program) -> the groups finalised in
+            # order with the pixel count of ALL ranks. The fused single-process launch ('stats') does the same without the exchange.
+            fsums = torch.empty(G * 2 * C, dtype=torch.float64, device=dev)
+            ops.bn_op('reduce', c=C, dtype=self.dtype, n_pixels=npix, groups=G, x=u, sums=fsums, ws=ws)
+            ops.host_call(lambda t=fsums: ops._allreduce_sum(t, None))
+            for g in range(G):
+                sl = slice(g * C, (g + 1) * C)
+                ops.bn_op('finalize', c=C, count=float(npix // G) * world, eps=bn.eps, momentum=bn.momentum,
+                          sums=fsums[g * 2 * C:(g + 1) * 2 * C], gamma=a.view(c.bn + '.weight'), beta=a.view(c.bn + '.bias'),
+                          mean=mean[sl], rstd=rstd[sl], scale=scale[sl], shift=shift[sl],
+                          running_mean=a.view(c.bn + '.running_mean'), running_var=a.view(c.bn + '.running_var'),
+                          counter=bn.num_batches_tracked)
+        else:
+            ops.bn_op('stats', c=C, dtype=self.dtype, n_pixels=npix, groups=G, eps=bn.eps, momentum=bn.momentum, x=u, ws=ws,
+                      gamma=a.view(c.bn + '.weight'), beta=a.view(c.bn + '.bias'), mean=mean, rstd=rstd, scale=scale, shift=shift,
+                      running_mean=a.view(c.bn + '.running_mean'), running_var=a.view(c.bn + '.running_var'),
+                      counter=bn.num_batches_tracked)
         y = torch.empty_like(u)
         ops.bn_op('apply', c=C, dtype=self.dtype, n_pixels=npix, groups=G, relu=relu, x=u, res=res, y=y, scale=scale,
                   shift=shift)
@@ -358,9 +374,12 @@ class DeepLabHipExecutor(object):
         npix = u.numel() // C
         ops.bn_op('reduce_bwd', c=C, dtype=self.dtype, n_pixels=npix, groups=G, x=u, dy=dy, y=y, mean=mean, rstd=rstd, sums=sums,
                   ws=ws)
+        world = ops._world(None)
+        if world > 1:                        # SyncBN: (sum dy', sum dy' xhat) of every group over all ranks
+            ops.host_call(lambda t=sums: ops._allreduce_sum(t, None))
         du = torch.empty_like(u)
         dres = torch.empty_like(u) if want_res else None
-        ops.bn_op('bwd_apply', c=C, dtype=self.dtype, n_pixels=npix, groups=G, count=npix // G, x=u, dy=dy, y=y, dx=du, dres=dres,
+        ops.bn_op('bwd_apply', c=C, dtype=self.dtype, n_pixels=npix, groups=G, count=(npix // G) * world, x=u, dy=dy, y=y, dx=du, dres=dres,
                   mean=mean,
                   rstd=rstd, gamma=self.arena.view(c.bn + '.weight'), sums=sums)
         return du, dres
@@ -1322,7 +1341,14 @@ class _BodyPairFn(torch.autograd.Function):
                 pt = ex_tea.forward_program(x_tea.shape, False)
                 ex_tea._prepare_forward()
                 pt.x_in.copy_(x_tea)
-            ops.run_pair(ps, [main], pt, [side])
+            if ps.host_ops or pt.host_ops:
+                # SyncBN all-reduces between the launches: the native interleave cannot stop for them -- one pass after the
+                # other (each on its stream; they still overlap where the host runs ahead)
+                with torch.cuda.stream(side):
+                    pt.run([side])
+                ps.run([main])
+            else:
+                ops.run_pair(ps, [main], pt, [side])
             ex_stu._stamp(ps)
             ex_tea._stamp(pt)
             logits_s = ps.logits.clone()

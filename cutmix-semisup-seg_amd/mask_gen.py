@@ -32,6 +32,19 @@ class MaskGenerator(object):
         raise NotImplementedError('Abstract')
 
 
+def gaussian_kernels(sigma, max_sigma=None, truncate=4.0):
+    """Rows of normalised 1-D Gaussian kernels, one per entry of `sigma` ((N,) array), all of the width the LARGEST sigma asks
+    for (radius = int(truncate * max_sigma + 0.5)) -- mask_gen.py:26-43 of the reference, a host-side helper of its mask
+    generators that the CutMix trainer itself never calls; kept so that `import mask_gen` offers the reference's names."""
+    sigma = np.asarray(sigma, dtype=np.float64)
+    if max_sigma is None:
+        max_sigma = sigma.max()
+    radius = int(truncate * max_sigma + 0.5)
+    offsets = np.arange(-radius, radius + 1, dtype=np.float64)[None, :]
+    weights = np.exp(offsets * offsets * (-0.5 / (sigma[:, None] * sigma[:, None])))
+    return weights / weights.sum(axis=1, keepdims=True)
+
+
 class BoxMaskGenerator(MaskGenerator):
     def __init__(self, prop_range, n_boxes=1, random_aspect_ratio=True, prop_by_area=True, within_bounds=True,
                  invert=False):

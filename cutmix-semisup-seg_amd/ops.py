@@ -591,16 +591,19 @@ class _BatchNormActFn(torch.autograd.Function):
         ws = bn_workspace(n_pix, c, dev, groups)
         world = _world(group)
         if world > 1:
-            if groups != 1:
-                raise ValueError('batch_norm_act: sample groups are a single-process feature')
-            stats = torch.empty(2 * c, dtype=torch.float64, device=dev)
-            check(fn['cms_bn_reduce_ws'](_ptr(x), None, None, _dtype_code(x), None, None, _ptr(stats), n_pix, c, 1, 0, _ptr(ws),
+            # SyncBN, sample groups included (round 4): every group's (sum x, sum x^2) summed over the ranks in ONE all-reduce of
+            # [G][2][C] doubles, then finalised group by group, in order (the running statistics move once per group, as in the
+            # reference's separate passes); count = the group's pixels on ALL ranks
+            stats = torch.empty(groups * 2 * c, dtype=torch.float64, device=dev)
+            check(fn['cms_bn_reduce_ws'](_ptr(x), None, None, _dtype_code(x), None, None, _ptr(stats), n_pix, c, groups, 0, _ptr(ws),
                                          _stream()), 'cms_bn_reduce_ws')
             _allreduce_sum(stats, group)
-            count = float(n_pix) * world       # (equal shards: the per-GPU batch is fixed under weak scaling)
-            check(fn['cms_bn_finalize'](_ptr(stats), count, _ptr(gamma), _ptr(beta), float(eps), float(momentum), _ptr(mean),
-                                        _ptr(rstd), _ptr(scale), _ptr(shift), _ptr(running_mean), _ptr(running_var), c,
-                                        _stream()), 'cms_bn_finalize')
+            count = float(n_pix // groups) * world       # (equal shards: the per-GPU batch is fixed under weak scaling)
+            for g in range(groups):
+                sl = slice(g * c, (g + 1) * c)
+                check(fn['cms_bn_finalize'](_ptr(stats[g * 2 * c:(g + 1) * 2 * c]), count, _ptr(gamma), _ptr(beta), float(eps),
+                                            float(momentum), _ptr(mean[sl]), _ptr(rstd[sl]), _ptr(scale[sl]), _ptr(shift[sl]),
+                                            _ptr(running_mean), _ptr(running_var), c, _stream()), 'cms_bn_finalize')
         else:                                  # statistics and their finalisation in ONE launch
             count = float(n_pix // groups)
             check(fn['cms_bn_stats'](_ptr(x), _dtype_code(x), n_pix, c, groups, _ptr(gamma), _ptr(beta), float(eps),
@@ -847,6 +850,8 @@ class Program(object):
                                 # the mixed HBM / MFMA roofline of one replay (bench.py: roofline.mixed)
         self.head_launches = 0
         self.n_streams = 1
+        self.host_ops = []      # (op index, stream index, callable): host work between two launches of a replay -- the
+                                # all-reduces of SyncBN statistics (recorded with `host_call`); `run` splits around them
 
     def __del__(self):
         h, self.h = getattr(self, 'h', None), None
@@ -872,6 +877,24 @@ class Program(object):
     def run(self, streams, first=0, last=-1):
         if len(streams) < self.n_streams:
             raise ValueError('program recorded on {} streams, {} given'.format(self.n_streams, len(streams)))
+        if self.host_ops:
+            # a host op recorded at index i happens after launches [0, i) and before launch i: it belongs to the range that
+            # STARTS at i (segmented replays call run(first, i) and then run(i, ...)), or to the last range when i == size
+            size = self.size()
+            end = size if (last < 0 or last >= size) else int(last)
+            handles = self._handles(streams)
+            pos = int(first)
+            for idx, si, call in self.host_ops:          # recorded in program order
+                if idx < pos or idx > end or (idx == end and end != size):
+                    continue
+                if idx > pos:
+                    check(fn['cms_program_run'](self.h, pos, idx, handles, len(streams)), 'cms_program_run')
+                    pos = idx
+                with torch.cuda.stream(streams[si]):
+                    call()
+            if pos < end:
+                check(fn['cms_program_run'](self.h, pos, end, handles, len(streams)), 'cms_program_run')
+            return
         check(fn['cms_program_run'](self.h, int(first), int(last), self._handles(streams), len(streams)),
               'cms_program_run')
 
@@ -920,6 +943,17 @@ def _rec_stream_index(stream=None):
         return _REC[1].index(h)
     except ValueError:
         raise RuntimeError('op recorded on a stream the program was not told about')
+
+
+def host_call(call):
+    """Host work at this point of the current stream: run now, or -- while recording -- at this point of every replay (between
+    two native launch calls: Program.run splits around it). Used for the all-reduce of SyncBN statistics, which is issued by
+    torch.distributed and cannot be a launch descriptor."""
+    if _REC is None:
+        call()
+        return
+    prog = _REC[0]
+    prog.host_ops.append((prog.size(), _rec_stream_index(), call))
 
 
 def memset_zero(t):

@@ -265,13 +265,13 @@ class CutMixMeanTeacherStep(object):
 
     def _sample_groups(self, n_sup, unsup_batches, use_unsup):
         """Batch-statistics BatchNorm couples the samples of a batch -- but only WITHIN a forward pass of the reference. When both
-        networks run on kernels that keep sample groups apart (`supports_sample_groups`: DeepLab v2 on the executor,
-        single-process), the passes can still travel as one batch: [supervised; mixed_1; ...] through the student and
+        networks run on kernels that keep sample groups apart (`supports_sample_groups`: DeepLab v2 on the executor; under data
+        parallelism every group's statistics are all-reduced on their own: SyncBN), the passes can still travel as one batch: [supervised; mixed_1; ...] through the student and
         [x0_1; x1_1; ...] through the teacher, every group normalised with its own statistics and the running statistics moved
         once per group in the reference's order. -> (student groups, teacher groups) or None. Needs equal group sizes and
         separate student / teacher networks (the Pi model interleaves both kinds of passes through ONE set of running
         statistics). Dropout (DeepLab v3+'s head) draws per element and couples nothing."""
-        if self.world > 1 or (use_unsup and self.teacher is self.student):
+        if use_unsup and self.teacher is self.student:
             return None
         for net in (self.student, self.teacher) if use_unsup else (self.student,):
             ok = getattr(net, 'supports_sample_groups', None)

@@ -770,8 +770,17 @@ def gen_vat():
         json.dump(meta, f, indent=0)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# 14. mask_gen.gaussian_kernels (mask_gen.py:26-43; a helper of the reference's mask generators, unused by the trainer)
+# ----------------------------------------------------------------------------------------------------------
+def gen_gauss():
+    sig = np.array([0.5, 1.0, 2.5, 4.0])
+    save('gaussian_kernels', sigma=sig, auto=mask_gen.gaussian_kernels(sig),
+         wide=mask_gen.gaussian_kernels(sig, max_sigma=6.0, truncate=3.0))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['boxmask', 'ema', 'evaluation', 'lr', 'losses', 'deeplab2', 'optim', 'step', 'cli', 'cli_vat',
-                             'checkpoint', 'affine', 'vat']
+                             'checkpoint', 'affine', 'vat', 'gauss']
     for w in which:
         globals()['gen_' + w]()

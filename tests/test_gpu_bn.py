@@ -276,3 +276,57 @@ def test_last_block_protocol_never_reads_a_stale_partial(fenced, monkeypatch):
     for i, o in outs:
         assert torch.equal(ref.setdefault(i, o), o)
     assert not torch.equal(ref[0], ref[1])
+
+
+def _sync_groups_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        q.put((rank,) + _grouped_bn_pass([rank, 2 + rank]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _grouped_bn_pass(idx):
+    """batch_norm_act with TWO sample groups on the samples `idx` of a fixed 4-sample batch [s0 s1 | s2 s3]."""
+    from cutmix_semisup_seg_amd import ops
+    dev = torch.device(DEV)
+    torch.cuda.set_device(dev)
+    g = torch.Generator().manual_seed(6)
+    C = 64
+    x = torch.randn(4, 9, 7, C, generator=g) * torch.tensor([1.0, 1.5, 0.5, 2.0]).view(4, 1, 1, 1)
+    dy = torch.randn(4, 9, 7, C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    xs = x[idx].contiguous().to(dev).requires_grad_(True)
+    gg, bg = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    y = ops.batch_norm_act(xs, gg, bg, rm, rv, 0.1, 1e-5, relu=True, groups=2)
+    y.backward(dy[idx].contiguous().to(dev))
+    return (y.detach().cpu().numpy(), xs.grad.cpu().numpy(), gg.grad.cpu().numpy(), bg.grad.cpu().numpy(), rm.cpu().numpy(),
+            rv.cpu().numpy())
+
+
+def test_sync_batchnorm_with_sample_groups_two_ranks_equal_one_process():
+    """Round 4: sample groups under data parallelism (the DeepLab v3+ head of BASELINE configs[3] on 4 GPUs): each rank holds one
+    sample of each group; the per-group sums are all-reduced in one exchange and finalised group by group."""
+    import torch.multiprocessing as mp
+    want = _grouped_bn_pass([0, 1, 2, 3])
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_groups_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        np.testing.assert_allclose(res[r][1], want[0][[r, 2 + r]], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(res[r][2], want[1][[r, 2 + r]], rtol=5e-4, atol=5e-5)
+        np.testing.assert_allclose(res[r][5], want[4], rtol=1e-5, atol=1e-6)       # running mean: global, both groups in order
+        np.testing.assert_allclose(res[r][6], want[5], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res[0][3] + res[1][3], want[2], rtol=5e-4, atol=5e-5)     # local dgamma / dbeta add up
+    np.testing.assert_allclose(res[0][4] + res[1][4], want[3], rtol=5e-4, atol=5e-5)

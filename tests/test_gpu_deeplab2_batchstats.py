@@ -153,3 +153,116 @@ def test_bf16_batch_statistics_iteration_runs_on_the_mfma_engine():
     assert isinstance(stu._hip_engine, HipConvEngine)            # (the stem's layer engine; body + head on the executor)
     assert stu._hip_executor is not None and stu._hip_executor.batch_statistics()
     assert all(np.isfinite(losses)) and min(losses[-5:]) < losses[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 4: the batch-statistics passes under DATA PARALLELISM stay on the executor (SyncBN with sample groups)
+def _dp_net(C, layers):
+    from architectures import deeplab2
+    from oracle import deeplab2 as odl
+    g = torch.Generator().manual_seed(77)
+    st = {}
+    for k, (shape, dt) in odl.state_spec(C, layers).items():
+        if dt == torch.int64:
+            st[k] = torch.zeros(shape, dtype=torch.int64)
+        elif len(shape) == 4:
+            st[k] = torch.randn(shape, generator=g) * (2.0 / (shape[1] * shape[2] * shape[3])) ** 0.5
+        elif k.endswith('running_var'):
+            st[k] = 0.8 + 0.4 * torch.rand(shape, generator=g)
+        elif k.endswith('running_mean'):
+            st[k] = 0.1 * torch.randn(shape, generator=g)
+        elif k.endswith('.weight'):
+            st[k] = 0.6 + 0.8 * torch.rand(shape, generator=g)
+        else:
+            st[k] = 0.1 * torch.randn(shape, generator=g)
+    net = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
+    net.load_state_dict(st)
+    net = net.to(DEV)
+    net.compute_dtype = torch.float32
+    net.engine_kind = 'hip'
+    net.train()                                       # batch statistics
+    return net
+
+
+def _dp_passes(net, x, wsum, groups, iters=2):
+    """`iters` grouped forward + backward passes (the second one REPLAYS the recorded programs); -> logits of the last pass,
+    gradient of three weights, three running statistics."""
+    keys = ['layer1.0.conv1.weight', 'layer3.0.conv2.weight', 'layer5.conv2d_list.0.weight']
+    named = dict(net.named_parameters())
+    lo = None
+    for _ in range(iters):
+        for p in net.parameters():
+            p.grad = None
+        net.set_sample_groups(groups)
+        try:
+            lo = net.forward_lowres(x)
+            (lo * wsum).sum().backward()
+        finally:
+            net.set_sample_groups(1)
+    torch.cuda.synchronize()
+    sd = net.state_dict()
+    return (lo.detach().float().cpu().numpy(), [named[k].grad.detach().float().cpu().numpy() for k in keys],
+            [sd[k].float().cpu().numpy() for k in ('layer1.0.bn1.running_mean', 'layer3.0.bn2.running_var', 'layer4.0.bn3.running_mean')],
+            int(sd['layer2.0.bn1.num_batches_tracked']))
+
+
+def _dp_inputs(C):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 3, 49, 65, generator=g)        # two sample groups of two: [s0 s1 | s2 s3]
+    wsum = torch.randn(4, C, 7, 9, generator=g)
+    return x, wsum
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(torch.device(DEV))
+        C, layers = 5, [1, 1, 1, 1]
+        net = _dp_net(C, layers)
+        assert net._use_hip_body() and net.supports_sample_groups()        # the executor, not the layer-engine fallback
+        x, wsum = _dp_inputs(C)
+        idx = [rank, 2 + rank]                         # this rank's shard: one sample of EACH group
+        out = _dp_passes(net, x[idx].to(DEV), wsum[idx].to(DEV), groups=2)
+        ex = net._hip_executor
+        assert ex is not None and any(p.host_ops for p in ex.programs()), 'the recorded passes carry the SyncBN all-reduces'
+        q.put((rank,) + out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grouped_syncbn_on_the_executor_two_ranks_equal_one_process_on_the_whole_batch():
+    """DeepLab v2 without --freeze_bn under data parallelism ("BN statistics"): two ranks (gloo, both on this
+    GPU), each with one sample of each of the two sample groups, run the grouped passes ON THE EXECUTOR -- every unit's
+    per-group sums are all-reduced between the reduction and the finalisation, inside the recorded programs -- and must
+    reproduce ONE process normalising the whole batch with two groups: same logits for their samples, the same running
+    statistics on both ranks, local weight gradients that add up to the single-process ones."""
+    import socket
+    import torch.multiprocessing as mp
+    C, layers = 5, [1, 1, 1, 1]
+    net = _dp_net(C, layers)
+    x, wsum = _dp_inputs(C)
+    want = _dp_passes(net, x.to(DEV), wsum.to(DEV), groups=2)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        np.testing.assert_allclose(res[r][1], want[0][[r, 2 + r]], rtol=2e-4, atol=2e-5)          # logits of the rank's samples
+        for a, b in zip(res[r][3], want[2]):                                                       # global running statistics
+            np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+        assert res[r][4] == want[3] == 4                                                            # 2 groups x 2 passes
+    for g0, g1, gw in zip(res[0][2], res[1][2], want[1]):                                           # local gradients add up
+        np.testing.assert_allclose(g0 + g1, gw, rtol=2e-3, atol=2e-4 * float(np.abs(gw).max()))

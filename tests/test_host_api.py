@@ -445,3 +445,15 @@ def test_vat_host_helpers_match_the_oracle():
     torch.testing.assert_close(n.reshape(3, -1).norm(dim=1), torch.full((3,), 2.5))
     with pytest.raises(ValueError):
         vat.VATConfig(cons_loss_fn='logits_smoothl1')
+
+
+def test_gaussian_kernels_match_the_reference_vectors():
+    """mask_gen.gaussian_kernels (reference mask_gen.py:26-43): rows of normalised 1-D Gaussians, width set by the largest
+    sigma -- against tests/golden/gaussian_kernels.npz, written by the reference's own function."""
+    import os
+    import numpy as np
+    import mask_gen
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'gaussian_kernels.npz'))
+    np.testing.assert_allclose(mask_gen.gaussian_kernels(g['sigma']), g['auto'], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(mask_gen.gaussian_kernels(g['sigma'], max_sigma=6.0, truncate=3.0), g['wide'], rtol=1e-14, atol=0)
+    assert g['auto'].shape == (4, 33) and g['wide'].shape == (4, 37)
