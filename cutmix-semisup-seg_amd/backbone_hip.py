@@ -116,6 +116,13 @@ class DeepLabHipExecutor(object):
         # on the weight-gradient stream, behind the data-gradient chain of the stretch; 0 = one launch per layer (round 1-3).
         # CMS_WGRAD_GROUP sets it (A/B switch, read once).
         self.wgrad_group_blocks = int(os.environ.get('CMS_WGRAD_GROUP', '0'))
+        # The backward pass normally ends with the main stream waiting for the weight-gradient stream(s): whoever reads a
+        # gradient afterwards finds it complete. A caller that knows where it next touches the gradients (the training step:
+        # at the gradient exchange / optimizer) sets this and calls `join_wgrad()` there instead -- what follows the body's
+        # backward on the main stream (max-pool and stem backward, 0.3 ms) then overlaps the tail of layer1's weight
+        # gradients (0.37 ms of small launches, profiles/r04n_step_timeline.txt) instead of waiting for it.
+        self.defer_wgrad_join = False
+        self._pending_join = None
         self._sides = []
         self.conv_tile = 0         # experiment knob: force a tile shape on the 128-multiple layers (tools, bench)
         self.tile_rules = {}       # output channels -> tile code (per-layer choice against the workgroup-count staircase)
@@ -470,8 +477,9 @@ class DeepLabHipExecutor(object):
                     hook(bi)
             dx = dres if b.cd is None else self._dgrad_raw(dud, b.cd, in_hw=in_hw)
             dOut = self._dgrad_raw(du1, b.c1, res=dx, in_hw=in_hw)
-        for sd_ in sides:
-            ops.stream_wait(main, sd_)
+        if not self.defer_wgrad_join:
+            for sd_ in sides:
+                ops.stream_wait(main, sd_)
         del keep
         return dOut, dwall
 
@@ -721,8 +729,9 @@ class DeepLabHipExecutor(object):
                 hook(bi)
             dres = dC if b.cd is None else self._dgrad(dC, b.cd, in_hw=in_hw)
             dC = self._dgrad(dU1, b.c1, res=dres, mask=None if bi == 0 else xin, in_hw=in_hw)
-        for sd in sides:
-            ops.stream_wait(main, sd)
+        if not self.defer_wgrad_join:
+            for sd in sides:
+                ops.stream_wait(main, sd)
         del keep
         return dC, dwall
 
@@ -746,6 +755,8 @@ class DeepLabHipExecutor(object):
         main = torch.cuda.current_stream()
         sides = self._side_streams(self.wgrad_streams) if (self.overlap_wgrad and want_w) else []
         if not self.use_programs:
+            if self.defer_wgrad_join and sides:
+                self._pending_join = list(sides)
             self._head_bias_grads(dlogits, want_w)
             box = {}
 
@@ -767,7 +778,9 @@ class DeepLabHipExecutor(object):
             raise RuntimeError('the activations of this forward pass were overwritten by a later forward pass of the '
                                'same shape through the same executor (programs keep ONE set of buffers per shape): '
                                'run backward before the next forward, or set executor.use_programs = False')
-        key = (want_w, len(sides))
+        key = (want_w, len(sides), bool(self.defer_wgrad_join))
+        if self.defer_wgrad_join and sides:
+            self._pending_join = list(sides)
         prog = fprog.bwd.get(key)
         if prog is None:
             prog = ops.Program()
@@ -805,6 +818,14 @@ class DeepLabHipExecutor(object):
                 self._head_weight_grads(prog.dwall)
         self._account(prog)
         return prog.dx.clone()
+
+    def join_wgrad(self):
+        """The current stream waits for the weight-gradient stream(s) of the last backward pass (see `defer_wgrad_join`)."""
+        sides, self._pending_join = self._pending_join, None
+        if sides:
+            main = torch.cuda.current_stream()
+            for sd in sides:
+                main.wait_stream(sd)
 
     def _block_wgrads(self, b, dC, dU2, dU1, xin, a1, a2):
         self._wgrad(dC, a2, b.c3)

@@ -58,6 +58,10 @@ class StepConfig(object):
         # measured: no gain (507 / 509 vs 507 / 505 img/s, profiles/r03eo_*) -- the 0.28 ms HBM-bound update only trades bandwidth
         # with the convolutions it overlaps -- so it is off by default
         self.early_optimizer = bool(early_optimizer)
+        # fused-batch step on the executor: the main stream joins the weight-gradient stream at the optimizer instead of at the
+        # end of the body's backward pass (the stem's backward then overlaps layer1's last weight gradients); CMS_DEFER_JOIN=0
+        # switches it off (A/B)
+        self.defer_wgrad_join = os.environ.get('CMS_DEFER_JOIN', '1') != '0'
         self.compute_dtype = compute_dtype
         self.cons = ops.ConsistencyConfig(mode='mix' if self.mix else 'cut', loss_fn=cons_loss_fn,
                                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, invert=invert)
@@ -405,11 +409,20 @@ class CutMixMeanTeacherStep(object):
                     s_off += n
                     cons_vals.append(sc)
             ex = self._arm_buckets() or self._arm_early_optimizer()
+            # the join of the weight-gradient stream moves from the end of the body's backward to where the gradients are next
+            # touched (exchange / optimizer, below): the stem's backward overlaps the last weight gradients
+            dex = self.student.hip_executor() if (getattr(self.student, '_use_hip_body', None) and self.student._use_hip_body()
+                                                  and hasattr(self.student.hip_executor(), 'join_wgrad')) else None
+            if dex is not None:
+                dex.defer_wgrad_join = self.cfg.defer_wgrad_join
             try:
                 stu_lo.backward(grad_lo.to(stu_lo.dtype))
             finally:
                 if ex is not None:
                     ex.grad_hook = None
+                if dex is not None:
+                    dex.defer_wgrad_join = False
+                    dex.join_wgrad()
         else:
             # reference order, separate passes (batch-statistics BN). The teacher's passes depend on nothing the student
             # does within the iteration (its weights only move in the EMA at the end), so they are issued FIRST, on
