@@ -109,6 +109,21 @@ def bn_unit_backward(u, y, dy, gamma, ctx, relu, has_res, frozen=False, storage=
     return du, dres, s1.sum(0).float(), s0.sum(0).float()
 
 
+def fused_frozen_unit(x, w, gamma, beta, running_mean, running_var, stride=1, padding=0, dilation=1, relu=True, res=None,
+                      storage='bf16', eps=BN_EPS):
+    """The EXECUTOR's unit (backbone on frozen statistics, backbone_hip.py): convolution, folded BatchNorm affine, residual and
+    ReLU in ONE epilogue, ONE rounding:  y = R(relu(conv(R(x), R(W)) * scale + shift (+ res)))."""
+    scale = gamma * torch.rsqrt(running_var + eps)
+    shift = beta - running_mean * scale
+    y = F.conv2d(rb(x, storage), rb(w, storage), None, stride, padding, dilation)
+    y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    return rb(y, storage)
+
+
 # ------------------------------------------------------------------------------------------------------------- the graph
 def _cba(x, st, conv_key, bn_prefix, stride, padding, dilation, relu, res, frozen, storage, taps, groups=1):
     u = conv_unit(x, st[conv_key], stride, padding, dilation, storage)

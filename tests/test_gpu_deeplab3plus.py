@@ -517,7 +517,50 @@ def test_bf16_engine_every_unit_teacher_forced_vs_the_bf16_storage_unit_oracle(n
               max(bn_b.values()), max(bn_p.values()), top(fwd), top(bwd_w), top(bn_b)))
     stem = 'deeplab.backbone.conv1'          # 49 taps = three chunks accumulated through the bf16 output: two more roundings
     assert all(v <= (3e-3 if k == stem else 2e-4) for k, v in fwd.items()), top(fwd)
-    assert max(bn_f.values()) <= 2e-4, top(bn_f)
+    # (the pooled ASPP branch normalises a 1 x 1 map over the batch: with ONE sample its variance is exactly 0, rstd = 1/sqrt(eps)
+    # = 316, and y = beta + 316 * gamma * (u - mean) is a cancellation of fp32 rounding errors -- fma vs mul + add decides
+    # the last bits; the reference has the same degenerate unit at batch 1)
+    degenerate = 'deeplab.classifier.aspp.convs.4.2' if n == 1 else None
+    assert all(v <= (2e-3 if k == degenerate else 2e-4) for k, v in bn_f.items()), top(bn_f)
     assert max(bwd_x.values()) <= 2e-3, top(bwd_x)
     assert max(bwd_w.values()) <= 1e-3, top(bwd_w)
     assert max(bn_b.values()) <= 2e-3 and max(bn_p.values()) <= 1e-3, (top(bn_b), top(bn_p))
+
+
+def test_bf16_backbone_executor_every_block_teacher_forced(no_library_convolutions):
+    """The TIMED route of BASELINE configs[3]: backbone on frozen statistics on the recorded executor (bf16). Every bottleneck's
+    three stored tensors (a1, a2, block output) are recomputed by the fused frozen unit of the storage oracle from the device's
+    own block input -- torchvision v1.5 geometry (stride and dilation on the 3 x 3, first block of a dilated layer on the
+    previous dilation), shortcut convolutions included -- and both taps the head consumes come out of that chain."""
+    from oracle import deeplab3plus as o3, deeplab3plus_chain as oc
+    layers, C = (2, 2, 3, 2), 6
+    st = _he_state(C, layers)
+    net = _net(C, layers, torch.bfloat16, st, kind='hip')
+    net.train()
+    net.freeze_batchnorm()                                     # backbone statistics frozen -> executor
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(2, 3, 129, 161, generator=g).to(DEV)
+    ex = net.hip_executor()
+    with no_library_convolutions, torch.no_grad():
+        s = ex.stem(x)
+        low, out, saved = ex.forward_taps(s, save=True)
+    saved = saved[0].saved if isinstance(saved, tuple) else saved
+    torch.cuda.synchronize()
+    nchw = lambda t: t.permute(0, 3, 1, 2).float().cpu()
+    plan = o3.layer_plan(layers)
+    assert len(saved) == len(plan) + 1
+    worst = 0.0
+    for bi, (pre, inplanes, planes, stride, dil, down) in enumerate(plan):
+        xin, a1d, a2d = (nchw(t) for t in saved[bi])
+        outd = nchw(saved[bi + 1][0] if bi + 1 < len(plan) else saved[-1])
+        bn = lambda k: (st[pre + k + '.weight'], st[pre + k + '.bias'], st[pre + k + '.running_mean'], st[pre + k + '.running_var'])
+        a1 = oc.fused_frozen_unit(xin, st[pre + '.conv1.weight'], *bn('.bn1'))
+        a2 = oc.fused_frozen_unit(a1d, st[pre + '.conv2.weight'], *bn('.bn2'), stride=stride, padding=dil, dilation=dil)
+        res = xin
+        if down:
+            res = oc.fused_frozen_unit(xin, st[pre + '.downsample.0.weight'], *bn('.downsample.1'), stride=stride, relu=False)
+        o = oc.fused_frozen_unit(a2d, st[pre + '.conv3.weight'], *bn('.bn3'), res=res)
+        worst = max(worst, _rel(a1d, a1), _rel(a2d, a2), _rel(outd, o))
+    print('\nPARITY v3+ bf16 backbone executor, every block teacher-forced vs the fused frozen unit: max rel {:.2e}'.format(worst))
+    assert worst <= 1.5e-4
+    assert torch.equal(low, saved[layers[0]][0]) and torch.equal(out, saved[-1])
