@@ -108,10 +108,13 @@ class DeepLabHipExecutor(object):
         self.grad_hook = None      # callable(block_index): weight gradients of that bottleneck are enqueued
         self.data_grad_only = False   # backward computes d/d input only (VAT direction: torch.autograd.grad wrt eps)
         self.overlap_wgrad = True
-        # number of extra streams the weight gradients of a bottleneck are spread over (they are independent launches
-        # of ~1.5 workgroups per CU each). Measured on cfg 2 (profiles/r02f_wgrad_streams.txt): 1 -> 443-445 img/s,
-        # 2 -> 433, 3 -> 443: one stream beside the data-gradient chain already keeps the machine busy
-        self.wgrad_streams = 1
+        # number of extra streams the weight gradients of a bottleneck are spread over (independent launches). With the
+        # 128 x 128 kernel (~1.5 workgroups per CU per launch: each launch fills the machine) one stream beside the
+        # data-gradient chain was enough (profiles/r02f_wgrad_streams.txt: 1 -> 443-445 img/s, 2 -> 433, 3 -> 443). The
+        # eight-phase 256 x 256 kernel (csrc/wgrad8.hip) puts ~56 workgroups = 56 CUs behind a launch: TWO streams of them
+        # fill the ~124 CUs the data-gradient convolution (132 tiles, one per CU) leaves free (profiles/r04ag-ai_*: 1 stream
+        # 561 img/s at its best split, 2 streams 575-601, 3 streams 500-563). CMS_WGRAD_STREAMS overrides (A/B switch).
+        self.wgrad_streams = int(os.environ.get('CMS_WGRAD_STREAMS', '2' if os.environ.get('CMS_WGRAD8', '1') != '0' else '1'))
         # Weight gradients of this many consecutive bottlenecks go out as ONE grouped launch per kind (ops.conv_wgrad_group)
         # on the weight-gradient stream, behind the data-gradient chain of the stretch; 0 = one launch per layer (round 1-3).
         # CMS_WGRAD_GROUP sets it (A/B switch, read once).

@@ -61,6 +61,13 @@ __device__ __forceinline__ void block_sum(float (&v)[K], float* smem /* >= K*16 
 size_t conv8_workspace_bytes(int n_cu);
 bool conv8_supported(const cms_conv_desc* d);
 int conv8_launch(const cms_conv_desc* d, hipStream_t s, int mode, int grid_cap, void* trace, int trace_wgs);
+// csrc/wgrad8.hip: the eight-phase 256 x 256 weight gradient
+bool wgrad8_supported(const cms_wgrad_desc* d);
+int wgrad8_plan(const cms_wgrad_desc* d, int* kt_per_slice);       // -> number of pixel slices
+int wgrad8_launch(const cms_wgrad_desc* d, hipStream_t s, void* trace, int trace_wgs);
+// csrc/conv.hip: dw += the slices of a split-K slab, in slice order
+void wgrad_reduce_launch(const float* slab, float* dw, int ksplit, size_t slice_elems, int ntaps, int cout, int cin, int cout_real,
+                         int dw_cout, hipStream_t s);
 
 inline int grid_for(size_t work_items, int block, int max_blocks = 256 * 8) {
     size_t b = (work_items + block - 1) / block;

@@ -1395,6 +1395,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+}  // namespace cms (reopened below)
+void cms::wgrad_reduce_launch(const float* slab, float* dw, int ksplit, size_t slice_elems, int ntaps, int cout, int cin, int cout_real,
+                              int dw_cout, hipStream_t s) {
+    const size_t total4 = (size_t)ntaps * cout_real * (cin / 4);
+    hipLaunchKernelGGL(cms::wgrad_reduce_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, s, slab, dw, ksplit, slice_elems, ntaps,
+                       cout, cin, cout_real, dw_cout);
+}
+namespace cms {
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t wg_off(int pix, int ch) {     // byte offset of channel `ch` (multiple of 4) of row `pix`
@@ -1955,6 +1964,25 @@ static int wgrad_plan(const cms_wgrad_desc* d, int* per_out, bool* dma_out, int*
     return ksplit;
 }
 
+// The eight-phase 256 x 256 kernel (csrc/wgrad8.hip) takes the launches it supports unless switched off: CMS_WGRAD8=0 in the
+// environment, or cms_conv_set_wgrad8 (A/B legs and the tests that compare the two kernels in one process).
+static int g_wgrad8_mode = -1;                   // -1 = environment (default on), 0 = off, 1 = on
+extern "C" int cms_conv_set_wgrad8(int mode) {
+    g_wgrad8_mode = mode;
+    return CMS_OK;
+}
+static bool wgrad8_selected(const cms_wgrad_desc* d) {
+    static int env = -1;
+    if (env < 0) {
+        const char* e = getenv("CMS_WGRAD8");
+        env = e ? (atoi(e) != 0) : 1;
+    }
+    const int on = g_wgrad8_mode >= 0 ? g_wgrad8_mode : env;
+    return on != 0 && wgrad8_supported(d);
+}
+
+extern "C" int cms_conv_wgrad_uses_wgrad8(const cms_wgrad_desc* d) { return wgrad8_selected(d) ? 1 : 0; }
+
 // Bytes of caller-owned scratch that make this launch DETERMINISTIC: with a workspace of at least this size the pixel
 // slices write their partial sums as plain stores ([slice][tap][Cout][Cin] fp32) and a second launch on the same stream
 // adds them to dw in slice order; without one (NULL) they are combined with fp32 atomics, whose order varies from run to
@@ -1963,7 +1991,7 @@ extern "C" long long cms_conv_wgrad_workspace_bytes(const cms_wgrad_desc* d) {
     if (!d || d->cin % 64 != 0 || d->cout % 64 != 0 || d->ntaps <= 0 || d->ntaps > CMS_CONV_MAX_TAPS || d->n <= 0 || d->ho <= 0 ||
         d->wo <= 0 || d->cin % 4 != 0)
         return 0;
-    const int ks = wgrad_plan(d, nullptr, nullptr, nullptr);
+    const int ks = wgrad8_selected(d) ? wgrad8_plan(d, nullptr) : wgrad_plan(d, nullptr, nullptr, nullptr);
     return ks > 1 ? (long long)ks * d->ntaps * d->cout * d->cin * (long long)sizeof(float) : 0;
 }
 
@@ -2001,6 +2029,7 @@ extern "C" int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream) {
     WgradArgs a;
     const int rc0 = wgrad_fill_args(d, a);
     if (rc0) return rc0;
+    if (wgrad8_selected(d)) return wgrad8_launch(d, (hipStream_t)stream, g_conv_trace, g_conv_trace_wgs);
     const int bco = d->cout % 128 == 0 ? 128 : 64, bci = d->cin % 128 == 0 ? 128 : 64;
     const int tiles = (d->cout / bco) * (d->cin / bci) * d->ntaps;
     int per = 64, stages = 1;

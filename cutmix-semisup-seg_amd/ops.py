@@ -1258,11 +1258,12 @@ def _wgrad_workspace(d, device, recording):
 
 
 def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, w_bf16=None, wdot=None, dbeta=None,
-               dw_cout=None):
+               dw_cout=None, query_kernel=False):
     """
     dw (fp32 (ntaps, Cout, Cin), accumulated into) += scale[co] * sum_pixels du[pix][co] * x[pix + tap][ci].
     du bf16 (N, Ho, Wo, Cout), x bf16 (N, H, W, Cin), both NHWC-contiguous. `dw_cout`: rows per tap of `dw` when it is
     narrower than du's (padded) channel axis -- only the first `cout_real` rows are written.
+    `query_kernel`: launch nothing, return 8 if this call would take the eight-phase 256 x 256 kernel (csrc/wgrad8.hip), else 0.
     """
     _need_cuda(du, x, dw, scale)
     if du.dtype not in (torch.bfloat16, torch.float32) or x.dtype != du.dtype or dw.dtype != torch.float32:
@@ -1293,6 +1294,8 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
     d.wdot = wdot.data_ptr() if wdot is not None else None
     d.dbeta = dbeta.data_ptr() if dbeta is not None else None
     d.dw_cout = 0 if dw_cout is None else int(dw_cout)
+    if query_kernel:
+        return 8 if (not f32 and int(fn['cms_conv_wgrad_uses_wgrad8'](C.byref(d)))) else 0
     ws = None
     if not f32 and (_WGRAD_DETERMINISTIC or (_WGRAD_SLAB_LARGE and len(taps) * cout * cin >= 262144)):
         ws = _wgrad_workspace(d, du.device, _REC is not None)

@@ -330,6 +330,12 @@ typedef struct cms_wgrad_desc {
 } cms_wgrad_desc;
 
 int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream);
+/* Kernel selection of cms_conv_wgrad (diagnostic / A-B switch; production leaves it alone). Launches with Cout % 256 == 0,
+ * Cin % 256 == 0, no BatchNorm-affine side outputs and >= 1024 pixels take the eight-phase 256 x 256 kernel of csrc/wgrad8.hip
+ * (few pixel slices, 40-170 K tiles per workgroup), everything else the 128 x 128 kernel of csrc/conv.hip.
+ *   mode -1 = the environment decides (CMS_WGRAD8, default 1), 0 = never the eight-phase kernel, 1 = wherever supported. */
+int cms_conv_set_wgrad8(int mode);
+int cms_conv_wgrad_uses_wgrad8(const cms_wgrad_desc* d);   /* 1: cms_conv_wgrad(d) would take the eight-phase kernel now */
 
 /* GROUPED weight gradients (round 4): the launches of MANY layers -- the bottlenecks of a stretch of the backward pass, autograd
  * of architectures/deeplab2.py:89-109 -- as ONE grid. A per-layer launch has 16 ... 144 output tiles and needs 8 ... 21 pixel
