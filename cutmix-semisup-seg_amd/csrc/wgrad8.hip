@@ -385,7 +385,8 @@ int wgrad8_plan(const cms_wgrad_desc* d, int* kt_per_slice) {
     if (target < 0) {
         // workgroups per launch the split aims at. In the training step two weight-gradient streams run beside the
         // data-gradient chain: 2 x 56 + the 132 tiles of a data-gradient convolution = the machine (profiles/r04ag-ai_*:
-        // 40 -> 545 img/s, 48 -> 575-581, 56 -> 588-601, 64 -> 573, 96 -> 564; "equal K tiles per workgroup" rules lost)
+        // 40 -> 545 img/s, 48 -> 575-581, 56 -> 588-601, 64 -> 573, 96 -> 564; "equal K tiles per workgroup" rules -- every
+        // launch about as long -- lost on one, two and three streams: 478-564, profiles/r04ah_*, r04am_*)
         target = wgrad8_env("CMS_WGRAD8_TARGET", 56);
         min_kt = std::max(2, wgrad8_env("CMS_WGRAD8_MIN_KT", 24));       // K tiles per slice below which a slice is not worth its epilogue
     }
