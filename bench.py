@@ -431,6 +431,7 @@ def run_workload(key, args, world, rank, dev):
             res = one_step(i)
         t_enqueue = time.perf_counter() - t0         # host time to enqueue the K steps (== elapsed when launch-bound)
         torch.cuda.synchronize()
+        t_local = time.perf_counter() - t0           # this rank's own K steps (before it waits for the slowest rank)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -444,6 +445,21 @@ def run_workload(key, args, world, rank, dev):
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax)
+        # per-rank view (the first SCALE run should be diagnosable from one line): every rank's own time for the K steps and
+        # the slowest wait of every gradient bucket over the ranks
+        rank_view = {'local_ms_per_step': [1e3 * t_local / args.steps]}
+        buckets = step.bucket_timing()
+        if world > 1:
+            tl = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(tl, torch.tensor([1e3 * t_local / args.steps], dtype=torch.float64, device=dev))
+            rank_view['local_ms_per_step'] = [float(v) for v in tl]
+            if buckets:
+                waits = torch.tensor([float(b['issue_to_wait_ms']) for b in buckets], dtype=torch.float64, device=dev)
+                wmax = waits.clone()
+                dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
+                rank_view['bucket_wait_ms_max_over_ranks'] = [float(v) for v in wmax]
+        rank_view['min'] = min(rank_view['local_ms_per_step'])
+        rank_view['max'] = max(rank_view['local_ms_per_step'])
 
         last = {k: (None if v is None else float(v)) for k, v in res.items()}
         if not np.isfinite(last['sup_loss']):
@@ -550,7 +566,8 @@ def run_workload(key, args, world, rank, dev):
                        'host_enqueue_ms_per_step': 1e3 * t_enqueue / args.steps,
                        'host_enqueue_ms_per_step_empty_queue': host_unblocked,
                        'last_losses': last,
-                       'allreduce': {'dtype': args.allreduce_dtype, 'buckets_last_step': step.bucket_timing()},
+                       'allreduce': {'dtype': args.allreduce_dtype, 'buckets_last_step': buckets},
+                       'ranks': rank_view,
                        'deterministic_wgrad': bool(args.deterministic),
                        'parity_config': ('this line is the bf16-STORAGE engine: held per layer (teacher-forced) to the bf16-storage '
                                          'oracle at 1.5e-4 forward / 2e-3 backward / 3e-4 weight gradients; the 1e-4 bar on whole-'
