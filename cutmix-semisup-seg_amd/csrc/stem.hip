@@ -211,6 +211,33 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_mfma_kernel(const uint16_t* _
 }
 
 // ---- max-pool 3x3 / 2 / pad 1, NHWC, C % 8 == 0
+// 8 channels per thread as ONE 16-byte (bf16) / two 16-byte (fp32) vector accesses and one 8-byte access to the argmax bytes
+// (round 4: the element-wise 2-byte loads and stores of the first version made the backward 158 us for 91 MB at 321 x 321 --
+// it sits alone at the end of the step, between the last data gradient and the optimizer)
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const uint16_t* p, float (&v)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = float4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<float4*>(p + 4) = float4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void st8(uint16_t* p, const float (&v)[8]) {
+    uint4 a;
+    a.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    a.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    a.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    a.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = a;
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ s, T* __restrict__ p,
                                                           uint8_t* __restrict__ idx, int N, int Hs, int Ws, int Hp,
@@ -224,7 +251,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         const int py = (int)(t % Hp);
         const int n = (int)(t / Hp);
         float best[8];
-        uint8_t bi[8];
+        uint32_t bi[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
 #pragma unroll
@@ -235,18 +262,19 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
             for (int kx = 0; kx < 3; ++kx) {
                 const int xx = px * 2 - 1 + kx;
                 if (xx < 0 || xx >= Ws) continue;
-                const T* src = s + (((size_t)n * Hs + yy) * Ws + xx) * C + c8 * 8;
+                float v[8];
+                ld8(s + (((size_t)n * Hs + yy) * Ws + xx) * C + c8 * 8, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = ld_f32(src + e);
-                    if (v > best[e] || v != v) { best[e] = v; bi[e] = (uint8_t)(ky * 3 + kx); }
-                }
+                for (int e = 0; e < 8; ++e)
+                    if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = (uint32_t)(ky * 3 + kx); }
             }
         }
-        T* dst = p + (((size_t)n * Hp + py) * Wp + px) * C + c8 * 8;
-        uint8_t* di = idx + (((size_t)n * Hp + py) * Wp + px) * C + c8 * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { st_f32(dst + e, best[e]); di[e] = bi[e]; }
+        const size_t o = (((size_t)n * Hp + py) * Wp + px) * C + c8 * 8;
+        st8(p + o, best);
+        uint2 pk;
+        pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+        *reinterpret_cast<uint2*>(idx + o) = pk;
     }
 }
 
@@ -276,15 +304,23 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
                 const int kx = x - (px * 2 - 1);
                 if (kx < 0 || kx > 2) continue;
                 const size_t o = (((size_t)n * Hp + py) * Wp + px) * C + c8 * 8;
-                const uint8_t want = (uint8_t)(ky * 3 + kx);
+                const uint32_t want = (uint32_t)(ky * 3 + kx);
+                const uint2 pk = *reinterpret_cast<const uint2*>(idx + o);
+                float v[8];
+                ld8(dp + o, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (idx[o + e] == want) g[e] += ld_f32(dp + o + e);
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t who = ((e < 4 ? pk.x : pk.y) >> (8 * (e & 3))) & 0xffu;
+                    g[e] += who == want ? v[e] : 0.0f;
+                }
             }
         }
         const size_t so = (((size_t)n * Hs + y) * Ws + x) * C + c8 * 8;
+        float sv[8];
+        ld8(s + so, sv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) st_f32(ds + so + e, ld_f32(s + so + e) > 0.0f ? g[e] : 0.0f);
+        for (int e = 0; e < 8; ++e) g[e] = sv[e] > 0.0f ? g[e] : 0.0f;
+        st8(ds + so, g);
     }
 }
 

@@ -62,6 +62,8 @@ class StepConfig(object):
         # end of the body's backward pass (the stem's backward then overlaps layer1's last weight gradients); CMS_DEFER_JOIN=0
         # switches it off (A/B)
         self.defer_wgrad_join = os.environ.get('CMS_DEFER_JOIN', '1') != '0'
+        # the consistency branch of the loss on the teacher's stream, concurrently with the cross entropy on the main stream
+        self.overlap_losses = os.environ.get('CMS_OVERLAP_LOSSES', '1') != '0'
         self.compute_dtype = compute_dtype
         self.cons = ops.ConsistencyConfig(mode='mix' if self.mix else 'cut', loss_fn=cons_loss_fn,
                                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, invert=invert)
@@ -390,12 +392,20 @@ class CutMixMeanTeacherStep(object):
             lo_det = stu_lo.detach()
             # the supervised loss needs nothing from the teacher: its kernels are issued BEFORE the join and overlap the tail
             # of the teacher's pass on the other stream
-            ce_sc, ce_ctx = ops.ce_forward(lo_det[:n_sup], sup_y, out_size, 255, self.align_corners, group=self.group)
-            ops.ce_backward(ce_ctx, ce_sc, grad_lo[:n_sup])
-            if use_unsup and side is not main:
-                main.wait_stream(side)
+            # Two independent branches between the forward passes and the backward pass: the supervised loss (student logits
+            # only) and the consistency loss (student + teacher logits). Each is a forward + backward kernel pair that is
+            # latency-bound on a few MB -- they write disjoint slices of grad_lo and run CONCURRENTLY: the
+            # consistency branch on the teacher's stream (behind the teacher's pass, where its second operand comes from),
+            # the cross entropy on the main stream.
+            split = use_unsup and side is not main and cfg.overlap_losses
+            if split:
+                side.wait_stream(main)                  # the student's logits (and grad_lo's zero fill)
+            else:
+                if use_unsup and side is not main:
+                    main.wait_stream(side)
             cons_vals = []
-            if use_unsup:
+
+            def consistency_branch():
                 s_off, t_off = n_sup, 0
                 for ub in unsup_batches:
                     n = ub.x0_tea.shape[0]
@@ -408,6 +418,15 @@ class CutMixMeanTeacherStep(object):
                     ops.consistency_backward(cctx, sc, grad_lo[s_off:s_off + n])
                     s_off += n
                     cons_vals.append(sc)
+            if split:
+                with torch.cuda.stream(side):
+                    consistency_branch()
+            ce_sc, ce_ctx = ops.ce_forward(lo_det[:n_sup], sup_y, out_size, 255, self.align_corners, group=self.group)
+            ops.ce_backward(ce_ctx, ce_sc, grad_lo[:n_sup])
+            if split:
+                main.wait_stream(side)
+            elif use_unsup:
+                consistency_branch()
             ex = self._arm_buckets() or self._arm_early_optimizer()
             # the join of the weight-gradient stream moves from the end of the body's backward to where the gradients are next
             # touched (exchange / optimizer, below): the stem's backward overlaps the last weight gradients
