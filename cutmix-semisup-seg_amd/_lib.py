@@ -74,7 +74,7 @@ class WgradDesc(C.Structure):
                 ('n', c_int), ('h', c_int), ('w_in', c_int), ('cin', c_int), ('ho', c_int), ('wo', c_int),
                 ('cout', c_int), ('cout_real', c_int), ('ntaps', c_int), ('tap_dy', c_int * 18), ('tap_dx', c_int * 18),
                 ('stride', c_int), ('ksplit', c_int), ('w', c_void_p), ('wdot', c_void_p), ('dbeta', c_void_p),
-                ('dw_cout', c_int), ('workspace', c_void_p), ('workspace_bytes', C.c_longlong)]
+                ('dw_cout', c_int), ('workspace', c_void_p), ('workspace_bytes', C.c_longlong), ('wg_target', c_int)]
 
 
 class BnOp(C.Structure):

@@ -430,7 +430,7 @@ class DeepLabHipExecutor(object):
                               out_full_hw=in_hw, tile=self._tile(c.cin))
 
     def _wgrad_raw(self, du, x, c):
-        ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride)
+        ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride, wg_target=self._wg_target())
 
     def _backward_chain_bn(self, saved, dlg, want_w, sides, hook, box=None):
         """The launches of the backward pass with BatchNorm on batch statistics (recordable): head, then per bottleneck
@@ -620,7 +620,15 @@ class DeepLabHipExecutor(object):
             ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride, scale=c.scale,
                            w_bf16=self._w(c), wdot=c.wdot, dbeta=c.dbeta)
         else:
-            ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride, scale=c.scale)
+            ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride, scale=c.scale,
+                           wg_target=self._wg_target())
+
+    def _wg_target(self):
+        """CUs a weight-gradient launch of the backward pass aims at (cms_wgrad_desc.wg_target): the launches run on
+        `wgrad_streams` side streams beside the data-gradient chain, whose eight-phase convolutions hold 132 CUs."""
+        if not self.overlap_wgrad:
+            return 0
+        return 56 if self.wgrad_streams >= 2 else 112
 
     def _dgrad(self, du, c, res=None, mask=None, in_hw=None):
         """gradient wrt the input of conv `c`; `in_hw` = spatial size of that input (needed for stride 2)."""

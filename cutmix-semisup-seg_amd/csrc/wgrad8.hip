@@ -370,26 +370,43 @@ bool wgrad8_supported(const cms_wgrad_desc* d) {
     if (!d || !d->du || !d->x || !d->dw) return false;
     if (d->cout % w8::BCO != 0 || d->cin % w8::BCI != 0) return false;
     if (d->cout_real > 0 && d->cout_real != d->cout) return false;
-    if (d->wdot || d->dbeta || d->w) return false;                       // BatchNorm-affine side outputs: conv_wgrad_kernel
+    // BatchNorm-affine side outputs (<W, G>, sum of dU) stay on conv_wgrad_kernel: an eight-phase variant with them was built
+    // and measured on DeepLab v3+ at 513 x 513 (170 K tiles per layer, ONE weight-gradient stream): 123 vs 149 img/s
+    // (profiles/r04at_*) -- too few K tiles per slice to pay for its epilogue there
+    if (d->wdot || d->dbeta || d->w) return false;
     if (d->ntaps <= 0 || d->ntaps > CMS_CONV_MAX_TAPS || d->n <= 0 || d->ho <= 0 || d->wo <= 0 || d->stride < 1) return false;
     if (d->ho <= 64 / d->wo + 1) return false;                           // the branch-free cursor wraps at most one image row + one image
     const size_t ub = (size_t)d->n * d->ho * d->wo * d->cout * 2, xb = (size_t)d->n * d->h * d->w_in * d->cin * 2;
     if (ub >= (1ull << 31) || xb >= (1ull << 31)) return false;
     const int M = d->n * d->ho * d->wo;
-    return M >= 16 * w8::BK;                                              // a pipeline this deep needs a K loop to fill
+    if (M < 16 * w8::BK) return false;                                    // a pipeline this deep needs a K loop to fill
+    // A launch that has the machine to itself (wg_target 0) is bound by the fp32 atomics of its slices (~0.7 TB/s in total,
+    // tools/atomic_probe.hip): with FEW 256 x 256 tiles the split that fills 256 CUs adds up 64 x |dW| -- the 128 x 128 kernel's
+    // 16-21 slices win there (1 x 1 1024->256 at cfg 2: 47 vs 64 us; 3 x 3 256->256: 87 vs 82; 3 x 3 512->512: 210 vs 163,
+    // profiles/r04ar_*). Beside other work (wg_target > 0) CU-time is what counts and the eight-phase kernel always wins.
+    const int tiles = (d->cout / w8::BCO) * (d->cin / w8::BCI) * d->ntaps;
+    return d->wg_target > 0 || d->ksplit > 0 || tiles >= 8;
 }
 
 // pixel slices of a launch: K tiles per slice (even) and the number of slices
 int wgrad8_plan(const cms_wgrad_desc* d, int* kt_per_slice) {
-    static int target = -1, min_kt = 0;
-    if (target < 0) {
-        // workgroups per launch the split aims at. In the training step two weight-gradient streams run beside the
-        // data-gradient chain: 2 x 56 + the 132 tiles of a data-gradient convolution = the machine (profiles/r04ag-ai_*:
-        // 40 -> 545 img/s, 48 -> 575-581, 56 -> 588-601, 64 -> 573, 96 -> 564; "equal K tiles per workgroup" rules -- every
-        // launch about as long -- lost on one, two and three streams: 478-564, profiles/r04ah_*, r04am_*)
-        target = wgrad8_env("CMS_WGRAD8_TARGET", 56);
-        min_kt = std::max(2, wgrad8_env("CMS_WGRAD8_MIN_KT", 24));       // K tiles per slice below which a slice is not worth its epilogue
+    static int alone = -1, override_target = 0;
+    if (alone < 0) {
+        // workgroups (= CUs) of a launch that has the machine to itself: all of them
+        int n_cu = 0;
+        if (cms_device_info(&n_cu, nullptr, 0) != CMS_OK || n_cu <= 0) n_cu = 256;
+        alone = wgrad8_env("CMS_WGRAD8_ALONE", n_cu);
+        // A/B override of what the CALLER asked for (cms_wgrad_desc.wg_target). The training step runs two weight-gradient
+        // streams beside the data-gradient chain and asks for 56 per launch: 2 x 56 + the 132 tiles of a data-gradient
+        // convolution = the machine (profiles/r04ag-ai_*: 40 -> 545 img/s, 48 -> 575-581, 56 -> 588-601, 64 -> 573, 96 ->
+        // 564; "equal K tiles per workgroup" rules -- every launch about as long -- lost on one, two and three streams:
+        // 478-564, profiles/r04ah_*, r04am_*)
+        override_target = wgrad8_env("CMS_WGRAD8_TARGET", 0);
     }
+    const int target = d->wg_target > 0 ? (override_target > 0 ? override_target : d->wg_target) : alone;
+    // K tiles per slice below which a slice is not worth its 256 KB epilogue: 24 beside other work (CU-time is the currency),
+    // 8 alone (wall time is)
+    const int min_kt = d->wg_target > 0 ? 24 : 8;
     const int M = d->n * d->ho * d->wo;
     const int kt = (M + w8::BK - 1) / w8::BK;
     const int tiles = (d->cout / w8::BCO) * (d->cin / w8::BCI) * d->ntaps;

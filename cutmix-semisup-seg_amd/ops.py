@@ -1258,11 +1258,12 @@ def _wgrad_workspace(d, device, recording):
 
 
 def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, w_bf16=None, wdot=None, dbeta=None,
-               dw_cout=None, query_kernel=False):
+               dw_cout=None, query_kernel=False, wg_target=0):
     """
     dw (fp32 (ntaps, Cout, Cin), accumulated into) += scale[co] * sum_pixels du[pix][co] * x[pix + tap][ci].
     du bf16 (N, Ho, Wo, Cout), x bf16 (N, H, W, Cin), both NHWC-contiguous. `dw_cout`: rows per tap of `dw` when it is
     narrower than du's (padded) channel axis -- only the first `cout_real` rows are written.
+    `wg_target`: CUs the eight-phase kernel should aim at when the launch runs BESIDE other work (0 = it has the machine).
     `query_kernel`: launch nothing, return 8 if this call would take the eight-phase 256 x 256 kernel (csrc/wgrad8.hip), else 0.
     """
     _need_cuda(du, x, dw, scale)
@@ -1294,6 +1295,7 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
     d.wdot = wdot.data_ptr() if wdot is not None else None
     d.dbeta = dbeta.data_ptr() if dbeta is not None else None
     d.dw_cout = 0 if dw_cout is None else int(dw_cout)
+    d.wg_target = int(wg_target)
     if query_kernel:
         return 8 if (not f32 and int(fn['cms_conv_wgrad_uses_wgrad8'](C.byref(d)))) else 0
     ws = None

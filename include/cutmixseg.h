@@ -327,6 +327,10 @@ typedef struct cms_wgrad_desc {
                               varies from run to run (6 % slower alone, 1.5-2 % FASTER inside the two-stream step: the
                               throughput default). The scratch must not be shared by launches that may overlap.       */
     long long workspace_bytes;
+    int wg_target;         /* eight-phase kernel only: workgroups (= CUs, one each) this launch should aim at; 0 = the whole
+                              machine (a launch that runs alone). A caller that runs weight gradients BESIDE other work says
+                              how many CUs are theirs: the DeepLab v2 executor passes 56 per launch on two streams next to
+                              the data-gradient chain                                                 */
 } cms_wgrad_desc;
 
 int cms_conv_wgrad(const cms_wgrad_desc* d, void* stream);

@@ -53,11 +53,11 @@ def _reference(t):
     return (w * scale.view(-1, 1, 1, 1)).permute(2, 3, 0, 1).reshape(k * k, du.shape[3], x.shape[3]).contiguous()
 
 
-def _run(ops, t, ksplit=0, dw=None):
+def _run(ops, t, ksplit=0, dw=None, wg_target=56):
     du, x, taps, scale, stride, _ = t
     if dw is None:
         dw = torch.zeros(len(taps), du.shape[3], x.shape[3], device=DEV)
-    return ops.conv_wgrad(du, x, taps, dw, stride=stride, scale=scale, ksplit=ksplit)
+    return ops.conv_wgrad(du, x, taps, dw, stride=stride, scale=scale, ksplit=ksplit, wg_target=wg_target)
 
 
 @pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
@@ -67,10 +67,10 @@ def test_eight_phase_weight_gradient_vs_fp32_and_the_128_tile_kernel(ops, kernel
     ref = _reference(t)
     den = ref.abs().max().item()
     kernel_switch(0)
-    assert ops.conv_wgrad(du, x, taps, torch.zeros(ref.shape, device=DEV), stride=stride, scale=scale, query_kernel=True) == 0
+    assert ops.conv_wgrad(du, x, taps, torch.zeros(ref.shape, device=DEV), stride=stride, scale=scale, query_kernel=True, wg_target=56) == 0
     old = _run(ops, t)
     kernel_switch(1)
-    assert ops.conv_wgrad(du, x, taps, torch.zeros(ref.shape, device=DEV), stride=stride, scale=scale, query_kernel=True) == 8
+    assert ops.conv_wgrad(du, x, taps, torch.zeros(ref.shape, device=DEV), stride=stride, scale=scale, query_kernel=True, wg_target=56) == 8
     for ks in (0, 1, 3, 5):                     # automatic split, one slice (plain accumulation), odd slice lengths
         for rep in range(2):
             new = _run(ops, t, ksplit=ks)
@@ -107,12 +107,14 @@ def test_dispatch_rule(ops, kernel_switch):
                                                  query_kernel=True, **kw)
     bf = lambda *s: torch.zeros(*s, device=DEV).bfloat16()
     one = ops.conv_taps(1, 1, 1, 0)
-    assert q(bf(2, 33, 33, 256), bf(2, 33, 33, 512), one) == 8
-    assert q(bf(2, 33, 33, 128), bf(2, 33, 33, 512), one) == 0             # Cout % 256
-    assert q(bf(2, 33, 33, 256), bf(2, 33, 33, 128), one) == 0             # Cin % 256
-    assert q(bf(1, 20, 20, 256), bf(1, 20, 20, 256), one) == 0             # fewer than 16 K tiles of pixels
-    assert q(bf(64, 4, 4, 256), bf(64, 4, 4, 256), one) == 0               # maps the branch-free cursor cannot walk
+    assert q(bf(2, 33, 33, 256), bf(2, 33, 33, 512), one, wg_target=56) == 8  # beside other work: always
+    assert q(bf(2, 33, 33, 256), bf(2, 33, 33, 512), one) == 0             # alone, 2 tiles: the atomics of a machine-wide split lose
+    assert q(bf(2, 33, 33, 512), bf(2, 33, 33, 1024), one) == 8            # alone, 8 tiles
+    assert q(bf(2, 33, 33, 128), bf(2, 33, 33, 512), one, wg_target=56) == 0             # Cout % 256
+    assert q(bf(2, 33, 33, 256), bf(2, 33, 33, 128), one, wg_target=56) == 0             # Cin % 256
+    assert q(bf(1, 20, 20, 256), bf(1, 20, 20, 256), one, wg_target=56) == 0             # fewer than 16 K tiles of pixels
+    assert q(bf(64, 4, 4, 256), bf(64, 4, 4, 256), one, wg_target=56) == 0               # maps the branch-free cursor cannot walk
     wdot, dbeta = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
-    assert q(bf(2, 33, 33, 256), bf(2, 33, 33, 512), one, w_bf16=bf(1, 256, 512), wdot=wdot, dbeta=dbeta) == 0   # BN-affine side outputs
+    assert q(bf(2, 33, 33, 256), bf(2, 33, 33, 512), one, w_bf16=bf(1, 256, 512), wdot=wdot, dbeta=dbeta, wg_target=56) == 0   # BN-affine side outputs
     kernel_switch(0)
-    assert q(bf(2, 33, 33, 256), bf(2, 33, 33, 512), one) == 0
+    assert q(bf(2, 33, 33, 256), bf(2, 33, 33, 512), one, wg_target=56) == 0

@@ -49,15 +49,18 @@ def make(case, seed=0):
     return du, x, ops.conv_taps(k, k, dil, pad), scale, stride, (k, dil, pad)
 
 
-def run(t, mode, dw=None, ksplit=0):
+def run(t, mode, dw=None, ksplit=0, wg_target=0):
     du, x, taps, scale, stride, _ = t
     if dw is None:
         dw = torch.zeros(len(taps), du.shape[3], x.shape[3], device=DEV)
     lib.cms_conv_set_wgrad8(mode)
     try:
-        if mode == 1 and ops.conv_wgrad(du, x, taps, dw, stride=stride, scale=scale, ksplit=ksplit, query_kernel=True) != 8:
+        if mode == 1 and ksplit == 0 and wg_target == 0:
+            wg_target = 256                      # (alone the dispatcher would send launches of few tiles to the 128 x 128 kernel)
+        if mode == 1 and ops.conv_wgrad(du, x, taps, dw, stride=stride, scale=scale, ksplit=ksplit, query_kernel=True,
+                                        wg_target=wg_target) != 8:
             raise RuntimeError('the eight-phase kernel does not take this launch')
-        ops.conv_wgrad(du, x, taps, dw, stride=stride, scale=scale, ksplit=ksplit)
+        ops.conv_wgrad(du, x, taps, dw, stride=stride, scale=scale, ksplit=ksplit, wg_target=wg_target)
     finally:
         lib.cms_conv_set_wgrad8(-1)
     return dw
