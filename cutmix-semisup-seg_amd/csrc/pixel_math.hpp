@@ -59,11 +59,18 @@ CMS_HD Tap bilin_tap(int dst, float scale, int in_size, bool align_corners) {
 
 // value of the upsampled map at one output pixel: wy0*(wx0*v00 + wx1*v01) + wy1*(wx0*v10 + wx1*v11)
 CMS_HD float bilin_gather(const float* plane, int w_in, const Tap& ty, const Tap& tx) {
+    // Explicit roundings (one product, then fused multiply-adds in a fixed order): left to the compiler's contraction, two
+    // inlined instances of this expression can be fused differently -- the student's and the teacher's gathers of the SAME
+    // logits then differ in the last bit and "identical distributions -> zero loss" no longer holds exactly
+    // (tests/test_gpu_parity.py::test_consistency_properties_full_size caught it when the surrounding code changed).
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     const float* r0 = plane + (size_t)ty.i0 * w_in;
     const float* r1 = plane + (size_t)ty.i1 * w_in;
-    float a = tx.w0 * r0[tx.i0] + tx.w1 * r0[tx.i1];
-    float b = tx.w0 * r1[tx.i0] + tx.w1 * r1[tx.i1];
-    return ty.w0 * a + ty.w1 * b;
+    const float a = fmaf(tx.w1, r0[tx.i1], tx.w0 * r0[tx.i0]);
+    const float b = fmaf(tx.w1, r1[tx.i1], tx.w0 * r1[tx.i0]);
+    return fmaf(ty.w1, b, ty.w0 * a);
 }
 
 // ---------------------------------------------------------------------------------------------- box membership
@@ -91,6 +98,51 @@ CMS_HD void softmax_stats(L l, int crt, float& mx, float& z) {
     for (int c = 0; c < C; ++c) z += expf(l(c) - mx);
 }
 
+// Softmax of a logit vector with the exponentials kept (round 4): the loss formulas below need exp(l_c - max) of every class
+// once for the normaliser and once more per class -- with a compile-time class count the 2 x C exponentials of a pixel live in
+// registers and the C divisions by the normaliser become multiplications with ONE reciprocal (the consistency forward spent
+// most of its 160 us in 84 expf + 42 divisions per pixel). CT == 0 (run-time class count) keeps the re-evaluating form.
+template <int CT>
+struct SoftmaxRegs {
+    float e[CT > 0 ? CT : 1];
+    float mx, z, rz;
+};
+
+template <int CT, class L>
+CMS_HD void softmax_regs(L l, int crt, SoftmaxRegs<CT>& s) {
+    // (no contraction: the statistics of two identical logit vectors must come out identical whatever surrounds the call)
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    if (CT > 0) {
+        s.mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) s.mx = fmaxf(s.mx, l(c));
+        s.z = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            s.e[c] = expf(l(c) - s.mx);
+            s.z += s.e[c];
+        }
+    } else {
+        softmax_stats<CT>(l, crt, s.mx, s.z);
+    }
+    s.rz = 1.0f / s.z;
+}
+
+// probability of class c
+template <int CT, class L>
+CMS_HD float softmax_prob(const SoftmaxRegs<CT>& s, L l, int c) {
+    // a ROUNDED product: contracted into the caller's subtraction (fma(e_s, rz_s, -t)) the difference of two identical
+    // distributions would no longer be exactly zero (tests/test_gpu_parity.py::test_consistency_properties_full_size)
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const float e = CT > 0 ? s.e[CT > 0 ? c : 0] : expf(l(c) - s.mx);
+    const float p = e * s.rz;
+    return p;
+}
+
 struct PixelFwd {
     float loss;   // per-pixel consistency value, already summed over classes (and / sqrt(C) where applicable)
     float conf;   // max_c softmax(teacher)_c
@@ -105,33 +157,42 @@ CMS_HD float smooth_l1(float d) {
 template <int CT, class LS, class LT>
 CMS_HD PixelFwd consistency_pixel_fwd(LS ls, LT lt, int crt, int loss_fn, float inv_root_c) {
     const int C = CT > 0 ? CT : crt;
-    float ms, zs, mt, zt;
-    softmax_stats<CT>(ls, crt, ms, zs);
-    softmax_stats<CT>(lt, crt, mt, zt);
+    SoftmaxRegs<CT> ss, st;
+    softmax_regs<CT>(ls, crt, ss);
+    softmax_regs<CT>(lt, crt, st);
     PixelFwd out;
-    out.conf = 1.0f / zt;
+    out.conf = st.rz;
     float acc = 0.0f;
-    const float log_zs = logf(zs);
-    const float log_zt = logf(zt);
+    if (loss_fn == LOSS_VAR) {
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const float a = ls(c), b = lt(c);
-        if (loss_fn == LOSS_VAR) {
-            float d = expf(a - ms) / zs - expf(b - mt) / zt;
+        for (int c = 0; c < C; ++c) {
+            const float d = softmax_prob<CT>(ss, ls, c) - softmax_prob<CT>(st, lt, c);
             acc += d * d;
-        } else if (loss_fn == LOSS_LOGITS_VAR) {
-            float d = a - b;
+        }
+    } else if (loss_fn == LOSS_LOGITS_VAR) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float d = ls(c) - lt(c);
             acc += d * d;
-        } else if (loss_fn == LOSS_LOGITS_SMOOTHL1) {
-            acc += smooth_l1(a - b);
-        } else if (loss_fn == LOSS_BCE) {
-            const float eps = 1e-6f;
-            float p = expf(a - ms) / zs, t = expf(b - mt) / zt;
+        }
+    } else if (loss_fn == LOSS_LOGITS_SMOOTHL1) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc += smooth_l1(ls(c) - lt(c));
+    } else if (loss_fn == LOSS_BCE) {
+        const float eps = 1e-6f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float p = softmax_prob<CT>(ss, ls, c), t = softmax_prob<CT>(st, lt, c);
             acc += -(t * logf(p + eps) + (1.0f - t) * logf(1.0f - p + eps));
-        } else {  // LOSS_KLD: t*(log t - log_softmax(ls)); 0 where t == 0
-            float t = expf(b - mt) / zt;
-            float logp = (a - ms) - log_zs;
-            float logt = (b - mt) - log_zt;
+        }
+    } else {  // LOSS_KLD: t*(log t - log_softmax(ls)); 0 where t == 0
+        const float log_zs = logf(ss.z);
+        const float log_zt = logf(st.z);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float t = softmax_prob<CT>(st, lt, c);
+            const float logp = (ls(c) - ss.mx) - log_zs;
+            const float logt = (lt(c) - st.mx) - log_zt;
             acc += t > 0.0f ? t * (logt - logp) : 0.0f;
         }
     }
@@ -144,10 +205,9 @@ CMS_HD PixelFwd consistency_pixel_fwd(LS ls, LT lt, int crt, int loss_fn, float 
 template <int CT, class LS, class LT, class E>
 CMS_HD float consistency_pixel_bwd(LS ls, LT lt, int crt, int loss_fn, float inv_root_c, E emit) {
     const int C = CT > 0 ? CT : crt;
-    float ms, zs, mt, zt;
-    softmax_stats<CT>(ls, crt, ms, zs);
-    softmax_stats<CT>(lt, crt, mt, zt);
-    const float conf = 1.0f / zt;
+    SoftmaxRegs<CT> ss, st;
+    softmax_regs<CT>(lt, crt, st);
+    const float conf = st.rz;
     if (loss_fn == LOSS_LOGITS_VAR) {
 #pragma unroll
         for (int k = 0; k < C; ++k) emit(k, 2.0f * (ls(k) - lt(k)) * inv_root_c);
@@ -162,12 +222,13 @@ CMS_HD float consistency_pixel_bwd(LS ls, LT lt, int crt, int loss_fn, float inv
         }
         return conf;
     }
+    softmax_regs<CT>(ls, crt, ss);
     // softmax-based losses: loss = sum_c f(p_c, t_c);  dl_k = p_k * (f'_k - sum_c f'_c p_c)
     float dot = 0.0f;
     float tsum = 0.0f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        float p = expf(ls(c) - ms) / zs, t = expf(lt(c) - mt) / zt;
+        const float p = softmax_prob<CT>(ss, ls, c), t = softmax_prob<CT>(st, lt, c);
         float fp;
         if (loss_fn == LOSS_VAR) {
             fp = 2.0f * (p - t);
@@ -182,7 +243,7 @@ CMS_HD float consistency_pixel_bwd(LS ls, LT lt, int crt, int loss_fn, float inv
     }
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-        float p = expf(ls(k) - ms) / zs, t = expf(lt(k) - mt) / zt;
+        const float p = softmax_prob<CT>(ss, ls, k), t = softmax_prob<CT>(st, lt, k);
         float g;
         if (loss_fn == LOSS_VAR) {
             g = p * (2.0f * (p - t) - dot);
@@ -209,10 +270,10 @@ CMS_HD float ce_pixel_fwd(L l, int crt, int label) {
 template <int CT, class L, class E>
 CMS_HD void ce_pixel_bwd(L l, int crt, int label, E emit) {
     const int C = CT > 0 ? CT : crt;
-    float mx, z;
-    softmax_stats<CT>(l, crt, mx, z);
+    SoftmaxRegs<CT> s;
+    softmax_regs<CT>(l, crt, s);
 #pragma unroll
-    for (int k = 0; k < C; ++k) emit(k, expf(l(k) - mx) / z - (k == label ? 1.0f : 0.0f));
+    for (int k = 0; k < C; ++k) emit(k, softmax_prob<CT>(s, l, k) - (k == label ? 1.0f : 0.0f));
 }
 
 // ---------------------------------------------------------------------------------------------- EMA (3 roundings)

@@ -424,6 +424,13 @@ class CutMixMeanTeacherStep(object):
             ce_sc, ce_ctx = ops.ce_forward(lo_det[:n_sup], sup_y, out_size, 255, self.align_corners, group=self.group)
             ops.ce_backward(ce_ctx, ce_sc, grad_lo[:n_sup])
             if split:
+                # the re-pack of the data-gradient operands (one HBM-bound launch, ~0.12 ms, needs only the weights) is due in
+                # front of the backward pass: issued HERE it runs beside the consistency kernels of the other stream instead
+                # of alone behind the join
+                pre = getattr(self.student, 'hip_executor', None)
+                if independent and groups is None and pre is not None and getattr(self.student, '_use_hip_body', None) \
+                        and self.student._use_hip_body() and hasattr(pre(), '_refresh_for_backward'):
+                    pre()._refresh_for_backward()        # (frozen-statistics passes: the chain that uses these operands)
                 main.wait_stream(side)
             elif use_unsup:
                 consistency_branch()
