@@ -310,10 +310,35 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
         set_soff();
         const int tap_first = itap;
         const uint32_t soff_x_first = soff_x;
+        // Pointwise launches (1 x 1, stride 1: the GEMM row IS the input pixel) know the offsets of their pixel rows without
+        // the tables: ALL six half tiles of the prologue go out here and fly while the tables are built (round 4: the tables
+        // + the wait for the first loads behind them were 7 k of the 70 k cycles of a 16-K-tile run)
+        const bool early = a.plain != 0;
         issue_w(IC<0>{}, IC<0>{});
         issue_w(IC<0>{}, IC<1>{});
-        step_cursor();
-        issue_w(IC<1>{}, IC<0>{});
+        if (early) {
+            uint32_t xd[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int m = m0 + (2 * i + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + lrow8;
+                    xd[h][i] = m < a.M ? (uint32_t)(m * a.Cin * 2 + clog * 16) : OOB;
+                    xv[h][i] = xd[h][i];
+                }
+            issue_x(IC<0>{}, IC<0>{});
+            issue_x(IC<0>{}, IC<1>{});
+            step_cursor();
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) xv[h][i] = live ? xd[h][i] : OOB;
+            issue_w(IC<1>{}, IC<0>{});
+            issue_x(IC<1>{}, IC<0>{});
+        } else {
+            step_cursor();
+            issue_w(IC<1>{}, IC<0>{});
+        }
 
         // ---- tables. Per row: geometry (for the epilogue); per (tap, row): byte offset of the input pixel that tap reads for
         // that GEMM row, or out of range (zero padding, rows past M) -- the K loop then needs no bounds test, no row table and
@@ -409,8 +434,9 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
 
         // ---- prologue, part 2: the pixel half tiles of the first K tiles. Issue order of the first six half tiles: W0 W1 | W0' |
         // X0 X1 | X0' (the K loop continues with X1', W1', ...): vmcnt(2) retires everything but X0' -- what phases 0 and 1 of
-        // the first K tile read; from the second phase on the steady-state count applies
-        {
+        // the first K tile read; from the second phase on the steady-state count applies. (Pointwise launches issued
+        // W0 W1 X0 X1 | W0' X0' above: vmcnt(4).)
+        if (!early) {
             const int tap_now = itap;
             const uint32_t soff_x_now = soff_x;
             const bool live_now = live;
@@ -421,8 +447,10 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
             itap = tap_now; soff_x = soff_x_now; live = live_now;
             load_xv();
             issue_x(IC<1>{}, IC<0>{});
+            asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         }
-        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
         if (grp == 1) asm volatile("s_barrier" ::: "memory");
         stamp(2);
         // two K tiles per trip; a run of odd length computes one K tile of zeros (its loads are out of range) -- the
@@ -562,7 +590,13 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
         }
         if (a.res || a.mask_src) stage_tile(a.res ? a.res : a.mask_src);
         stamp(6);
-        auto nest = [&](auto RES_, auto MSK_, auto RELU_) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        // (round 4) two values per vector instruction wherever the ISA has one: v_pk_fma_f32 for the BN affine, v_pk_add_f32 for
+        // the residual, and the ReLU on the PACKED bf16 pair (v_pk_max_i16 with 0: a bf16 is negative iff its bit pattern is a
+        // negative int16; rounding first and clamping then gives the bits of clamping first) -- the residual + ReLU nest was 730
+        // vector instructions per wave, the whole epilogue VALU-bound. The data-gradient nests skip the (1, 0) affine.
+        auto nest = [&](auto AFF_, auto RES_, auto MSK_, auto RELU_) {
+            constexpr int AFF = decltype(AFF_)::value;      // 1: y = acc * scale + bias (forward); 0: the accumulator itself
             constexpr int RES = decltype(RES_)::value;      // 1: residual / gradient add from the staged tile
             constexpr int MSK = decltype(MSK_)::value;      // 1: ReLU mask bits (both operands), 2: mask from the staged tile
             constexpr int RELU = decltype(RELU_)::value;
@@ -571,55 +605,70 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int co_l = (wn * 4 + i) * 32 + 8 * q + 4 * fhalf;
-                    const float4 sc = *reinterpret_cast<const float4*>(lds_sb + co_l);
-                    const float4 b = *reinterpret_cast<const float4*>(lds_sb + BN + co_l);
+                    f32x2 sc01 = {1.0f, 1.0f}, sc23 = {1.0f, 1.0f}, b01 = {0.0f, 0.0f}, b23 = {0.0f, 0.0f};
+                    if constexpr (AFF) {
+                        const float4 sc = *reinterpret_cast<const float4*>(lds_sb + co_l);
+                        const float4 b = *reinterpret_cast<const float4*>(lds_sb + BN + co_l);
+                        sc01 = f32x2{sc.x, sc.y}; sc23 = f32x2{sc.z, sc.w};
+                        b01 = f32x2{b.x, b.y}; b23 = f32x2{b.z, b.w};
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int prow_l = (wm * 2 + j) * 32 + frow;
                         unsigned char* cell = smem + slot(prow_l, co_l);
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                        v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
-                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                        f32x2 v01 = {acc[i][j][4 * q], acc[i][j][4 * q + 1]}, v23 = {acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        uint2 keep = {0u, 0u};
+                        if constexpr (AFF) {
+                            v01 = v01 * sc01 + b01;
+                            v23 = v23 * sc23 + b23;
+                        }
                         if constexpr (RES == 1 || MSK == 2) {
                             const uint2 rr = *reinterpret_cast<const uint2*>(cell);
                             if constexpr (RES == 1) {
-                                v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                                v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                                v01 += f32x2{__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xffff0000u)};
+                                v23 += f32x2{__uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xffff0000u)};
                             } else {
-                                // bf16 > 0  <=>  as a signed 16-bit integer it is > 0
-                                v[0] = (int16_t)(rr.x & 0xffffu) > 0 ? v[0] : 0.0f;
-                                v[1] = (int16_t)(rr.x >> 16) > 0 ? v[1] : 0.0f;
-                                v[2] = (int16_t)(rr.y & 0xffffu) > 0 ? v[2] : 0.0f;
-                                v[3] = (int16_t)(rr.y >> 16) > 0 ? v[3] : 0.0f;
+                                keep = rr;
                             }
-                        }
-                        if constexpr (RELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
                         }
                         if constexpr (MSK == 1) {
                             const int bit = ((i * 2 + j) * 4 + q) * 4;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = ((mbits[bit >> 6] >> ((bit & 63) + e)) & 1u) ? v[e] : 0.0f;
+                            const uint32_t m4 = (uint32_t)(mbits[bit >> 6] >> (bit & 63));
+                            v01.x = (m4 & 1u) ? v01.x : 0.0f; v01.y = (m4 & 2u) ? v01.y : 0.0f;
+                            v23.x = (m4 & 4u) ? v23.x : 0.0f; v23.y = (m4 & 8u) ? v23.y : 0.0f;
                         }
                         uint2 o;
-                        o.x = pack_bf16x2(v[0], v[1]);
-                        o.y = pack_bf16x2(v[2], v[3]);
+                        o.x = pack_bf16x2(v01.x, v01.y);
+                        o.y = pack_bf16x2(v23.x, v23.y);
+                        if constexpr (MSK == 2) {
+                            // ReLU mask from the staged bf16 pair, on the PACKED result: a bf16 is > 0 iff its bits are a
+                            // positive int16 -> max(x, 0) is non-zero -> min(.., 1) * 0xffff = all ones in that half
+                            uint32_t mx, my;
+                            asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_min_u16 %0, %0, %2\n\tv_pk_mul_lo_u16 %0, %0, %3"
+                                : "=&v"(mx) : "v"(keep.x), "s"(0x00010001u), "s"(0xffffffffu));
+                            asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_min_u16 %0, %0, %2\n\tv_pk_mul_lo_u16 %0, %0, %3"
+                                : "=&v"(my) : "v"(keep.y), "s"(0x00010001u), "s"(0xffffffffu));
+                            o.x &= mx;
+                            o.y &= my;
+                        }
+                        if constexpr (RELU) {
+                            // (inline: as a vector max the compiler converts the two halves separately and re-packs them)
+                            asm("v_pk_max_i16 %0, %1, 0" : "=v"(o.x) : "v"(o.x));
+                            asm("v_pk_max_i16 %0, %1, 0" : "=v"(o.y) : "v"(o.y));
+                        }
                         *reinterpret_cast<uint2*>(cell) = o;
                     }
                 }
             }
         };
         if (a.mode == 0) {
-            if (a.res) { if (a.relu) nest(IC<1>{}, IC<0>{}, IC<1>{}); else nest(IC<1>{}, IC<0>{}, IC<0>{}); }
-            else { if (a.relu) nest(IC<0>{}, IC<0>{}, IC<1>{}); else nest(IC<0>{}, IC<0>{}, IC<0>{}); }
+            if (a.res) { if (a.relu) nest(IC<1>{}, IC<1>{}, IC<0>{}, IC<1>{}); else nest(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}); }
+            else { if (a.relu) nest(IC<1>{}, IC<0>{}, IC<0>{}, IC<1>{}); else nest(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}); }
         } else {
-            if (both) nest(IC<1>{}, IC<1>{}, IC<0>{});
-            else if (a.mask_src) nest(IC<0>{}, IC<2>{}, IC<0>{});
-            else if (a.res) nest(IC<1>{}, IC<0>{}, IC<0>{});
-            else nest(IC<0>{}, IC<0>{}, IC<0>{});
+            if (both) nest(IC<0>{}, IC<1>{}, IC<1>{}, IC<0>{});
+            else if (a.mask_src) nest(IC<0>{}, IC<0>{}, IC<2>{}, IC<0>{});
+            else if (a.res) nest(IC<0>{}, IC<1>{}, IC<0>{}, IC<0>{});
+            else nest(IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{});
         }
         __syncthreads();
         stamp(7);
