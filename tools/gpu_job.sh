@@ -9,6 +9,9 @@
 #                               bench:plain0:CMS_CONV_PLAIN=0:--workload pascal --steps 30 --no_cpu_baseline
 #   rocprof:<bench args>        rocprofv3 --kernel-trace --stats of bench.py, summarised with tools/rocpd_summary.py
 #   pmc:<bench args>            TCC FETCH_SIZE / WRITE_SIZE passes (separate runs, kernel-trace only) -> per-kernel traffic
+#   timeline:<step>:<bench args> rocprofv3 kernel trace of bench.py -> kernel stats + the timeline of training step <step>
+#                               (tools/step_timeline.py: which queue runs what, where the step is serial)
+#   power:<bench args>          shader clock / socket power sampled with rocm-smi while bench.py runs (tools/power_probe.sh)
 #   py:<script and args>        python <script ...> (tools/*.py micro-benchmarks)
 TAG=$1; shift
 export TMPDIR=/tmp
@@ -62,6 +65,16 @@ for l in sys.stdin:
       done
       python tools/pmc_traffic.py $OUT/${TAG}_pmc $OUT/${TAG}_pmc_traffic_per_kernel.json | tee -a $SUM
       rm -rf $OUT/${TAG}_pmc/FETCH_SIZE $OUT/${TAG}_pmc/WRITE_SIZE ;;
+    timeline)
+      stepno=${rest%%:*}; args=${rest#*:}
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o bench -- python $ROOT/bench.py $args ) > $OUT/${TAG}_rocprof.log 2>&1
+      echo "timeline rocprof rc=$?" | tee -a $SUM
+      python tools/rocpd_summary.py $OUT/${TAG}_prof/bench_results.db 40 > $OUT/${TAG}_kernel_stats.csv 2>> $OUT/${TAG}_rocprof.log
+      python tools/step_timeline.py $OUT/${TAG}_prof/bench_results.db $stepno > $OUT/${TAG}_timeline.txt 2>> $OUT/${TAG}_rocprof.log
+      rm -rf $OUT/${TAG}_prof
+      head -n 3 $OUT/${TAG}_timeline.txt | tee -a $SUM ;;
+    power)
+      bash tools/power_probe.sh $TAG $rest | tee -a $SUM ;;
     py)
       ( time timeout 900 python $rest ) > $OUT/${TAG}_py$i.log 2>&1; echo "py[$rest] rc=$?" | tee -a $SUM
       tail -n 40 $OUT/${TAG}_py$i.log | cut -c1-250 ;;
