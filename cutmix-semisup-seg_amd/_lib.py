@@ -66,7 +66,7 @@ class ConvDesc(C.Structure):
                 ('tap_dy', c_int * 18), ('tap_dx', c_int * 18), ('stride', c_int),
                 ('out_h', c_int), ('out_w', c_int), ('out_stride', c_int), ('relu', c_int), ('mode', c_int),
                 ('tile', c_int), ('ksplit', c_int), ('zeros', c_void_p), ('variant', c_int), ('zeros_bytes', c_int),
-                ('workspace', c_void_p), ('workspace_bytes', C.c_longlong)]
+                ('workspace', c_void_p), ('workspace_bytes', C.c_longlong), ('mask_bits_out', c_void_p), ('mask_bits', c_void_p)]
 
 
 class WgradDesc(C.Structure):

@@ -119,6 +119,9 @@ class DeepLabHipExecutor(object):
         # on the weight-gradient stream, behind the data-gradient chain of the stretch; 0 = one launch per layer (round 1-3).
         # CMS_WGRAD_GROUP sets it (A/B switch, read once).
         self.wgrad_group_blocks = int(os.environ.get('CMS_WGRAD_GROUP', '0'))
+        # ReLU masks of the block outputs as bits (written by the expansion's epilogue, read by the data gradients that need the
+        # activation only for its sign); CMS_RELU_BITS=0 switches them off (A/B)
+        self.relu_bits = os.environ.get('CMS_RELU_BITS', '1') != '0'
         # The backward pass normally ends with the main stream waiting for the weight-gradient stream(s): whoever reads a
         # gradient afterwards finds it complete. A caller that knows where it next touches the gradients (the training step:
         # at the gradient exchange / optimizer) sets this and calls `join_wgrad()` there instead -- what follows the body's
@@ -269,11 +272,24 @@ class DeepLabHipExecutor(object):
     def _out_hw(h, w, stride):
         return (h - 1) // stride + 1, (w - 1) // stride + 1
 
-    def _fwd(self, x, c, relu, res=None):
+    def _fwd(self, x, c, relu, res=None, bits=False):
+        """`bits`: also write the ReLU mask of the output as bits (cms_conv_desc.mask_bits_out) and hang them on the returned
+        tensor (`_cms_relu_bits`): the data gradient that needs this activation only for its sign reads 1/16 of the bytes."""
         n, h, w, _ = x.shape
         ho, wo = self._out_hw(h, w, c.stride)
-        return ops.conv_igemm(x, self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), scale=c.scale, bias=c.bias,
-                              res=res, relu=relu, tile=self._tile(c.cout))
+        mb = None
+        if bits and relu and self.relu_bits and self.dtype == torch.bfloat16 and not self._eight_phase(len(c.taps), c.cin, c.cout):
+            mb = torch.empty((n, ho, wo, c.cout // 8), dtype=torch.uint8, device=x.device)
+        y = ops.conv_igemm(x, self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), scale=c.scale, bias=c.bias,
+                           res=res, relu=relu, tile=self._tile(c.cout), mask_bits_out=mb)
+        if mb is not None:
+            y._cms_relu_bits = mb
+        return y
+
+    @staticmethod
+    def _eight_phase(ntaps, cin, cout):
+        """Would cms_conv_igemm send a convolution of this shape to the eight-phase 256 x 256 kernel (which has no mask bits)?"""
+        return cout % 256 == 0 and cin % 64 == 0 and ntaps * (cin // 64) >= 16
 
     def _tile(self, cout):
         """Workgroup tile code for a convolution with `cout` output channels (0 = the library's choice)."""
@@ -299,7 +315,7 @@ class DeepLabHipExecutor(object):
         a1 = self._fwd(cur, b.c1, True)
         a2 = self._fwd(a1, b.c2, True)
         res = cur if b.cd is None else self._fwd(cur, b.cd, False)
-        st['cur'] = self._fwd(a2, b.c3, True, res=res)
+        st['cur'] = self._fwd(a2, b.c3, True, res=res, bits=st['saved'] is not None)
         if st['saved'] is not None:
             st['saved'].append((cur, a1, a2))
 
@@ -633,10 +649,15 @@ class DeepLabHipExecutor(object):
     def _dgrad(self, du, c, res=None, mask=None, in_hw=None):
         """gradient wrt the input of conv `c`; `in_hw` = spatial size of that input (needed for stride 2)."""
         n, ho, wo, _ = du.shape
+        mb = getattr(mask, '_cms_relu_bits', None) if mask is not None else None
+        if mb is not None and (not self.relu_bits or self._eight_phase(len(c.taps), c.cout, c.cin)):
+            mb = None
+        if mb is not None:
+            mask = None                      # the bits the producing launch wrote instead of the activation itself
         if c.stride == 1:
-            return ops.conv_igemm(du, c.wT, c.neg_taps, res=res, mode=1, mask_src=mask, tile=self._tile(c.cin))
+            return ops.conv_igemm(du, c.wT, c.neg_taps, res=res, mode=1, mask_src=mask, tile=self._tile(c.cin), mask_bits=mb)
         return ops.conv_igemm(du, c.wT, c.neg_taps, res=res, mode=1, mask_src=mask, out_hw=(ho, wo),
-                              out_stride=c.stride, out_full_hw=in_hw, tile=self._tile(c.cin))
+                              out_stride=c.stride, out_full_hw=in_hw, tile=self._tile(c.cin), mask_bits=mb)
 
     def _grad_sentinel(self):
         if getattr(self, '_sentinel', None) is None:
@@ -689,7 +710,8 @@ class DeepLabHipExecutor(object):
             ops.conv_wgrad(d, x4, [(0, 0)], dwall)
             if box is not None:
                 box['dwall'] = dwall
-        dC = ops.conv_igemm(d, self.aspp_wallT, [(0, 0)], mode=1, mask_src=x4)
+        x4b = getattr(x4, '_cms_relu_bits', None) if self.relu_bits else None
+        dC = ops.conv_igemm(d, self.aspp_wallT, [(0, 0)], mode=1, mask_src=None if x4b is not None else x4, mask_bits=x4b)
         capture = getattr(self, 'debug_capture', None)
         keep = []                 # tensors read on the side stream must outlive the python scope that made them
         closes = set(self.bucket_starts())

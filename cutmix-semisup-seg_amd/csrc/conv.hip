@@ -69,6 +69,8 @@ struct ConvArgs {
     int n_main, rem_tile_base;   // conv_igemm_mixed_kernel: workgroups of the main tile shape, first pixel tile of the rest
     int krot;               // != 0: workgroup (tile_m) starts its K loop krot * tile_m steps in and wraps (variant 20)
     int plain;              // 1x1, stride 1, tap (0, 0), output grid == input grid: GEMM row m IS input and output pixel m
+    uint8_t* mask_bits_out;       // forward + ReLU: bit (pixel, channel) = [y > 0], [out pixels][Cout / 8] bytes, or NULL
+    const uint8_t* mask_bits;     // dgrad: the ReLU mask as such bits instead of mask_src, or NULL
 };
 
 
@@ -660,8 +662,31 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
     };
     uint64_t mbits[2] = {0, 0};                  // ReLU mask of this lane's (<= 128) elements when BOTH operands are staged
     static_assert(TN * TM * 16 <= 128, "mask bit field");
-    const bool both = staged && a.res && a.mask_src;
+    // (round 4) the ReLU mask of a data gradient can come as BITS the producing forward launch wrote (mask_bits: 1/16 of the
+    // bytes of the bf16 activation it would otherwise re-read -- 69 MB per layer-3 expansion at cfg 2): one dword per lane and
+    // (i, j) = the 32 channels of an MFMA tile of its pixel row, straight from global memory into the same bit field
+    const bool bits_in = staged && a.mask_bits != nullptr;
+    const bool both = staged && a.res && a.mask_src && !bits_in;
     if constexpr (GLDS) {
+        if (bits_in) {
+            const int bpr = a.Cout >> 3;                 // bytes per pixel row
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const uint32_t op = lds_row[(wm * TM + j) * 32 + frow].opix;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    uint32_t wbits = 0u;
+                    if (op != 0xffffffffu)
+                        wbits = *reinterpret_cast<const uint32_t*>(a.mask_bits + (size_t)op * bpr + ((co0 + (wn * TN + i) * 32) >> 3));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int bit = ((i * TM + j) * 4 + q) * 4;
+                        const uint64_t m4 = (wbits >> (8 * q + 4 * fhalf)) & 0xfu;
+                        mbits[bit >> 6] |= m4 << (bit & 63);
+                    }
+                }
+            }
+        }
         if (both) {
             stage_tile(a.mask_src);
 #pragma unroll
@@ -679,7 +704,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
                     }
             __syncthreads();                     // everybody has its bits: the tile may be overwritten
         }
-        if (staged && (a.res || a.mask_src)) stage_tile(a.res ? a.res : a.mask_src);
+        if (staged && (a.res || (a.mask_src && !bits_in))) stage_tile(a.res ? a.res : a.mask_src);
     }
     // value of this lane's 4 consecutive channels (i, q) of pixel row j: BN affine, residual / gradient add, ReLU or
     // ReLU mask. Reads the staged operand from `cell` when there is one (so it must run before the cell is overwritten).
@@ -705,7 +730,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
             }
-        } else if (both) {
+        } else if (both || bits_in) {
             const int bit = ((i * TM + j) * 4 + q) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ((mbits[bit >> 6] >> ((bit & 63) + e)) & 1u) ? v[e] : 0.0f;
@@ -759,10 +784,16 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
     }
     // bf16 output, operands (if any) staged in LDS: one straight-line nest per epilogue kind, chosen once per
     // workgroup (wave-uniform), so that the compiler sees 32 independent LDS read -> arithmetic -> LDS write chains
-    auto nest = [&](auto RES_, auto MSK_, auto RELU_) {
+    auto nest = [&](auto RES_, auto MSK_, auto RELU_, auto BITS_) {
         constexpr int RES = decltype(RES_)::value;      // 1: residual / gradient add from the staged tile
-        constexpr int MSK = decltype(MSK_)::value;      // 1: ReLU mask bits (both operands), 2: mask from the staged tile
+        constexpr int MSK = decltype(MSK_)::value;      // 1: ReLU mask bits (both operands / mask_bits), 2: mask from the staged tile
         constexpr int RELU = decltype(RELU_)::value;
+        constexpr int BITS = decltype(BITS_)::value;    // 1: also write [y > 0] of the ROUNDED output as bits (mask_bits_out)
+        uint32_t obits[BITS ? TN : 1][BITS ? TM : 1];
+#pragma unroll
+        for (int i = 0; i < (BITS ? TN : 1); ++i)
+#pragma unroll
+            for (int j = 0; j < (BITS ? TM : 1); ++j) obits[i][j] = 0u;
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
 #pragma unroll
@@ -804,6 +835,26 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
                     o.x = pack_bf16x2(v[0], v[1]);
                     o.y = pack_bf16x2(v[2], v[3]);
                     *reinterpret_cast<uint2*>(cell) = o;
+                    if constexpr (BITS) {
+                        // of the STORED value: exactly what a data gradient reading the activation back would test
+                        const uint32_t m4 = ((int16_t)(o.x & 0xffffu) > 0 ? 1u : 0u) | ((int16_t)(o.x >> 16) > 0 ? 2u : 0u) |
+                                            ((int16_t)(o.y & 0xffffu) > 0 ? 4u : 0u) | ((int16_t)(o.y >> 16) > 0 ? 8u : 0u);
+                        obits[i][j] |= m4 << (8 * q + 4 * fhalf);
+                    }
+                }
+            }
+        }
+        if constexpr (BITS) {
+            const int bpr = a.Cout >> 3;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const uint32_t op = lds_row[(wm * TM + j) * 32 + frow].opix;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    // lanes l and l + 32 hold the two nibbles of every byte of the pixel row's 32 channels
+                    const uint32_t wbits = obits[i][j] | (uint32_t)__shfl_xor((int)obits[i][j], 32, 64);
+                    if (fhalf == 0 && op != 0xffffffffu)
+                        *reinterpret_cast<uint32_t*>(a.mask_bits_out + (size_t)op * bpr + ((co0 + (wn * TN + i) * 32) >> 3)) = wbits;
                 }
             }
         }
@@ -813,13 +864,15 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
     using K2 = std::integral_constant<int, 2>;
     if (to_lds && (staged || (!a.res && !a.mask_src))) {
         if (a.mode == 0) {
-            if (a.res) { if (a.relu) nest(K1{}, K0{}, K1{}); else nest(K1{}, K0{}, K0{}); }
-            else { if (a.relu) nest(K0{}, K0{}, K1{}); else nest(K0{}, K0{}, K0{}); }
+            if (a.relu && a.mask_bits_out) { if (a.res) nest(K1{}, K0{}, K1{}, K1{}); else nest(K0{}, K0{}, K1{}, K1{}); }
+            else if (a.res) { if (a.relu) nest(K1{}, K0{}, K1{}, K0{}); else nest(K1{}, K0{}, K0{}, K0{}); }
+            else { if (a.relu) nest(K0{}, K0{}, K1{}, K0{}); else nest(K0{}, K0{}, K0{}, K0{}); }
         } else {
-            if (both) nest(K1{}, K1{}, K0{});
-            else if (a.mask_src) nest(K0{}, K2{}, K0{});
-            else if (a.res) nest(K1{}, K0{}, K0{});
-            else nest(K0{}, K0{}, K0{});
+            if (both || (bits_in && a.res)) nest(K1{}, K1{}, K0{}, K0{});
+            else if (bits_in) nest(K0{}, K1{}, K0{}, K0{});
+            else if (a.mask_src) nest(K0{}, K2{}, K0{}, K0{});
+            else if (a.res) nest(K1{}, K0{}, K0{}, K0{});
+            else nest(K0{}, K0{}, K0{}, K0{});
         }
     } else if (to_lds) {            // register-staged loader: operands come from global memory in accumulator layout
 #pragma unroll
@@ -1097,6 +1150,7 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
         d_no8.variant = 0;
         d_in = &d_no8;
     } else if (d_in->variant == 0 && d_in->tile == 0 && conv8_env(0) > 0 && cms::conv8_supported(d_in) &&
+        d_in->mask_bits == nullptr && d_in->mask_bits_out == nullptr &&
         d_in->ntaps * (d_in->cin / 64) >= conv8_env(1) && conv_default_variant() == 0 &&
         ((conv8_env(3) >> (d_in->mode == 0 ? 0 : 1)) & 1))
         return cms::conv8_launch(d_in, (hipStream_t)stream, conv8_env(0) - 1, conv8_env(2), nullptr, 0);
@@ -1119,6 +1173,12 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
     ConvArgs a;
     a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.y = (uint16_t*)d->y; a.y32 = d->y32;
     a.scale = d->scale; a.bias = d->bias; a.res = (const uint16_t*)d->res; a.mask_src = (const uint16_t*)d->mask_src;
+    a.mask_bits_out = d->mask_bits_out; a.mask_bits = d->mask_bits;
+    CMS_REQUIRE((d->mask_bits_out == nullptr && d->mask_bits == nullptr) ||
+                    (d->y != nullptr && d->zeros != nullptr && d->variant == 0 && d->ksplit <= 1),
+                "conv: ReLU mask bits need the bf16 output on the default (direct-to-LDS) kernel");
+    CMS_REQUIRE(d->mask_bits_out == nullptr || (d->mode == 0 && d->relu != 0), "conv: mask_bits_out is written by forward + ReLU launches");
+    CMS_REQUIRE(d->mask_bits == nullptr || (d->mode == 1 && d->mask_src == nullptr), "conv: mask_bits replaces mask_src of a data gradient");
     a.N = d->n; a.H = d->h; a.W = d->w_in; a.Cin = d->cin;
     a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout; a.cout_real = d->cout_real;
     a.ntaps = d->ntaps; a.stride = d->stride;

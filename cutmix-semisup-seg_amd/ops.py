@@ -1079,7 +1079,7 @@ def conv_taps(kh, kw, dilation, padding):
 
 def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, res=None, relu=False, mode=0,
                mask_src=None, out=None, out_f32_nchw=None, cout_real=None, out_stride=1, out_full_hw=None, tile=0,
-               ksplit=1, variant=0, out_pixel_offset=0):
+               ksplit=1, variant=0, out_pixel_offset=0, mask_bits_out=None, mask_bits=None):
     """
     Implicit-GEMM convolution on the MFMA units (csrc/conv.hip).
       x         bf16 NHWC-contiguous tensor of logical shape (N, H, W, Cin)
@@ -1088,8 +1088,15 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     Returns the bf16 (N, out_h, out_w, Cout) output (or the fp32 NCHW tensor given in `out_f32_nchw`).
     `out_pixel_offset` (with `out`, `out_stride` > 1): the strided scatter starts at that pixel of the output tensor
     instead of pixel 0 -- residual / mask are read at the same shifted positions (the phases of a transposed convolution).
+    `mask_bits_out` (forward + ReLU): uint8 (N, out_h, out_w, Cout / 8) that receives [y > 0] as bits; `mask_bits` (mode 1):
+    such a tensor INSTEAD of `mask_src` -- the ReLU mask of a data gradient at 1/16 of the bytes (cms_conv_desc).
     """
-    _need_cuda(x, w_packed, scale, bias, res, mask_src, out, out_f32_nchw)
+    _need_cuda(x, w_packed, scale, bias, res, mask_src, out, out_f32_nchw, mask_bits_out, mask_bits)
+    for t in (mask_bits_out, mask_bits):
+        if t is not None and (t.dtype != torch.uint8 or not t.is_contiguous() or x.dtype != torch.bfloat16):
+            raise TypeError('conv_igemm: ReLU mask bits are contiguous uint8 tensors of the bf16 entry point')
+    if mask_bits is not None and mask_src is not None:
+        raise ValueError('conv_igemm: mask_bits replaces mask_src')
     if x.dtype not in (torch.bfloat16, torch.float32) or w_packed.dtype != x.dtype or not x.is_contiguous() \
             or not w_packed.is_contiguous():
         raise TypeError('conv_igemm: contiguous NHWC input and packed weights of one dtype (bf16 or fp32) required')
@@ -1122,6 +1129,9 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     d.res = res.data_ptr() + shift if res is not None else None
     d.mask_src = mask_src.data_ptr() + shift if mask_src is not None else None
     d.n, d.h, d.w_in, d.cin = n, h, w_in, cin
+    bshift = int(out_pixel_offset) * (int(w_packed.shape[1]) // 8) if out_f32_nchw is None else 0
+    d.mask_bits_out = mask_bits_out.data_ptr() + bshift if mask_bits_out is not None else None
+    d.mask_bits = mask_bits.data_ptr() + bshift if mask_bits is not None else None
     d.ho, d.wo, d.cout = ho, wo, cout
     d.cout_real = cout if cout_real is None else int(cout_real)
     d.ntaps = ntaps
@@ -1143,12 +1153,14 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
         idx = fn['cms_program_add_conv'](prog.h, C.byref(d), int(f32), _rec_stream_index(), prog.group)
         if idx < 0:
             check(idx, 'cms_program_add_conv')
-        prog.keep += [t for t in (x, w_packed, out, out_f32_nchw, scale, bias, res, mask_src, zp) if t is not None]
+        prog.keep += [t for t in (x, w_packed, out, out_f32_nchw, scale, bias, res, mask_src, zp, mask_bits_out, mask_bits)
+                      if t is not None]
         esz = x.element_size()
         prog.flops += 2.0 * n * ho * wo * cout * cin * ntaps
         nbytes = esz * (x.numel() + w_packed.numel()) + float(n * ho * wo) * (
             (4.0 * d.cout_real if out_f32_nchw is not None else esz * cout)
-            + (esz * cout if res is not None else 0.0) + (esz * cout if mask_src is not None else 0.0))
+            + (esz * cout if res is not None else 0.0) + (esz * cout if mask_src is not None else 0.0)
+            + (cout / 8.0 if mask_bits is not None else 0.0) + (cout / 8.0 if mask_bits_out is not None else 0.0))
         prog.floor_s += max(nbytes / HBM_PEAK_BPS, 2.0 * n * ho * wo * cout * cin * ntaps / MFMA_PEAK_FLOPS)
         if out_f32_nchw is not None:
             prog.head_launches += 1

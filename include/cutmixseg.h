@@ -261,6 +261,13 @@ typedef struct cms_conv_desc {
                               every CU; the last arriver of a tile adds the pieces in a fixed order). Launches that may
                               overlap (different streams) need different workspaces. NULL: whole tiles only.        */
     long long workspace_bytes;
+    /* ReLU masks as BITS (round 4). A forward launch with `relu` can also write, per output pixel, Cout / 8 bytes whose bit
+     * c & 7 of byte c >> 3 says [y[pixel][c] > 0] (of the stored bf16 value): mask_bits_out = uint8 [N][out_h][out_w][cout / 8].
+     * The data gradient that would re-read that activation only for its sign (`mask_src`) takes the bits instead
+     * (`mask_bits`, mask_src NULL): 1/16 of the bytes -- 69 MB less per layer-3 expansion of BASELINE configs[1] -- and the same
+     * result bit for bit. 128 x 128 kernel only (the eight-phase kernel is not dispatched for such a launch).              */
+    uint8_t* mask_bits_out;
+    const uint8_t* mask_bits;
 } cms_conv_desc;
 
 int cms_conv_igemm(const cms_conv_desc* d, void* stream);

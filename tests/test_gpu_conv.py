@@ -389,3 +389,43 @@ def test_grouped_weight_gradients_equal_the_per_layer_launches(ops):
     for (du, x, taps, dw, stride, scale), ref in zip(jobs, refs):
         tol = 2e-5 * float(ref.abs().max())
         assert float((dw - ref).abs().max()) <= tol, (tuple(dw.shape), float((dw - ref).abs().max()), tol)
+
+
+# ------------------------------------------------------------------------------------------------- ReLU masks as bits
+@pytest.mark.parametrize('shape', [(2, 19, 23, 64, 256, 1), (3, 41, 41, 256, 1024, 1), (2, 17, 21, 128, 96, 1), (1, 33, 35, 64, 64, 3),
+                                   (20, 41, 41, 256, 1024, 1)],
+                         ids=['256 out', 'expansion', '96 out (32-channel tiles)', '3x3 64 out', 'cfg 2 expansion (balanced launch)'])
+def test_relu_mask_bits_written_by_the_forward_launch_and_read_by_the_data_gradient(ops, shape):
+    """cms_conv_desc.mask_bits_out / mask_bits: the forward + ReLU launch also writes [y > 0] as bits (of the stored bf16
+    value), the data gradient that needs that activation only for its sign takes the bits instead of re-reading it -- same
+    result bit for bit, with and without the gradient of the residual branch."""
+    N, H, W, Cin, Cout, k = shape
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(N, H, W, Cin, generator=g, device=DEV).bfloat16()
+    w = (torch.randn(k * k, Cout, Cin, generator=g, device=DEV) * (1.0 / (Cin * k * k)) ** 0.5).bfloat16()
+    taps = ops.conv_taps(k, k, 1, (k - 1) // 2)
+    scale = torch.rand(Cout, generator=g, device=DEV) + 0.5
+    bias = torch.randn(Cout, generator=g, device=DEV) * 0.2
+    res = torch.randn(N, H, W, Cout, generator=g, device=DEV).bfloat16()
+    for r in (None, res):
+        y_ref = ops.conv_igemm(x, w, taps, scale=scale, bias=bias, res=r, relu=True, variant=99)
+        bits = torch.full((N, H, W, Cout // 8), 0xAA, dtype=torch.uint8, device=DEV)
+        y = ops.conv_igemm(x, w, taps, scale=scale, bias=bias, res=r, relu=True, mask_bits_out=bits)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref)
+        want = (y.float() > 0).view(N, H, W, Cout // 8, 8).to(torch.int32)
+        want = (want * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8)
+        assert torch.equal(bits, want)
+    # the data gradient of a convolution whose INPUT is y (Cout channels in, any width out)
+    Cd = 256
+    du = (torch.randn(N, H, W, Cd, generator=g, device=DEV) * 0.1).bfloat16()
+    wT = (torch.randn(1, Cout, Cd, generator=g, device=DEV) * 0.05).bfloat16()          # [tap][ci = Cout of y][co = Cd]
+    add = torch.randn(N, H, W, Cout, generator=g, device=DEV).bfloat16()
+    one = ops.conv_taps(1, 1, 1, 0)
+    for r in (None, add):
+        a = ops.conv_igemm(du, wT, one, res=r, mode=1, mask_src=y, variant=99)
+        b = ops.conv_igemm(du, wT, one, res=r, mode=1, mask_bits=bits)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        ops.conv_igemm(du, wT, one, mode=1, mask_src=y, mask_bits=bits)
