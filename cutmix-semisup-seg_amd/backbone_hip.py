@@ -1003,6 +1003,7 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
             ops.memset_zero(self._wdot_all)
             ops.memset_zero(self._dbeta_all)
         keep = []
+        capture = getattr(self, 'debug_capture', None)      # {block: (dC, dU2, dU1)} of the pass being issued (diagnostics)
         for bi in range(len(self.blocks) - 1, -1, -1):
             if rec is not None:
                 rec.group = bi
@@ -1014,6 +1015,8 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
                 dU1 = self._dgrad(dU2, b.c2, mask=a1)
             else:
                 dU1 = self._dgrad_strided(dU2, b.c2, a1, (a1.shape[1], a1.shape[2]))
+            if capture is not None:
+                capture[bi] = (dC, dU2, dU1)
             if side is not None:
                 ops.stream_wait(side, main)
                 keep.append((dC, dU2, dU1))
