@@ -698,11 +698,15 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback)')
+    # CMS_BENCH_SAME_DEVICE=1 (with CMS_BENCH_BACKEND=gloo): every rank on cuda:0 -- the only way to exercise the N > 1 code path
+    # of this file on a 1-GPU box (numbers of such a run mean nothing; the driver never sets these)
+    if os.environ.get('CMS_BENCH_SAME_DEVICE'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
+        dist.init_process_group(os.environ.get('CMS_BENCH_BACKEND', 'nccl'))
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)                     # RCCL really spans `world` ranks
         rccl_world = int(probe.item())
