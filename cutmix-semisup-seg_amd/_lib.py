@@ -141,6 +141,7 @@ PROTOTYPES = {
     'cms_conv_igemm_workspace_bytes': (C.c_longlong, []),
     'cms_conv_set_trace': (c_int, [c_void_p, c_int]),
     'cms_conv_set_wgrad8': (c_int, [c_int]),
+    'cms_loss_set_deterministic': (c_int, [c_int]),
     'cms_conv_wgrad_uses_wgrad8': (c_int, [_P(WgradDesc)]),
     'cms_conv_wgrad': (c_int, [_P(WgradDesc), c_void_p]),
     'cms_conv_wgrad_workspace_bytes': (C.c_longlong, [_P(WgradDesc)]),

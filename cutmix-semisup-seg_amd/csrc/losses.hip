@@ -15,6 +15,7 @@
 // adjoint of the bilinear upsample (x-reduce, then y-reduce, fixed order inside a tile), so global atomics are
 // issued per low-res cell per tile instead of per pixel per tap.
 #include <algorithm>
+#include <cstdlib>
 #include "common.hpp"
 
 namespace cms {
@@ -249,7 +250,13 @@ __global__ __launch_bounds__(256) void cons_bwd_ident_kernel(ConsArgs a, const f
 // order on the stream: within a launch every cell receives exactly one add (round 3: the logit gradients, and with them
 // every weight gradient downstream, are run-to-run reproducible).
 constexpr int TILE_W = 64;
-constexpr int TILE_H = 8;
+#ifndef CMS_LOSS_TILE_H
+#define CMS_LOSS_TILE_H 8
+#endif
+constexpr int TILE_H = CMS_LOSS_TILE_H;     // 4 or 8 (256 threads = 64 columns x 4 rows, TILE_H / 4 pixels per thread). Measured with 4
+                                            // (half the LDS, twice the workgroups): consistency / CE backward 205 -> 160 / 170 -> 120 us,
+                                            // the step unchanged (620.4 vs 619.4 img/s, profiles/r04zw_*): these launches run beside the
+                                            // operand re-pack and are no longer what the step waits for
 constexpr int G_LD = TILE_W + 1;  // +1 float: conflict-free column access for class-major readers
 
 struct TileTables {
@@ -328,7 +335,7 @@ __device__ __forceinline__ void tiled_scatter(const Geo& g, PixelGrad pixel_grad
     // phase 1
     const int col = tid & (TILE_W - 1);
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
+    for (int rr = 0; rr < TILE_H / 4; ++rr) {
         const int row = (tid >> 6) + rr * 4;
         float* gcol = G + ((size_t)row * C) * G_LD + col;
         const bool valid = col < tw && row < th;
@@ -401,10 +408,30 @@ inline int tile_colour_period(int full, int low, float scale, bool align, int ti
     }
 }
 
-// Issues `launch(geo, tiles)` once per colour class of the tile grid, in a fixed order.
+// Run-to-run reproducible backward of the two losses (cms_loss_set_deterministic / CMS_LOSS_DETERMINISTIC=1): the tiles go
+// out as colour classes (below). Off (the throughput default, like the fp32 atomics of the weight gradients): ALL tiles in one
+// launch -- tiles that share a low-resolution cell then add into it in a run-dependent order (fp32 atomics, ~1e-7), and the
+// launch has four times the workgroups of a colour class: the four launches of a class each kept < 1 round of the machine
+// busy and sat on the critical path between the forward and the backward pass (4 x 45-65 us per loss at 321 x 321).
+static int g_loss_deterministic = -1;
+static bool loss_deterministic() {
+    if (g_loss_deterministic < 0) {
+        const char* e = getenv("CMS_LOSS_DETERMINISTIC");
+        g_loss_deterministic = e ? (atoi(e) != 0) : 0;
+    }
+    return g_loss_deterministic != 0;
+}
+
+// Issues `launch(geo, tiles)` once per colour class of the tile grid, in a fixed order (or once for all tiles, see above).
 template <class F>
 inline void tiled_launches(Geo g, F launch) {
     const int tiles_x = (g.W + TILE_W - 1) / TILE_W, tiles_y = (g.H + TILE_H - 1) / TILE_H;
+    if (!loss_deterministic()) {
+        g.col_kx = g.col_ky = 1;
+        g.col_x = g.col_y = 0;
+        launch(g, tiles_x * tiles_y * g.n);
+        return;
+    }
     g.col_kx = tile_colour_period(g.W, g.w, g.sx, g.align != 0, TILE_W);
     g.col_ky = tile_colour_period(g.H, g.h, g.sy, g.align != 0, TILE_H);
     for (int cy = 0; cy < g.col_ky; ++cy)
@@ -658,6 +685,11 @@ extern "C" int cms_consistency_finalize(const double* stats_local, const double*
     hipLaunchKernelGGL(cons_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats_local, stats_global,
                        conf_thresh, conf_per_pixel, ramp_val, cons_weight, scalars_out);
     return launch_status("cms_consistency_finalize");
+}
+
+extern "C" int cms_loss_set_deterministic(int on) {
+    cms::g_loss_deterministic = on ? 1 : 0;
+    return CMS_OK;
 }
 
 extern "C" int cms_consistency_bwd(const cms_consistency_desc* d, const float* scalars, float* grad_l_stu,

@@ -1241,12 +1241,15 @@ _WGRAD_DETERMINISTIC = _os.environ.get('CMS_WGRAD_SLAB', '0') not in ('', '0', '
 # CMS_WGRAD_SLAB=2 (experiment): slabs only for the large layers (|dW| >= 256 k elements: layer3 / layer4), atomics for the rest
 _WGRAD_SLAB_LARGE = _os.environ.get('CMS_WGRAD_SLAB', '0') == '2'
 _WGRAD_WS = {}            # (device index, stream handle) -> uint8 scratch of eagerly issued launches
+if _WGRAD_DETERMINISTIC:
+    fn['cms_loss_set_deterministic'](1)
 
 
 def set_deterministic_wgrad(on):
     """Run-to-run deterministic weight gradients for every launch issued (or RECORDED) from now on."""
     global _WGRAD_DETERMINISTIC
     _WGRAD_DETERMINISTIC = bool(on)
+    fn['cms_loss_set_deterministic'](int(bool(on)))     # the loss kernels' backward: colour classes instead of one launch
 
 
 def deterministic_wgrad():

@@ -135,6 +135,11 @@ int cms_ce_fwd(const cms_ce_desc* d, void* workspace, double* stats_out, void* s
  * stats */
 int cms_ce_finalize(const double* stats, float loss_weight, float* scalars_out, void* stream);
 int cms_ce_bwd(const cms_ce_desc* d, const float* scalars, float* grad_logits, void* stream);
+/* The backward kernels of both losses scatter through tiles that share low-resolution cells with their neighbours. on = 1:
+ * the tiles are issued as colour classes that never share a cell (four launches, run-to-run reproducible gradients -- what
+ * `--deterministic` asks for); 0 (default; CMS_LOSS_DETERMINISTIC=1 in the environment flips it): one launch, fp32 atomics in a
+ * run-dependent order (~1e-7), like the weight gradients' default. */
+int cms_loss_set_deterministic(int on);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Bilinear upsample (F.interpolate(mode='bilinear'), architectures/deeplab2.py:204, deeplab3plus.py:54-55,77)

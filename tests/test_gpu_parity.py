@@ -651,3 +651,38 @@ def test_pi_model_step_vs_oracle(ops, fuse):
         # Adam's first updates are lr * sign-like: an element whose gradient is ~0 may step the other way (measured: 1 of
         # 9408 stem weights off by one lr-sized step); everything else agrees
         assert float(bad.float().mean()) <= 1e-3 and float((got - want_w).abs().max()) <= 2.5 * lr, k
+
+
+def test_loss_backward_one_launch_equals_colour_classes(ops):
+    """cms_loss_set_deterministic: the tiled backward kernels as ONE launch (default: fp32 atomics between tiles that share a
+    low-resolution cell, run-dependent order) give the gradient of the colour-class launches (run-to-run reproducible) up to the
+    order of a handful of fp32 additions; the colour-class mode reproduces itself bit for bit."""
+    from cutmix_semisup_seg_amd._lib import fn
+    N, C, h, w, H, W = 4, 21, 41, 41, 321, 321
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    ls = torch.randn(N, C, h, w, generator=gen, device=DEV) * 2
+    l0 = torch.randn(N, C, h, w, generator=gen, device=DEV) * 2
+    l1 = torch.randn(N, C, h, w, generator=gen, device=DEV) * 2
+    y = torch.randint(0, C, (N, 1, H, W), generator=gen, device=DEV).to(torch.uint8)
+    import mask_gen
+    ranges = ops.ranges_to_device(mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(N, (H, W), rng=np.random.RandomState(2)), DEV)
+    cfg = ops.ConsistencyConfig(mode='mix', loss_fn='var', conf_thresh=0.0)
+
+    def grads():
+        sc, ctx = ops.consistency_forward(cfg, ls, l0, l1, (H, W), ranges=ranges)
+        g1 = ops.consistency_backward(ctx, sc)
+        cs, cctx = ops.ce_forward(ls, y, (H, W), 255, True)
+        g2 = ops.ce_backward(cctx, cs)
+        torch.cuda.synchronize()
+        return g1.clone(), g2.clone()
+    try:
+        fn['cms_loss_set_deterministic'](1)
+        a1, a2 = grads()
+        b1, b2 = grads()
+        assert torch.equal(a1, b1) and torch.equal(a2, b2)
+        fn['cms_loss_set_deterministic'](0)
+        c1, c2 = grads()
+    finally:
+        fn['cms_loss_set_deterministic'](1 if ops.deterministic_wgrad() else 0)
+    assert float((c1 - a1).abs().max()) <= 1e-6 * float(a1.abs().max())
+    assert float((c2 - a2).abs().max()) <= 1e-6 * float(a2.abs().max())
