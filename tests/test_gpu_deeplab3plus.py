@@ -262,44 +262,6 @@ def test_no_grad_passes_run_the_backbone_on_the_mfma_executor():
         assert float((e2 - e1).norm()) > 10 * float((e2 - ref2).norm())          # the update is what moved it
 
 
-def test_training_pass_on_the_executor_matches_the_library_gradients():
-    """Forward + backward of the backbone on the MFMA executor (incl. the library-run strided 3x3 data gradient and the
-    BatchNorm-affine gradients assembled from the weight-gradient side outputs) against the fp32 library engine;
-    yardstick: the library's own bf16 path."""
-    layers, C = (2, 2, 3, 2), 6
-    st = _he_state(C, layers)
-    g = torch.Generator().manual_seed(19)
-    x = torch.randn(4, 3, 97, 129, generator=g).to(DEV)
-    tgt = torch.randn(4, C, 25, 33, generator=g).to(DEV)
-
-    def grads(dtype, kind):
-        net = _net(C, layers, dtype, st)
-        net.engine_kind = kind
-        net.eval()                                   # every BatchNorm on running statistics: a clean comparison
-        out = net.forward_lowres(x)
-        ((out - tgt) ** 2).mean().backward()
-        used = net._hip_executor is not None
-        return {k: p.grad.float().cpu() for k, p in net.named_parameters()}, used
-
-    ref, _ = grads(torch.float32, 'torch')
-    lib, used_l = grads(torch.bfloat16, 'torch')
-    hip, used_h = grads(torch.bfloat16, 'auto')
-    assert used_h and not used_l
-    worst = []
-    for k in ref:
-        r = ref[k]
-        eh = float((hip[k] - r).norm() / (r.norm() + 1e-30))
-        el = float((lib[k] - r).norm() / (r.norm() + 1e-30))
-        worst.append((eh / max(el, 1e-3), k, eh, el))
-        assert eh <= max(1.75 * el, 6e-2), (k, eh, el)
-    ratios = sorted(w[0] for w in worst)
-    assert ratios[len(ratios) // 2] <= 1.15, ratios[len(ratios) // 2]      # typically no worse than the library
-    # the BatchNorm affine gradients of the backbone really come from the executor
-    for k in ('deeplab.backbone.layer2.0.bn2.weight', 'deeplab.backbone.layer3.1.bn3.bias',
-              'deeplab.backbone.layer1.0.downsample.1.weight'):
-        assert float(hip[k].abs().max()) > 0
-
-
 def test_fp32_hand_written_backward_matches_the_oracle_autograd(no_library_convolutions):
     """The whole network (backbone executor incl. the four-phase strided data gradient and the BatchNorm-affine gradients,
     head on csrc/conv_f32.hip) in the fp32 parity configuration, forward + backward, against the ORACLE's autograd -- not
@@ -564,3 +526,78 @@ def test_bf16_backbone_executor_every_block_teacher_forced(no_library_convolutio
     print('\nPARITY v3+ bf16 backbone executor, every block teacher-forced vs the fused frozen unit: max rel {:.2e}'.format(worst))
     assert worst <= 1.5e-4
     assert torch.equal(low, saved[layers[0]][0]) and torch.equal(out, saved[-1])
+
+
+def test_bf16_backbone_executor_backward_every_block_teacher_forced(no_library_convolutions):
+    """The backward pass of the TIMED route of BASELINE configs[3] (backbone on frozen statistics on the executor, bf16), block by
+    block and teacher-forced, with no library call: from the device's OWN gradient at the block output and its saved
+    activations the bf16-storage unit oracle recomputes both inner data gradients (ReLU masks in the epilogue; the
+    phase-decomposed transposed convolution of the stride-2 3 x 3), the gradient the block hands to its predecessor (shortcut
+    convolution or identity added in the epilogue, the second gradient at the layer1 tap, the mask of the block input) and the
+    four weight gradients (BatchNorm scale folded: dW = scale x dU^T X). Replaces the round-3 comparison with the library's
+    gradients."""
+    from oracle import deeplab3plus as o3, deeplab3plus_chain as oc
+    layers, C = (2, 2, 3, 2), 6
+    st = _he_state(C, layers)
+    net = _net(C, layers, torch.bfloat16, st, kind='hip')
+    net.train()
+    net.freeze_batchnorm()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 3, 129, 161, generator=g).to(DEV)
+    ex = net.hip_executor()
+    cap = {}
+    ex.debug_capture = cap
+    with no_library_convolutions:
+        with torch.no_grad():
+            s = ex.stem(x)
+        low, out, token = ex.forward_taps(s, save=True)
+        d_out = (torch.randn(out.shape, generator=g) * 0.1).to(DEV).to(out.dtype)
+        d_low = (torch.randn(low.shape, generator=g) * 0.1).to(DEV).to(low.dtype)
+        ex.arena.grad.zero_()
+        ex.backward_taps(token, d_low, d_out)
+    torch.cuda.synchronize()
+    saved = token[0].saved if isinstance(token, tuple) else token
+    nchw = lambda t: t.permute(0, 3, 1, 2).float().cpu()
+    plan = o3.layer_plan(layers)
+    assert len(cap) == len(plan)
+    eps = 1e-5
+    scale = lambda pre, k: st[pre + k + '.weight'] * torch.rsqrt(st[pre + k + '.running_var'] + eps)
+    wgrad = lambda key: ex.arena.packed(key, ex.arena.grad).float().cpu()          # (taps, Cout, Cin)
+    as_packed = lambda dw: dw.permute(2, 3, 0, 1).reshape(-1, dw.shape[0], dw.shape[1])
+    e_data, e_w = {}, {}
+    for bi, (pre, inplanes, planes, stride, dil, down) in enumerate(plan):
+        xin, a1, a2 = (nchw(t) for t in saved[bi])
+        dC, dU2, dU1 = (nchw(t) for t in cap[bi])
+        s1, s2, s3 = scale(pre, '.bn1'), scale(pre, '.bn2'), scale(pre, '.bn3')
+        w1, w2, w3 = st[pre + '.conv1.weight'], st[pre + '.conv2.weight'], st[pre + '.conv3.weight']
+        # the data-gradient operand is made from the bf16 weight copy: R(R(W) * scale) (backbone_hip._refresh_backward_weights)
+        fold = lambda w, sc: oc.rb(w, 'bf16') * sc.view(-1, 1, 1, 1)
+        r2, g3 = oc.conv_unit_backward(a2, fold(w3, s3), dC, 1, 0, 1, 'bf16')
+        e_data[pre + ' dU2'] = _rel(dU2, r2 * (a2 > 0))
+        r1, g2 = oc.conv_unit_backward(a1, fold(w2, s2), dU2, stride, dil, dil, 'bf16')
+        e_data[pre + ' dU1'] = _rel(dU1, r1 * (a1 > 0))
+        # weight gradients: the unit's wgrad is of the UNSCALED kernel operand; the device folds the BatchNorm scale per output row
+        e_w[pre + '.conv3'] = _rel(wgrad(pre + '.conv3.weight'), as_packed(oc.conv_unit_backward(a2, w3, dC, 1, 0, 1, 'bf16')[1] * s3.view(-1, 1, 1, 1)))
+        e_w[pre + '.conv2'] = _rel(wgrad(pre + '.conv2.weight'),
+                                   as_packed(oc.conv_unit_backward(a1, w2, dU2, stride, dil, dil, 'bf16')[1] * s2.view(-1, 1, 1, 1)))
+        r0, _ = oc.conv_unit_backward(xin, fold(w1, s1), dU1, 1, 0, 1, 'fp32')      # (rounded once, after the add and the mask)
+        e_w[pre + '.conv1'] = _rel(wgrad(pre + '.conv1.weight'), as_packed(oc.conv_unit_backward(xin, w1, dU1, 1, 0, 1, 'bf16')[1] * s1.view(-1, 1, 1, 1)))
+        if down:
+            sd, wd = scale(pre, '.downsample.1'), st[pre + '.downsample.0.weight']
+            dres, _ = oc.conv_unit_backward(xin, fold(wd, sd), dC, stride, 0, 1, 'bf16')
+            e_w[pre + '.downsample'] = _rel(wgrad(pre + '.downsample.0.weight'),
+                                            as_packed(oc.conv_unit_backward(xin, wd, dC, stride, 0, 1, 'bf16')[1] * sd.view(-1, 1, 1, 1)))
+        else:
+            dres = dC
+        if bi == layers[0]:                                        # the layer1 tap: its gradient joins the shortcut's (bf16 add)
+            dres = oc.rb(dres + nchw(d_low), 'bf16')
+        if bi > 0:
+            # conv^T(dU1, R(W1 s1)) in fp32 + the bf16 shortcut gradient, masked with the block input, rounded once
+            ws = oc.rb(fold(w1, s1), 'bf16')
+            full = torch.nn.grad.conv2d_input(xin.shape, ws, dU1, 1, 0, 1) + dres
+            e_data[pre + ' dC_prev'] = _rel(nchw(cap[bi - 1][0]), oc.rb(full * (xin > 0), 'bf16'))
+    top = lambda d: sorted(d.items(), key=lambda kv: -kv[1])[:3]
+    print('\nPARITY v3+ bf16 backbone executor BACKWARD, every block teacher-forced: {} data gradients max {:.2e}, {} weight gradients '
+          'max {:.2e}; worst {} {}'.format(len(e_data), max(e_data.values()), len(e_w), max(e_w.values()), top(e_data), top(e_w)))
+    # measured: data gradients 1.5e-4 (bf16 ties flipped by the fp32 summation order), weight gradients 1.6e-7
+    assert max(e_data.values()) <= 5e-4 and max(e_w.values()) <= 1e-5, (top(e_data), top(e_w))
