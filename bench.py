@@ -403,7 +403,7 @@ def run_workload(key, args, world, rank, dev):
         return tot
 
     def issued():
-        tot = dict(flops=0.0, conv_launches=0, conv_bytes=0.0, head_launches=0, head_bytes=0.0, floor_s=0.0)
+        tot = dict(flops=0.0, conv_launches=0, conv_bytes=0.0, head_launches=0, head_bytes=0.0, head_bytes_alg=0.0, floor_s=0.0)
         for e in executors():
             for kk in tot:
                 tot[kk] += e.issued.get(kk, 0.0)
@@ -614,10 +614,13 @@ def run_workload(key, args, world, rank, dev):
             nb, mv, parts = hbm_tot
             if prog_t['head_launches']:              # ASPP head launches issued by the program runner
                 ms['aspp_head_fwd'] = ms.get('aspp_head_fwd', 0.0) + prog_t['head_ms']
-                hb = prog_i['head_bytes'] * prog_t['head_launches'] / max(prog_i['head_launches'], 1)
-                nb, mv = nb + hb, mv + hb
+                # the head's ALGORITHMIC bytes are the 2048-channel input once + weights + logits; the fp32 Z planes
+                # the single-pass formulation writes and re-reads are counted as MOVED bytes only
+                share = prog_t['head_launches'] / max(prog_i['head_launches'], 1)
+                hb, hm = prog_i['head_bytes_alg'] * share, prog_i['head_bytes'] * share
+                nb, mv = nb + hb, mv + hm
                 pp = parts.setdefault('aspp_head_fwd', [0.0, 0.0, 0])
-                pp[0] += hb; pp[1] += hb; pp[2] += prog_t['head_launches']
+                pp[0] += hb; pp[1] += hm; pp[2] += prog_t['head_launches']
             tot_ms = sum(ms.values())
             out['roofline_hbm'] = {
                 'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -630,8 +633,17 @@ def run_workload(key, args, world, rank, dev):
                 'achieved_on_moved_bytes': mv / (tot_ms * 1e-3) / 1e9,
                 'ms_per_step': tot_ms / args.steps,
                 'parts': {k: {'ms_per_step': ms[k] / args.steps, 'GBps': parts[k][0] / (ms[k] * 1e-3) / 1e9,
+                              'GBps_moved': parts[k][1] / (ms[k] * 1e-3) / 1e9,
                               'launches_per_step': parts[k][2] / args.steps} for k in ms},
                 'traffic': None}
+        # scalar copies of the nested objects (the driver's record keeps scalar keys of `roofline` / `config` only)
+        rf = out['roofline']
+        for name in ('mixed', 'step_mfma', 'isolated'):
+            if isinstance(rf.get(name), dict):
+                rf[name + '_frac'] = rf[name]['frac']
+        if 'roofline_hbm' in out:
+            rf['hbm_group_frac'] = out['roofline_hbm']['frac']
+            rf['hbm_group_ms_per_step'] = out['roofline_hbm']['ms_per_step']
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl, seconds_budget=30.0 if key == 'pascal' else 20.0)
     del step, opt, ema, stu, tea, pool
@@ -733,7 +745,8 @@ def main():
                 r = run_workload(key, a2, world, rank, dev)
                 also.append({'name': name, 'value': r['value'], 'unit': 'images/sec', 'ms_per_step': r['ms_per_step'],
                              'steps': a2.steps, 'warmup': a2.warmup, 'config': r['config'],
-                             'roofline': {k: r['roofline'].get(k) for k in ('kernel', 'frac', 'avg_launch_ms', 'step_mfma', 'mixed')},
+                             'roofline': {k: r['roofline'].get(k) for k in ('kernel', 'frac', 'avg_launch_ms', 'step_mfma', 'mixed',
+                                                                            'mixed_frac', 'step_mfma_frac')},
                              'roofline_hbm': ({k: r['roofline_hbm'].get(k) for k in ('group', 'frac', 'achieved', 'achieved_on_moved_bytes',
                                                                                     'ms_per_step')}
                                               if 'roofline_hbm' in r else None)})
@@ -768,9 +781,17 @@ def main():
                 out['value_321x321'] = r['value']
             if r['workload'] == 'cityscapes':
                 out['value_512x1024'] = r['value']
+                # the 512 x 1024 shape of the metric as SCALAR keys of the objects the driver's record keeps
+                out['config'] = dict(out['config'], value_512x1024=r['value'], ms_per_step_512x1024=r['ms_per_step'])
+                rr = r['roofline']
+                out['roofline'] = dict(out['roofline'], **{k + '_512x1024': rr[k] for k in
+                                                           ('frac', 'mixed_frac', 'step_mfma_frac', 'isolated_frac', 'hbm_group_frac',
+                                                            'hbm_group_ms_per_step', 'avg_launch_ms') if rr.get(k) is not None})
         out['configs'] = results
         if also:
             out['also'] = also
+            for a_, k_ in zip(also, ('also_v3plus_513x513_img_s', 'also_no_freeze_bn_321x321_img_s')):
+                out['config'][k_] = a_.get('value')
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -142,7 +142,7 @@ class DeepLabHipExecutor(object):
         self._generation = 0      # forward passes issued; a backward pass checks that its activations are still there
         # what was enqueued through programs so far (bench.py): algorithmic MFMA FLOPs, body-convolution launches
         # and their algorithmic bytes, ASPP-head launches and bytes
-        self.issued = dict(flops=0.0, conv_launches=0, conv_bytes=0.0, head_launches=0, head_bytes=0.0, floor_s=0.0)
+        self.issued = dict(flops=0.0, conv_launches=0, conv_bytes=0.0, head_launches=0, head_bytes=0.0, head_bytes_alg=0.0, floor_s=0.0)
         net.register_load_state_dict_post_hook(lambda module, incompatible: self.invalidate())
 
     def _add_blocks(self, prefix, layers):
@@ -606,6 +606,7 @@ class DeepLabHipExecutor(object):
         i['conv_bytes'] += prog.conv_bytes
         i['head_launches'] += prog.head_launches
         i['head_bytes'] += prog.head_bytes
+        i['head_bytes_alg'] += prog.head_bytes_alg
         i['floor_s'] += prog.floor_s
 
     def forward(self, x, save):

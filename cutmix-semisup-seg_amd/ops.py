@@ -845,7 +845,8 @@ class Program(object):
         self.flops = 0.0        # algorithmic MFMA FLOPs of one replay (convolutions + weight gradients)
         self.conv_launches = 0
         self.conv_bytes = 0.0   # algorithmic HBM bytes of the convolution launches (operands once, output once)
-        self.head_bytes = 0.0   # ... of the ASPP head launches among them (fp32 NCHW logits)
+        self.head_bytes = 0.0   # bytes the ASPP head launches MOVE (incl. the fp32 Z planes the GEMM writes and the gather re-reads)
+        self.head_bytes_alg = 0.0   # ... their ALGORITHMIC bytes per SURVEY 8(d): the 2048-channel input once + weights + logits
         self.floor_s = 0.0      # sum over the convolution / weight-gradient launches of max(bytes / 8 TB/s, FLOPs / 2.5 PFLOP/s):
                                 # the mixed HBM / MFMA roofline of one replay (bench.py: roofline.mixed)
         self.head_launches = 0
@@ -1008,6 +1009,7 @@ def aspp_gather_fwd(z, bias, taps, num_classes, out=None):
             check(idx, 'cms_program_add_aspp_gather')
         prog.keep += [t for t in (z, bias, out) if t is not None]
         prog.head_bytes += 4.0 * nt * int(num_classes) * n * h * w + 4.0 * out.numel()
+        prog.head_bytes_alg += 4.0 * out.numel()
         return out
     check(fn['cms_aspp_gather_fwd'](_ptr(z), _ptr(bias), _ptr(out), dy, dx, nt, n, int(num_classes), zc, h, w, _stream()),
           'cms_aspp_gather_fwd')
@@ -1161,10 +1163,14 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
             (4.0 * d.cout_real if out_f32_nchw is not None else esz * cout)
             + (esz * cout if res is not None else 0.0) + (esz * cout if mask_src is not None else 0.0)
             + (cout / 8.0 if mask_bits is not None else 0.0) + (cout / 8.0 if mask_bits_out is not None else 0.0))
-        prog.floor_s += max(nbytes / HBM_PEAK_BPS, 2.0 * n * ho * wo * cout * cin * ntaps / MFMA_PEAK_FLOPS)
+        # (the head's fp32 Z planes are an intermediate of the single-pass formulation, not algorithmic output: its floor counts
+        # the input and the weights here and the logits at the gather)
+        fbytes = esz * (x.numel() + w_packed.numel()) if (out_f32_nchw is not None and d.cout_real > 32) else nbytes
+        prog.floor_s += max(fbytes / HBM_PEAK_BPS, 2.0 * n * ho * wo * cout * cin * ntaps / MFMA_PEAK_FLOPS)
         if out_f32_nchw is not None:
             prog.head_launches += 1
             prog.head_bytes += nbytes
+            prog.head_bytes_alg += esz * (x.numel() + w_packed.numel())      # (its Z planes are an intermediate, not an output)
         else:
             prog.conv_launches += 1
             prog.conv_bytes += nbytes
