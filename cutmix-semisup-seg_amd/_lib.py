@@ -134,6 +134,7 @@ PROTOTYPES = {
     'cms_adam_ema_step': (c_int, [_P(OptimDesc), c_void_p]),
     'cms_sgd_ema_step': (c_int, [_P(OptimDesc), c_void_p]),
     'cms_increment_counter': (c_int, [c_void_p, c_void_p]),
+    'cms_bn_fold': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'cms_argmax_confusion': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p, c_void_p, c_void_p]),
     'cms_confusion': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),

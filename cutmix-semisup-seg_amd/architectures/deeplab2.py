@@ -245,7 +245,7 @@ class ResNetDeepLab(nn.Module):
         reference CLI's default, no --freeze_bn: deeplab2.py:72-84, train_seg_semisup_mask_mt.py:268-275,587). 'auto' in
         bf16: MFMA kernels for the convolutions that fit them well, csrc/bn.hip for BatchNorm; 'hip': every convolution
         (stem as tap chunks, strided 1x1s, the class-wide head) and every BatchNorm on the hand-written kernels, in bf16
-        or fp32, or an error; 'torch' (and 'auto' in fp32): library convolutions."""
+        or fp32, or an error; 'torch': library convolutions (the comparison engine of the tests)."""
         from .deeplab3plus import _engine_of
         return _engine_of(self, x)
 
@@ -282,8 +282,6 @@ class ResNetDeepLab(nn.Module):
                 raise RuntimeError('batch-statistics passes on the executor need the BatchNorm affine frozen (requires_grad = '
                                    'False, as the reference has it); use engine_kind = "auto" for a trainable affine')
             return False
-        if self.compute_dtype == torch.float32 and self.engine_kind != 'hip':
-            return False                       # 'auto' in fp32: the library comparison engine, as for the other networks
         return True            # (round 4: under torch.distributed the executor's units all-reduce their statistics -- SyncBN)
 
     def hip_executor(self):

@@ -122,6 +122,7 @@ class DeepLabHipExecutor(object):
         # ReLU masks of the block outputs as bits (written by the expansion's epilogue, read by the data gradients that need the
         # activation only for its sign); CMS_RELU_BITS=0 switches them off (A/B)
         self.relu_bits = os.environ.get('CMS_RELU_BITS', '1') != '0'
+        self.relu_bits_inner = os.environ.get('CMS_RELU_BITS_INNER', '1') != '0'     # ... of a1 / a2 as well (round 5; A/B)
         # The backward pass normally ends with the main stream waiting for the weight-gradient stream(s): whoever reads a
         # gradient afterwards finds it complete. A caller that knows where it next touches the gradients (the training step:
         # at the gradient exchange / optimizer) sets this and calls `join_wgrad()` there instead -- what follows the body's
@@ -129,6 +130,7 @@ class DeepLabHipExecutor(object):
         # gradients (0.37 ms of small launches, profiles/r04n_step_timeline.txt) instead of waiting for it.
         self.defer_wgrad_join = False
         self._pending_join = None
+        self.head_wgrad_side = os.environ.get('CMS_HEAD_WGRAD_SIDE', '1') != '0'
         self._sides = []
         self.conv_tile = 0         # experiment knob: force a tile shape on the 128-multiple layers (tools, bench)
         self.tile_rules = {}       # output channels -> tile code (per-layer choice against the workgroup-count staircase)
@@ -227,8 +229,8 @@ class DeepLabHipExecutor(object):
         if self._bn_idx is None:
             self._build_affine_tables()
         flat, ix = self.arena.flat, self._bn_idx
-        torch.mul(flat[ix['weight']], torch.rsqrt(flat[ix['running_var']] + 1e-5), out=self._scale_all)
-        torch.sub(flat[ix['bias']], flat[ix['running_mean']] * self._scale_all, out=self._bias_all)
+        # (round 5) ONE launch instead of nine tensor ops per refresh (the teacher's statistics move with every EMA step)
+        ops.bn_fold(flat, ix['weight'], ix['bias'], ix['running_mean'], ix['running_var'], 1e-5, self._scale_all, self._bias_all)
         self._affine_ready = True
 
     def _wbuf(self):
@@ -278,18 +280,13 @@ class DeepLabHipExecutor(object):
         n, h, w, _ = x.shape
         ho, wo = self._out_hw(h, w, c.stride)
         mb = None
-        if bits and relu and self.relu_bits and self.dtype == torch.bfloat16 and not self._eight_phase(len(c.taps), c.cin, c.cout):
+        if bits and relu and self.relu_bits and self.dtype == torch.bfloat16 and c.cout % 32 == 0:
             mb = torch.empty((n, ho, wo, c.cout // 8), dtype=torch.uint8, device=x.device)
         y = ops.conv_igemm(x, self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), scale=c.scale, bias=c.bias,
                            res=res, relu=relu, tile=self._tile(c.cout), mask_bits_out=mb)
         if mb is not None:
             y._cms_relu_bits = mb
         return y
-
-    @staticmethod
-    def _eight_phase(ntaps, cin, cout):
-        """Would cms_conv_igemm send a convolution of this shape to the eight-phase 256 x 256 kernel (which has no mask bits)?"""
-        return cout % 256 == 0 and cin % 64 == 0 and ntaps * (cin // 64) >= 16
 
     def _tile(self, cout):
         """Workgroup tile code for a convolution with `cout` output channels (0 = the library's choice)."""
@@ -312,8 +309,11 @@ class DeepLabHipExecutor(object):
         if st.get('bn'):
             return self._fwd_block_bn(st, bi)
         b, cur = self.blocks[bi], st['cur']
-        a1 = self._fwd(cur, b.c1, True)
-        a2 = self._fwd(a1, b.c2, True)
+        # (round 5) a1 / a2 get mask bits too: both kernels of cms_conv_igemm write and read them (the library alone decides
+        # which one runs a launch), so the data gradients of conv2 / conv3 no longer re-read these activations for their sign
+        inner = st['saved'] is not None and self.relu_bits_inner
+        a1 = self._fwd(cur, b.c1, True, bits=inner)
+        a2 = self._fwd(a1, b.c2, True, bits=inner)
         res = cur if b.cd is None else self._fwd(cur, b.cd, False)
         st['cur'] = self._fwd(a2, b.c3, True, res=res, bits=st['saved'] is not None)
         if st['saved'] is not None:
@@ -346,6 +346,11 @@ class DeepLabHipExecutor(object):
         fn = getattr(self.net, 'sample_groups', None)
         return 1 if fn is None else int(fn())
 
+    def _dist_group(self):
+        """Process group of the SyncBN exchanges: the one the training step hands to the network (`net.dist_group`, set by
+        CutMixMeanTeacherStep: the group its gradient exchange uses) -- None = the default group."""
+        return getattr(self.net, 'dist_group', None)
+
     def _bn_module(self, c):
         mods = self.__dict__.setdefault('_bn_modules', {})
         m = mods.get(c.bn)
@@ -367,14 +372,15 @@ class DeepLabHipExecutor(object):
         bsums = torch.empty(G * 2 * C, dtype=torch.float64, device=dev) if save else None
         mean, rstd, scale, shift = (torch.empty(G * C, dtype=torch.float32, device=dev) for _ in range(4))
         ws = ops.bn_workspace(npix, C, dev, G)      # this unit's: tile counters + partial sums (forward, then backward)
-        world = ops._world(None)
+        grp = self._dist_group()
+        world = ops._world(grp)
         if world > 1:
             # SyncBN on the executor (round 4; SURVEY 8(e) "BN statistics"): per-group (sum x, sum x^2) -> ONE all-reduce of
             # [G][2][C] doubles between two launches of the recorded pass (a host op of the program) -> the groups finalised in
             # order with the pixel count of ALL ranks. The fused single-process launch ('stats') does the same without the exchange.
             fsums = torch.empty(G * 2 * C, dtype=torch.float64, device=dev)
             ops.bn_op('reduce', c=C, dtype=self.dtype, n_pixels=npix, groups=G, x=u, sums=fsums, ws=ws)
-            ops.host_call(lambda t=fsums: ops._allreduce_sum(t, None))
+            ops.host_call(lambda t=fsums, g_=grp: ops._allreduce_sum(t, g_))
             for g in range(G):
                 sl = slice(g * C, (g + 1) * C)
                 ops.bn_op('finalize', c=C, count=float(npix // G) * world, eps=bn.eps, momentum=bn.momentum,
@@ -400,9 +406,10 @@ class DeepLabHipExecutor(object):
         npix = u.numel() // C
         ops.bn_op('reduce_bwd', c=C, dtype=self.dtype, n_pixels=npix, groups=G, x=u, dy=dy, y=y, mean=mean, rstd=rstd, sums=sums,
                   ws=ws)
-        world = ops._world(None)
+        grp = self._dist_group()
+        world = ops._world(grp)
         if world > 1:                        # SyncBN: (sum dy', sum dy' xhat) of every group over all ranks
-            ops.host_call(lambda t=sums: ops._allreduce_sum(t, None))
+            ops.host_call(lambda t=sums, g_=grp: ops._allreduce_sum(t, g_))
         du = torch.empty_like(u)
         dres = torch.empty_like(u) if want_res else None
         ops.bn_op('bwd_apply', c=C, dtype=self.dtype, n_pixels=npix, groups=G, count=(npix // G) * world, x=u, dy=dy, y=y, dx=du, dres=dres,
@@ -499,7 +506,7 @@ class DeepLabHipExecutor(object):
         if not self.defer_wgrad_join:
             for sd_ in sides:
                 ops.stream_wait(main, sd_)
-        del keep
+        self._retire_keep(keep)
         return dOut, dwall
 
     # ------------------------------------------------------------------------------------------ stem
@@ -651,7 +658,7 @@ class DeepLabHipExecutor(object):
         """gradient wrt the input of conv `c`; `in_hw` = spatial size of that input (needed for stride 2)."""
         n, ho, wo, _ = du.shape
         mb = getattr(mask, '_cms_relu_bits', None) if mask is not None else None
-        if mb is not None and (not self.relu_bits or self._eight_phase(len(c.taps), c.cout, c.cin)):
+        if mb is not None and not self.relu_bits:
             mb = None
         if mb is not None:
             mask = None                      # the bits the producing launch wrote instead of the activation itself
@@ -674,19 +681,33 @@ class DeepLabHipExecutor(object):
             self._refresh_backward_weights()
             self._wT_version = self.version
 
-    def _head_bias_grads(self, dlogits, want_w):
-        """Bias gradients of the two live ASPP branches (plain reduction: torch ops on the current stream)."""
+    def _head_bias_grads(self, dlogits, want_w, side=None):
+        """Bias gradients of the two live ASPP branches (plain reduction: torch ops). `side`: the weight-gradient stream they
+        are issued on (behind the main stream's work so far) instead of in front of the data-gradient chain."""
         if want_w:
-            db = dlogits.sum(dim=(0, 2, 3))
-            for k in self.aspp_keys:
-                self.arena.view(k + '.bias', self.arena.grad).add_(db)
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                dlogits.record_stream(side)
+            with torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
+                db = dlogits.sum(dim=(0, 2, 3))
+                for k in self.aspp_keys:
+                    self.arena.view(k + '.bias', self.arena.grad).add_(db)
 
-    def _head_weight_grads(self, dwall):
-        """dWall rows (tap*C + class) -> the (9, C, 2048) gradient tensors of the two branches."""
+    def _head_weight_grads(self, dwall, side=None):
+        """dWall rows (tap*C + class) -> the (9, C, 2048) gradient tensors of the two branches. `side`: the stream the head's
+        weight gradient ran on (the adds must follow it there)."""
         C = self.num_classes
         a = self.arena
-        for i, k in enumerate(self.aspp_keys):
-            a.packed(k + '.weight', a.grad).add_(dwall[0, 9 * C * i:9 * C * (i + 1)].view(9, C, 2048))
+        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
+            for i, k in enumerate(self.aspp_keys):
+                a.packed(k + '.weight', a.grad).add_(dwall[0, 9 * C * i:9 * C * (i + 1)].view(9, C, 2048))
+
+    def _finish_head(self, dwall, side):
+        """The head's weight gradient into the arena, on the stream that computed it; a pass that joins its weight-gradient
+        streams itself (no deferred join) makes the current stream wait for these adds too."""
+        self._head_weight_grads(dwall, side)
+        if side is not None and not self.defer_wgrad_join:
+            torch.cuda.current_stream().wait_stream(side)
 
     def bucket_starts(self):
         """Bottleneck indices at which a gradient bucket of the data-parallel all-reduce closes (step.GradBuckets):
@@ -705,16 +726,23 @@ class DeepLabHipExecutor(object):
         # head: D[n][y][x][tap*C + c] = dlogits[n][c][y - dy][x - dx]; dX = D . Wall, dWall = D^T . X (csrc/aspp.hip)
         d = ops.aspp_spread_bwd(dlg, self.aspp_taps, self.aspp_zc, self.dtype)
         dwall = None
+        keep = []                 # tensors read on the side stream must outlive the python scope that made them
         if want_w:
             dwall = torch.empty((1, self.aspp_zc, 2048), dtype=torch.float32, device=d.device)
-            ops.memset_zero(dwall)
-            ops.conv_wgrad(d, x4, [(0, 0)], dwall)
+            # (round 5) the head's weight gradient (91 us at cfg 2) feeds nothing but the optimizer: on the first weight-gradient
+            # stream, like every other weight gradient, instead of in front of the data-gradient chain; CMS_HEAD_WGRAD_SIDE=0: A/B
+            hs = sides[0] if (sides and self.head_wgrad_side) else None
+            if hs is not None:
+                ops.stream_wait(hs, main)
+                keep.append((d, dwall))
+            with torch.cuda.stream(hs if hs is not None else main):
+                ops.memset_zero(dwall)
+                ops.conv_wgrad(d, x4, [(0, 0)], dwall)
             if box is not None:
                 box['dwall'] = dwall
         x4b = getattr(x4, '_cms_relu_bits', None) if self.relu_bits else None
         dC = ops.conv_igemm(d, self.aspp_wallT, [(0, 0)], mode=1, mask_src=None if x4b is not None else x4, mask_bits=x4b)
         capture = getattr(self, 'debug_capture', None)
-        keep = []                 # tensors read on the side stream must outlive the python scope that made them
         closes = set(self.bucket_starts())
         pending, pending_blocks = [], []
         for bi in range(len(self.blocks) - 1, -1, -1):
@@ -766,7 +794,7 @@ class DeepLabHipExecutor(object):
         if not self.defer_wgrad_join:
             for sd in sides:
                 ops.stream_wait(main, sd)
-        del keep
+        self._retire_keep(keep)
         return dC, dwall
 
     def backward(self, token, dlogits):
@@ -788,10 +816,11 @@ class DeepLabHipExecutor(object):
         n, _, h, w = dlogits.shape
         main = torch.cuda.current_stream()
         sides = self._side_streams(self.wgrad_streams) if (self.overlap_wgrad and want_w) else []
+        hside = sides[0] if (sides and self.head_wgrad_side and not bn) else None     # where the head's gradients are formed
         if not self.use_programs:
             if self.defer_wgrad_join and sides:
                 self._pending_join = list(sides)
-            self._head_bias_grads(dlogits, want_w)
+            self._head_bias_grads(dlogits, want_w, hside)
             box = {}
 
             def hook(bi):
@@ -805,7 +834,7 @@ class DeepLabHipExecutor(object):
             # the chain creates dwall before its first hook call: hand it over through the box
             dx, dwall = chain(token, dlogits, want_w, sides, hook, box)
             if dwall is not None and 'done' not in box:
-                self._head_weight_grads(dwall)
+                self._finish_head(dwall, hside)
             return dx
         fprog, gen = token
         if fprog.generation != gen:
@@ -825,19 +854,22 @@ class DeepLabHipExecutor(object):
             prog.dlg, prog.dx, prog.dwall = dlg, dx, dwall
             fprog.bwd[key] = prog
         prog.dlg.copy_(dlogits)
-        self._head_bias_grads(dlogits, want_w)
+        self._head_bias_grads(dlogits, want_w, hside)
         streams = [main] + sides
         if self.grad_hook is None or not want_w:
             prog.run(streams)
             if prog.dwall is not None:
-                self._head_weight_grads(prog.dwall)      # (after the program's final join of the weight-gradient stream)
+                self._finish_head(prog.dwall, hside)     # (behind the head's weight gradient, on the stream it ran on)
         else:
             # segments between the recorded block marks: the hook (bucketed all-reduce) is host work that must see the
             # weight-gradient stream as its current stream, right after the weight gradients of its block
             first = 0
             hook_stream = sides[0] if sides else main
             head_done = False
+            wanted = getattr(self.grad_hook, 'blocks', None)      # a hook that only acts at some bottlenecks: fewer segments
             for idx, bi in prog.marks:
+                if wanted is not None and bi not in wanted:
+                    continue
                 prog.run(streams, first, idx)
                 first = idx
                 with torch.cuda.stream(hook_stream):
@@ -849,9 +881,18 @@ class DeepLabHipExecutor(object):
                     self.grad_hook(bi)
             prog.run(streams, first, -1)
             if prog.dwall is not None and not head_done:
-                self._head_weight_grads(prog.dwall)
+                self._finish_head(prog.dwall, hside)
         self._account(prog)
         return prog.dx.clone()
+
+    def _retire_keep(self, keep):
+        """End of a backward chain: the gradient tensors the weight-gradient streams read. Joined chain (or a recording: the
+        program owns the buffers): they may go now. EAGER chain with a deferred join: they are main-stream
+        allocations still being read on the side streams -- freed here the caching allocator could hand their blocks to the
+        max-pool / stem backward that follows on the main stream; they stay alive until `join_wgrad()` has made the main
+        stream wait for the side streams."""
+        if keep and self.defer_wgrad_join and ops._REC is None:
+            self._pending_keep = (self.__dict__.get('_pending_keep') or []) + [keep]
 
     def join_wgrad(self):
         """The current stream waits for the weight-gradient stream(s) of the last backward pass (see `defer_wgrad_join`)."""
@@ -860,6 +901,7 @@ class DeepLabHipExecutor(object):
             main = torch.cuda.current_stream()
             for sd in sides:
                 main.wait_stream(sd)
+        self._pending_keep = None          # (after the waits: frees are ordered behind the side streams' reads)
 
     def _block_wgrads(self, b, dC, dU2, dU1, xin, a1, a2):
         self._wgrad(dC, a2, b.c3)
@@ -1311,12 +1353,26 @@ def hip_conv2d(x, conv, arena, key, dtype=torch.bfloat16):
     return _HipConvGeneralFn.apply(x, conv.weight, arena, key, geom, dtype)
 
 
+def _auto_keeps_library():
+    """CMS_AUTO_LIBRARY=1 (A/B switch, read once): engine_kind 'auto' as in rounds 2-4 -- stems, strided and narrow layers go
+    to the library (MIOpen), see `hip_conv2d_eligible`."""
+    v = _auto_keeps_library.__dict__.get('v')
+    if v is None:
+        v = _auto_keeps_library.__dict__['v'] = os.environ.get('CMS_AUTO_LIBRARY', '0') not in ('0', '')
+    return v
+
+
 def hip_conv2d_eligible(x, conv, dtype=torch.bfloat16):
     """The layers the 'auto' engine sends to the MFMA kernels: stride 1, 'same' padding, >= 128 input channels (padded to
     a multiple of 64 if need be), output channels in multiples of 64 (or >= 32, padded), >= 64 pixels -- where the
     padding copies cost less than the kernels gain (round 3: the pixel count is that of the BATCH, which brings
     DenseNet-161's fourth dense block, 7 x 7 maps at a 224 crop, to the MFMA kernels). (`engine_kind = 'hip'` sends EVERY convolution there.)"""
     kh, kw = conv.kernel_size
+    if not _auto_keeps_library():
+        # (round 5) 'auto' = the hand-written kernels for EVERY convolution the general path can express (strided layers as
+        # phases, 7 x 7 stems as tap chunks, narrow / odd channel counts padded): a library dispatch is not an implementation,
+        # and the one library kernel left in DeepLab v3+'s step (the pooled branch's 1 x 1-map GEMM) made it irreproducible
+        return x.is_cuda and x.dtype == dtype and hip_conv_geometry(conv) is not None
     return (x.is_cuda and x.dtype == dtype and conv.groups == 1
             and conv.stride == (1, 1) and kh == kw and kh * kw <= 18
             and conv.padding == (conv.dilation[0] * (kh - 1) // 2,) * 2 and conv.dilation[0] == conv.dilation[1]

@@ -1150,7 +1150,7 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
         d_no8.variant = 0;
         d_in = &d_no8;
     } else if (d_in->variant == 0 && d_in->tile == 0 && conv8_env(0) > 0 && cms::conv8_supported(d_in) &&
-        d_in->mask_bits == nullptr && d_in->mask_bits_out == nullptr &&
+        ((d_in->mask_bits == nullptr && d_in->mask_bits_out == nullptr) || conv8_env(0) == 1) &&     // (bits: whole tiles only)
         d_in->ntaps * (d_in->cin / 64) >= conv8_env(1) && conv_default_variant() == 0 &&
         ((conv8_env(3) >> (d_in->mode == 0 ? 0 : 1)) & 1))
         return cms::conv8_launch(d_in, (hipStream_t)stream, conv8_env(0) - 1, conv8_env(2), nullptr, 0);

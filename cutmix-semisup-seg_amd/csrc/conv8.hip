@@ -69,6 +69,8 @@ struct Args {
     const float* bias;         // [Cout] or NULL (forward)
     const uint16_t* res;       // bf16, indexed like y, or NULL
     const uint16_t* mask_src;  // bf16, indexed like y, or NULL (dgrad)
+    uint8_t* mask_bits_out;    // forward + ReLU: [y > 0] of the stored output as bits, [out pixels][Cout / 8] bytes, or NULL
+    const uint8_t* mask_bits;  // dgrad: the ReLU mask as such bits instead of mask_src, or NULL
     float* slab;               // stream-K partial tiles [2 * grid][SLAB_FLOATS] or NULL
     unsigned* counters;        // stream-K arrival counters [tiles of the stream-K round], all zero between launches
     int N, H, W, Cin, Ho, Wo, Cout, ntaps, stride, out_H, out_W, out_stride, relu, mode, M, plain;
@@ -571,6 +573,28 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
         };
         uint64_t mbits[2] = {0, 0};                 // ReLU mask of this lane's 128 elements when BOTH operands are present
         const bool both = a.res && a.mask_src;
+        // (round 5) the ReLU mask of a data gradient as BITS the producing forward launch wrote (conv.hip's layout: one dword
+        // per pixel row and 32-channel MFMA tile, bit = channel): 1/16 of the bytes of the bf16 activation, no staged tile
+        const bool bits_in = a.mask_bits != nullptr;
+        if (bits_in) {
+            const int bpr = a.Cout >> 3;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t op = lds_row[(wm * 2 + j) * 32 + frow].opix;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t wbits = 0u;
+                    if (op != 0xffffffffu)
+                        wbits = *reinterpret_cast<const uint32_t*>(a.mask_bits + (size_t)op * bpr + ((co0 + (wn * 4 + i) * 32) >> 3));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int bit = ((i * 2 + j) * 4 + q) * 4;
+                        const uint64_t m4 = (wbits >> (8 * q + 4 * fhalf)) & 0xfu;
+                        mbits[bit >> 6] |= m4 << (bit & 63);
+                    }
+                }
+            }
+        }
         if (both) {
             stage_tile(a.mask_src);
 #pragma unroll
@@ -595,11 +619,17 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
         // the residual, and the ReLU on the PACKED bf16 pair (v_pk_max_i16 with 0: a bf16 is negative iff its bit pattern is a
         // negative int16; rounding first and clamping then gives the bits of clamping first) -- the residual + ReLU nest was 730
         // vector instructions per wave, the whole epilogue VALU-bound. The data-gradient nests skip the (1, 0) affine.
-        auto nest = [&](auto AFF_, auto RES_, auto MSK_, auto RELU_) {
+        auto nest = [&](auto AFF_, auto RES_, auto MSK_, auto RELU_, auto BITS_) {
             constexpr int AFF = decltype(AFF_)::value;      // 1: y = acc * scale + bias (forward); 0: the accumulator itself
             constexpr int RES = decltype(RES_)::value;      // 1: residual / gradient add from the staged tile
-            constexpr int MSK = decltype(MSK_)::value;      // 1: ReLU mask bits (both operands), 2: mask from the staged tile
+            constexpr int MSK = decltype(MSK_)::value;      // 1: ReLU mask bits (both operands / mask_bits), 2: mask from the staged tile
             constexpr int RELU = decltype(RELU_)::value;
+            constexpr int BITS = decltype(BITS_)::value;    // 1: also write [y > 0] of the STORED output as bits (mask_bits_out)
+            uint32_t obits[BITS ? 4 : 1][BITS ? 2 : 1];
+#pragma unroll
+            for (int i = 0; i < (BITS ? 4 : 1); ++i)
+#pragma unroll
+                for (int j = 0; j < (BITS ? 2 : 1); ++j) obits[i][j] = 0u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -657,18 +687,42 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
                             asm("v_pk_max_i16 %0, %1, 0" : "=v"(o.y) : "v"(o.y));
                         }
                         *reinterpret_cast<uint2*>(cell) = o;
+                        if constexpr (BITS) {
+                            // of the STORED value: exactly what a data gradient reading the activation back would test
+                            const uint32_t m4 = ((int16_t)(o.x & 0xffffu) > 0 ? 1u : 0u) | ((int16_t)(o.x >> 16) > 0 ? 2u : 0u) |
+                                                ((int16_t)(o.y & 0xffffu) > 0 ? 4u : 0u) | ((int16_t)(o.y >> 16) > 0 ? 8u : 0u);
+                            obits[i][j] |= m4 << (8 * q + 4 * fhalf);
+                        }
+                    }
+                }
+            }
+            if constexpr (BITS) {
+                const int bpr = a.Cout >> 3;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint32_t op = lds_row[(wm * 2 + j) * 32 + frow].opix;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // lanes l and l + 32 hold the two nibbles of every byte of the pixel row's 32 channels
+                        const uint32_t wbits = obits[i][j] | (uint32_t)__shfl_xor((int)obits[i][j], 32, 64);
+                        if (fhalf == 0 && op != 0xffffffffu)
+                            *reinterpret_cast<uint32_t*>(a.mask_bits_out + (size_t)op * bpr + ((co0 + (wn * 4 + i) * 32) >> 3)) = wbits;
                     }
                 }
             }
         };
         if (a.mode == 0) {
-            if (a.res) { if (a.relu) nest(IC<1>{}, IC<1>{}, IC<0>{}, IC<1>{}); else nest(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}); }
-            else { if (a.relu) nest(IC<1>{}, IC<0>{}, IC<0>{}, IC<1>{}); else nest(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}); }
+            if (a.relu && a.mask_bits_out) {
+                if (a.res) nest(IC<1>{}, IC<1>{}, IC<0>{}, IC<1>{}, IC<1>{}); else nest(IC<1>{}, IC<0>{}, IC<0>{}, IC<1>{}, IC<1>{});
+            }
+            else if (a.res) { if (a.relu) nest(IC<1>{}, IC<1>{}, IC<0>{}, IC<1>{}, IC<0>{}); else nest(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}); }
+            else { if (a.relu) nest(IC<1>{}, IC<0>{}, IC<0>{}, IC<1>{}, IC<0>{}); else nest(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}); }
         } else {
-            if (both) nest(IC<0>{}, IC<1>{}, IC<1>{}, IC<0>{});
-            else if (a.mask_src) nest(IC<0>{}, IC<0>{}, IC<2>{}, IC<0>{});
-            else if (a.res) nest(IC<0>{}, IC<1>{}, IC<0>{}, IC<0>{});
-            else nest(IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{});
+            if (both || (bits_in && a.res)) nest(IC<0>{}, IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{});
+            else if (bits_in) nest(IC<0>{}, IC<0>{}, IC<1>{}, IC<0>{}, IC<0>{});
+            else if (a.mask_src) nest(IC<0>{}, IC<0>{}, IC<2>{}, IC<0>{}, IC<0>{});
+            else if (a.res) nest(IC<0>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{});
+            else nest(IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{});
         }
         __syncthreads();
         stamp(7);
@@ -737,6 +791,11 @@ int conv8_launch(const cms_conv_desc* d, hipStream_t s, int mode, int grid_cap, 
     c8::Args a;
     a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.y = (uint16_t*)d->y;
     a.scale = d->scale; a.bias = d->bias; a.res = (const uint16_t*)d->res; a.mask_src = (const uint16_t*)d->mask_src;
+    a.mask_bits_out = d->mask_bits_out; a.mask_bits = d->mask_bits;
+    CMS_REQUIRE(d->mask_bits_out == nullptr || (d->mode == 0 && d->relu != 0), "conv8: mask_bits_out is written by forward + ReLU launches");
+    CMS_REQUIRE(d->mask_bits == nullptr || (d->mode == 1 && d->mask_src == nullptr), "conv8: mask_bits replaces mask_src of a data gradient");
+    CMS_REQUIRE((d->mask_bits_out == nullptr && d->mask_bits == nullptr) || mode == 0,
+                "conv8: ReLU mask bits with whole tiles per workgroup only (not the stream-K launch)");
     a.N = d->n; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
     a.ntaps = d->ntaps; a.stride = d->stride; a.out_H = d->out_h; a.out_W = d->out_w; a.out_stride = d->out_stride;
     a.relu = d->relu; a.mode = d->mode;

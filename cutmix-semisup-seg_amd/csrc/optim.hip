@@ -177,6 +177,21 @@ __global__ void increment_kernel(int64_t* c) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1;
 }
 
+// Frozen BatchNorm folded into the convolution epilogues' (scale, bias) for ALL layers of a network in one launch
+// (architectures/deeplab2.py:92-107 with the statistics frozen): the operands are gathered from the flat parameter arena
+// through element-index tables. Same operations and roundings as the tensor expression it replaces -- rsqrt(var + eps),
+// one product, then product and difference rounded separately (no contraction).
+__global__ void bn_fold_kernel(const float* __restrict__ flat, const int64_t* __restrict__ iw, const int64_t* __restrict__ ib,
+                               const int64_t* __restrict__ im, const int64_t* __restrict__ iv, int n, float eps,
+                               float* __restrict__ scale, float* __restrict__ bias) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float r = rsqrtf(__fadd_rn(flat[iv[i]], eps));
+        const float sc = __fmul_rn(flat[iw[i]], r);
+        scale[i] = sc;
+        bias[i] = __fsub_rn(flat[ib[i]], __fmul_rn(flat[im[i]], sc));
+    }
+}
+
 static int check_optim(const cms_optim_desc* d) {
     CMS_REQUIRE(d != nullptr, "optim: null descriptor");
     CMS_REQUIRE(d->param && d->grad && d->slot0 && d->segments && d->chunk_seg && d->chunk_off && d->lrs &&
@@ -221,4 +236,13 @@ extern "C" int cms_increment_counter(int64_t* counter, void* stream) {
     CMS_REQUIRE(counter, "increment_counter: NULL pointer");
     hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter);
     return launch_status("cms_increment_counter");
+}
+
+extern "C" int cms_bn_fold(const float* flat, const int64_t* idx_weight, const int64_t* idx_bias, const int64_t* idx_mean,
+                           const int64_t* idx_var, int n, float eps, float* scale, float* bias, void* stream) {
+    CMS_REQUIRE(flat && idx_weight && idx_bias && idx_mean && idx_var && scale && bias, "bn_fold: NULL pointer");
+    if (n <= 0) return CMS_OK;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(grid_for((size_t)n, 256, 256)), dim3(256), 0, (hipStream_t)stream, flat, idx_weight,
+                       idx_bias, idx_mean, idx_var, n, eps, scale, bias);
+    return launch_status("cms_bn_fold");
 }

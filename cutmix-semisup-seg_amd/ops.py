@@ -825,6 +825,19 @@ def stem_dgrad(ds, w147, scale, x_shape):
     return dx
 
 
+def bn_fold(flat, idx_weight, idx_bias, idx_mean, idx_var, eps, scale, bias):
+    """scale = flat[idx_weight] * rsqrt(flat[idx_var] + eps); bias = flat[idx_bias] - flat[idx_mean] * scale -- frozen BatchNorm of
+    all layers folded in one launch (csrc/optim.hip: cms_bn_fold; deeplab2.py:92-107)."""
+    _need_cuda(flat, idx_weight, idx_bias, idx_mean, idx_var, scale, bias)
+    n = int(scale.numel())
+    if flat.dtype != torch.float32 or scale.dtype != torch.float32 or bias.dtype != torch.float32 \
+            or any(t.dtype != torch.int64 or int(t.numel()) != n or not t.is_contiguous() for t in (idx_weight, idx_bias, idx_mean, idx_var)) \
+            or int(bias.numel()) != n or not (scale.is_contiguous() and bias.is_contiguous() and flat.is_contiguous()):
+        raise TypeError('bn_fold: fp32 arena / outputs and int64 index tables of the outputs\' length required')
+    check(fn['cms_bn_fold'](_ptr(flat), _ptr(idx_weight), _ptr(idx_bias), _ptr(idx_mean), _ptr(idx_var), n, float(eps), _ptr(scale),
+                            _ptr(bias), _stream()), 'cms_bn_fold')
+
+
 # ---------------------------------------------------------------------------------------------- launch programs
 HBM_PEAK_BPS, MFMA_PEAK_FLOPS = 8.0e12, 2.5e15       # MI355X_MICROARCH.md: HBM3E, dense bf16 MFMA
 
@@ -913,7 +926,11 @@ class Program(object):
 
 
 def run_pair(prog_a, streams_a, prog_b, streams_b):
-    """Two programs issued interleaved group by group (student on one stream, teacher on another)."""
+    """Two programs issued interleaved group by group (student on one stream, teacher on another). Programs with host
+    operations between their launches (SyncBN all-reduces) cannot be interleaved from the native side: refused, so that a
+    caller can never drop the exchanges silently (`_BodyPairFn` issues such passes one after the other)."""
+    if prog_a.host_ops or prog_b.host_ops:
+        raise RuntimeError('run_pair: a program with host operations (SyncBN exchanges) must be replayed with Program.run')
     check(fn['cms_program_run_pair'](prog_a.h, Program._handles(streams_a), len(streams_a), prog_b.h,
                                      Program._handles(streams_b), len(streams_b)), 'cms_program_run_pair')
 

@@ -58,6 +58,10 @@ class StepConfig(object):
         # measured: no gain (507 / 509 vs 507 / 505 img/s, profiles/r03eo_*) -- the 0.28 ms HBM-bound update only trades bandwidth
         # with the convolutions it overlaps -- so it is off by default
         self.early_optimizer = bool(early_optimizer)
+        # (round 5) the TAIL version of it: ONE early launch, for everything but the stem's slice, on a third stream as soon as the
+        # body's last weight gradient is enqueued -- the 0.3 ms HBM-bound update then runs beside the max-pool / stem backward
+        # (MFMA / LDS-bound, 0.2 ms) instead of alone behind them; CMS_TAIL_OPT=0 switches it off (A/B)
+        self.tail_optimizer = os.environ.get('CMS_TAIL_OPT', '1') != '0'
         # fused-batch step on the executor: the main stream joins the weight-gradient stream at the optimizer instead of at the
         # end of the body's backward pass (the stem's backward then overlaps layer1's last weight gradients); CMS_DEFER_JOIN=0
         # switches it off (A/B)
@@ -166,6 +170,9 @@ class CutMixMeanTeacherStep(object):
         self.teacher_optim = teacher_optim
         self.cfg = cfg
         self.group = group
+        if group is not None:
+            # the executors' SyncBN exchanges must run over the SAME ranks as the gradient exchange
+            student_net.dist_group = teacher_net.dist_group = group
         self.align_corners = getattr(student_net, 'upsample_align_corners', True)
         cfg.cons.align_corners = self.align_corners
         import torch.distributed as dist
@@ -227,7 +234,9 @@ class CutMixMeanTeacherStep(object):
         as soon as that slice's gradients are final -- [layer4 + head], the two halves of layer3, [layer1 - layer2], at the
         bottlenecks the data-parallel buckets close at -- instead of one 0.28 ms launch after the whole backward pass; the
         stem's slice follows in `student_optim.step()`. Same arithmetic per element, so the results are bit-identical."""
-        if self.world > 1 or not getattr(self.cfg, 'early_optimizer', False) or not hasattr(self.student_optim, 'step_range'):
+        every = getattr(self.cfg, 'early_optimizer', False)
+        if self.world > 1 or not (every or getattr(self.cfg, 'tail_optimizer', False)) \
+                or not hasattr(self.student_optim, 'step_range'):
             return None
         use_hip = getattr(self.student, '_use_hip_body', None)
         if use_hip is None or not use_hip() or not hasattr(self.student.hip_executor(), 'block_grad_offsets'):
@@ -236,7 +245,7 @@ class CutMixMeanTeacherStep(object):
         if not ex.use_programs or not ex._want_w():
             return None
         opt = self.student_optim
-        offs, starts = ex.block_grad_offsets(), set(ex.bucket_starts())
+        offs, starts = ex.block_grad_offsets(), (set(ex.bucket_starts()) if every else {0})
         state = {'hi': int(opt.arena.flat.numel())}
         opt.begin_ranged()
         if self.__dict__.get('_opt_stream') is None:
@@ -251,6 +260,7 @@ class CutMixMeanTeacherStep(object):
                 with torch.cuda.stream(side):
                     opt.step_range(offs[bi], state['hi'])
                 state['hi'] = int(offs[bi])
+        on_block.blocks = starts                  # the executor cuts its recorded backward pass at these bottlenecks only
         ex.grad_hook = on_block
         self._early_armed = True
         return ex
@@ -417,6 +427,8 @@ class CutMixMeanTeacherStep(object):
                                                        cons_weight=cfg.cons_weight, group=self.group)
                     ops.consistency_backward(cctx, sc, grad_lo[s_off:s_off + n])
                     s_off += n
+                    if split and isinstance(sc, torch.Tensor):
+                        sc.record_stream(main)          # allocated on the teacher's stream, read (and freed) on the main one
                     cons_vals.append(sc)
             if split:
                 with torch.cuda.stream(side):

@@ -203,6 +203,13 @@ int cms_adam_ema_step(const cms_optim_desc* d, void* stream);
 int cms_sgd_ema_step(const cms_optim_desc* d, void* stream);
 /* *counter += 1 on the device (keeps the optimizer step counter graph-replayable) */
 int cms_increment_counter(int64_t* counter, void* stream);
+/* Frozen BatchNorm of ALL layers of a network folded into the convolution epilogues' affine in one launch
+ * (architectures/deeplab2.py:92-107, BatchNorm in eval mode: y = (x - mean) / sqrt(var + eps) * weight + bias):
+ *   scale[i] = flat[idx_weight[i]] * rsqrt(flat[idx_var[i]] + eps),  bias[i] = flat[idx_bias[i]] - flat[idx_mean[i]] * scale[i]
+ * `flat`: the fp32 parameter arena; idx_*: n element indices into it (int64, device); every product / difference rounded
+ * separately, like the tensor expression of the reference's modules. */
+int cms_bn_fold(const float* flat, const int64_t* idx_weight, const int64_t* idx_bias, const int64_t* idx_mean,
+                const int64_t* idx_var, int n, float eps, float* scale, float* bias, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Evaluation: fused upsample + argmax + confusion matrix   (train_seg_semisup_mask_mt.py:510-514 ; evaluation.py)

@@ -156,3 +156,48 @@ def test_conv8_two_streams_with_their_own_workspaces(ops):
         for i in range(2):
             d = (outs[i].float() - refs[i].float()).abs()
             assert bool((d <= 2.0 ** -7 * torch.maximum(outs[i].float().abs(), refs[i].float().abs()) + 1e-5).all())
+
+
+# ------------------------------------------------------------------------------------------------- ReLU masks as bits (round 5)
+@pytest.mark.parametrize('shape', [(2, 41, 41, 1024, 256, 1, 1), (2, 41, 41, 256, 256, 3, 2), (1, 9, 13, 128, 512, 3, 1),
+                                   (3, 20, 21, 192, 768, 3, 3)],
+                         ids=['l3 conv1', 'l3 conv2', 'ragged tile, 2 channel tiles', 'tiles 5x3'])
+def test_conv8_relu_mask_bits_written_forward_and_read_by_the_data_gradient(ops, shape):
+    """cms_conv_desc.mask_bits_out / mask_bits on the eight-phase kernel: same bit layout as the 128 x 128 kernel's (one dword
+    per pixel row and 32 channels, bit = channel), outputs bit-identical to the launches that take / re-read the activation."""
+    N, H, W, Cin, Cout, k, dil = shape
+    g = torch.Generator(device=DEV).manual_seed(31 + Cin)
+    pad = dil * (k - 1) // 2
+    x = _mk((N, H, W, Cin), g)
+    w = _pack(_mk((Cout, Cin, k, k), g, (2.0 / (Cin * k * k)) ** 0.5))
+    taps = ops.conv_taps(k, k, dil, pad)
+    scale = torch.rand(Cout, generator=g, device=DEV) + 0.5
+    bias = torch.randn(Cout, generator=g, device=DEV) * 0.2
+    res = _mk((N, H, W, Cout), g)
+    for r in (None, res):
+        y_ref = ops.conv_igemm(x, w, taps, scale=scale, bias=bias, res=r, relu=True, variant=99)
+        bits = torch.full((N, H, W, Cout // 8), 0xAA, dtype=torch.uint8, device=DEV)
+        y = ops.conv_igemm(x, w, taps, scale=scale, bias=bias, res=r, relu=True, mask_bits_out=bits, variant=90)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref)
+        want = (y.float() > 0).view(N, H, W, Cout // 8, 8).to(torch.int32)
+        want = (want * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8)
+        assert torch.equal(bits, want)
+        bits128 = torch.zeros_like(bits)
+        ops.conv_igemm(x, w, taps, scale=scale, bias=bias, res=r, relu=True, mask_bits_out=bits128, variant=0, tile=128)
+        torch.cuda.synchronize()
+        assert torch.equal(bits, bits128)                 # the two kernels of cms_conv_igemm write the same bits
+    # the data gradient of a convolution whose INPUT is y: K = Cd channels of du -> Cout channels of dx, masked by [y > 0]
+    Cd = 1024
+    du = _mk((N, H, W, Cd), g, 0.1)
+    wT = _mk((1, Cout, Cd), g, 0.05)
+    add = _mk((N, H, W, Cout), g)
+    one = ops.conv_taps(1, 1, 1, 0)
+    for r in (None, add):
+        a = ops.conv_igemm(du, wT, one, res=r, mode=1, mask_src=y, variant=99)
+        b = ops.conv_igemm(du, wT, one, res=r, mode=1, mask_bits=bits, variant=90)
+        c = ops.conv_igemm(du, wT, one, res=r, mode=1, mask_bits=bits)                    # the library's own choice of kernel
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and torch.equal(a, c)
+    with pytest.raises(ValueError):
+        ops.conv_igemm(du, wT, one, mode=1, mask_bits=bits, variant=91)                   # stream-K launch: no bits

@@ -253,3 +253,28 @@ def test_eval_and_full_resolution_forward_with_hip_engine():
     for i in range(2):
         ev2.sample(y[i, 0], pred[i].to(torch.uint8), ignore_value=255)
     assert abs(ev.score().mean() - ev2.score().mean()) < 2e-3     # fused vs materialised path (fp ties aside)
+
+
+def test_frozen_batchnorm_fold_kernel_equals_the_tensor_expression():
+    """cms_bn_fold (round 5: one launch for all layers of a network instead of nine tensor ops) against the expression it replaces,
+    scale = gamma * rsqrt(var + eps), bias = beta - mean * scale (deeplab2.py:92-107 with frozen statistics): bit for bit."""
+    from cutmix_semisup_seg_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    flat = torch.randn(50000, generator=g, device=DEV)
+    n = 7777
+    ix = {k: torch.randint(0, 50000, (n,), generator=g, device=DEV) for k in ('w', 'b', 'm', 'v')}
+    flat[ix['v']] = flat[ix['v']].abs() + 1e-3                       # variances
+    scale, bias = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    ops.bn_fold(flat, ix['w'], ix['b'], ix['m'], ix['v'], 1e-5, scale, bias)
+    want_s = flat[ix['w']] * torch.rsqrt(flat[ix['v']] + 1e-5)
+    want_b = flat[ix['b']] - flat[ix['m']] * want_s
+    torch.cuda.synchronize()
+    assert torch.equal(scale, want_s) and torch.equal(bias, want_b)
+    # ... and through the executor: the folded affine of a real network
+    net = _build([1, 1, 1, 1], 5, 'hip')
+    ex = net.hip_executor()
+    ex._refresh_affine()
+    bn = net.layer3[0].bn2
+    s = bn.weight * torch.rsqrt(bn.running_var + 1e-5)
+    c = ex.blocks[ex.layer_first_blocks()[2]].c2
+    assert torch.equal(c.scale, s) and torch.equal(c.bias, bn.bias - bn.running_mean * s)

@@ -351,19 +351,36 @@ def test_which_convolutions_of_the_v3plus_head_are_routed_to_the_mfma_kernels():
         def __init__(self, shape, dtype=torch.bfloat16, cuda=True):
             self.shape, self.dtype, self.is_cuda = shape, dtype, cuda
 
+    from cutmix_semisup_seg_amd import backbone_hip
     head = d3.DeepLabHeadV3Plus(2048, 256, 21)
     x65 = lambda c: FakeCuda((10, c, 65, 65))
-    assert all(hip_conv2d_eligible(x65(2048), head.aspp.convs[i][0]) for i in range(4))     # 1x1 + three dilated 3x3
-    assert hip_conv2d_eligible(x65(1280), head.aspp.project[0])
-    assert hip_conv2d_eligible(FakeCuda((10, 304, 129, 129)), head.classifier[0])            # padded to 320 channels
-    assert hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.classifier[3])
-    assert not hip_conv2d_eligible(FakeCuda((10, 2048, 1, 1)), head.aspp.convs[4][1])        # pooled branch: 1 pixel
-    assert hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.project[0])               # 48 outputs, padded to 64
-    assert not hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.classifier[6])        # bias, 21 outputs
-    assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), torch.float32), head.aspp.convs[1][0])
-    assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), cuda=False), head.aspp.convs[1][0])
     stem = torch.nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
-    assert not hip_conv2d_eligible(FakeCuda((10, 3, 513, 513)), stem)
+    grouped = torch.nn.Conv2d(64, 64, 3, padding=1, groups=2, bias=False)
+    saved = backbone_hip._auto_keeps_library.__dict__.get('v')
+    try:
+        # round 5 default: 'auto' sends EVERY convolution the general hand-written path can express to it -- the pooled
+        # branch's 1 x 1-map GEMM (the last library kernel of the cfg 4 step), strided layers, the 7 x 7 stem included
+        backbone_hip._auto_keeps_library.__dict__['v'] = False
+        assert all(hip_conv2d_eligible(x65(2048), head.aspp.convs[i][0]) for i in range(4))
+        assert hip_conv2d_eligible(FakeCuda((10, 2048, 1, 1)), head.aspp.convs[4][1])
+        assert hip_conv2d_eligible(FakeCuda((10, 3, 513, 513)), stem)
+        assert hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), torch.float32), head.aspp.convs[1][0], torch.float32)
+        assert not hip_conv2d_eligible(FakeCuda((10, 64, 65, 65)), grouped)                  # no hand-written grouped convolution
+        assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), torch.float32), head.aspp.convs[1][0])      # engine dtype differs
+        assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), cuda=False), head.aspp.convs[1][0])
+        # CMS_AUTO_LIBRARY=1: the rule of rounds 2-4 (A/B switch)
+        backbone_hip._auto_keeps_library.__dict__['v'] = True
+        assert all(hip_conv2d_eligible(x65(2048), head.aspp.convs[i][0]) for i in range(4))     # 1x1 + three dilated 3x3
+        assert hip_conv2d_eligible(x65(1280), head.aspp.project[0])
+        assert hip_conv2d_eligible(FakeCuda((10, 304, 129, 129)), head.classifier[0])            # padded to 320 channels
+        assert hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.classifier[3])
+        assert not hip_conv2d_eligible(FakeCuda((10, 2048, 1, 1)), head.aspp.convs[4][1])        # pooled branch: 1 pixel
+        assert hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.project[0])               # 48 outputs, padded to 64
+        assert not hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.classifier[6])        # bias, 21 outputs
+        assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), torch.float32), head.aspp.convs[1][0])
+        assert not hip_conv2d_eligible(FakeCuda((10, 3, 513, 513)), stem)
+    finally:
+        backbone_hip._auto_keeps_library.__dict__['v'] = saved
 
 
 def test_v3plus_engine_selection_flags():
@@ -380,7 +397,9 @@ def test_v3plus_engine_selection_flags():
     w.engine_kind = 'torch'
     assert not w._use_hip_backbone()
     w.engine_kind, w.compute_dtype = 'auto', torch.float32
-    assert not w._use_hip_backbone()
+    assert w._use_hip_backbone()                           # round 5: 'auto' in fp32 is the hand-written fp32 configuration too
+    w.engine_kind = 'hip_nograd'
+    assert not w._use_hip_backbone()                       # (fp32 + 'hip_nograd': not a configuration of the executor)
 
 
 # ------------------------------------------------------------------------------------------------------------------
