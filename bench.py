@@ -121,6 +121,8 @@ def measure_traffic(key):
         return {'traffic': None, 'traffic_source': 'rocprofv3 not found'}
     kb = {}
     launches = 0
+    per_kernel = {}            # rocprofv3 kernel name -> {counter: [sum of KB, launches]}
+    sub_by_kernel = None       # algorithmic bytes per kernel of the profiled (serial-stream) run itself, from its own JSON line
     tmp = tempfile.mkdtemp(prefix='cms_pmc_', dir='/tmp')
     try:
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -133,8 +135,21 @@ def measure_traffic(key):
             vals = []
             for f in glob.glob(os.path.join(outdir, '**', '*counter_collection.csv'), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if row.get('Counter_Name') == counter and ('conv_igemm' in row.get('Kernel_Name', '') or 'conv8_kernel' in row.get('Kernel_Name', '')):
+                    if row.get('Counter_Name') != counter:
+                        continue
+                    kn = row.get('Kernel_Name', '')
+                    if 'conv_igemm' in kn or 'conv8_kernel' in kn:
                         vals.append(float(row['Counter_Value']))
+                    if 'cms::' in kn:
+                        acc = per_kernel.setdefault(kn, {}).setdefault(counter, [0.0, 0])
+                        acc[0] += float(row['Counter_Value']); acc[1] += 1
+            if sub_by_kernel is None:
+                for line in r.stdout.decode(errors='replace').splitlines():
+                    if line.startswith('{"metric"'):
+                        try:
+                            sub_by_kernel = json.loads(line)['roofline'].get('by_kernel')
+                        except Exception:              # noqa: BLE001
+                            sub_by_kernel = None
             if r.returncode != 0 or not vals:
                 return {'traffic': None, 'traffic_source': 'rocprofv3 --pmc {} pass gave no conv_igemm rows (rc {})'.format(
                     counter, r.returncode)}
@@ -145,7 +160,20 @@ def measure_traffic(key):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     traffic = (2.0 * kb['FETCH_SIZE'] + kb['WRITE_SIZE']) * 1024.0
-    return {'traffic': traffic, 'traffic_launches': launches,
+    # per kernel: counter bytes per launch beside the algorithmic bytes per launch of the SAME (serial-stream) run -> which
+    # kernel over-fetches (ratio > 1: re-reads of tiles from HBM, partial-line writes; < 1: operands served by the L2 / MALL)
+    by_kernel = {}
+    for kn, cs in per_kernel.items():
+        if 'FETCH_SIZE' not in cs or 'WRITE_SIZE' not in cs:
+            continue
+        pmc = (2.0 * cs['FETCH_SIZE'][0] / cs['FETCH_SIZE'][1] + cs['WRITE_SIZE'][0] / cs['WRITE_SIZE'][1]) * 1024.0
+        entry = {'pmc_bytes_per_launch': pmc, 'launches': cs['FETCH_SIZE'][1]}
+        for route, info in (sub_by_kernel or {}).items():
+            if route in kn:
+                entry['algorithmic_bytes_per_launch'] = info['algorithmic_bytes_per_launch']
+                entry['ratio'] = pmc / max(info['algorithmic_bytes_per_launch'], 1.0)
+        by_kernel[kn[:100]] = entry
+    return {'traffic': traffic, 'traffic_launches': launches, 'traffic_by_kernel': by_kernel,
             'traffic_fetch_kb_per_launch': kb['FETCH_SIZE'], 'traffic_write_kb_per_launch': kb['WRITE_SIZE'],
             'traffic_source': 'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes of '
                               'bench.py --workload {} --steps 2 --no_overlap), averaged over the conv_igemm_* / conv8_kernel launches; gfx950: '
@@ -409,6 +437,14 @@ def run_workload(key, args, world, rank, dev):
                 tot[kk] += e.issued.get(kk, 0.0)
         return tot
 
+    def by_route():
+        tot = {}
+        for e in executors():
+            for k, v in e.issued.get('by_route', {}).items():
+                r = tot.setdefault(k, [0, 0.0, 0.0])
+                r[0] += v[0]; r[1] += v[1]; r[2] += v[2]
+        return tot
+
     def one_step(i):
         b = pool[i % len(pool)]
         ranges = ops.ranges_to_device(boxgen.generate_ranges(B, (H, W), rng=mask_rng), dev)
@@ -426,6 +462,7 @@ def run_workload(key, args, world, rank, dev):
         read_timing()                                # drop whatever the warm-up left
         arm_timing(sample_every if roofline_kernel == 'conv' else 0)
         issued0 = issued()
+        route0 = by_route()
         t0 = time.perf_counter()
         for i in range(args.steps):
             res = one_step(i)
@@ -441,6 +478,8 @@ def run_workload(key, args, world, rank, dev):
         prog_t = read_timing()
         issued1 = issued()
         prog_i = {k: issued1[k] - issued0[k] for k in issued1}
+        route1 = by_route()
+        routes = {k: [v[j] - route0.get(k, [0, 0.0, 0.0])[j] for j in range(3)] for k, v in route1.items()}
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -582,6 +621,12 @@ def run_workload(key, args, world, rank, dev):
                          'sampling': 'every launch' if args.roofline_sample <= 1 else
                                      'every {}th launch'.format(args.roofline_sample)},
         }
+        if routes:
+            # algorithmic work per KERNEL of the recorded launches (the library's own routing, cms_conv_igemm_route /
+            # cms_conv_wgrad_uses_wgrad8): what `traffic_by_kernel` puts beside the PMC counters
+            out['roofline']['by_kernel'] = {k: {'launches_per_step': v[0] / args.steps,
+                                                'algorithmic_bytes_per_launch': v[1] / max(v[0], 1),
+                                                'flops_per_launch': v[2] / max(v[0], 1)} for k, v in sorted(routes.items()) if v[0] > 0}
         if roofline_kernel == 'conv' and timed['launches']:
             out['roofline']['algorithmic_bytes_per_launch'] = timed['bytes'] / timed['launches']
             if key == 'pascal' and getattr(args, 'traffic', 'omit') == 'measure' and world == 1:

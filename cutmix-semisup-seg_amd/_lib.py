@@ -140,6 +140,7 @@ PROTOTYPES = {
     'cms_confusion': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
     'cms_conv_igemm': (c_int, [_P(ConvDesc), c_void_p]),
     'cms_conv_igemm_workspace_bytes': (C.c_longlong, []),
+    'cms_conv_igemm_route': (c_int, [_P(ConvDesc)]),
     'cms_conv_set_trace': (c_int, [c_void_p, c_int]),
     'cms_conv_set_wgrad8': (c_int, [c_int]),
     'cms_loss_set_deterministic': (c_int, [c_int]),

@@ -615,6 +615,10 @@ class DeepLabHipExecutor(object):
         i['head_bytes'] += prog.head_bytes
         i['head_bytes_alg'] += prog.head_bytes_alg
         i['floor_s'] += prog.floor_s
+        br = i.setdefault('by_route', {})
+        for k, v in prog.by_route.items():
+            r = br.setdefault(k, [0, 0.0, 0.0])
+            r[0] += v[0]; r[1] += v[1]; r[2] += v[2]
 
     def forward(self, x, save):
         """-> (logits fp32 NCHW, token for `backward`)."""

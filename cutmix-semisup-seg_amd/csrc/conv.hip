@@ -1138,6 +1138,46 @@ extern "C" long long cms_conv_igemm_workspace_bytes(void) {
     return (long long)cms::conv8_workspace_bytes(n_cu);
 }
 
+// Would the default dispatch (variant 0, tile 0) send this launch to the eight-phase kernel?
+static bool conv_takes_conv8(const cms_conv_desc* d) {
+    return d->variant == 0 && d->tile == 0 && conv8_env(0) > 0 && cms::conv8_supported(d) &&
+           ((d->mask_bits == nullptr && d->mask_bits_out == nullptr) || conv8_env(0) == 1) &&     // (bits: whole tiles only)
+           d->ntaps * (d->cin / 64) >= conv8_env(1) && conv_default_variant() == 0 &&
+           ((conv8_env(3) >> (d->mode == 0 ? 0 : 1)) & 1);
+}
+
+static int conv_mixed_env() {                       // balanced launch; CMS_CONV_MIXED=0 switches it off (A/B, read once)
+    static int env_mixed = -1;
+    if (env_mixed < 0) {
+        const char* e = getenv("CMS_CONV_MIXED");
+        env_mixed = e ? atoi(e) : 1;
+    }
+    return env_mixed;
+}
+
+// Which kernel cms_conv_igemm runs a descriptor on (measurement tooling: per-kernel algorithmic bytes beside the PMC
+// counters): CMS_ROUTE_CONV8 = conv8_kernel, CMS_ROUTE_MIXED = conv_igemm_mixed_kernel (balanced 128 x 128
+// launch), CMS_ROUTE_TILE128 = conv_igemm_kernel<2,2,2,2>, CMS_ROUTE_TILE64 / _TILE32 = the 64- / 32-channel tiles,
+// CMS_ROUTE_OTHER = an explicit variant / tile request. Negative: the descriptor is invalid.
+extern "C" int cms_conv_igemm_route(const cms_conv_desc* d) {
+    int rc = conv_check(d);
+    if (rc) return rc;
+    if (d->variant != 0 || d->tile != 0 || conv_default_variant() != 0) return CMS_ROUTE_OTHER;
+    if (conv_takes_conv8(d)) return CMS_ROUTE_CONV8;
+    if (d->cout % 128 == 0) {
+        const bool small = (size_t)d->n * d->h * d->w_in * d->cin * 2 < (1ull << 31) &&
+                           (size_t)d->ntaps * d->cout * d->cin * 2 < (1ull << 31);
+        const int M = d->n * d->ho * d->wo;
+        const int ntn = d->cout / 128, mtiles = (M + 127) / 128, total = mtiles * ntn;
+        const int rounds = total / 256, rem = total % 256;
+        if (conv_mixed_env() != 0 && d->zeros != nullptr && small && d->ksplit <= 1 && 256 % ntn == 0 && rounds >= 1 && rounds <= 9 &&
+            rem > 0 && rem <= 100)
+            return CMS_ROUTE_MIXED;
+        return CMS_ROUTE_TILE128;
+    }
+    return d->cout % 64 == 0 ? CMS_ROUTE_TILE64 : CMS_ROUTE_TILE32;
+}
+
 extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
     int rc = conv_check(d_in);
     if (rc) return rc;
@@ -1149,10 +1189,7 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
         d_no8 = *d_in;
         d_no8.variant = 0;
         d_in = &d_no8;
-    } else if (d_in->variant == 0 && d_in->tile == 0 && conv8_env(0) > 0 && cms::conv8_supported(d_in) &&
-        ((d_in->mask_bits == nullptr && d_in->mask_bits_out == nullptr) || conv8_env(0) == 1) &&     // (bits: whole tiles only)
-        d_in->ntaps * (d_in->cin / 64) >= conv8_env(1) && conv_default_variant() == 0 &&
-        ((conv8_env(3) >> (d_in->mode == 0 ? 0 : 1)) & 1))
+    } else if (conv_takes_conv8(d_in))
         return cms::conv8_launch(d_in, (hipStream_t)stream, conv8_env(0) - 1, conv8_env(2), nullptr, 0);
     cms_conv_desc d_copy;
     const cms_conv_desc* d = d_in;
@@ -1320,11 +1357,7 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
         CMS_REQUIRE(d->cout % 128 == 0, "conv: tile 128 needs Cout %% 128 == 0");
         // balanced launch (conv_igemm_mixed_kernel): when the 128 x 128 grid is a few workgroups more than a multiple of
         // the 256 CUs, those few are cut into 32-channel slices. CMS_CONV_MIXED=0 switches it off (A/B).
-        static int env_mixed = -1;
-        if (env_mixed < 0) {
-            const char* e = getenv("CMS_CONV_MIXED");
-            env_mixed = e ? atoi(e) : 1;
-        }
+        const int env_mixed = conv_mixed_env();
         const int ntn = d->cout / 128, mtiles = (a.M + 127) / 128, total = mtiles * ntn;
         const int rounds = total / 256, rem = total % 256;
         if (env_mixed != 0 && tile == 0 && d->variant == 0 && (glds == 4 || glds == 1) && a.ksplit == 1 && 256 % ntn == 0 &&

@@ -65,6 +65,7 @@ struct ConsPixel {
     bool m;
     float um;
     const float* tea;
+    int which;          // 0: l_tea0, 1: l_tea1 -- for callers that read the teacher logits from an LDS copy
 };
 
 __device__ __forceinline__ ConsPixel cons_pixel_inputs(const ConsArgs& a, int n, int y, int x) {
@@ -80,14 +81,126 @@ __device__ __forceinline__ ConsPixel cons_pixel_inputs(const ConsArgs& a, int n,
     if (d.mode == MODE_MIX) {
         // paste of teacher logits and of the validity masks with the same box mask (:351, :363)
         p.tea = (p.m ? d.l_tea1 : d.l_tea0) + sample;
+        p.which = p.m ? 1 : 0;
         const float* um = p.m ? d.um1 : d.um0;
         p.um = um ? um[pix] : 1.0f;
     } else {
         // cut mode: loss_mask = cut_mask * um (:401)
         p.tea = d.l_tea0 + sample;
+        p.which = 0;
         p.um = p.m ? (d.um0 ? d.um0[pix] : 1.0f) : 0.0f;
     }
     return p;
+}
+
+// ---- LDS-staged low-resolution patches (round 5) ---------------------------------------------------------------
+// A workgroup owns a tile of output pixels of ONE sample; the bilinear taps of the whole tile fall into a small rectangle
+// of low-resolution cells (3 rows x 11 columns at the 1/8 scale of the DeepLab heads). The kernels used to gather every tap
+// of every class of every pixel from global memory (168 four-byte loads per pixel for 21 classes and two tensors: latency-
+// bound, 0.07-0.08 of the HBM rate on moved bytes); now the rectangle of each logit tensor is copied to LDS once
+// per workgroup, [class][row][column], and the per-pixel gathers read it there with the taps rebased -- the same arithmetic
+// (bilin_gather) on the same values, so every per-pixel result is bit-identical.
+constexpr int TILE_W = 64;
+constexpr int FWD_TILE_H = 8;               // forward kernels: 64 x 8 pixels per workgroup, 2 per thread
+struct Patch {
+    int x_lo, n_cols, y_lo, n_rows;
+};
+
+__device__ __forceinline__ Patch tile_patch(const Geo& g, int x0, int y0, int tw, int th) {
+    // i0 / i1 are monotone in the output coordinate: the first pixel's i0 and the last pixel's i1 bound the rectangle
+    const Tap xa = bilin_tap(x0, g.sx, g.w, g.align != 0), xb = bilin_tap(x0 + tw - 1, g.sx, g.w, g.align != 0);
+    const Tap ya = bilin_tap(y0, g.sy, g.h, g.align != 0), yb = bilin_tap(y0 + th - 1, g.sy, g.h, g.align != 0);
+    Patch p;
+    p.x_lo = xa.i0; p.n_cols = xb.i1 - xa.i0 + 1;
+    p.y_lo = ya.i0; p.n_rows = yb.i1 - ya.i0 + 1;
+    return p;
+}
+
+// dst[c][r][j] = src[c][y_lo + r][x_lo + j] for the C class planes of one sample (`src` = its class-0 plane)
+__device__ __forceinline__ void stage_patch(float* __restrict__ dst, const float* __restrict__ src, int C, size_t plane, int w,
+                                            const Patch& p) {
+    const int per = p.n_rows * p.n_cols, total = C * per;
+    for (int i = (int)threadIdx.x; i < total; i += (int)blockDim.x) {
+        const int c = i / per, rj = i - c * per;
+        const int r = rj / p.n_cols, j = rj - r * p.n_cols;
+        dst[i] = src[(size_t)c * plane + (size_t)(p.y_lo + r) * w + (p.x_lo + j)];
+    }
+}
+
+__device__ __forceinline__ void rebase(Tap& ty, Tap& tx, const Patch& p) {
+    ty.i0 -= p.y_lo; ty.i1 -= p.y_lo;
+    tx.i0 -= p.x_lo; tx.i1 -= p.x_lo;
+}
+
+inline int tile_max_cols(float sx) { return (int)((TILE_W - 1) * sx) + 3; }
+inline int tile_max_rows_of(float sy, int tile_h) { return (int)((tile_h - 1) * sy) + 3; }
+inline size_t patch_floats(int C, float sy, float sx, int tile_h) {
+    return (size_t)C * tile_max_rows_of(sy, tile_h) * tile_max_cols(sx);
+}
+constexpr size_t FWD_PATCH_LDS_MAX = 96 * 1024;      // beyond (scales near 1 with many classes): the direct-gather kernels
+
+template <int CT>
+__global__ __launch_bounds__(256) void cons_fwd_tiled_kernel(ConsArgs a, float* __restrict__ partials, int patch_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Geo& g = a.g;
+    const int tiles_x = (g.W + TILE_W - 1) / TILE_W, tiles_y = (g.H + FWD_TILE_H - 1) / FWD_TILE_H;
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x;
+    b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int x0 = tx_i * TILE_W, y0 = ty_i * FWD_TILE_H;
+    const int tw = min(TILE_W, g.W - x0), th = min(FWD_TILE_H, g.H - y0);
+    const Patch p = tile_patch(g, x0, y0, tw, th);
+    const size_t plane = (size_t)g.h * g.w;
+    float* Ps = smem;
+    float* Pt0 = smem + patch_stride;
+    float* Pt1 = smem + 2 * patch_stride;
+    const size_t sample = (size_t)n * g.c * plane;
+    stage_patch(Ps, a.d.l_stu + sample, g.c, plane, g.w, p);
+    stage_patch(Pt0, a.d.l_tea0 + sample, g.c, plane, g.w, p);
+    if (a.d.mode == MODE_MIX) stage_patch(Pt1, a.d.l_tea1 + sample, g.c, plane, g.w, p);
+    __syncthreads();
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    const int col = threadIdx.x & (TILE_W - 1);
+#pragma unroll 1
+    for (int rr = 0; rr < FWD_TILE_H / 4; ++rr) {
+        const int row = (threadIdx.x >> 6) + rr * 4;
+        if (col < tw && row < th) {
+            const int y = y0 + row, x = x0 + col;
+            const ConsPixel px = cons_pixel_inputs(a, n, y, x);
+            Gather<false> gs, gt;
+            gs.base = Ps;
+            gt.base = px.which ? Pt1 : Pt0;
+            gs.plane = gt.plane = (size_t)p.n_rows * p.n_cols;
+            gs.w_in = gt.w_in = p.n_cols;
+            Tap ty = bilin_tap(y, g.sy, g.h, g.align != 0), tx = bilin_tap(x, g.sx, g.w, g.align != 0);
+            rebase(ty, tx, p);
+            gs.ty = gt.ty = ty;
+            gs.tx = gt.tx = tx;
+            PixelFwd r;
+            if (CT > 0) {
+                RegVec<CT> rs, rt;
+                fill<CT, false>(rs, gs);
+                fill<CT, false>(rt, gt);
+                r = consistency_pixel_fwd<CT>(rs, rt, g.c, a.d.loss_fn, a.inv_root_c);
+            } else {
+                r = consistency_pixel_fwd<0>(gs, gt, g.c, a.d.loss_fn, a.inv_root_c);
+            }
+            const float lm = r.loss * px.um;
+            const float cf = (a.tau > 0.0f && r.conf >= a.tau) ? 1.0f : 0.0f;
+            acc[0] += lm;
+            acc[1] += lm * cf;
+            acc[2] += cf;
+        }
+    }
+    __shared__ float red[3 * 16];
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 3 + 0] = acc[0];
+        partials[blockIdx.x * 3 + 1] = acc[1];
+        partials[blockIdx.x * 3 + 2] = acc[2];
+    }
 }
 
 template <int CT, bool IDENT>
@@ -249,14 +362,14 @@ __global__ __launch_bounds__(256) void cons_bwd_ident_kernel(ConsArgs a, const f
 // an order that changes from run to run, the tile grid is issued as kx * ky COLOUR classes, one launch each, in a fixed
 // order on the stream: within a launch every cell receives exactly one add (round 3: the logit gradients, and with them
 // every weight gradient downstream, are run-to-run reproducible).
-constexpr int TILE_W = 64;
 #ifndef CMS_LOSS_TILE_H
-#define CMS_LOSS_TILE_H 8
+#define CMS_LOSS_TILE_H 4
 #endif
 constexpr int TILE_H = CMS_LOSS_TILE_H;     // 4 or 8 (256 threads = 64 columns x 4 rows, TILE_H / 4 pixels per thread). Measured with 4
                                             // (half the LDS, twice the workgroups): consistency / CE backward 205 -> 160 / 170 -> 120 us,
                                             // the step unchanged (620.4 vs 619.4 img/s, profiles/r04zw_*): these launches run beside the
-                                            // operand re-pack and are no longer what the step waits for
+                                            // operand re-pack and are no longer what the step waits for. Round 5: 4 is the default --
+                                            // with the logit rectangles staged in LDS next to G and R a 4-row tile keeps 4 workgroups per CU
 constexpr int G_LD = TILE_W + 1;  // +1 float: conflict-free column access for class-major readers
 
 struct TileTables {
@@ -268,17 +381,17 @@ struct TileTables {
     int xbeg[TILE_W + 2], xend[TILE_W + 2];
 };
 
-inline int tile_max_cols(float sx) { return (int)((TILE_W - 1) * sx) + 3; }
-inline int tile_max_rows(float sy) { return (int)((TILE_H - 1) * sy) + 3; }
+inline int tile_max_rows(float sy) { return tile_max_rows_of(sy, TILE_H); }
 
-inline size_t tile_lds_bytes(int C, float sy, float sx) {
+// G + R + `n_patches` staged logit rectangles (student / teacher 0 / teacher 1, or the one tensor of the cross entropy)
+inline size_t tile_lds_bytes(int C, float sy, float sx, int n_patches) {
     size_t g = (size_t)TILE_H * C * G_LD;
     size_t r = (size_t)TILE_H * C * tile_max_cols(sx);
-    return (g + r) * sizeof(float);
+    return (g + r + (size_t)n_patches * patch_floats(C, sy, sx, TILE_H)) * sizeof(float);
 }
 
-template <class PixelGrad>
-__device__ __forceinline__ void tiled_scatter(const Geo& g, PixelGrad pixel_grad, float* __restrict__ grad_lo,
+template <class Stage, class PixelGrad>
+__device__ __forceinline__ void tiled_scatter(const Geo& g, Stage stage, PixelGrad pixel_grad, float* __restrict__ grad_lo,
                                               float* smem) {
     __shared__ TileTables tb;
     const int tiles_x = (g.W + TILE_W - 1) / TILE_W;
@@ -331,6 +444,12 @@ __device__ __forceinline__ void tiled_scatter(const Geo& g, PixelGrad pixel_grad
 
     float* G = smem;                                 // [TILE_H][C][G_LD]
     float* R = smem + (size_t)TILE_H * C * G_LD;     // [TILE_H][C][n_cols]
+    // (round 5) phase 0: the tile's rectangle of every logit tensor -> LDS behind G and R; phase 1 gathers from there
+    Patch patch;
+    patch.x_lo = tb.x_lo; patch.n_cols = tb.n_cols; patch.y_lo = tb.y_lo; patch.n_rows = tb.n_rows;
+    float* P = R + (size_t)TILE_H * C * tb.n_cols;
+    stage(n, patch, P);
+    __syncthreads();
 
     // phase 1
     const int col = tid & (TILE_W - 1);
@@ -344,7 +463,8 @@ __device__ __forceinline__ void tiled_scatter(const Geo& g, PixelGrad pixel_grad
             Tap ty, tx;
             ty.i0 = tb.yi0[row]; ty.i1 = tb.yi1[row]; ty.w1 = tb.yw1[row]; ty.w0 = 1.0f - ty.w1;
             tx.i0 = tb.xi0[col]; tx.i1 = tb.xi1[col]; tx.w1 = tb.xw1[col]; tx.w0 = 1.0f - tx.w1;
-            wrote = pixel_grad(n, y0 + row, x0 + col, ty, tx, [&](int k, float v) { gcol[(size_t)k * G_LD] = v; });
+            rebase(ty, tx, patch);
+            wrote = pixel_grad(n, y0 + row, x0 + col, ty, tx, patch, P, [&](int k, float v) { gcol[(size_t)k * G_LD] = v; });
         }
         if (!wrote) {
             for (int k = 0; k < C; ++k) gcol[(size_t)k * G_LD] = 0.0f;
@@ -446,22 +566,30 @@ inline void tiled_launches(Geo g, F launch) {
 
 template <int CT>
 __global__ __launch_bounds__(256) void cons_bwd_tiled_kernel(ConsArgs a, const float* __restrict__ scalars,
-                                                             float* __restrict__ grad) {
+                                                             float* __restrict__ grad, int patch_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Geo& g = a.g;
     const float gscale = scalars[2];
     const size_t plane = (size_t)g.h * g.w;
     const bool pp = a.tau > 0.0f && a.d.conf_per_pixel;
-    auto pixel_grad = [&](int n, int y, int x, const Tap& ty, const Tap& tx, auto emit) -> bool {
+    // LDS copies of the tile's logit rectangles: student | teacher 0 | teacher 1, `pstride` floats apart
+    const int pstride = patch_stride;
+    auto stage = [&](int n, const Patch& p, float* P) {
+        const size_t sample = (size_t)n * g.c * plane;
+        stage_patch(P, a.d.l_stu + sample, g.c, plane, g.w, p);
+        stage_patch(P + pstride, a.d.l_tea0 + sample, g.c, plane, g.w, p);
+        if (a.d.mode == MODE_MIX) stage_patch(P + 2 * pstride, a.d.l_tea1 + sample, g.c, plane, g.w, p);
+    };
+    auto pixel_grad = [&](int n, int y, int x, const Tap& ty, const Tap& tx, const Patch& p, const float* P, auto emit) -> bool {
         const ConsPixel px = cons_pixel_inputs(a, n, y, x);
         const float base_f = gscale * px.um;
         // (no early-out on base_f == 0, see cons_bwd_ident_kernel)
         Gather<false> gs, gt;
-        gs.base = a.d.l_stu + (size_t)n * g.c * plane;
-        gt.base = px.tea;
-        gs.plane = gt.plane = plane;
-        gs.w_in = gt.w_in = g.w;
-        gs.ty = gt.ty = ty;
+        gs.base = P;
+        gt.base = P + (px.which ? 2 * pstride : pstride);
+        gs.plane = gt.plane = (size_t)p.n_rows * p.n_cols;
+        gs.w_in = gt.w_in = p.n_cols;
+        gs.ty = gt.ty = ty;                      // (taps already rebased to the rectangle)
         gs.tx = gt.tx = tx;
         if (CT > 0) {
             RegVec<CT> rs, rt;
@@ -482,7 +610,7 @@ __global__ __launch_bounds__(256) void cons_bwd_tiled_kernel(ConsArgs a, const f
         }
         return true;
     };
-    tiled_scatter(g, pixel_grad, grad, smem);
+    tiled_scatter(g, stage, pixel_grad, grad, smem);
 }
 
 // ------------------------------------------------------------------------------------------------ cross entropy
@@ -541,6 +669,62 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(CeArgs a, float* __restrict
     }
 }
 
+template <int CT>
+__global__ __launch_bounds__(256) void ce_fwd_tiled_kernel(CeArgs a, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Geo& g = a.g;
+    const int tiles_x = (g.W + TILE_W - 1) / TILE_W, tiles_y = (g.H + FWD_TILE_H - 1) / FWD_TILE_H;
+    int b = blockIdx.x;
+    const int tx_i = b % tiles_x;
+    b /= tiles_x;
+    const int ty_i = b % tiles_y;
+    const int n = b / tiles_y;
+    const int x0 = tx_i * TILE_W, y0 = ty_i * FWD_TILE_H;
+    const int tw = min(TILE_W, g.W - x0), th = min(FWD_TILE_H, g.H - y0);
+    const Patch p = tile_patch(g, x0, y0, tw, th);
+    const size_t plane = (size_t)g.h * g.w;
+    stage_patch(smem, a.d.logits + (size_t)n * g.c * plane, g.c, plane, g.w, p);
+    __syncthreads();
+    float acc[2] = {0.0f, 0.0f};
+    const int col = threadIdx.x & (TILE_W - 1);
+#pragma unroll
+    for (int rr = 0; rr < FWD_TILE_H / 4; ++rr) {
+        const int row = (threadIdx.x >> 6) + rr * 4;
+        if (col < tw && row < th) {
+            const int y = y0 + row, x = x0 + col;
+            const int label = load_label(a, ((size_t)n * g.H + y) * g.W + x);
+            if (!(label == a.d.ignore_index || label < 0 || label >= g.c)) {
+                Gather<false> gl;
+                gl.base = smem;
+                gl.plane = (size_t)p.n_rows * p.n_cols;
+                gl.w_in = p.n_cols;
+                Tap ty = bilin_tap(y, g.sy, g.h, g.align != 0), tx = bilin_tap(x, g.sx, g.w, g.align != 0);
+                rebase(ty, tx, p);
+                gl.ty = ty;
+                gl.tx = tx;
+                float v;
+                if (CT > 0) {
+                    RegVec<CT> r;
+                    fill<CT, false>(r, gl);
+                    float mx, z;
+                    softmax_stats<CT>(r, g.c, mx, z);
+                    v = -((gl(label) - mx) - logf(z));   // label is a run-time index: re-gather instead of indexing registers
+                } else {
+                    v = ce_pixel_fwd<0>(gl, g.c, label);
+                }
+                acc[0] += v;
+                acc[1] += 1.0f;
+            }
+        }
+    }
+    __shared__ float red[2 * 16];
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 2 + 0] = acc[0];
+        partials[blockIdx.x * 2 + 1] = acc[1];
+    }
+}
+
 __global__ void ce_finalize_kernel(const double* __restrict__ stats, float weight, float* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     out[0] = (float)(stats[0] / stats[1]);
@@ -584,15 +768,18 @@ __global__ __launch_bounds__(256) void ce_bwd_tiled_kernel(CeArgs a, const float
     const Geo& g = a.g;
     const float gscale = scalars[1];
     const size_t plane = (size_t)g.h * g.w;
-    auto pixel_grad = [&](int n, int y, int x, const Tap& ty, const Tap& tx, auto emit) -> bool {
+    auto stage = [&](int n, const Patch& p, float* P) {
+        stage_patch(P, a.d.logits + (size_t)n * g.c * plane, g.c, plane, g.w, p);
+    };
+    auto pixel_grad = [&](int n, int y, int x, const Tap& ty, const Tap& tx, const Patch& p, const float* P, auto emit) -> bool {
         const size_t pix = ((size_t)n * g.H + y) * g.W + x;
         const int label = load_label(a, pix);
         if (label == a.d.ignore_index || label < 0 || label >= g.c) return false;
         Gather<false> gl;
-        gl.base = a.d.logits + (size_t)n * g.c * plane;
-        gl.plane = plane;
-        gl.w_in = g.w;
-        gl.ty = ty;
+        gl.base = P;
+        gl.plane = (size_t)p.n_rows * p.n_cols;
+        gl.w_in = p.n_cols;
+        gl.ty = ty;                              // (taps already rebased to the rectangle)
         gl.tx = tx;
         if (CT > 0) {
             RegVec<CT> r;
@@ -603,7 +790,7 @@ __global__ __launch_bounds__(256) void ce_bwd_tiled_kernel(CeArgs a, const float
         }
         return true;
     };
-    tiled_scatter(g, pixel_grad, grad, smem);
+    tiled_scatter(g, stage, pixel_grad, grad, smem);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -641,6 +828,27 @@ static ConsArgs make_cons_args(const cms_consistency_desc* d) {
 }
 
 static int fwd_grid(size_t P) { return grid_for(P, 256, 2048); }
+// the LDS-staged forward kernels: one workgroup per 64 x 8 tile of one sample (0 = use the direct-gather kernels: identity
+// geometry, or rectangles beyond FWD_PATCH_LDS_MAX)
+static int fwd_tiles(const Geo& g, int n_patches, size_t* lds_out, int* stride_out) {
+    if (g.h == g.H && g.w == g.W) return 0;
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("CMS_LOSS_FWD_TILED");     // A/B switch, read once
+        on = e ? (atoi(e) != 0) : 1;
+    }
+    if (!on) return 0;
+    const size_t pf = patch_floats(g.c, g.sy, g.sx, FWD_TILE_H);
+    const size_t lds = pf * n_patches * sizeof(float);
+    if (lds > FWD_PATCH_LDS_MAX) return 0;
+    if (lds_out) *lds_out = lds;
+    if (stride_out) *stride_out = (int)pf;
+    return ((g.W + TILE_W - 1) / TILE_W) * ((g.H + FWD_TILE_H - 1) / FWD_TILE_H) * g.n;
+}
+static int fwd_blocks(const Geo& g, int n_patches) {
+    const int t = fwd_tiles(g, n_patches, nullptr, nullptr);
+    return t > 0 ? t : fwd_grid((size_t)g.n * g.H * g.W);
+}
 
 #define CMS_DISPATCH_C(C, ...)                    \
     switch (C) {                                  \
@@ -657,7 +865,8 @@ using namespace cms;
 
 extern "C" size_t cms_consistency_workspace_bytes(const cms_consistency_desc* d) {
     if (!d) return 0;
-    return (size_t)fwd_grid((size_t)d->n * d->H * d->W) * 3 * sizeof(float);
+    const Geo g = make_geo(d->n, d->c, d->h, d->w, d->H, d->W, d->align_corners);
+    return (size_t)fwd_blocks(g, 3) * 3 * sizeof(float);
 }
 
 extern "C" int cms_consistency_fwd(const cms_consistency_desc* d, void* workspace, double* stats_out, void* stream) {
@@ -666,12 +875,20 @@ extern "C" int cms_consistency_fwd(const cms_consistency_desc* d, void* workspac
     CMS_REQUIRE(workspace && stats_out, "consistency_fwd: workspace / stats_out NULL");
     ConsArgs a = make_cons_args(d);
     const size_t P = (size_t)d->n * d->H * d->W;
-    const int grid = fwd_grid(P);
     hipStream_t s = (hipStream_t)stream;
     const bool ident = d->h == d->H && d->w == d->W;
     float* partials = (float*)workspace;
+    size_t lds = 0;
+    int pstride = 0;
+    const int tiles = fwd_tiles(a.g, 3, &lds, &pstride);
+    const int grid = tiles > 0 ? tiles : fwd_grid(P);
     CMS_DISPATCH_C(d->c, {
-        if (ident) hipLaunchKernelGGL((cons_fwd_kernel<CT, true>), dim3(grid), dim3(256), 0, s, a, partials);
+        if (tiles > 0) {
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute((const void*)cons_fwd_tiled_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((cons_fwd_tiled_kernel<CT>), dim3(grid), dim3(256), lds, s, a, partials, pstride);
+        }
+        else if (ident) hipLaunchKernelGGL((cons_fwd_kernel<CT, true>), dim3(grid), dim3(256), 0, s, a, partials);
         else hipLaunchKernelGGL((cons_fwd_kernel<CT, false>), dim3(grid), dim3(256), 0, s, a, partials);
     });
     hipLaunchKernelGGL((reduce_partials_kernel<3>), dim3(1), dim3(256), 0, s, partials, grid, stats_out, (double)P, 3);
@@ -706,7 +923,8 @@ extern "C" int cms_consistency_bwd(const cms_consistency_desc* d, const float* s
             hipLaunchKernelGGL((cons_bwd_ident_kernel<CT>), dim3(grid), dim3(256), 0, s, a, scalars, grad_l_stu);
         });
     } else {
-        const size_t lds = tile_lds_bytes(d->c, a.g.sy, a.g.sx);
+        const size_t lds = tile_lds_bytes(d->c, a.g.sy, a.g.sx, 3);
+        const int pstride = (int)patch_floats(d->c, a.g.sy, a.g.sx, TILE_H);
         CMS_REQUIRE(lds <= 160 * 1024 - 4096, "consistency_bwd: %d classes at this scale need %zu B of LDS", d->c, lds);
         CMS_DISPATCH_C(d->c, {
             if (lds > 48 * 1024)
@@ -715,7 +933,7 @@ extern "C" int cms_consistency_bwd(const cms_consistency_desc* d, const float* s
             tiled_launches(a.g, [&](const Geo& gc, int tiles) {
                 ConsArgs ac = a;
                 ac.g = gc;
-                hipLaunchKernelGGL((cons_bwd_tiled_kernel<CT>), dim3(tiles), dim3(256), lds, s, ac, scalars, grad_l_stu);
+                hipLaunchKernelGGL((cons_bwd_tiled_kernel<CT>), dim3(tiles), dim3(256), lds, s, ac, scalars, grad_l_stu, pstride);
             });
         });
     }
@@ -733,7 +951,8 @@ static int check_ce(const cms_ce_desc* d) {
 
 extern "C" size_t cms_ce_workspace_bytes(const cms_ce_desc* d) {
     if (!d) return 0;
-    return (size_t)fwd_grid((size_t)d->n * d->H * d->W) * 2 * sizeof(float);
+    const Geo g = make_geo(d->n, d->c, d->h, d->w, d->H, d->W, d->align_corners);
+    return (size_t)fwd_blocks(g, 1) * 2 * sizeof(float);
 }
 
 extern "C" int cms_ce_fwd(const cms_ce_desc* d, void* workspace, double* stats_out, void* stream) {
@@ -743,12 +962,19 @@ extern "C" int cms_ce_fwd(const cms_ce_desc* d, void* workspace, double* stats_o
     CeArgs a;
     a.d = *d;
     a.g = make_geo(d->n, d->c, d->h, d->w, d->H, d->W, d->align_corners);
-    const int grid = fwd_grid((size_t)d->n * d->H * d->W);
     hipStream_t s = (hipStream_t)stream;
     const bool ident = d->h == d->H && d->w == d->W;
     float* partials = (float*)workspace;
+    size_t lds = 0;
+    const int tiles = fwd_tiles(a.g, 1, &lds, nullptr);
+    const int grid = tiles > 0 ? tiles : fwd_grid((size_t)d->n * d->H * d->W);
     CMS_DISPATCH_C(d->c, {
-        if (ident) hipLaunchKernelGGL((ce_fwd_kernel<CT, true>), dim3(grid), dim3(256), 0, s, a, partials);
+        if (tiles > 0) {
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute((const void*)ce_fwd_tiled_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((ce_fwd_tiled_kernel<CT>), dim3(grid), dim3(256), lds, s, a, partials);
+        }
+        else if (ident) hipLaunchKernelGGL((ce_fwd_kernel<CT, true>), dim3(grid), dim3(256), 0, s, a, partials);
         else hipLaunchKernelGGL((ce_fwd_kernel<CT, false>), dim3(grid), dim3(256), 0, s, a, partials);
     });
     hipLaunchKernelGGL((reduce_partials_kernel<2>), dim3(1), dim3(256), 0, s, partials, grid, stats_out, 0.0, -1);
@@ -776,7 +1002,7 @@ extern "C" int cms_ce_bwd(const cms_ce_desc* d, const float* scalars, float* gra
             hipLaunchKernelGGL((ce_bwd_ident_kernel<CT>), dim3(grid), dim3(256), 0, s, a, scalars, grad_logits);
         });
     } else {
-        const size_t lds = tile_lds_bytes(d->c, a.g.sy, a.g.sx);
+        const size_t lds = tile_lds_bytes(d->c, a.g.sy, a.g.sx, 1);
         CMS_REQUIRE(lds <= 160 * 1024 - 4096, "ce_bwd: %d classes at this scale need %zu B of LDS", d->c, lds);
         CMS_DISPATCH_C(d->c, {
             if (lds > 48 * 1024)

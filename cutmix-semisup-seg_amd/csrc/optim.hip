@@ -179,13 +179,14 @@ __global__ void increment_kernel(int64_t* c) {
 
 // Frozen BatchNorm folded into the convolution epilogues' (scale, bias) for ALL layers of a network in one launch
 // (architectures/deeplab2.py:92-107 with the statistics frozen): the operands are gathered from the flat parameter arena
-// through element-index tables. Same operations and roundings as the tensor expression it replaces -- rsqrt(var + eps),
-// one product, then product and difference rounded separately (no contraction).
+// through element-index tables. Same operations and roundings as the tensor expression of the CPU oracle -- 1 / sqrt(var + eps)
+// with a correctly rounded square root and division (ATen's CPU rsqrt; the GPU library's rsqrt is an approximation that may
+// differ from it by an ulp), one product, then product and difference rounded separately (no contraction).
 __global__ void bn_fold_kernel(const float* __restrict__ flat, const int64_t* __restrict__ iw, const int64_t* __restrict__ ib,
                                const int64_t* __restrict__ im, const int64_t* __restrict__ iv, int n, float eps,
                                float* __restrict__ scale, float* __restrict__ bias) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float r = rsqrtf(__fadd_rn(flat[iv[i]], eps));
+        const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(flat[iv[i]], eps)));
         const float sc = __fmul_rn(flat[iw[i]], r);
         scale[i] = sc;
         bias[i] = __fsub_rn(flat[ib[i]], __fmul_rn(flat[im[i]], sc));

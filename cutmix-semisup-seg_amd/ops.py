@@ -863,6 +863,7 @@ class Program(object):
         self.floor_s = 0.0      # sum over the convolution / weight-gradient launches of max(bytes / 8 TB/s, FLOPs / 2.5 PFLOP/s):
                                 # the mixed HBM / MFMA roofline of one replay (bench.py: roofline.mixed)
         self.head_launches = 0
+        self.by_route = {}      # kernel route (cms_conv_igemm_route / 'wgrad8' / 'wgrad128') -> [launches, algorithmic bytes, FLOPs]
         self.n_streams = 1
         self.host_ops = []      # (op index, stream index, callable): host work between two launches of a replay -- the
                                 # all-reduces of SyncBN statistics (recorded with `host_call`); `run` splits around them
@@ -1070,6 +1071,9 @@ def _zero_page(device):
 
 
 _CONV8_WS = {}
+# cms_conv_igemm_route -> the kernel name rocprofv3 reports (prefix)
+_ROUTE_NAMES = {8: 'conv8_kernel', 2: 'conv_igemm_mixed_kernel', 1: 'conv_igemm_kernel<2, 2, 2, 2', 3: 'conv_igemm_kernel<1, 4, 2, 1',
+                4: 'conv_igemm_kernel<1, 4, 1, 1', 0: 'other'}
 
 
 def conv8_workspace(device):
@@ -1184,6 +1188,10 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
         # the input and the weights here and the logits at the gather)
         fbytes = esz * (x.numel() + w_packed.numel()) if (out_f32_nchw is not None and d.cout_real > 32) else nbytes
         prog.floor_s += max(fbytes / HBM_PEAK_BPS, 2.0 * n * ho * wo * cout * cin * ntaps / MFMA_PEAK_FLOPS)
+        if not f32:
+            route = _ROUTE_NAMES.get(int(fn['cms_conv_igemm_route'](C.byref(d))), 'other')
+            r = prog.by_route.setdefault(route, [0, 0.0, 0.0])
+            r[0] += 1; r[1] += nbytes; r[2] += 2.0 * n * ho * wo * cout * cin * ntaps
         if out_f32_nchw is not None:
             prog.head_launches += 1
             prog.head_bytes += nbytes
@@ -1350,6 +1358,11 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
         prog.flops += 2.0 * n * ho * wo * cout * cin * len(taps)
         prog.floor_s += max((du.element_size() * (du.numel() + x.numel()) + 4.0 * dw.numel()) / HBM_PEAK_BPS,
                             2.0 * n * ho * wo * cout * cin * len(taps) / MFMA_PEAK_FLOPS)
+        if not f32:
+            route = 'wgrad8_kernel' if int(fn['cms_conv_wgrad_uses_wgrad8'](C.byref(d))) else 'conv_wgrad_kernel'
+            r = prog.by_route.setdefault(route, [0, 0.0, 0.0])
+            r[0] += 1; r[1] += du.element_size() * (du.numel() + x.numel()) + 4.0 * dw.numel()
+            r[2] += 2.0 * n * ho * wo * cout * cin * len(taps)
         return dw
     name = 'cms_conv_wgrad_f32' if f32 else 'cms_conv_wgrad'
     check(fn[name](C.byref(d), _stream()), name)

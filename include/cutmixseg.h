@@ -277,12 +277,22 @@ typedef struct cms_conv_desc {
      * c & 7 of byte c >> 3 says [y[pixel][c] > 0] (of the stored bf16 value): mask_bits_out = uint8 [N][out_h][out_w][cout / 8].
      * The data gradient that would re-read that activation only for its sign (`mask_src`) takes the bits instead
      * (`mask_bits`, mask_src NULL): 1/16 of the bytes -- 69 MB less per layer-3 expansion of BASELINE configs[1] -- and the same
-     * result bit for bit. 128 x 128 kernel only (the eight-phase kernel is not dispatched for such a launch).              */
+     * result bit for bit. Both kernels of cms_conv_igemm write and read the same layout (round 5: the eight-phase kernel too,
+     * whole-tile launches).                                                                                                  */
     uint8_t* mask_bits_out;
     const uint8_t* mask_bits;
 } cms_conv_desc;
 
 int cms_conv_igemm(const cms_conv_desc* d, void* stream);
+/* Which kernel cms_conv_igemm runs this descriptor on (measurement tooling: algorithmic bytes per KERNEL beside the PMC
+ * counters; the choice depends on the geometry and on the CMS_CONV8 / CMS_CONV_MIXED switches of the process). */
+#define CMS_ROUTE_OTHER 0     /* an explicit variant / tile request */
+#define CMS_ROUTE_TILE128 1   /* conv_igemm_kernel, 128 channels x 128 pixels */
+#define CMS_ROUTE_MIXED 2     /* conv_igemm_mixed_kernel: the balanced 128 x 128 launch */
+#define CMS_ROUTE_TILE64 3    /* 64-channel tile */
+#define CMS_ROUTE_TILE32 4    /* 32-channel tile */
+#define CMS_ROUTE_CONV8 8     /* conv8_kernel: eight-phase 256 x 256 */
+int cms_conv_igemm_route(const cms_conv_desc* d);
 /* bytes of cms_conv_desc.workspace that every launch on this device is satisfied with */
 long long cms_conv_igemm_workspace_bytes(void);
 

@@ -159,7 +159,7 @@ def test_trained_miou_matches_the_oracle_within_0p2_points():
 _LAST = {}
 
 
-def _device_run_seed(seed, dtype, T):
+def _device_run_seed(seed, dtype, T, deterministic=True):
     from architectures import deeplab2
     import evaluation
     import optim_weight_ema
@@ -179,7 +179,7 @@ def _device_run_seed(seed, dtype, T):
     ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, T.ALPHA)
     ema.fuse_into(opt)
     stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()
-    step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=T.TAU, compute_dtype=dtype, deterministic=True))
+    step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=T.TAU, compute_dtype=dtype, deterministic=deterministic))
     cu = lambda t: t.to(DEV).to(dtype)
     log = []
     for x, y, u0, u1, ranges in train:
@@ -232,3 +232,27 @@ def test_device_trained_miou_vs_oracle_trained_over_seeds():
     # and 0.5 pt (any single seed)
     assert abs(m32 - mo) <= 0.002 and abs(m16 - mo) <= 0.002, (mo, m32, m16)
     assert all(abs(r[2] - r[1]) <= 0.005 and abs(r[3] - r[1]) <= 0.005 for r in rows), rows
+
+
+def test_device_trained_miou_on_the_timed_default_configuration():
+    """N1 on the configuration bench.py TIMES -- bf16, fp32 ATOMICS in the weight gradients and the loss
+    backward (`deterministic=False`, the throughput default), every convolution on the hand-written engine. The runs are not
+    bit-reproducible (that is what `--deterministic` buys for 2 %), the statement is the north star's: mean teacher mIoU over the
+    seeds within 0.2 pt of the oracle-trained runs, every seed within 0.5 pt."""
+    import json
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import n1_task as T
+    ref = json.load(open(os.path.join(GOLDEN, 'n1_oracle_runs.json')))
+    seeds = [s for s in T.SEEDS if str(s) in ref]
+    rows = []
+    for s in seeds:
+        m16, l16 = _device_run_seed(s, torch.bfloat16, T, deterministic=False)
+        rows.append((s, ref[str(s)]['miou'], m16, ref[str(s)]['sup_loss'][-1], l16[-1]))
+    mo, m16 = (float(np.mean([r[i] for r in rows])) for i in (1, 2))
+    print('\nN1 on the TIMED default (bf16, atomics), per seed (oracle mIoU, device mIoU, last sup loss x2): {}; means {:.4f} / {:.4f}'.format(
+        [tuple(round(v, 4) if isinstance(v, float) else v for v in r) for r in rows], mo, m16))
+    assert abs(m16 - mo) <= 0.002, (mo, m16)
+    assert all(abs(r[2] - r[1]) <= 0.005 for r in rows), rows

@@ -13,6 +13,7 @@
 #                               (tools/step_timeline.py: which queue runs what, where the step is serial)
 #   power:<bench args>          shader clock / socket power sampled with rocm-smi while bench.py runs (tools/power_probe.sh)
 #   py:<script and args>        python <script ...> (tools/*.py micro-benchmarks)
+#   envpy:<ENV=V,...>:<script and args>   the same with environment overrides (A/B legs)
 TAG=$1; shift
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -78,6 +79,11 @@ for l in sys.stdin:
     py)
       ( time timeout 900 python $rest ) > $OUT/${TAG}_py$i.log 2>&1; echo "py[$rest] rc=$?" | tee -a $SUM
       tail -n 40 $OUT/${TAG}_py$i.log | cut -c1-250 ;;
+    envpy)
+      envs=${rest%%:*}; args=${rest#*:}
+      ( IFS=','; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; unset IFS
+        time timeout 900 python $args ) > $OUT/${TAG}_py$i.log 2>&1; echo "envpy[$rest] rc=$?" | tee -a $SUM
+      tail -n 6 $OUT/${TAG}_py$i.log | cut -c1-250 | tee -a $SUM ;;
     *) echo "unknown step $step" | tee -a $SUM ;;
   esac
 done
