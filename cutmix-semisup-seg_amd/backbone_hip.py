@@ -716,8 +716,10 @@ class DeepLabHipExecutor(object):
     def bucket_starts(self):
         """Bottleneck indices at which a gradient bucket of the data-parallel all-reduce closes (step.GradBuckets):
         [layer4 + head], the two halves of layer3, [layer1 - layer2]; the stem's slice follows the autograd backward."""
-        l3, l4 = self._layer_first[2], self._layer_first[3]
-        return sorted(set([0, l3, (l3 + l4 + 1) // 2, l4]))
+        l2, l3, l4 = self._layer_first[1], self._layer_first[2], self._layer_first[3]
+        # (round 5: layer2's first bottleneck closes a slice too -- the weight-gradient streams meet there, which is what an early
+        # optimizer launch over [layer2 .. head] needs, step._arm_early_optimizer with CMS_TAIL_OPT_CUT=l2)
+        return sorted(set([0, l2, l3, (l3 + l4 + 1) // 2, l4]))
 
     def _backward_chain(self, saved, dlg, want_w, sides, hook, box=None):
         """The launches of the backward pass (recordable): ASPP head weight + data gradients, then the bottlenecks

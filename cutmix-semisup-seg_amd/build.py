@@ -36,6 +36,19 @@ def _digest():
     return h.hexdigest()
 
 
+def _obj_digest(src):
+    """Digest of what one object file depends on: its source, every shared header, the flags."""
+    h = hashlib.sha256()
+    deps = [src] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hpp'))
+    deps.append(os.path.join(os.path.dirname(HERE), 'include', 'cutmixseg.h'))
+    for p in deps:
+        h.update(os.path.basename(p).encode())
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=True):
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
@@ -45,13 +58,19 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = src[:-4] + '.o'
         objs.append(obj)
+        # per-object stamp (git-ignored, next to the object): only sources that changed are recompiled
+        ostamp, odig = obj + '.stamp', _obj_digest(src)
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == odig:
+            continue
         cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
+        procs.append((src, subprocess.Popen(cmd), ostamp, odig))
+    for src, p, ostamp, odig in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed on {}'.format(src))
+        with open(ostamp, 'w') as f:
+            f.write(odig)
     cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
     if verbose:
         print(' '.join(cmd), flush=True)

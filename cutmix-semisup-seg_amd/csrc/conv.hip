@@ -69,6 +69,7 @@ struct ConvArgs {
     int n_main, rem_tile_base;   // conv_igemm_mixed_kernel: workgroups of the main tile shape, first pixel tile of the rest
     int krot;               // != 0: workgroup (tile_m) starts its K loop krot * tile_m steps in and wraps (variant 20)
     int plain;              // 1x1, stride 1, tap (0, 0), output grid == input grid: GEMM row m IS input and output pixel m
+    int nt_store;           // bf16 output rows as non-temporal stores (CMS_CONV_NT, A/B: streaming stores evicting re-read operands)
     uint8_t* mask_bits_out;       // forward + ReLU: bit (pixel, channel) = [y > 0], [out pixels][Cout / 8] bytes, or NULL
     const uint8_t* mask_bits;     // dgrad: the ReLU mask as such bits instead of mask_src, or NULL
 };
@@ -908,7 +909,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
             if (op != 0xffffffffu) {
                 const u32x4 val = *reinterpret_cast<const u32x4*>(smem + r * EROW + ch * 16);
                 const int clog = ch ^ (r & (CPR - 1));
-                *reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + clog * 8) = val;
+                u32x4* dst = reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + clog * 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (a.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(val) : "memory");
+                else
+#endif
+                    *dst = val;
             }
         }
     }
@@ -1245,6 +1251,12 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
         const char* e = getenv("CMS_CONV_PLAIN");
         env_plain = e ? atoi(e) : 1;
     }
+    static int env_nt = -1;
+    if (env_nt < 0) {
+        const char* e = getenv("CMS_CONV_NT");          // A/B switch, read once
+        env_nt = e ? atoi(e) : 0;
+    }
+    a.nt_store = env_nt;
     a.plain = (env_plain != 0 && d->ntaps == 1 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 && d->stride == 1 && d->h == d->ho &&
                d->w_in == d->wo && d->out_stride == 1 && d->out_h == d->ho && d->out_w == d->wo && a.ksplit == 1 && a.krot == 0 &&
                (size_t)a.M * d->cin * 2 < (1ull << 31)) ? 1 : 0;

@@ -74,6 +74,8 @@ struct Args {
     float* slab;               // stream-K partial tiles [2 * grid][SLAB_FLOATS] or NULL
     unsigned* counters;        // stream-K arrival counters [tiles of the stream-K round], all zero between launches
     int N, H, W, Cin, Ho, Wo, Cout, ntaps, stride, out_H, out_W, out_stride, relu, mode, M, plain;
+    int nt_store;              // output rows as non-temporal stores (CMS_CONV8_NT): streaming data must not evict the halo rows
+                               // and weights neighbouring tiles of the XCD re-read from its L2 (profiles/r05b: 1.30 x over-fetch)
     int ntn;                   // channel tiles (Cout / 256); tile t = (pixel tile t / ntn, channel tile t % ntn)
     int KT, kc_per_tap;        // K tiles per output tile, K tiles per tap
     int ku;                    // K tiles per stream-K unit (2 when KT is even: runs then have even lengths, see the K loop)
@@ -734,7 +736,12 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
                 if (op != 0xffffffffu) {
                     const u32x4 val = *reinterpret_cast<const u32x4*>(smem + r * EROW + ch * 16);
                     const int cl = ch ^ (r & (CPR - 1));
-                    *reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + cl * 8) = val;
+                    u32x4* dst = reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + cl * 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if (a.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(val) : "memory");
+                    else
+#endif
+                        *dst = val;
                 }
             }
         }
@@ -814,6 +821,12 @@ int conv8_launch(const cms_conv_desc* d, hipStream_t s, int mode, int grid_cap, 
     a.ku = a.KT % 2 == 0 ? 2 : 1;
     a.slab = nullptr; a.counters = nullptr;
     a.trace = (uint32_t*)trace; a.trace_wgs = trace_wgs;
+    static int env_nt = -1;
+    if (env_nt < 0) {
+        const char* e = getenv("CMS_CONV8_NT");       // A/B switch, read once
+        env_nt = e ? atoi(e) : 0;
+    }
+    a.nt_store = env_nt;
     int grid = a.ntiles;
     a.sk_tiles = 0;
     a.dp_rounds = 1;

@@ -185,11 +185,18 @@ __global__ void increment_kernel(int64_t* c) {
 __global__ void bn_fold_kernel(const float* __restrict__ flat, const int64_t* __restrict__ iw, const int64_t* __restrict__ ib,
                                const int64_t* __restrict__ im, const int64_t* __restrict__ iv, int n, float eps,
                                float* __restrict__ scale, float* __restrict__ bias) {
+    // (plain operators under `fp contract(off)`: HIP's __fmul_rn / __fsqrt_rn are a contractable product and the NATIVE square
+    // root unless OCML's rounded operations are compiled in; sqrtf and / are correctly rounded by default)
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(flat[iv[i]], eps)));
-        const float sc = __fmul_rn(flat[iw[i]], r);
+        const float var_eps = flat[iv[i]] + eps;
+        const float r = 1.0f / sqrtf(var_eps);
+        const float sc = flat[iw[i]] * r;
+        const float prod = flat[im[i]] * sc;
         scale[i] = sc;
-        bias[i] = __fsub_rn(flat[ib[i]], __fmul_rn(flat[im[i]], sc));
+        bias[i] = flat[ib[i]] - prod;
     }
 }
 

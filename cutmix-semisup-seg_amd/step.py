@@ -245,7 +245,17 @@ class CutMixMeanTeacherStep(object):
         if not ex.use_programs or not ex._want_w():
             return None
         opt = self.student_optim
-        offs, starts = ex.block_grad_offsets(), (set(ex.bucket_starts()) if every else {0})
+        offs = ex.block_grad_offsets()
+        if every:
+            starts = set(ex.bucket_starts())
+        else:
+            # where the early launch(es) go. 'l1' (default): one launch behind the LAST weight gradient, beside the stem's backward.
+            # 'l2': behind the first bottleneck of layer2 -- 99 % of the parameters (layer2 .. head) are final there and the update
+            # runs beside layer1's backward (HBM-heavy itself); layer1's slice follows at the end. CMS_TAIL_OPT_CUT: A/B switch
+            cut = os.environ.get('CMS_TAIL_OPT_CUT', 'l1')
+            starts = {0}
+            if cut in ('l2', 'l3') and hasattr(ex, 'layer_first_blocks'):
+                starts.add(ex.layer_first_blocks()[1 if cut == 'l2' else 2])
         state = {'hi': int(opt.arena.flat.numel())}
         opt.begin_ranged()
         if self.__dict__.get('_opt_stream') is None:

@@ -79,6 +79,16 @@ for l in sys.stdin:
     py)
       ( time timeout 900 python $rest ) > $OUT/${TAG}_py$i.log 2>&1; echo "py[$rest] rc=$?" | tee -a $SUM
       tail -n 40 $OUT/${TAG}_py$i.log | cut -c1-250 ;;
+    prof)
+      # prof:<name>:<ENV=V,...>:<script and args>  rocprofv3 kernel trace of any python script -> kernel stats csv
+      name=${rest%%:*}; rest=${rest#*:}; envs=${rest%%:*}; args=${rest#*:}
+      ( IFS=','; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; unset IFS
+        cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_$name -o p -- python $ROOT/$args ) > $OUT/${TAG}_prof_$name.log 2>&1
+      echo "prof[$name] rc=$?" | tee -a $SUM
+      python tools/rocpd_summary.py $OUT/${TAG}_prof_$name/p_results.db 50 > $OUT/${TAG}_kernel_stats_$name.csv 2>> $OUT/${TAG}_prof_$name.log
+      rm -rf $OUT/${TAG}_prof_$name
+      grep -E "^VAT step" $OUT/${TAG}_prof_$name.log | tee -a $SUM
+      head -n 6 $OUT/${TAG}_kernel_stats_$name.csv | cut -c1-160 | tee -a $SUM ;;
     envpy)
       envs=${rest%%:*}; args=${rest#*:}
       ( IFS=','; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; unset IFS
