@@ -92,6 +92,24 @@ class Classifier_Module(nn.Module):
         return eng.aspp_head(x, [self.conv2d_list[i] for i in range(ASPP_LIVE)])
 
 
+# The library (MIOpen) convolution engine below is a COMPARISON engine: the tests hold the hand-written kernels against it and
+# A/B runs time it. The product never selects it by itself (round 5: engine_kind 'auto' is the hand-written engine for every
+# layer, in bf16 and fp32), and a process that wants it says so: `enable_library_engine()` / CMS_LIBRARY_ENGINE=1 (tests/conftest.py
+# does). Without that, every library convolution raises -- so "no library kernel ran" is a property of the product, not a habit.
+_LIBRARY_ENGINE = [os.environ.get('CMS_LIBRARY_ENGINE', '0') not in ('0', '')]
+
+
+def enable_library_engine(on=True):
+    _LIBRARY_ENGINE[0] = bool(on)
+
+
+def _library_conv_guard(what):
+    if not _LIBRARY_ENGINE[0]:
+        raise RuntimeError('cutmix-semisup-seg_amd: {} would run on the LIBRARY (MIOpen) convolution engine, which is the comparison '
+                           'engine of the tests -- call architectures.deeplab2.enable_library_engine() (or set CMS_LIBRARY_ENGINE=1) '
+                           'to use it; the default engines run every convolution on the hand-written kernels'.format(what))
+
+
 class TorchEngine(object):
     """
     Executes conv(+BatchNorm)(+residual)(+ReLU) units layer by layer with LIBRARY convolutions (MIOpen via torch) in
@@ -114,6 +132,7 @@ class TorchEngine(object):
         return x.to(dtype=self.dtype, memory_format=torch.channels_last)
 
     def conv2d(self, x, conv):
+        _library_conv_guard('convolution {}'.format(conv))
         return F.conv2d(x, self._weight(conv), None, conv.stride, conv.padding, conv.dilation)
 
     def conv_bn_act(self, x, conv, bn, relu, residual=None):
@@ -156,6 +175,7 @@ class TorchEngine(object):
         return y
 
     def aspp_head(self, x, convs):
+        _library_conv_guard('the ASPP head')
         out = None
         for conv in convs:
             y = F.conv2d(x, self._weight(conv), None, conv.stride, conv.padding, conv.dilation)

@@ -195,6 +195,8 @@ class DeepLabHeadV3Plus(nn.Module):
             return clf(y, last)                                 # MFMA kernel, fp32 NCHW logits from the epilogue
         if getattr(eng, 'strict', False):
             raise RuntimeError('engine_kind = "hip": classifier {} has no hand-written kernel'.format(last))
+        from .deeplab2 import _library_conv_guard
+        _library_conv_guard('classifier {}'.format(last))
         y = F.conv2d(y, last.weight.to(y.dtype), None)
         return y.float() + last.bias.view(1, -1, 1, 1)
 

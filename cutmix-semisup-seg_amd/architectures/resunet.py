@@ -57,6 +57,8 @@ def unet_tail(net, x, eng):
         return hip_clf(x, clf)                                  # MFMA kernel, fp32 NCHW logits from the epilogue
     if getattr(eng, 'strict', False):
         raise RuntimeError('engine_kind = "hip": classifier {} has no hand-written kernel'.format(clf))
+    from .deeplab2 import _library_conv_guard
+    _library_conv_guard('classifier {}'.format(clf))
     y = F.conv2d(x, clf.weight.to(x.dtype), None)
     return y.float() + clf.bias.view(1, -1, 1, 1)
 

@@ -2,6 +2,10 @@ import os
 import sys
 import json
 
+# the library (MIOpen) convolution engine is the COMPARISON engine of these tests (engine_kind = 'torch'); the product refuses to
+# run it unless a process asks for it (architectures/deeplab2.py: enable_library_engine) -- the tests do, before the package loads
+os.environ.setdefault('CMS_LIBRARY_ENGINE', '1')
+
 import numpy as np
 import pytest
 

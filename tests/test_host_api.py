@@ -476,3 +476,20 @@ def test_gaussian_kernels_match_the_reference_vectors():
     np.testing.assert_allclose(mask_gen.gaussian_kernels(g['sigma']), g['auto'], rtol=1e-14, atol=0)
     np.testing.assert_allclose(mask_gen.gaussian_kernels(g['sigma'], max_sigma=6.0, truncate=3.0), g['wide'], rtol=1e-14, atol=0)
     assert g['auto'].shape == (4, 33) and g['wide'].shape == (4, 37)
+
+
+def test_library_convolution_engine_needs_an_explicit_enable():
+    """Round 5: the library (MIOpen) engine is the tests' comparison engine; the product refuses to run a
+    library convolution unless the process enabled it (tests/conftest.py does, through CMS_LIBRARY_ENGINE=1)."""
+    from cutmix_semisup_seg_amd.architectures import deeplab2
+    conv = torch.nn.Conv2d(8, 8, 3, padding=1, bias=False)
+    eng = deeplab2.TorchEngine(torch.float32)
+    was = deeplab2._LIBRARY_ENGINE[0]
+    try:
+        deeplab2.enable_library_engine(False)
+        with pytest.raises(RuntimeError, match='LIBRARY'):
+            eng.conv2d(torch.zeros(1, 8, 4, 4), conv)
+        deeplab2.enable_library_engine(True)
+        assert tuple(eng.conv2d(torch.zeros(1, 8, 4, 4), conv).shape) == (1, 8, 4, 4)      # (the engine itself is plain torch)
+    finally:
+        deeplab2.enable_library_engine(was)
