@@ -324,9 +324,12 @@ def run_workload(key, args, world, rank, dev):
                                         lambda cfg_, ls, *a, **k: (2.0 * C + 2.0) * P_(ls.shape[0]) * 4.0,
                                         lambda cfg_, ls, *a, **k: 3.0 * C * lowres(ls) * 4.0)
     saved_fns['consistency_backward'] = ops.consistency_backward
+    def _frac(ctx, k):             # a launch over a run of the samples (step.py issues the backward as two halves on two streams)
+        sm = k.get('samples')
+        return 1.0 if sm is None else float(sm[1] - sm[0]) / float(ctx[1][0].shape[0])
     ops.consistency_backward = hbm_timed('consistency_bwd', saved_fns['consistency_backward'],
-                                         lambda ctx, sc, *a, **k: (3.0 * C + 2.0) * P_(ctx[1][0].shape[0]) * 4.0,
-                                         lambda ctx, sc, *a, **k: 4.0 * C * lowres(ctx[1][0]) * 4.0)
+                                         lambda ctx, sc, *a, **k: (3.0 * C + 2.0) * P_(ctx[1][0].shape[0]) * 4.0 * _frac(ctx, k),
+                                         lambda ctx, sc, *a, **k: 4.0 * C * lowres(ctx[1][0]) * 4.0 * _frac(ctx, k))
     saved_fns['ce_forward'] = ops.ce_forward
     ops.ce_forward = hbm_timed('ce_fwd', saved_fns['ce_forward'],
                                lambda lg, lab, *a, **k: C * P_(lg.shape[0]) * 4.0 + P_(lg.shape[0]) * 1.0,

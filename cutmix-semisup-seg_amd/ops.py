@@ -168,16 +168,27 @@ def consistency_forward(cfg, l_stu, l_tea0, l_tea1, out_size, ranges=None, mask=
     check(fn['cms_consistency_finalize'](_ptr(stats), _ptr(stats_g), cfg.conf_thresh, int(cfg.conf_per_pixel),
                                          float(ramp_val), float(cons_weight), _ptr(scalars), _stream()),
           'cms_consistency_finalize')
-    keep = (l_stu, l_tea0, l_tea1, ranges, mask, um0, um1)
+    keep = (l_stu, l_tea0, l_tea1, ranges, mask, um0, um1, cfg, tuple(int(v) for v in out_size))
     return scalars, (d, keep, stats)
 
 
-def consistency_backward(ctx, scalars, grad_out=None):
-    """grad wrt the (low-res) student logits; `grad_out` f32 (N,C,h,w) is accumulated into when given."""
+def consistency_backward(ctx, scalars, grad_out=None, samples=None):
+    """grad wrt the (low-res) student logits; `grad_out` f32 (N,C,h,w) is accumulated into when given. `samples` = (s0, s1): only
+    that run of samples (rows s0:s1 of `grad_out` are written) -- the per-pixel work of the backward is independent between samples,
+    so a caller may issue disjoint runs on different streams (step.py: half of it on the main stream beside the other half)."""
     d, keep, _ = ctx
     l_stu = keep[0]
     if grad_out is None:
         grad_out = torch.zeros_like(l_stu)
+    if samples is not None:
+        s0, s1 = int(samples[0]), int(samples[1])
+        if not (0 <= s0 < s1 <= int(l_stu.shape[0])):
+            raise ValueError('consistency_backward: bad sample range')
+        sl = lambda t: None if t is None else t[s0:s1]
+        l_s, l_t0, l_t1, ranges, mask, um0, um1, cfg, out_size = keep
+        d = _cons_desc(cfg, sl(l_s), sl(l_t0), sl(l_t1), sl(ranges), sl(mask), sl(um0), sl(um1), out_size)
+        check(fn['cms_consistency_bwd'](C.byref(d), _ptr(scalars), _ptr(grad_out[s0:s1]), _stream()), 'cms_consistency_bwd')
+        return grad_out
     check(fn['cms_consistency_bwd'](C.byref(d), _ptr(scalars), _ptr(grad_out), _stream()), 'cms_consistency_bwd')
     return grad_out
 

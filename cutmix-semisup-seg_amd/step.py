@@ -68,6 +68,7 @@ class StepConfig(object):
         self.defer_wgrad_join = os.environ.get('CMS_DEFER_JOIN', '1') != '0'
         # the consistency branch of the loss on the teacher's stream, concurrently with the cross entropy on the main stream
         self.overlap_losses = os.environ.get('CMS_OVERLAP_LOSSES', '1') != '0'
+        self.split_cons_bwd = os.environ.get('CMS_SPLIT_CONS_BWD', '1') != '0'
         self.compute_dtype = compute_dtype
         self.cons = ops.ConsistencyConfig(mode='mix' if self.mix else 'cut', loss_fn=cons_loss_fn,
                                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, invert=invert)
@@ -424,6 +425,11 @@ class CutMixMeanTeacherStep(object):
                 if use_unsup and side is not main:
                     main.wait_stream(side)
             cons_vals = []
+            # (round 5) the consistency branch is the longer of the two (forward 0.12 + backward 0.17 ms against 0.05 + 0.10 for the
+            # cross entropy): when the branches run on two streams, the SECOND half of the samples of its backward is issued on the main
+            # stream behind the cross entropy (per-pixel work, independent between samples; it only needs the finalised scalars).
+            # CMS_SPLIT_CONS_BWD=0: A/B
+            deferred = []                   # (context, scalars, grad rows, (s0, s1), event): backward halves the main stream takes
 
             def consistency_branch():
                 s_off, t_off = n_sup, 0
@@ -435,7 +441,13 @@ class CutMixMeanTeacherStep(object):
                     sc, cctx = ops.consistency_forward(cfg.cons, lo_det[s_off:s_off + n], l0, l1, out_size,
                                                        ranges=ub.ranges, um0=ub.um0, um1=ub.um1, ramp_val=ramp,
                                                        cons_weight=cfg.cons_weight, group=self.group)
-                    ops.consistency_backward(cctx, sc, grad_lo[s_off:s_off + n])
+                    if split and self.cfg.split_cons_bwd and n >= 2:
+                        ev = torch.cuda.Event()
+                        ev.record()                                       # scalars final on the teacher's stream
+                        ops.consistency_backward(cctx, sc, grad_lo[s_off:s_off + n], samples=(0, n // 2))
+                        deferred.append((cctx, sc, grad_lo[s_off:s_off + n], (n // 2, n), ev))
+                    else:
+                        ops.consistency_backward(cctx, sc, grad_lo[s_off:s_off + n])
                     s_off += n
                     if split and isinstance(sc, torch.Tensor):
                         sc.record_stream(main)          # allocated on the teacher's stream, read (and freed) on the main one
@@ -445,6 +457,9 @@ class CutMixMeanTeacherStep(object):
                     consistency_branch()
             ce_sc, ce_ctx = ops.ce_forward(lo_det[:n_sup], sup_y, out_size, 255, self.align_corners, group=self.group)
             ops.ce_backward(ce_ctx, ce_sc, grad_lo[:n_sup])
+            for cctx, sc, rows, rng_, ev in deferred:
+                main.wait_event(ev)
+                ops.consistency_backward(cctx, sc, rows, samples=rng_)
             if split:
                 # the re-pack of the data-gradient operands (one HBM-bound launch, ~0.12 ms, needs only the weights) is due in
                 # front of the backward pass: issued HERE it runs beside the consistency kernels of the other stream instead

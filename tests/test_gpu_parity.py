@@ -185,6 +185,36 @@ def test_consistency_properties_full_size(ops):
     assert torch.equal(torch.nan_to_num(s1, nan=-1.0), torch.nan_to_num(s1b, nan=-1.0))
 
 
+def test_consistency_backward_over_runs_of_samples_equals_the_whole_launch(ops):
+    """Round 5: `consistency_backward(..., samples=(s0, s1))` -- the step issues the backward as two halves on two streams. The per-pixel
+    work is independent between samples: with the reproducible tile order the two halves equal the whole launch bit for bit."""
+    N, C, h, w, H, W = 6, 21, 41, 41, 321, 321
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    ls, l0, l1 = (torch.randn(N, C, h, w, generator=gen, device=DEV) * 3 for _ in range(3))
+    import mask_gen
+    ranges = ops.ranges_to_device(mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(
+        N, (H, W), rng=np.random.RandomState(3)), DEV)
+    um0 = (torch.rand(N, 1, H, W, generator=gen, device=DEV) > 0.1).float()
+    cfg = ops.ConsistencyConfig(mode='mix', loss_fn='var', conf_thresh=0.3)
+    ops.set_deterministic_wgrad(True)            # (colour-class launches: one add per low-resolution cell and launch)
+    try:
+        sc, ctx = ops.consistency_forward(cfg, ls, l0, l1, (H, W), ranges=ranges, um0=um0, um1=None)
+        whole = ops.consistency_backward(ctx, sc, torch.zeros_like(ls))
+        parts = torch.zeros_like(ls)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.consistency_backward(ctx, sc, parts, samples=(0, 2))
+        ops.consistency_backward(ctx, sc, parts, samples=(2, N))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_deterministic_wgrad(False)
+    assert float(whole.abs().max()) > 0 and torch.equal(whole, parts)
+    with pytest.raises(ValueError):
+        ops.consistency_backward(ctx, sc, parts, samples=(3, 3))
+
+
 def test_consistency_error_behaviour(ops):
     with pytest.raises(ValueError, match='Unknown consistency loss function'):
         ops.ConsistencyConfig(loss_fn='nope')

@@ -16,4 +16,7 @@ run v3plus_freeze_bn train_seg_semisup_mask_mt.py --job_desc v3f $V3 --freeze_bn
 run v3plus_default_cli train_seg_semisup_mask_mt.py --job_desc v3d $V3
 run cut_mode_default_cli train_seg_semisup_mask_mt.py --job_desc cut $COMMON --mask_mode zero
 run vat train_seg_semisup_vat_mt.py --job_desc v --synthetic --arch resnet101_deeplab_imagenet --freeze_bn --batch_size 2 --crop_size 65,65 --num_epochs 1 --iters_per_epoch 2 --synthetic_val_batches 1
+# round 5: the U-Nets through the default ('auto' = all hand-written) engine -- no library convolution may be reached (it would raise)
+run resunet_cutmix train_seg_semisup_mask_mt.py --job_desc ru --synthetic --arch resnet50unet_imagenet --batch_size 2 --crop_size 64,64 --learning_rate 3e-5 --num_epochs 1 --iters_per_epoch 2 --synthetic_val_batches 1
+run denseunet_vat train_seg_semisup_vat_mt.py --job_desc dv --synthetic --arch densenet161unet_imagenet --batch_size 2 --crop_size 64,64 --num_epochs 1 --iters_per_epoch 2 --synthetic_val_batches 1
 echo "cli_smoke OK"
