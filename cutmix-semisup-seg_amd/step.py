@@ -68,7 +68,9 @@ class StepConfig(object):
         self.defer_wgrad_join = os.environ.get('CMS_DEFER_JOIN', '1') != '0'
         # the consistency branch of the loss on the teacher's stream, concurrently with the cross entropy on the main stream
         self.overlap_losses = os.environ.get('CMS_OVERLAP_LOSSES', '1') != '0'
-        self.split_cons_bwd = os.environ.get('CMS_SPLIT_CONS_BWD', '1') != '0'
+        # (measured: 626.1 vs 629.2 img/s at cfg 2, 134.2 vs 134.9 at cfg 3 WITHOUT it, profiles/r05f_*: the two halves slow each other
+        # and the cross entropy down by more than the overlap buys -- off; CMS_SPLIT_CONS_BWD=1 switches it on)
+        self.split_cons_bwd = os.environ.get('CMS_SPLIT_CONS_BWD', '0') not in ('0', '')
         self.compute_dtype = compute_dtype
         self.cons = ops.ConsistencyConfig(mode='mix' if self.mix else 'cut', loss_fn=cons_loss_fn,
                                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, invert=invert)
@@ -428,7 +430,7 @@ class CutMixMeanTeacherStep(object):
             # (round 5) the consistency branch is the longer of the two (forward 0.12 + backward 0.17 ms against 0.05 + 0.10 for the
             # cross entropy): when the branches run on two streams, the SECOND half of the samples of its backward is issued on the main
             # stream behind the cross entropy (per-pixel work, independent between samples; it only needs the finalised scalars).
-            # CMS_SPLIT_CONS_BWD=0: A/B
+            # Measured slower (StepConfig.split_cons_bwd): off by default
             deferred = []                   # (context, scalars, grad rows, (s0, s1), event): backward halves the main stream takes
 
             def consistency_branch():
