@@ -131,6 +131,10 @@ class DeepLabHipExecutor(object):
         self.defer_wgrad_join = False
         self._pending_join = None
         self.head_wgrad_side = os.environ.get('CMS_HEAD_WGRAD_SIDE', '1') != '0'
+        # EXPERIMENT (round 5, CMS_FWD_SPLIT bit 0: trainable network, bit 1: network without gradients): a recorded frozen-BN forward
+        # pass issues every convolution as TWO launches over the halves of the batch on two streams (samples are independent; both
+        # halves write slices of the same buffers, so the backward pass is unchanged): more, smaller launches in flight
+        self.fwd_split = int(os.environ.get('CMS_FWD_SPLIT', '0'))
         self._sides = []
         self.conv_tile = 0         # experiment knob: force a tile shape on the 128-multiple layers (tools, bench)
         self.tile_rules = {}       # output channels -> tile code (per-layer choice against the workgroup-count staircase)
@@ -274,14 +278,25 @@ class DeepLabHipExecutor(object):
     def _out_hw(h, w, stride):
         return (h - 1) // stride + 1, (w - 1) // stride + 1
 
-    def _fwd(self, x, c, relu, res=None, bits=False):
+    def _fwd(self, x, c, relu, res=None, bits=False, halves=None):
         """`bits`: also write the ReLU mask of the output as bits (cms_conv_desc.mask_bits_out) and hang them on the returned
-        tensor (`_cms_relu_bits`): the data gradient that needs this activation only for its sign reads 1/16 of the bytes."""
+        tensor (`_cms_relu_bits`): the data gradient that needs this activation only for its sign reads 1/16 of the bytes.
+        `halves`: two streams -- the launch goes out as two, over the two halves of the batch (see `fwd_split`)."""
         n, h, w, _ = x.shape
         ho, wo = self._out_hw(h, w, c.stride)
         mb = None
         if bits and relu and self.relu_bits and self.dtype == torch.bfloat16 and c.cout % 32 == 0:
             mb = torch.empty((n, ho, wo, c.cout // 8), dtype=torch.uint8, device=x.device)
+        if halves is not None:
+            y = torch.empty((n, ho, wo, c.cout), dtype=x.dtype, device=x.device)
+            for hi, (s0, s1) in enumerate(((0, n // 2), (n // 2, n))):
+                with torch.cuda.stream(halves[hi]):
+                    ops.conv_igemm(x[s0:s1], self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), scale=c.scale, bias=c.bias,
+                                   res=None if res is None else res[s0:s1], relu=relu, tile=self._tile(c.cout),
+                                   mask_bits_out=None if mb is None else mb[s0:s1], out=y[s0:s1])
+            if mb is not None:
+                y._cms_relu_bits = mb
+            return y
         y = ops.conv_igemm(x, self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), scale=c.scale, bias=c.bias,
                            res=res, relu=relu, tile=self._tile(c.cout), mask_bits_out=mb)
         if mb is not None:
@@ -312,10 +327,11 @@ class DeepLabHipExecutor(object):
         # (round 5) a1 / a2 get mask bits too: both kernels of cms_conv_igemm write and read them (the library alone decides
         # which one runs a launch), so the data gradients of conv2 / conv3 no longer re-read these activations for their sign
         inner = st['saved'] is not None and self.relu_bits_inner
-        a1 = self._fwd(cur, b.c1, True, bits=inner)
-        a2 = self._fwd(a1, b.c2, True, bits=inner)
-        res = cur if b.cd is None else self._fwd(cur, b.cd, False)
-        st['cur'] = self._fwd(a2, b.c3, True, res=res, bits=st['saved'] is not None)
+        hv = st.get('halves')
+        a1 = self._fwd(cur, b.c1, True, bits=inner, halves=hv)
+        a2 = self._fwd(a1, b.c2, True, bits=inner, halves=hv)
+        res = cur if b.cd is None else self._fwd(cur, b.cd, False, halves=hv)
+        st['cur'] = self._fwd(a2, b.c3, True, res=res, bits=st['saved'] is not None, halves=hv)
         if st['saved'] is not None:
             st['saved'].append((cur, a1, a2))
 
@@ -579,13 +595,22 @@ class DeepLabHipExecutor(object):
             self._prepare_forward()
             prog = ops.Program()
             x_in = torch.empty(tuple(shape), dtype=self.dtype, device=self.arena.device)
-            with ops.recording(prog, [torch.cuda.current_stream()]):
+            main = torch.cuda.current_stream()
+            split = (self.fwd_split >> (0 if self.trainable else 1)) & 1
+            extra = [self._fwd_side_stream()] if (split and not key[-1] and int(shape[0]) >= 2 and int(shape[0]) % 2 == 0) else []
+            with ops.recording(prog, [main] + extra):
                 st = self.fwd_begin(x_in, save)
+                if extra:
+                    st['halves'] = [main, extra[0]]
+                    ops.stream_wait(extra[0], main)          # the input buffer (and whatever the caller enqueued before the pass)
                 for bi in range(len(self.blocks)):
                     prog.group = bi
                     self.fwd_block(st, bi)
                 prog.group = len(self.blocks)
+                if extra:
+                    ops.stream_wait(main, extra[0])          # the head runs over the whole batch on the first stream
                 logits, saved = self.fwd_end(st)
+            prog.extra_streams = extra
             prog.x_in, prog.logits, prog.saved = x_in, logits, saved
             prog.bn = bool(key[-1])
             prog.bwd = {}
@@ -630,7 +655,7 @@ class DeepLabHipExecutor(object):
         prog = self.forward_program(x.shape, save)
         self._prepare_forward()
         prog.x_in.copy_(x)
-        prog.run([torch.cuda.current_stream()])
+        prog.run([torch.cuda.current_stream()] + list(getattr(prog, 'extra_streams', [])))
         self._stamp(prog)
         # the logits buffer belongs to the program (the next pass of this shape overwrites it): hand out a copy
         return prog.logits.clone(), ((prog, prog.generation) if save else None)
@@ -921,6 +946,11 @@ class DeepLabHipExecutor(object):
         while len(self._sides) < k:
             self._sides.append(ops.pooled_stream(self.arena.device, 'wgrad{}'.format(len(self._sides))))
         return self._sides[:k]
+
+    def _fwd_side_stream(self):
+        if self.__dict__.get('_fwd_side') is None:
+            self._fwd_side = ops.pooled_stream(self.arena.device, 'fwd_half_{}'.format('s' if self.trainable else 't'))
+        return self._fwd_side
 
     def _side_stream(self):
         if self._side is None:
@@ -1465,10 +1495,10 @@ class _BodyPairFn(torch.autograd.Function):
                 # SyncBN all-reduces between the launches: the native interleave cannot stop for them -- one pass after the
                 # other (each on its stream; they still overlap where the host runs ahead)
                 with torch.cuda.stream(side):
-                    pt.run([side])
-                ps.run([main])
+                    pt.run([side] + list(getattr(pt, 'extra_streams', [])))
+                ps.run([main] + list(getattr(ps, 'extra_streams', [])))
             else:
-                ops.run_pair(ps, [main], pt, [side])
+                ops.run_pair(ps, [main] + list(getattr(ps, 'extra_streams', [])), pt, [side] + list(getattr(pt, 'extra_streams', [])))
             ex_stu._stamp(ps)
             ex_tea._stamp(pt)
             logits_s = ps.logits.clone()

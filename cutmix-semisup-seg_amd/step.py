@@ -229,7 +229,15 @@ class CutMixMeanTeacherStep(object):
         self._bucket_obj.timing = self.time_buckets
         self._buckets = self._bucket_obj
         self._buckets.begin()
-        ex.grad_hook = self._buckets.on_block
+        hook = self._buckets.on_block
+        if self.__dict__.get('_bucket_hook') is None or self._bucket_hook[0] is not self._buckets:
+            buckets = self._buckets
+
+            def hook(bi):
+                buckets.on_block(bi)
+            hook.blocks = set(buckets.starts)       # the executor cuts its recorded backward pass at the bucket boundaries only
+            self._bucket_hook = (buckets, hook)
+        ex.grad_hook = self._bucket_hook[1]
         return ex
 
     def _arm_early_optimizer(self):
