@@ -284,6 +284,7 @@ def run_workload(key, args, world, rank, dev):
 
     # ---- roofline instrumentation: HIP events on the launch stream around the launches of the measured kernels
     timing_on = [False]
+    bracket_on = [True]            # event brackets armed for the current step (the work counters run on every timed step)
     conv = dict(pairs=[], work=[], flops=0.0, bytes=0.0, launches=0)       # conv_igemm_kernel (MFMA)
     hbm = dict(pairs=[], bytes=0.0, moved=0.0, parts={})                   # the HBM-bound group
     other = dict(pairs=[], work=[])                                        # --roofline_kernel adam_ema / consistency
@@ -294,7 +295,7 @@ def run_workload(key, args, world, rank, dev):
 
     def hbm_timed(part, fn, nbytes, moved):
         def wrapper(*a, **k):
-            if not timing_on[0] or args.no_roofline_events:
+            if not timing_on[0] or args.no_roofline_events or not bracket_on[0]:
                 return fn(*a, **k)
             e0, e1 = ev_pair()
             e0.record()
@@ -360,7 +361,7 @@ def run_workload(key, args, world, rank, dev):
             + (esz * w_packed.shape[1] if k.get('mask_src') is not None else 0.0))
         conv['bytes'] += nb
         conv['launches'] += 1
-        if args.no_roofline_events:
+        if args.no_roofline_events or not bracket_on[0]:
             return orig_conv(x, w_packed, taps, *a, **k)
         if head:            # the ASPP head (2048 -> C, dilations 6 + 12): HBM-bound group, every launch timed
             e0, e1 = ev_pair()
@@ -466,9 +467,18 @@ def run_workload(key, args, world, rank, dev):
         arm_timing(sample_every if roofline_kernel == 'conv' else 0)
         issued0 = issued()
         route0 = by_route()
+        # Event brackets cost throughput (a bracketed launch cannot overlap its neighbours on the queue: 626-629 img/s with every 5th
+        # convolution launch of EVERY step bracketed against 636 with none, profiles/r05h_*, r05i_*): they are armed on every
+        # `--roofline_steps_every`-th timed step only (default 4) -- still a few hundred timed launches inside the timed region
+        every_s = max(1, args.roofline_steps_every)
         t0 = time.perf_counter()
         for i in range(args.steps):
+            armed = (i % every_s) == 0
+            if every_s > 1:
+                bracket_on[0] = armed
+                arm_timing((sample_every if roofline_kernel == 'conv' else 0) if armed else 0)
             res = one_step(i)
+        bracket_on[0] = True
         t_enqueue = time.perf_counter() - t0         # host time to enqueue the K steps (== elapsed when launch-bound)
         torch.cuda.synchronize()
         t_local = time.perf_counter() - t0           # this rank's own K steps (before it waits for the slowest rank)
@@ -621,8 +631,10 @@ def run_workload(key, args, world, rank, dev):
                          'avg_launch_ms': ms_kernel,
                          'algorithmic_{}_per_launch'.format('flops' if roof['bound'] == 'mfma' else 'bytes'): per_launch,
                          'launches_timed': n_timed,
-                         'sampling': 'every launch' if args.roofline_sample <= 1 else
-                                     'every {}th launch'.format(args.roofline_sample)},
+                         'sampling': ('every launch' if args.roofline_sample <= 1 else
+                                      'every {}th launch'.format(args.roofline_sample)) +
+                                     ('' if args.roofline_steps_every <= 1 else
+                                      ' of every {}th timed step'.format(args.roofline_steps_every))},
         }
         if routes:
             # algorithmic work per KERNEL of the recorded launches (the library's own routing, cms_conv_igemm_route /
@@ -670,6 +682,7 @@ def run_workload(key, args, world, rank, dev):
                 pp = parts.setdefault('aspp_head_fwd', [0.0, 0.0, 0])
                 pp[0] += hb; pp[1] += hm; pp[2] += prog_t['head_launches']
             tot_ms = sum(ms.values())
+            n_br = max(1, (args.steps + max(1, args.roofline_steps_every) - 1) // max(1, args.roofline_steps_every))   # bracketed steps
             out['roofline_hbm'] = {
                 'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'group': 'cutmix paste + masked consistency fwd/bwd + cross entropy fwd/bwd + ASPP head convolution',
@@ -677,12 +690,12 @@ def run_workload(key, args, world, rank, dev):
                 'basis': 'SURVEY.md 8(d): compulsory bytes of the reference-equivalent formulation (full-resolution '
                          'logits materialised); the fused kernels evaluate the bilinear upsample in-kernel and move '
                          '`moved_bytes_per_step` instead',
-                'bytes_per_step': nb / args.steps, 'moved_bytes_per_step': mv / args.steps,
+                'bytes_per_step': nb / n_br, 'moved_bytes_per_step': mv / n_br,
                 'achieved_on_moved_bytes': mv / (tot_ms * 1e-3) / 1e9,
-                'ms_per_step': tot_ms / args.steps,
-                'parts': {k: {'ms_per_step': ms[k] / args.steps, 'GBps': parts[k][0] / (ms[k] * 1e-3) / 1e9,
+                'ms_per_step': tot_ms / n_br, 'steps_bracketed': n_br,
+                'parts': {k: {'ms_per_step': ms[k] / n_br, 'GBps': parts[k][0] / (ms[k] * 1e-3) / 1e9,
                               'GBps_moved': parts[k][1] / (ms[k] * 1e-3) / 1e9,
-                              'launches_per_step': parts[k][2] / args.steps} for k in ms},
+                              'launches_per_step': parts[k][2] / n_br} for k in ms},
                 'traffic': None}
         # scalar copies of the nested objects (the driver's record keeps scalar keys of `roofline` / `config` only)
         rf = out['roofline']
@@ -731,6 +744,8 @@ def main():
                          '--stats run of this command averages in-step launches only)')
     ap.add_argument('--copy_profile', action='store_true', help='torch.profiler: python sources of the device copies / fills of two steps (stderr)')
     ap.add_argument('--host_profile', action='store_true', help='cProfile of three steps after the timed region (stderr)')
+    ap.add_argument('--roofline_steps_every', type=int, default=4,
+                    help='arm the event brackets (convolution launches, HBM group) on every k-th timed step only')
     ap.add_argument('--roofline_sample', type=int, default=5,
                     help='bracket every k-th launch of the conv kernel with events (1 = all; the brackets cost ~3 %% '
                          'of the step when every launch carries them)')
