@@ -788,6 +788,11 @@ def main():
     else:
         rccl_world = 1
 
+    if os.environ.get('CMS_BENCH_DUMMY_STREAMS'):      # EXPERIMENT: foreign streams created first (what RCCL / another library does)
+        _dummy = [torch.cuda.Stream() for _ in range(int(os.environ['CMS_BENCH_DUMMY_STREAMS']))]
+        for st_ in _dummy:
+            with torch.cuda.stream(st_):
+                torch.zeros(1, device=dev)
     keys = ['pascal', 'cityscapes'] if args.workload == 'both' else [args.workload]
     results = [run_workload(k, args, world, rank, dev) for k in keys]
     also = []

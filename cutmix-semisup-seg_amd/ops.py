@@ -330,6 +330,9 @@ def upsample_bilinear(x, size, align_corners=True):
 _STREAM_POOL = {}
 
 
+_ROLE_ALIAS = {'wgrad0': 'teacher', 'optimizer': 'wgrad1'}
+
+
 def pooled_stream(device, role):
     """A process-wide side stream per (device, role): roles 'teacher', 'wgrad0..2', 'side', 'optimizer'. HIP multiplexes its
     streams onto a handful of hardware queues; a process that keeps creating streams (bench.py runs four workloads, a
@@ -339,6 +342,13 @@ def pooled_stream(device, role):
     dev = torch.device(device)
     if dev.index is None:
         dev = torch.device('cuda', torch.cuda.current_device())
+    # (round 5) Roles that are never busy at the same time share ONE stream: the first weight-gradient stream is the teacher's (forward
+    # / loss branch vs backward), the optimizer's early launch goes behind the second weight-gradient stream's last launch (where it has
+    # to wait anyway). The step then needs the current stream + TWO side streams. Why it matters: the runtime multiplexes streams onto a
+    # few hardware queues in creation order, and whenever two streams that should run side by side land on one queue the step loses 20-45 %
+    # (profiles/r05h_*: any GPU_MAX_HW_QUEUES setting, or one more stream in the forward pass: 437-507 img/s against 626) -- with five
+    # streams of its own the step depended on that assignment being lucky, also against the streams RCCL creates. CMS_STREAM_ALIAS=0: A/B
+    role = _ROLE_ALIAS.get(str(role), str(role)) if _os.environ.get('CMS_STREAM_ALIAS', '1') != '0' else str(role)
     key = (dev.index, str(role))
     st = _STREAM_POOL.get(key)
     if st is None:
