@@ -330,7 +330,53 @@ def upsample_bilinear(x, size, align_corners=True):
 _STREAM_POOL = {}
 
 
-_ROLE_ALIAS = {'wgrad0': 'teacher', 'optimizer': 'wgrad1'}
+_ROLE_ALIASES = {'1': {'wgrad0': 'teacher', 'optimizer': 'wgrad1'}, 'opt': {'optimizer': 'wgrad1'}, 'tea': {'wgrad0': 'teacher'}, '0': {}}
+_GOOD_STREAMS = {}          # device index -> candidate side streams that run CONCURRENTLY with the default stream (probed once)
+_STREAM_PROBE_LOG = []
+
+
+def _probe_side_streams(dev):
+    """Side streams that really run beside the current stream. The runtime multiplexes streams onto a few hardware queues
+    (4 here) in CREATION order, the null stream included: of any four consecutively created streams exactly one shares the current
+    stream's queue, and which one depends on how many streams other code created before (PyTorch's pool, RCCL ...). Two streams on
+    one queue execute in order: a step whose teacher or weight-gradient stream lands on the main stream's queue loses 20-45 %
+    (profiles/r05h_*, r05k_*: 482 img/s against 635 with ONE foreign stream created first). Probe: a ~100 us spin kernel on the
+    current stream and one on the candidate, started together; same queue <=> they take twice as long. One host synchronisation,
+    once per device and process. CMS_STREAM_PROBE=0 switches it off (streams are then taken in creation order)."""
+    good = _GOOD_STREAMS.get(dev.index)
+    if good is not None:
+        return good
+    cands = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    if _os.environ.get('CMS_STREAM_PROBE', '1') == '0':
+        good = _GOOD_STREAMS[dev.index] = cands
+        return good
+    cur = torch.cuda.current_stream(dev)
+    spin = 200000                                         # cycles of torch.cuda._sleep: ~0.1 ms
+    times = []
+    with torch.cuda.device(dev):
+        for rep in range(2):                              # (first pass warms the kernel up)
+            times = []
+            for c in [None] + cands:
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                if c is not None:
+                    c.wait_event(e0)
+                    with torch.cuda.stream(c):
+                        torch.cuda._sleep(spin)
+                torch.cuda._sleep(spin)
+                if c is not None:
+                    cur.wait_stream(c)
+                e1.record(cur)
+                torch.cuda.synchronize(dev)
+                times.append(e0.elapsed_time(e1))
+    alone = max(times[0], 1e-3)
+    good = [c for c, t in zip(cands, times[1:]) if t < 1.5 * alone]
+    _STREAM_PROBE_LOG.append((dev.index, [round(t, 4) for t in times], len(good)))
+    if len(good) < 2:                                     # a runtime this model does not fit: keep the creation order
+        good = cands
+    _GOOD_STREAMS[dev.index] = good
+    return good
 
 
 def pooled_stream(device, role):
@@ -338,17 +384,14 @@ def pooled_stream(device, role):
     streams onto a handful of hardware queues; a process that keeps creating streams (bench.py runs four workloads, a
     notebook rebuilds its step object) ends up with its 'concurrent' streams on ONE queue and loses the overlap the step is
     built on (configs[1] without --freeze_bn as the fourth workload of one process: 277 img/s against 312 alone,
-    profiles/r03also_*). Objects that need a side stream take it from here instead of creating their own."""
+    profiles/r03also_*). Objects that need a side stream take it from here instead of creating their own.
+    Round 5: (i) the streams come from a PROBED set that does not share the default stream's hardware queue (`_probe_side_streams`);
+    (ii) roles that are never busy at the same time may share one stream (CMS_STREAM_ALIAS: '1' teacher = first weight-gradient stream and
+    optimizer behind the second, 'opt' / 'tea' one of the two, '0' none), so that the step needs fewer queues of its own."""
     dev = torch.device(device)
     if dev.index is None:
         dev = torch.device('cuda', torch.cuda.current_device())
-    # (round 5) Roles that are never busy at the same time share ONE stream: the first weight-gradient stream is the teacher's (forward
-    # / loss branch vs backward), the optimizer's early launch goes behind the second weight-gradient stream's last launch (where it has
-    # to wait anyway). The step then needs the current stream + TWO side streams. Why it matters: the runtime multiplexes streams onto a
-    # few hardware queues in creation order, and whenever two streams that should run side by side land on one queue the step loses 20-45 %
-    # (profiles/r05h_*: any GPU_MAX_HW_QUEUES setting, or one more stream in the forward pass: 437-507 img/s against 626) -- with five
-    # streams of its own the step depended on that assignment being lucky, also against the streams RCCL creates. CMS_STREAM_ALIAS=0: A/B
-    role = _ROLE_ALIAS.get(str(role), str(role)) if _os.environ.get('CMS_STREAM_ALIAS', '1') != '0' else str(role)
+    role = _ROLE_ALIASES.get(_os.environ.get('CMS_STREAM_ALIAS', 'opt'), {}).get(str(role), str(role))
     key = (dev.index, str(role))
     st = _STREAM_POOL.get(key)
     if st is None:
@@ -357,7 +400,18 @@ def pooled_stream(device, role):
         for item in _os.environ.get('CMS_STREAM_PRIO', '').split('+'):
             if '=' in item and str(role).startswith(item.split('=')[0]):
                 prio = int(item.split('=')[1])
-        st = _STREAM_POOL[key] = torch.cuda.Stream(device=dev, priority=prio)
+        if prio != 0:
+            st = torch.cuda.Stream(device=dev, priority=prio)
+        else:
+            # slot of a role among the probed streams: roles that run side by side sit on different slots -- teacher | first
+            # weight-gradient stream (DeepLab v3+'s single one: 'side') | second weight-gradient stream (+ the optimizer's early launch)
+            good = _probe_side_streams(dev)
+            slot = {'teacher': 0, 'wgrad0': 1, 'side': 1, 'wgrad1': 2, 'optimizer': 2, 'wgrad2': 0, 'fwd_half_s': 1,
+                    'fwd_half_t': 2}.get(str(role))
+            if slot is None:
+                slot = sum(1 for k in _STREAM_POOL if k[0] == dev.index)
+            st = good[slot % len(good)]
+        _STREAM_POOL[key] = st
     return st
 
 
