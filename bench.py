@@ -621,8 +621,8 @@ def run_workload(key, args, world, rank, dev):
                        'allreduce': {'dtype': args.allreduce_dtype, 'buckets_last_step': buckets},
                        'ranks': rank_view,
                        'deterministic_wgrad': bool(args.deterministic),
-                       # (device, [ms of the spin kernel alone, beside candidate 0..3], side streams that do NOT share the default
-                       # stream's hardware queue): ops._probe_side_streams
+                       # (device, ms of the spin kernel alone, clash matrix of {default stream, six candidates}: 1 = the pair shares a
+                       # hardware queue, candidates chosen as side streams): ops._probe_side_streams
                        'stream_probe': [list(p_) for p_ in ops._STREAM_PROBE_LOG],
                        'parity_config': ('this line is the bf16-STORAGE engine: held per layer (teacher-forced) to the bf16-storage '
                                          'oracle at 1.5e-4 forward / 2e-3 backward / 3e-4 weight gradients; the 1e-4 bar on whole-'

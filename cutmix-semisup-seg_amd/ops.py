@@ -336,43 +336,59 @@ _STREAM_PROBE_LOG = []
 
 
 def _probe_side_streams(dev):
-    """Side streams that really run beside the current stream. The runtime multiplexes streams onto a few hardware queues
-    (4 here) in CREATION order, the null stream included: of any four consecutively created streams exactly one shares the current
-    stream's queue, and which one depends on how many streams other code created before (PyTorch's pool, RCCL ...). Two streams on
-    one queue execute in order: a step whose teacher or weight-gradient stream lands on the main stream's queue loses 20-45 %
-    (profiles/r05h_*, r05k_*: 482 img/s against 635 with ONE foreign stream created first). Probe: a ~100 us spin kernel on the
-    current stream and one on the candidate, started together; same queue <=> they take twice as long. One host synchronisation,
-    once per device and process. CMS_STREAM_PROBE=0 switches it off (streams are then taken in creation order)."""
+    """Side streams that really run beside the current stream AND beside each other. The runtime multiplexes streams onto a few
+    hardware queues (4 here); which streams share one depends on what was created / used before (PyTorch's pool, RCCL, a
+    notebook's leftovers), and two streams on one queue execute in order: a step whose teacher or weight-gradient stream shares
+    a queue with the main stream -- or with each other -- loses 20-45 % (profiles/r05h_*, r05k_*, r05l_*: 482 img/s against 635 with
+    ONE foreign stream created first). Probe (once per device and process, a few host synchronisations): every pair out of
+    {current stream, six candidates} runs a ~100 us spin kernel side by side; same queue <=> the pair takes twice as long. Result:
+    the largest set of candidates that overlap with the current stream and with one another (three, with four queues).
+    CMS_STREAM_PROBE=0 switches the probe off (streams are then taken in creation order)."""
     good = _GOOD_STREAMS.get(dev.index)
     if good is not None:
         return good
-    cands = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    n_cand = 6
+    cands = [torch.cuda.Stream(device=dev) for _ in range(n_cand)]
     if _os.environ.get('CMS_STREAM_PROBE', '1') == '0':
         good = _GOOD_STREAMS[dev.index] = cands
         return good
     cur = torch.cuda.current_stream(dev)
     spin = 200000                                         # cycles of torch.cuda._sleep: ~0.1 ms
-    times = []
-    with torch.cuda.device(dev):
-        for rep in range(2):                              # (first pass warms the kernel up)
-            times = []
-            for c in [None] + cands:
-                torch.cuda.synchronize(dev)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(cur)
-                if c is not None:
-                    c.wait_event(e0)
-                    with torch.cuda.stream(c):
-                        torch.cuda._sleep(spin)
+    streams = [cur] + cands
+
+    def pair_ms(a, b):
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(a)
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(spin)
+        if b is not None:
+            b.wait_event(e0)
+            with torch.cuda.stream(b):
                 torch.cuda._sleep(spin)
-                if c is not None:
-                    cur.wait_stream(c)
-                e1.record(cur)
-                torch.cuda.synchronize(dev)
-                times.append(e0.elapsed_time(e1))
-    alone = max(times[0], 1e-3)
-    good = [c for c, t in zip(cands, times[1:]) if t < 1.5 * alone]
-    _STREAM_PROBE_LOG.append((dev.index, [round(t, 4) for t in times], len(good)))
+            a.wait_stream(b)
+        e1.record(a)
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1)
+
+    with torch.cuda.device(dev):
+        for st_ in streams:                               # every stream has run something: its queue is assigned
+            with torch.cuda.stream(st_):
+                torch.cuda._sleep(1000)
+        pair_ms(cur, cands[0])                            # warm-up
+        alone = max(pair_ms(cur, None), 1e-3)
+        n = len(streams)
+        clash = [[False] * n for _ in range(n)]
+        for i in range(n):
+            for j in range(i + 1, n):
+                clash[i][j] = clash[j][i] = pair_ms(streams[i], streams[j]) >= 1.5 * alone
+    # greedy: candidates in creation order that clash neither with the current stream nor with one already chosen
+    chosen = []
+    for j in range(1, n):
+        if not clash[0][j] and all(not clash[j][k] for k in chosen):
+            chosen.append(j)
+    _STREAM_PROBE_LOG.append((dev.index, round(alone, 4), [[int(v) for v in row] for row in clash], [j - 1 for j in chosen]))
+    good = [streams[j] for j in chosen]
     if len(good) < 2:                                     # a runtime this model does not fit: keep the creation order
         good = cands
     _GOOD_STREAMS[dev.index] = good
