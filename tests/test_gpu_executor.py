@@ -282,3 +282,39 @@ def test_frozen_batchnorm_fold_kernel_equals_the_tensor_expression():
     s = w_ * torch.rsqrt(v_ + 1e-5)
     c = ex.blocks[ex.layer_first_blocks()[2]].c2
     assert torch.equal(c.scale.cpu(), s) and torch.equal(c.bias.cpu(), b_ - m_ * s)
+
+
+def test_side_streams_are_probed_to_overlap_with_the_default_stream_and_each_other():
+    """Round 5: `ops.pooled_stream` hands out streams from a PROBED set -- the runtime maps streams onto a few hardware queues and two
+    streams on one queue run in order (a teacher / weight-gradient stream on the main stream's queue costs the step 20-45 %,
+    profiles/r05k_*). The chosen streams must overlap pairwise: two ~0.1 ms spin kernels side by side take about as long as one."""
+    from cutmix_semisup_seg_amd import ops
+    dev = torch.device(DEV)
+    tea, w0, w1 = (ops.pooled_stream(dev, r) for r in ('teacher', 'wgrad0', 'wgrad1'))
+    assert ops._STREAM_PROBE_LOG and len(ops._STREAM_PROBE_LOG[0][3]) >= 2
+    assert ops.pooled_stream(dev, 'optimizer') is w1                       # default alias: the early optimizer launch behind wgrad1
+    cur = torch.cuda.current_stream()
+    spin = 200000
+
+    def pair_ms(a, b):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(a)
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(spin)
+        if b is not None:
+            b.wait_event(e0)
+            with torch.cuda.stream(b):
+                torch.cuda._sleep(spin)
+            a.wait_stream(b)
+        e1.record(a)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    pair_ms(cur, tea)
+    alone = pair_ms(cur, None)
+    streams = [cur, tea, w0, w1]
+    distinct = len({int(s.cuda_stream) for s in streams})
+    if distinct == 4:
+        for i in range(4):
+            for j in range(i + 1, 4):
+                assert pair_ms(streams[i], streams[j]) < 1.5 * alone, (i, j, alone)
