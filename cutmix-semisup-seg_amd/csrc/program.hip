@@ -11,6 +11,7 @@
 // into a hipGraph by the caller since all it does is launch work and record / wait events.
 //
 // Optional: every k-th convolution launch is bracketed with HIP events on its own stream (bench.py's `roofline`).
+#include <cstdlib>
 #include "common.hpp"
 #include <new>
 #include <vector>
@@ -63,6 +64,9 @@ struct cms_program {
     long acc_launches = 0;
     long last_head = -1;       // index into `timed` of the head GEMM bracket the next gather op extends
     int last_head_stream = -1;
+    hipEvent_t prev_sync_ev = nullptr;   // the event the PREVIOUS issued op recorded, if that op was a sync from `prev_sync_from`:
+    void* prev_sync_from = nullptr;      // consecutive syncs from one stream (both weight-gradient streams waiting for the main
+                                         // stream, once per bottleneck) share ONE event record (round 5)
 };
 
 using namespace cms;
@@ -71,6 +75,16 @@ static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
     CMS_REQUIRE(o.stream >= 0 && o.stream < n_streams, "program: op on stream %d but only %d streams given", o.stream,
                 n_streams);
     hipStream_t s = (hipStream_t)streams[o.stream];
+    hipEvent_t shared_ev = nullptr;
+    static int share_events = -1;
+    if (share_events < 0) {
+        const char* e = getenv("CMS_PROG_SHARE_EVENTS");     // A/B switch, read once
+        share_events = e ? atoi(e) : 1;
+    }
+    if (share_events && o.kind == OP_SYNC && p->prev_sync_ev != nullptr && o.from >= 0 && o.from < n_streams &&
+        p->prev_sync_from == streams[o.from])
+        shared_ev = p->prev_sync_ev;         // nothing was issued since that record: the same point of the `from` stream
+    p->prev_sync_ev = nullptr;
     switch (o.kind) {
     case OP_CONV: {
         Timed* t = nullptr;
@@ -148,11 +162,22 @@ static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
         CMS_REQUIRE(o.from >= 0 && o.from < n_streams, "program: sync from stream %d but only %d streams given", o.from,
                     n_streams);
         if (streams[o.from] == streams[o.stream]) return CMS_OK;      // same stream: already ordered
+        if (shared_ev != nullptr) {
+            if (hipStreamWaitEvent(s, shared_ev, 0) != hipSuccess) {
+                set_error("program: event wait failed");
+                return CMS_ELAUNCH;
+            }
+            p->prev_sync_ev = shared_ev;
+            p->prev_sync_from = streams[o.from];
+            return CMS_OK;
+        }
         if (hipEventRecord(o.ev, (hipStream_t)streams[o.from]) != hipSuccess ||
             hipStreamWaitEvent(s, o.ev, 0) != hipSuccess) {
             set_error("program: event record / wait failed");
             return CMS_ELAUNCH;
         }
+        p->prev_sync_ev = o.ev;
+        p->prev_sync_from = streams[o.from];
         return CMS_OK;
     }
     }
@@ -279,6 +304,7 @@ extern "C" int cms_program_run(cms_program* p, int first, int last, void* const*
     const int n = (int)p->ops.size();
     if (last < 0 || last > n) last = n;
     CMS_REQUIRE(first >= 0 && first <= last, "program_run: bad range [%d, %d) of %d ops", first, last, n);
+    p->prev_sync_ev = nullptr;               // (the host may have enqueued anything since the last call)
     for (int i = first; i < last; ++i) {
         const int rc = issue(p, p->ops[i], streams, n_streams);
         if (rc != CMS_OK) return rc;
@@ -298,10 +324,12 @@ extern "C" int cms_program_run_pair(cms_program* a, void* const* streams_a, int 
         const int ga = ia < ea ? a->ops[ia].group : 0x7fffffff;
         const int gb = ib < eb ? b->ops[ib].group : 0x7fffffff;
         const int g = ga < gb ? ga : gb;
+        a->prev_sync_ev = nullptr;           // (the other program's ops were issued in between, possibly on shared streams)
         while (ia < ea && a->ops[ia].group <= g) {
             const int rc = issue(a, a->ops[ia++], streams_a, na);
             if (rc != CMS_OK) return rc;
         }
+        b->prev_sync_ev = nullptr;
         while (ib < eb && b->ops[ib].group <= g) {
             const int rc = issue(b, b->ops[ib++], streams_b, nb);
             if (rc != CMS_OK) return rc;
