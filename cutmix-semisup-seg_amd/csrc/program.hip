@@ -78,8 +78,10 @@ static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
     hipEvent_t shared_ev = nullptr;
     static int share_events = -1;
     if (share_events < 0) {
-        const char* e = getenv("CMS_PROG_SHARE_EVENTS");     // A/B switch, read once
-        share_events = e ? atoi(e) : 1;
+        // A/B switch, read once. OFF by default: measured SLOWER (629.3 / 630.8 against 634.9 / 635.9 img/s at cfg 2,
+        // profiles/r05p_*) -- with one record both weight-gradient streams are released at the same instant
+        const char* e = getenv("CMS_PROG_SHARE_EVENTS");
+        share_events = e ? atoi(e) : 0;
     }
     if (share_events && o.kind == OP_SYNC && p->prev_sync_ev != nullptr && o.from >= 0 && o.from < n_streams &&
         p->prev_sync_from == streams[o.from])
