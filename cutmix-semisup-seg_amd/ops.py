@@ -349,7 +349,7 @@ def _probe_side_streams(dev):
         return good
     n_cand = 6
     cands = [torch.cuda.Stream(device=dev) for _ in range(n_cand)]
-    if _os.environ.get('CMS_STREAM_PROBE', '1') == '0':
+    if _os.environ.get('CMS_STREAM_PROBE', '1') == '0' or not hasattr(torch.cuda, '_sleep'):
         good = _GOOD_STREAMS[dev.index] = cands
         return good
     cur = torch.cuda.current_stream(dev)
