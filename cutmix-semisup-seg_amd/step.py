@@ -68,6 +68,8 @@ class StepConfig(object):
         self.defer_wgrad_join = os.environ.get('CMS_DEFER_JOIN', '1') != '0'
         # the consistency branch of the loss on the teacher's stream, concurrently with the cross entropy on the main stream
         self.overlap_losses = os.environ.get('CMS_OVERLAP_LOSSES', '1') != '0'
+        # the teacher's stream forks at the head of the step instead of behind the paste / concatenation of the student's inputs (A/B)
+        self.early_teacher_fork = os.environ.get('CMS_EARLY_TEACHER_FORK', '1') != '0'
         # (measured: 626.1 vs 629.2 img/s at cfg 2, 134.2 vs 134.9 at cfg 3 WITHOUT it, profiles/r05f_*: the two halves slow each other
         # and the cross entropy down by more than the overlap buys -- off; CMS_SPLIT_CONS_BWD=1 switches it on)
         self.split_cons_bwd = os.environ.get('CMS_SPLIT_CONS_BWD', '0') not in ('0', '')
@@ -364,7 +366,6 @@ class CutMixMeanTeacherStep(object):
         """
         cfg = self.cfg
         out_size = sup_x.shape[2:4]
-        self.student_optim.zero_grad()
         use_unsup = cfg.cons_weight > 0.0 and len(unsup_batches) > 0
         n_sup = sup_x.shape[0]
         ramp = ramp_val if cfg.rampup > 0 else 1.0
@@ -391,20 +392,33 @@ class CutMixMeanTeacherStep(object):
             stu_in = [sup_x]
             tea_in = []
             if use_unsup:
-                for ub in unsup_batches:
-                    stu_in.append(self._student_inputs(ub))
-                    tea_in.append(ub.x0_tea)
-                    if cfg.mix:
-                        tea_in.append(ub.x1_tea)
                 # the teacher pass only meets the student at the loss: it runs on its own HIP stream, concurrently
                 # with the student's forward pass (the two fill each other's launch tails and memory stalls)
                 main = torch.cuda.current_stream()
                 # Pi model (teacher IS the student): one network, one executor -- its lazily refreshed operand tables
                 # (BN affine, ASPP weights) must not be rewritten on one stream while the other reads them
                 side = self._teacher_stream() if (cfg.overlap_teacher and self.teacher is not self.student) else main
-                x_tea = torch.cat(tea_in, dim=0) if len(tea_in) > 1 else tea_in[0]
-                if side is not main:
-                    side.wait_stream(main)              # inputs (and last step's optimizer / EMA writes) are ready
+                early = side is not main and cfg.early_teacher_fork
+                if early:
+                    # (round 5) the teacher's inputs are the caller's tensors: its stream forks HERE -- behind last step's optimizer /
+                    # EMA writes, in front of this step's gradient clear, paste and concatenation on the main stream, which it does not need
+                    side.wait_stream(main)
+                self.student_optim.zero_grad()
+                for ub in unsup_batches:
+                    tea_in.append(ub.x0_tea)
+                    if cfg.mix:
+                        tea_in.append(ub.x1_tea)
+                if early:
+                    with torch.cuda.stream(side):
+                        x_tea = torch.cat(tea_in, dim=0) if len(tea_in) > 1 else tea_in[0]
+                for ub in unsup_batches:
+                    stu_in.append(self._student_inputs(ub))
+                if not early:
+                    x_tea = torch.cat(tea_in, dim=0) if len(tea_in) > 1 else tea_in[0]
+                    if side is not main:
+                        side.wait_stream(main)              # inputs (and last step's optimizer / EMA writes) are ready
+            else:
+                self.student_optim.zero_grad()
             x_stu = torch.cat(stu_in, dim=0) if len(stu_in) > 1 else stu_in[0]
             if use_unsup and side is not main and self._both_on_executor():
                 # both bodies on the MFMA executor: issue them interleaved, bottleneck by bottleneck
@@ -502,6 +516,7 @@ class CutMixMeanTeacherStep(object):
             # the side stream, and run concurrently with the student's supervised forward / backward and mixed
             # forward; the teacher's own two passes keep their order (they update the same running statistics).
             main = torch.cuda.current_stream()
+            self.student_optim.zero_grad()
             tea_out = []
             overlap = use_unsup and cfg.overlap_teacher and self.teacher is not self.student
             if overlap:
