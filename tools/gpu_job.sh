@@ -9,6 +9,7 @@
 #                               bench:plain0:CMS_CONV_PLAIN=0:--workload pascal --steps 30 --no_cpu_baseline
 #   rocprof:<bench args>        rocprofv3 --kernel-trace --stats of bench.py, summarised with tools/rocpd_summary.py
 #   pmc:<bench args>            TCC FETCH_SIZE / WRITE_SIZE passes (separate runs, kernel-trace only) -> per-kernel traffic
+#   mfma:<bench args>           one --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, kernel-trace only) -> MFMA utilisation per kernel
 #   timeline:<step>:<bench args> rocprofv3 kernel trace of bench.py -> kernel stats + the timeline of training step <step>
 #                               (tools/step_timeline.py: which queue runs what, where the step is serial)
 #   power:<bench args>          shader clock / socket power sampled with rocm-smi while bench.py runs (tools/power_probe.sh)
@@ -66,6 +67,12 @@ for l in sys.stdin:
       done
       python tools/pmc_traffic.py $OUT/${TAG}_pmc $OUT/${TAG}_pmc_traffic_per_kernel.json | tee -a $SUM
       rm -rf $OUT/${TAG}_pmc/FETCH_SIZE $OUT/${TAG}_pmc/WRITE_SIZE ;;
+    mfma)
+      mkdir -p $OUT/${TAG}_mfma
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_mfma -o p --output-format csv -- python $ROOT/bench.py $rest ) > $OUT/${TAG}_mfma.log 2>&1
+      echo "mfma pmc rc=$?" | tee -a $SUM
+      python tools/pmc_mfma.py $OUT/${TAG}_mfma $OUT/${TAG}_pmc_mfma_util_per_kernel.json | tee -a $SUM
+      rm -rf $OUT/${TAG}_mfma ;;
     timeline)
       stepno=${rest%%:*}; args=${rest#*:}
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o bench -- python $ROOT/bench.py $args ) > $OUT/${TAG}_rocprof.log 2>&1
