@@ -66,7 +66,8 @@ class ConvDesc(C.Structure):
                 ('tap_dy', c_int * 18), ('tap_dx', c_int * 18), ('stride', c_int),
                 ('out_h', c_int), ('out_w', c_int), ('out_stride', c_int), ('relu', c_int), ('mode', c_int),
                 ('tile', c_int), ('ksplit', c_int), ('zeros', c_void_p), ('variant', c_int), ('zeros_bytes', c_int),
-                ('workspace', c_void_p), ('workspace_bytes', C.c_longlong), ('mask_bits_out', c_void_p), ('mask_bits', c_void_p)]
+                ('workspace', c_void_p), ('workspace_bytes', C.c_longlong), ('mask_bits_out', c_void_p), ('mask_bits', c_void_p),
+                ('stats_out', c_void_p), ('stats_rows_per_group', c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -141,6 +142,9 @@ PROTOTYPES = {
     'cms_conv_igemm': (c_int, [_P(ConvDesc), c_void_p]),
     'cms_conv_igemm_workspace_bytes': (C.c_longlong, []),
     'cms_conv_igemm_route': (c_int, [_P(ConvDesc)]),
+    'cms_conv_igemm_stats_tile_rows': (c_int, [_P(ConvDesc)]),
+    'cms_bn_finalize_tiles': (c_int, [c_void_p, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'cms_conv_set_trace': (c_int, [c_void_p, c_int]),
     'cms_conv_set_wgrad8': (c_int, [c_int]),
     'cms_loss_set_deterministic': (c_int, [c_int]),

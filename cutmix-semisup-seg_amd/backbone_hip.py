@@ -380,17 +380,27 @@ class DeepLabHipExecutor(object):
         residual + ReLU. -> (y, saved), saved = (u, y, mean, rstd, backward sums, workspace) for `_bwd_unit_bn`."""
         n, h, w, _ = x.shape
         ho, wo = self._out_hw(h, w, c.stride)
-        u = ops.conv_igemm(x, self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), tile=self._tile(c.cout))
+        G = int(groups)
+        grp = self._dist_group()
+        world = ops._world(grp)
+        # (round 5) single process, bf16: the convolution's epilogue leaves per-tile channel sums of what it stores and the
+        # statistics launch only adds those up -- the pass over u it used to be is gone (cms_conv_desc.stats_out)
+        st = {'groups': G} if (world == 1 and self.dtype == torch.bfloat16 and _fused_bn_stats()) else None
+        u = ops.conv_igemm(x, self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), tile=self._tile(c.cout), stats=st)
         a, bn, C = self.arena, self._bn_module(c), c.cout
         npix = n * ho * wo
         dev = x.device
-        G = int(groups)
         bsums = torch.empty(G * 2 * C, dtype=torch.float64, device=dev) if save else None
         mean, rstd, scale, shift = (torch.empty(G * C, dtype=torch.float32, device=dev) for _ in range(4))
         ws = ops.bn_workspace(npix, C, dev, G)      # this unit's: tile counters + partial sums (forward, then backward)
-        grp = self._dist_group()
-        world = ops._world(grp)
-        if world > 1:
+        if st is not None and st['tile_rows'] > 0 and os.environ.get('CMS_BN_DIAG_SKIP_FINALIZE') == '1':
+            pass        # TIMING DIAGNOSTIC ONLY (wrong numerics): what a free statistics launch would be worth
+        elif st is not None and st['tile_rows'] > 0:
+            ops.bn_op('finalize_tiles', c=C, dtype=self.dtype, n_pixels=npix, groups=G, eps=bn.eps, momentum=bn.momentum,
+                      tile_rows=st['tile_rows'], ws=st['tile_sums'], gamma=a.view(c.bn + '.weight'), beta=a.view(c.bn + '.bias'),
+                      mean=mean, rstd=rstd, scale=scale, shift=shift, running_mean=a.view(c.bn + '.running_mean'),
+                      running_var=a.view(c.bn + '.running_var'), counter=bn.num_batches_tracked)
+        elif world > 1:
             # SyncBN on the executor (round 4; SURVEY 8(e) "BN statistics"): per-group (sum x, sum x^2) -> ONE all-reduce of
             # [G][2][C] doubles between two launches of the recorded pass (a host op of the program) -> the groups finalised in
             # order with the pixel count of ALL ranks. The fused single-process launch ('stats') does the same without the exchange.
@@ -1387,6 +1397,12 @@ def hip_conv2d(x, conv, arena, key, dtype=torch.bfloat16):
     if geom is None:
         raise NotImplementedError('no hand-written kernel for this convolution geometry: {}'.format(conv))
     return _HipConvGeneralFn.apply(x, conv.weight, arena, key, geom, dtype)
+
+
+def _fused_bn_stats():
+    """CMS_BN_FUSED_STATS (default 1; A/B switch, read per recording): batch-statistics units take their statistics from the tile
+    sums the convolution's epilogue writes (`_fwd_unit_bn`); 0 = the round-3/4 pass over the convolution output."""
+    return os.environ.get('CMS_BN_FUSED_STATS', '1') != '0'
 
 
 def _auto_keeps_library():

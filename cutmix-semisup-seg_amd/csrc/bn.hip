@@ -612,6 +612,110 @@ extern "C" int cms_bn_stats(const void* x, int dtype, size_t n_pixels, int c, in
     return launch_status("cms_bn_stats");
 }
 
+// Statistics from the tile sums a convolution's epilogue wrote (cms_conv_desc.stats_out, csrc/tile_stats.hpp): no pass over the
+// activation at all. tile_sums: float [tiles][2 slots][2][C]; tile t covers pixel rows [t T, (t + 1) T), slot 0 = its rows of the
+// sample group its first row is in, slot 1 = its rows of the next group (written only by a straddling tile).
+// The launch sits on the dependency chain conv -> statistics -> normalise of every unit, and inside the training step a memory round
+// trip costs 4-5 us (loaded latency), so it is built around ONE round trip: a block owns 16 channels, 64 lanes per channel; every
+// lane issues ALL its loads (tiles k, k + 64, ...; up to 20 of them = 1280 tiles, plus the slot-1 sums of the <= G - 1 straddling
+// tiles) before it looks at any, then sorts them into the sample groups in registers. fp64 sums, lanes joined by shuffles and a
+// fixed-order pass over the 16 waves -- reproducible; groups finalised in order (the running statistics move once per group).
+// (A two-level version -- 264 small blocks + a last-block ticket -- measured the same 19 us in the step as a naive single-level one:
+// its chain is loads -> store -> ticket -> loads, profiles/r05s_*.) More tiles than 1280: rounds of loads per group (rare: 512 x 1024 crops).
+constexpr int BNT_CH = 16, BNT_LANES = 64, BNT_J = 20;
+
+__global__ __launch_bounds__(BNT_CH * BNT_LANES) void bn_finalize_tiles_kernel(const float* __restrict__ tile_sums, unsigned T, unsigned Pg,
+                                                                               int C, int G, unsigned nt, BnFin fin) {
+    __shared__ double red[BNT_LANES / 4][2 * BNT_CH];       // [wave][stat][channel]
+    const int tid = threadIdx.x, cl = tid % BNT_CH, k = tid / BNT_CH, wave = tid >> 6;
+    const int c = blockIdx.x * BNT_CH + cl;
+    const bool live = c < C;
+    const size_t row = 2 * (size_t)C;                       // floats per (tile, slot)
+    const bool fast = nt <= (unsigned)(BNT_LANES * BNT_J);
+    float x[BNT_J], y[BNT_J];
+    float ex0 = 0.0f, ex1 = 0.0f;                           // lane k: slot 1 of the tile that straddles the boundary into group k + 1
+    if (fast) {
+        // uniform base + 32-bit byte offset per lane: one VGPR per address (global_load ... saddr), not a 64-bit pair -- with the 40
+        // loads of a lane in flight at once the pairs alone would overflow the 128 registers a 1024-thread block has
+        const char* base = reinterpret_cast<const char*>(tile_sums);
+        const unsigned cb = (unsigned)(live ? c : 0) * 4u, rowb = (unsigned)C * 16u;       // bytes per tile = 2 slots x 2 x C floats
+        const unsigned off0 = (unsigned)k * rowb + cb, stride = (unsigned)BNT_LANES * rowb, off_max = (nt - 1) * rowb + cb;
+#pragma unroll
+        for (int j = 0; j < BNT_J; ++j) {
+            const unsigned off = min(off0 + (unsigned)j * stride, off_max);      // (past the end: a valid address, never counted)
+            x[j] = *reinterpret_cast<const float*>(base + (size_t)off);
+            y[j] = *reinterpret_cast<const float*>(base + (size_t)(off + (unsigned)C * 4u));
+        }
+        if (live && k + 1 < G) {
+            const unsigned brow = (unsigned)(k + 1) * Pg;   // first row of group k + 1
+            if (brow % T != 0) {
+                const float* p = tile_sums + ((size_t)(brow / T) * 2 + 1) * row + c;
+                ex0 = p[0];
+                ex1 = p[C];
+            }
+        }
+    }
+    for (int g = 0; g < G; ++g) {
+        double s0 = 0.0, s1 = 0.0;
+        if (fast) {
+            // slot 0 of tile t belongs to the group of its first row: g Pg <= t T < (g + 1) Pg
+            const unsigned lo = ((unsigned)g * Pg + T - 1) / T, hi = ((unsigned)(g + 1) * Pg + T - 1) / T;
+#pragma unroll
+            for (int j = 0; j < BNT_J; ++j) {
+                const unsigned t = (unsigned)k + (unsigned)(BNT_LANES * j);
+                const bool mine = t >= lo && t < hi;
+                float a = mine ? x[j] : 0.0f, b = mine ? y[j] : 0.0f;
+                asm volatile("" : "+v"(a), "+v"(b));       // (keeps the 40 fp64 conversions inside the group loop: hoisted, they spill)
+                s0 += (double)a;
+                s1 += (double)b;
+            }
+            if (g >= 1 && k == g - 1) { s0 += (double)ex0; s1 += (double)ex1; }
+        } else if (live) {
+            const unsigned row_lo = (unsigned)g * Pg, row_hi = row_lo + Pg - 1;
+            const unsigned t_lo = row_lo / T, t_hi = row_hi / T;
+            for (unsigned t = t_lo + (unsigned)k; t <= t_hi; t += BNT_LANES) {
+                const unsigned sl = (t * T) / Pg == (unsigned)g ? 0u : 1u;
+                const float* p = tile_sums + ((size_t)t * 2 + sl) * row + c;
+                s0 += (double)p[0];
+                s1 += (double)p[C];
+            }
+        }
+        // lanes k = 4 w .. 4 w + 3 of a channel sit in wave w at lane distance 16
+        s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64);
+        s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+        __syncthreads();                                    // (the previous group's readers of red are done)
+        if ((tid & 63) < BNT_CH) { red[wave][cl] = s0; red[wave][BNT_CH + cl] = s1; }
+        __syncthreads();
+        if (tid < BNT_CH && live) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int w = 0; w < BNT_LANES / 4; ++w) { a0 += red[w][cl]; a1 += red[w][BNT_CH + cl]; }
+            BnFin f = fin;
+            f.mean += (size_t)g * C; f.rstd += (size_t)g * C; f.scale += (size_t)g * C; f.shift += (size_t)g * C;
+            bn_finalize_channel(f, c, a0, a1);
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0 && fin.counter) *fin.counter += G;
+}
+
+extern "C" int cms_bn_finalize_tiles(const float* tile_sums, int tile_rows, size_t n_pixels, int c, int groups, const float* gamma,
+                                     const float* beta, float eps, float momentum, float* mean, float* rstd, float* scale,
+                                     float* shift, float* running_mean, float* running_var, long long* counter, void* stream) {
+    CMS_REQUIRE(tile_sums && mean && rstd && scale && shift, "bn_finalize_tiles: NULL pointer");
+    CMS_REQUIRE(n_pixels > 0 && c > 0 && tile_rows > 0, "bn_finalize_tiles: bad geometry");
+    CMS_REQUIRE(n_pixels + (size_t)tile_rows < (1ull << 31), "bn_finalize_tiles: more than 2^31 pixel rows");
+    CMS_REQUIRE(((n_pixels + (size_t)tile_rows - 1) / (size_t)tile_rows) * 16 * (size_t)c < (1ull << 32), "bn_finalize_tiles: tile sums beyond 4 GB");
+    CMS_REQUIRE(bn_groups_ok(n_pixels, groups) && groups <= BNT_LANES, "bn_finalize_tiles: %d groups do not divide %zu pixel rows (or > 64 groups)",
+                groups, n_pixels);
+    const size_t pg = n_pixels / (size_t)groups;
+    CMS_REQUIRE(pg >= (size_t)tile_rows, "bn_finalize_tiles: a sample group (%zu rows) is shorter than a tile (%d rows)", pg, tile_rows);
+    const size_t nt = (n_pixels + (size_t)tile_rows - 1) / (size_t)tile_rows;
+    BnFin f{gamma, beta, mean, rstd, scale, shift, running_mean, running_var, counter, (double)pg, eps, momentum};
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3((c + BNT_CH - 1) / BNT_CH), dim3(BNT_CH * BNT_LANES), 0, (hipStream_t)stream,
+                       tile_sums, (unsigned)tile_rows, (unsigned)pg, c, groups, (unsigned)nt, f);
+    return launch_status("cms_bn_finalize_tiles");
+}
+
 extern "C" int cms_bn_finalize_ex(const double* sums, double count, const float* gamma, const float* beta, float eps,
                                   float momentum, float* mean, float* rstd, float* scale, float* shift, float* running_mean,
                                   float* running_var, int c, double* clear_a, double* clear_b, long long* counter,

@@ -32,6 +32,7 @@
 #include <cstring>
 #include <type_traits>
 #include "common.hpp"
+#include "tile_stats.hpp"
 
 namespace cms {
 
@@ -72,6 +73,8 @@ struct ConvArgs {
     int nt_store;           // bf16 output rows as non-temporal stores (CMS_CONV_NT, A/B: streaming stores evicting re-read operands)
     uint8_t* mask_bits_out;       // forward + ReLU: bit (pixel, channel) = [y > 0], [out pixels][Cout / 8] bytes, or NULL
     const uint8_t* mask_bits;     // dgrad: the ReLU mask as such bits instead of mask_src, or NULL
+    float* stats_out;             // [pixel tiles][2 slots][2][Cout] per-tile (sum, sum of squares) of the stored output, or NULL
+    int stats_rpg;                // pixel rows per sample group (>= the tile's rows; M for one group)
 };
 
 
@@ -902,20 +905,38 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
     if (to_lds) {
         __syncthreads();
         constexpr int RPP = NT / CPR;               // rows per pass
+        // thread -> LOGICAL chunk ch of rows r0, r0 + RPP, ... (its place in the swizzled LDS row changes with the row): the
+        // 8 channels a thread stores are the same in every pass, which is what the statistics below accumulate over
         const int ch = tid % CPR, r0 = tid / CPR;
+        auto rows = [&](auto STATS_, TileStats& ts, int boundary) {
+            constexpr bool STATS = decltype(STATS_)::value;
 #pragma unroll
-        for (int r = r0; r < BM; r += RPP) {
-            const uint32_t op = lds_row[r].opix;
-            if (op != 0xffffffffu) {
-                const u32x4 val = *reinterpret_cast<const u32x4*>(smem + r * EROW + ch * 16);
-                const int clog = ch ^ (r & (CPR - 1));
-                u32x4* dst = reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + clog * 8);
+            for (int r = r0; r < BM; r += RPP) {
+                const uint32_t op = lds_row[r].opix;
+                if (op != 0xffffffffu) {
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(smem + r * EROW + ((ch ^ (r & (CPR - 1))) << 4));
+                    u32x4* dst = reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + ch * 8);
 #if defined(__HIP_DEVICE_COMPILE__)
-                if (a.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(val) : "memory");
-                else
+                    if (a.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(val) : "memory");
+                    else
 #endif
-                    *dst = val;
+                        *dst = val;
+                    if constexpr (STATS) ts.add(val.x, val.y, val.z, val.w, (m0 + r) >= boundary);
+                }
             }
+        };
+        TileStats ts;
+        if (a.stats_out == nullptr) {
+            rows(std::false_type{}, ts, 0);
+        } else {
+            // BatchNorm statistics out of the epilogue (round 5, tile_stats.hpp): per-channel sums of what this tile stores
+            const int boundary = (m0 / a.stats_rpg + 1) * a.stats_rpg;          // first row of the next sample group
+            const int m_end = m0 + BM < a.M ? m0 + BM : a.M;
+            ts.zero();
+            rows(std::true_type{}, ts, boundary);
+            __syncthreads();                        // the tile has been read by every wave: its LDS is the scratch now
+            tile_stats_finish<CPR, NW, NT>(ts, boundary < m_end, reinterpret_cast<float*>(smem),
+                                           a.stats_out + (size_t)tile_m * 4 * a.Cout + co0, a.Cout);
         }
     }
     if (tracing) {                                  // diagnostic dump: header + stamps of thread 0 (tools/conv_trace.py)
@@ -1184,6 +1205,23 @@ extern "C" int cms_conv_igemm_route(const cms_conv_desc* d) {
     return d->cout % 64 == 0 ? CMS_ROUTE_TILE64 : CMS_ROUTE_TILE32;
 }
 
+// Pixel rows per tile of the per-tile statistics a launch of this descriptor would write to stats_out ([ceil(M / rows)][2][2][Cout]
+// floats), 0 when it cannot (then cms_bn_stats reads the output back instead), negative for an invalid descriptor.
+extern "C" int cms_conv_igemm_stats_tile_rows(const cms_conv_desc* d) {
+    int rc = conv_check(d);
+    if (rc) return rc;
+    if (d->y == nullptr || d->mode != 0 || d->ksplit > 1 || d->out_stride != 1 || d->out_h != d->ho || d->out_w != d->wo) return 0;
+    const int route = cms_conv_igemm_route(d);
+    if (route < 0) return route;
+    if (route == CMS_ROUTE_CONV8 && conv8_env(0) != 1) return 0;        // (whole tiles per workgroup only, not the stream-K launch)
+    const int rows = route == CMS_ROUTE_CONV8 ? 256 : (route == CMS_ROUTE_OTHER ? 0 : 128);
+    if (rows == 0) return 0;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const long long rpg = d->stats_rows_per_group > 0 ? d->stats_rows_per_group : M;
+    if (M % rpg != 0 || rpg < rows) return 0;       // a tile may straddle ONE group boundary
+    return rows;
+}
+
 extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
     int rc = conv_check(d_in);
     if (rc) return rc;
@@ -1217,6 +1255,11 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
     a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.y = (uint16_t*)d->y; a.y32 = d->y32;
     a.scale = d->scale; a.bias = d->bias; a.res = (const uint16_t*)d->res; a.mask_src = (const uint16_t*)d->mask_src;
     a.mask_bits_out = d->mask_bits_out; a.mask_bits = d->mask_bits;
+    a.stats_out = (float*)d->stats_out;
+    a.stats_rpg = d->stats_rows_per_group > 0 ? d->stats_rows_per_group : d->n * d->ho * d->wo;
+    CMS_REQUIRE(d->stats_out == nullptr || cms_conv_igemm_stats_tile_rows(d) == 128,
+                "conv: stats_out needs a launch cms_conv_igemm_stats_tile_rows() accepts (bf16 output of a forward launch on a default "
+                "tile, sample groups of whole rows no shorter than a tile)");
     CMS_REQUIRE((d->mask_bits_out == nullptr && d->mask_bits == nullptr) ||
                     (d->y != nullptr && d->zeros != nullptr && d->variant == 0 && d->ksplit <= 1),
                 "conv: ReLU mask bits need the bf16 output on the default (direct-to-LDS) kernel");

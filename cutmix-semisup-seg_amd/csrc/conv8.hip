@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.hpp"
+#include "tile_stats.hpp"
 
 namespace cms {
 
@@ -74,6 +75,8 @@ struct Args {
     float* slab;               // stream-K partial tiles [2 * grid][SLAB_FLOATS] or NULL
     unsigned* counters;        // stream-K arrival counters [tiles of the stream-K round], all zero between launches
     int N, H, W, Cin, Ho, Wo, Cout, ntaps, stride, out_H, out_W, out_stride, relu, mode, M, plain;
+    float* stats_out;          // [pixel tiles][2 slots][2][Cout] per-tile (sum, sum of squares) of the stored output, or NULL
+    int stats_rpg;             // pixel rows per sample group (>= 256; M for one group)
     int nt_store;              // output rows as non-temporal stores (CMS_CONV8_NT): streaming data must not evict the halo rows
                                // and weights neighbouring tiles of the XCD re-read from its L2 (profiles/r05b: 1.30 x over-fetch)
     int ntn;                   // channel tiles (Cout / 256); tile t = (pixel tile t / ntn, channel tile t % ntn)
@@ -168,7 +171,9 @@ __device__ __forceinline__ int run_of_unit(uint64_t u, uint64_t total, uint64_t 
     return (int)(((u + 1) * G + total - 1) / total) - 1;
 }
 
-template <bool SK>
+// STATS: the store loop also takes the per-tile channel sums (Args.stats_out) -- its own instantiation, so that the statistics'
+// 32 accumulators cost the default kernel nothing (it sits at 254 VGPRs without scratch)
+template <bool SK, bool STATS = false>
 __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     short* lds_tap = reinterpret_cast<short*>(smem + TAB_OFF);
@@ -729,20 +734,39 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
         __syncthreads();
         stamp(7);
         {
+            // thread -> LOGICAL chunk ch (8 channels) of rows r0, r0 + 16, ...: the same channels in every pass (tile_stats.hpp)
             const int ch = tid % CPR, r0 = tid / CPR;       // 16 rows per pass
+            auto rows = [&](auto ST_, TileStats& ts, int boundary) {
+                constexpr bool ST = decltype(ST_)::value;
 #pragma unroll
-            for (int r = r0; r < BM; r += NT / CPR) {
-                const uint32_t op = lds_row[r].opix;
-                if (op != 0xffffffffu) {
-                    const u32x4 val = *reinterpret_cast<const u32x4*>(smem + r * EROW + ch * 16);
-                    const int cl = ch ^ (r & (CPR - 1));
-                    u32x4* dst = reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + cl * 8);
+                for (int r = r0; r < BM; r += NT / CPR) {
+                    const uint32_t op = lds_row[r].opix;
+                    if (op != 0xffffffffu) {
+                        const u32x4 val = *reinterpret_cast<const u32x4*>(smem + r * EROW + ((ch ^ (r & (CPR - 1))) << 4));
+                        u32x4* dst = reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + ch * 8);
 #if defined(__HIP_DEVICE_COMPILE__)
-                    if (a.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(val) : "memory");
-                    else
+                        if (a.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(val) : "memory");
+                        else
 #endif
-                        *dst = val;
+                            *dst = val;
+                        if constexpr (ST) ts.add(val.x, val.y, val.z, val.w, (m0 + r) >= boundary);
+                    }
                 }
+            };
+            if constexpr (!STATS) {
+                TileStats none;
+                rows(std::false_type{}, none, 0);
+            } else {
+                TileStats ts;
+                // BatchNorm statistics out of the epilogue (round 5): per-channel sums of what this tile stores, [tile][slot][stat][Cout]
+                const int boundary = (m0 / a.stats_rpg + 1) * a.stats_rpg;      // first row of the next sample group
+                const int m_end = m0 + BM < a.M ? m0 + BM : a.M;
+                ts.zero();
+                rows(std::true_type{}, ts, boundary);
+                __syncthreads();                    // every wave has read the tile: its LDS is the scratch now
+                tile_stats_finish<CPR, NT / 64, NT>(ts, boundary < m_end, reinterpret_cast<float*>(smem),
+                                                    a.stats_out + (size_t)tile_m * 4 * a.Cout + co0, a.Cout);
+                __syncthreads();                    // (a persistent workgroup stages its next tile into the same LDS)
             }
         }
         stamp(8);
@@ -803,6 +827,12 @@ int conv8_launch(const cms_conv_desc* d, hipStream_t s, int mode, int grid_cap, 
     CMS_REQUIRE(d->mask_bits == nullptr || (d->mode == 1 && d->mask_src == nullptr), "conv8: mask_bits replaces mask_src of a data gradient");
     CMS_REQUIRE((d->mask_bits_out == nullptr && d->mask_bits == nullptr) || mode == 0,
                 "conv8: ReLU mask bits with whole tiles per workgroup only (not the stream-K launch)");
+    a.stats_out = (float*)d->stats_out;
+    a.stats_rpg = d->stats_rows_per_group > 0 ? d->stats_rows_per_group : d->n * d->ho * d->wo;
+    CMS_REQUIRE(d->stats_out == nullptr ||
+                    (d->mode == 0 && d->out_stride == 1 && d->out_h == d->ho && d->out_w == d->wo && a.stats_rpg >= c8::BM &&
+                     (d->n * d->ho * d->wo) % a.stats_rpg == 0),
+                "conv8: stats_out is written by forward launches whose sample groups are whole runs of >= 256 pixel rows");
     a.N = d->n; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
     a.ntaps = d->ntaps; a.stride = d->stride; a.out_H = d->out_h; a.out_W = d->out_w; a.out_stride = d->out_stride;
     a.relu = d->relu; a.mode = d->mode;
@@ -855,11 +885,15 @@ int conv8_launch(const cms_conv_desc* d, hipStream_t s, int mode, int grid_cap, 
     if (!raised) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(c8::conv8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(c8::conv8_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(c8::conv8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         raised = true;
     }
-    if (a.sk_tiles > 0) hipLaunchKernelGGL(c8::conv8_kernel<true>, dim3(grid), dim3(c8::NT), c8::LDS_BYTES, s, a);
+    CMS_REQUIRE(a.stats_out == nullptr || a.sk_tiles == 0, "conv8: stats_out with whole tiles per workgroup only (not the stream-K launch)");
+    if (a.stats_out) hipLaunchKernelGGL((c8::conv8_kernel<false, true>), dim3(grid), dim3(c8::NT), c8::LDS_BYTES, s, a);
+    else if (a.sk_tiles > 0) hipLaunchKernelGGL(c8::conv8_kernel<true>, dim3(grid), dim3(c8::NT), c8::LDS_BYTES, s, a);
     else hipLaunchKernelGGL(c8::conv8_kernel<false>, dim3(grid), dim3(c8::NT), c8::LDS_BYTES, s, a);
     return launch_status("cms_conv_igemm (8-phase)");
 }

@@ -1,0 +1,76 @@
+// Per-channel (sum, sum of squares) of the bf16 output tile a convolution workgroup has built in LDS, taken inside its store loop
+// (round 5: BatchNorm statistics out of the convolution epilogue, cms_conv_desc.stats_out). Shared by conv.hip and conv8.hip.
+//
+// The store loop gives thread t the 16-byte chunk ch = t % CPR (8 channels) of the rows r0 = t / CPR, r0 + NT / CPR, ...: it adds
+// what it stores. A tile may straddle ONE boundary between sample groups (groups are >= one tile long): rows of the group the
+// tile's first row belongs to go to slot 0, rows of the next group to slot 1. After the loop: lanes of a wave that hold the same
+// chunk are summed with shuffles, the waves' partial sums meet in LDS (the tile itself is done with), and the workgroup writes
+// out[tile][slot][stat][Cout] for its channels -- plain stores, fixed order: reproducible.
+#pragma once
+#include "common.hpp"
+
+namespace cms {
+
+struct TileStats {
+    float s0[8], q0[8], s1[8], q1[8];      // (sum, sum of squares) of slot 0 / slot 1, per channel of the chunk
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s0[e] = q0[e] = s1[e] = q1[e] = 0.0f;
+    }
+    // the 8 bf16 values of a chunk (4 dwords). Branch-free: an if / else over the slot is turned into a dynamically indexed
+    // array by the compiler, i.e. into scratch memory.
+    __device__ __forceinline__ void add(uint32_t x, uint32_t y, uint32_t z, uint32_t w, bool second) {
+        float v[8];
+        v[0] = __uint_as_float(x << 16); v[1] = __uint_as_float(x & 0xffff0000u);
+        v[2] = __uint_as_float(y << 16); v[3] = __uint_as_float(y & 0xffff0000u);
+        v[4] = __uint_as_float(z << 16); v[5] = __uint_as_float(z & 0xffff0000u);
+        v[6] = __uint_as_float(w << 16); v[7] = __uint_as_float(w & 0xffff0000u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = second ? 0.0f : v[e], b = second ? v[e] : 0.0f;
+            s0[e] += a; q0[e] = fmaf(a, a, q0[e]);
+            s1[e] += b; q1[e] = fmaf(b, b, q1[e]);
+        }
+    }
+};
+
+// CPR = chunks per tile row (BN / 8), NW = waves of the workgroup, NT = threads. `scratch` = LDS every wave is done with (the tile;
+// the caller has synchronised), >= NW * 4 * BN floats. `dst` = out + ((tile * 2) * 2) * Cout + co0: this tile's [slot][stat][Cout] block.
+template <int CPR, int NW, int NT>
+__device__ __forceinline__ void tile_stats_finish(TileStats& t, bool straddle, float* scratch, float* dst, int Cout) {
+    constexpr int BN = CPR * 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // lanes l, l + CPR, l + 2 CPR ... of a wave hold the same chunk
+#pragma unroll
+    for (int off = 32; off >= CPR; off >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            t.s0[e] += __shfl_xor(t.s0[e], off, 64);
+            t.q0[e] += __shfl_xor(t.q0[e], off, 64);
+            t.s1[e] += __shfl_xor(t.s1[e], off, 64);
+            t.q1[e] += __shfl_xor(t.q1[e], off, 64);
+        }
+    }
+    if (lane < CPR) {
+        // scratch[wave][slot][stat][BN]
+        float* p = scratch + (size_t)wave * 4 * BN + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            p[e] = t.s0[e];
+            p[BN + e] = t.q0[e];
+            p[2 * BN + e] = t.s1[e];
+            p[3 * BN + e] = t.q1[e];
+        }
+    }
+    __syncthreads();
+    const int n_out = (straddle ? 2 : 1) * 2 * BN;          // slot 1 only for a tile that straddles a group boundary
+    for (int i = tid; i < n_out; i += NT) {
+        const int c = i % BN, ks = i / BN;                   // ks = slot * 2 + stat
+        float acc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc += scratch[(w * 4 + ks) * BN + c];
+        dst[(size_t)ks * Cout + c] = acc;
+    }
+}
+
+}  // namespace cms

@@ -760,13 +760,14 @@ def bn_workspace(n_pixels, c, device, groups=1):
     return ws
 
 
-_BN_WHAT = {'reduce': 0, 'finalize': 1, 'apply': 2, 'reduce_bwd': 3, 'bwd_apply': 4, 'count': 5, 'stats': 6}
+_BN_WHAT = {'reduce': 0, 'finalize': 1, 'apply': 2, 'reduce_bwd': 3, 'bwd_apply': 4, 'count': 5, 'stats': 6, 'finalize_tiles': 7}
 
 
-def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, momentum=0.1, groups=1, **t):
+def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, momentum=0.1, groups=1, tile_rows=0, **t):
     """One launch of the batch-statistics BatchNorm protocol (csrc/bn.hip) on caller-owned buffers -- issued now, or appended
     to the program being recorded (cms_program_add_bn): the executor's batch-statistics passes (backbone_hip.py) are made of
-    these. `what`: reduce | finalize | apply | reduce_bwd | bwd_apply | count | stats (= reduce + finalize in one launch);
+    these. `what`: reduce | finalize | apply | reduce_bwd | bwd_apply | count | stats (= reduce + finalize in one launch) |
+    finalize_tiles (statistics from the tile sums the unit's convolution wrote: ws = conv_igemm's stats['tile_sums'], tile_rows);
     tensors by keyword (x, res, y, dy, dx, dres, sums, gamma, beta, mean, rstd, scale, shift, running_mean, running_var,
     counter, clear_a, clear_b, ws). With `ws` (bn_workspace) the reductions take the atomics-free kernels; `groups` > 1
     (sample groups normalised separately, include/cutmixseg.h) needs them. `count` = pixels of one group."""
@@ -779,6 +780,7 @@ def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, mo
         setattr(d, k, None if v is None else v.data_ptr())
     d.count, d.n_pixels = float(count), int(n_pixels)
     d.eps, d.momentum = float(eps), float(momentum)
+    d.reserved = int(tile_rows)
     has_ws = t.get('ws') is not None
     if d.groups > 1 and what in ('reduce', 'reduce_bwd') and not has_ws:
         raise ValueError('bn_op: grouped reductions need a workspace')
@@ -800,6 +802,10 @@ def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, mo
         check(fn['cms_bn_stats'](g('x'), d.dtype, d.n_pixels, d.c, G, g('gamma'), g('beta'), d.eps, d.momentum, g('mean'),
                                  g('rstd'), g('scale'), g('shift'), g('running_mean'), g('running_var'), g('counter'), g('sums'),
                                  g('ws'), _stream()), 'cms_bn_stats')
+    elif what == 'finalize_tiles':
+        check(fn['cms_bn_finalize_tiles'](g('ws'), int(tile_rows), d.n_pixels, d.c, G, g('gamma'), g('beta'), d.eps, d.momentum,
+                                          g('mean'), g('rstd'), g('scale'), g('shift'), g('running_mean'), g('running_var'),
+                                          g('counter'), _stream()), 'cms_bn_finalize_tiles')
     elif what == 'finalize':
         check(fn['cms_bn_finalize_ex'](g('sums'), d.count, g('gamma'), g('beta'), d.eps, d.momentum, g('mean'), g('rstd'),
                                        g('scale'), g('shift'), g('running_mean'), g('running_var'), d.c, g('clear_a'),
@@ -1193,7 +1199,7 @@ def conv_taps(kh, kw, dilation, padding):
 
 def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, res=None, relu=False, mode=0,
                mask_src=None, out=None, out_f32_nchw=None, cout_real=None, out_stride=1, out_full_hw=None, tile=0,
-               ksplit=1, variant=0, out_pixel_offset=0, mask_bits_out=None, mask_bits=None):
+               ksplit=1, variant=0, out_pixel_offset=0, mask_bits_out=None, mask_bits=None, stats=None):
     """
     Implicit-GEMM convolution on the MFMA units (csrc/conv.hip).
       x         bf16 NHWC-contiguous tensor of logical shape (N, H, W, Cin)
@@ -1204,6 +1210,10 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     instead of pixel 0 -- residual / mask are read at the same shifted positions (the phases of a transposed convolution).
     `mask_bits_out` (forward + ReLU): uint8 (N, out_h, out_w, Cout / 8) that receives [y > 0] as bits; `mask_bits` (mode 1):
     such a tensor INSTEAD of `mask_src` -- the ReLU mask of a data gradient at 1/16 of the bytes (cms_conv_desc).
+    `stats` (bf16 forward launches): a dict {'groups': G}; when the kernel that takes the launch can, its epilogue also writes the
+    per-channel (sum, sum of squares) of every pixel tile it stores (cms_conv_desc.stats_out) and the dict comes back with
+    'tile_rows' (128 / 256) and 'tile_sums' (fp32 [tiles][2][2][Cout]) for bn_op('finalize_tiles'); 'tile_rows' = 0 when it cannot
+    (the statistics then take a pass over the output: bn_op('stats')).
     """
     _need_cuda(x, w_packed, scale, bias, res, mask_src, out, out_f32_nchw, mask_bits_out, mask_bits)
     for t in (mask_bits_out, mask_bits):
@@ -1262,12 +1272,26 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
             and ((int(variant) == 0 and ntaps * (cin // 64) >= 8) or int(variant) in (91, 93)):
         ws = conv8_workspace(x.device)       # wide, K-deep layer: the library may take the eight-phase kernel (csrc/conv8.hip)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    tile_sums = None
+    if stats is not None:
+        stats['tile_rows'], stats['tile_sums'] = 0, None
+        G = max(1, int(stats.get('groups', 1)))
+        M = n * ho * wo
+        if not f32 and out_f32_nchw is None and M % G == 0:
+            d.stats_rows_per_group = M // G
+            rows = int(fn['cms_conv_igemm_stats_tile_rows'](C.byref(d)))
+            if rows < 0:
+                check(rows, 'cms_conv_igemm_stats_tile_rows')
+            if rows > 0:
+                tile_sums = torch.empty(((M + rows - 1) // rows) * 4 * cout, dtype=torch.float32, device=x.device)
+                d.stats_out = tile_sums.data_ptr()
+                stats['tile_rows'], stats['tile_sums'] = rows, tile_sums
     if _REC is not None:
         prog = _REC[0]
         idx = fn['cms_program_add_conv'](prog.h, C.byref(d), int(f32), _rec_stream_index(), prog.group)
         if idx < 0:
             check(idx, 'cms_program_add_conv')
-        prog.keep += [t for t in (x, w_packed, out, out_f32_nchw, scale, bias, res, mask_src, zp, mask_bits_out, mask_bits)
+        prog.keep += [t for t in (x, w_packed, out, out_f32_nchw, scale, bias, res, mask_src, zp, mask_bits_out, mask_bits, tile_sums)
                       if t is not None]
         esz = x.element_size()
         prog.flops += 2.0 * n * ho * wo * cout * cin * ntaps

@@ -281,6 +281,17 @@ typedef struct cms_conv_desc {
      * whole-tile launches).                                                                                                  */
     uint8_t* mask_bits_out;
     const uint8_t* mask_bits;
+    /* Round 5: BatchNorm statistics out of the convolution epilogue (the batch-statistics units of
+     * architectures/deeplab2.py:72-84 -- the reference CLI's default, train_seg_semisup_mask_mt.py:587 -- are
+     * u = conv(x); y = relu(bn_batch(u) (+ res)): the statistics pass over u, one of the unit's memory passes, disappears).
+     * stats_out != NULL (bf16 NHWC output, mode 0): every workgroup also writes the per-channel (sum, sum of squares) of the bf16
+     * values it STORES, per pixel tile: float [tiles][2 slots][2][cout], tiles = ceil(n * ho * wo / T), T =
+     * cms_conv_igemm_stats_tile_rows(desc) (128 or 256 rows: the kernel that runs the launch; 0 = this launch cannot, use
+     * cms_bn_stats). The pixel rows are `groups` equal runs of stats_rows_per_group rows (sample groups normalised separately);
+     * slot 0 = the tile's rows of the group its FIRST row belongs to, slot 1 = its rows of the next group (written only by a tile that
+     * straddles a boundary). cms_bn_finalize_tiles turns them into mean / rstd / scale / shift and moves the running statistics. */
+    float* stats_out;
+    int stats_rows_per_group;
 } cms_conv_desc;
 
 int cms_conv_igemm(const cms_conv_desc* d, void* stream);
@@ -293,6 +304,8 @@ int cms_conv_igemm(const cms_conv_desc* d, void* stream);
 #define CMS_ROUTE_TILE32 4    /* 32-channel tile */
 #define CMS_ROUTE_CONV8 8     /* conv8_kernel: eight-phase 256 x 256 */
 int cms_conv_igemm_route(const cms_conv_desc* d);
+/* pixel rows per statistics tile of a launch with stats_out (see cms_conv_desc), or 0 when the launch cannot write them */
+int cms_conv_igemm_stats_tile_rows(const cms_conv_desc* d);
 /* bytes of cms_conv_desc.workspace that every launch on this device is satisfied with */
 long long cms_conv_igemm_workspace_bytes(void);
 
@@ -578,9 +591,17 @@ int cms_program_add_aspp_spread(cms_program* p, const float* dlogits, void* d_nh
 int cms_program_add_sync(cms_program* p, int from_stream, int to_stream, int group);
 /* Batch-statistics BatchNorm launches inside a program (round 3: DeepLab v2 WITHOUT --freeze_bn on the executor,
  * architectures/deeplab2.py:72-84 / train_seg_semisup_mask_mt.py:587). `what`: 0 = cms_bn_reduce(mode 0), 1 = cms_bn_finalize,
- * 2 = cms_bn_apply, 3 = cms_bn_reduce(mode 1), 4 = cms_bn_bwd_apply, 5 = cms_increment_counter(counter), 6 = cms_bn_stats; unused pointers NULL. With `ws` set, what 0 / 3
+ * 2 = cms_bn_apply, 3 = cms_bn_reduce(mode 1), 4 = cms_bn_bwd_apply, 5 = cms_increment_counter(counter), 6 = cms_bn_stats,
+ * 7 = cms_bn_finalize_tiles (tile sums in `ws`, tile rows in `reserved`); unused pointers NULL. With `ws` set, what 0 / 3
  * run cms_bn_reduce_ws.
  * All buffers are the caller's and persistent (a program is replayed many times). */
+/* Statistics of a unit from the tile sums its convolution wrote (cms_conv_desc.stats_out): per group and channel the tiles' sums are
+ * added in a fixed order in fp64, then finalised exactly like cms_bn_stats (mean / rstd / scale / shift [groups][c], running statistics
+ * moved once per group in group order, *counter += groups). tile_rows = cms_conv_igemm_stats_tile_rows of that launch. */
+int cms_bn_finalize_tiles(const float* tile_sums, int tile_rows, size_t n_pixels, int c, int groups, const float* gamma,
+                          const float* beta, float eps, float momentum, float* mean, float* rstd, float* scale, float* shift,
+                          float* running_mean, float* running_var, long long* counter, void* stream);
+
 typedef struct cms_bn_op {
     int what, dtype, c, relu;
     const void* x;             /* conv output u, NHWC                                                          */
@@ -601,12 +622,13 @@ typedef struct cms_bn_op {
     long long* counter;        /* what 1 (optional) / what 5: num_batches_tracked                              */
     double* clear_a;           /* what 1: zeroed after the statistics were read (cms_bn_finalize_ex), or NULL  */
     double* clear_b;
-    void* ws;                  /* what 0 / 3 (optional), 6: cms_bn_workspace_bytes(n_pixels, c, groups) bytes  */
+    void* ws;                  /* what 0 / 3 (optional), 6: cms_bn_workspace_bytes(n_pixels, c, groups) bytes;
+                                * what 7: the tile sums (cms_conv_desc.stats_out of the unit's convolution)   */
     double count;              /* pixels the statistics run over                                               */
     unsigned long long n_pixels;
     float eps, momentum;
     int groups;                /* sample groups (0 / 1: one); needs `ws` for what 0 / 3                       */
-    int reserved;
+    int reserved;              /* what 7: pixel rows per statistics tile (cms_conv_igemm_stats_tile_rows)      */
 } cms_bn_op;
 int cms_program_add_bn(cms_program* p, const cms_bn_op* op, int stream_idx, int group);
 int cms_program_size(const cms_program* p);
