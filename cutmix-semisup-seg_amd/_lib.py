@@ -67,7 +67,7 @@ class ConvDesc(C.Structure):
                 ('out_h', c_int), ('out_w', c_int), ('out_stride', c_int), ('relu', c_int), ('mode', c_int),
                 ('tile', c_int), ('ksplit', c_int), ('zeros', c_void_p), ('variant', c_int), ('zeros_bytes', c_int),
                 ('workspace', c_void_p), ('workspace_bytes', C.c_longlong), ('mask_bits_out', c_void_p), ('mask_bits', c_void_p),
-                ('stats_out', c_void_p), ('stats_rows_per_group', c_int)]
+                ('stats_out', c_void_p), ('stats_rows_per_group', c_int), ('mask_gates_res', c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -84,7 +84,7 @@ class BnOp(C.Structure):
                 ('sums', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('mean', c_void_p), ('rstd', c_void_p),
                 ('scale', c_void_p), ('shift', c_void_p), ('running_mean', c_void_p), ('running_var', c_void_p),
                 ('counter', c_void_p), ('clear_a', c_void_p), ('clear_b', c_void_p), ('ws', c_void_p), ('count', C.c_double), ('n_pixels', C.c_ulonglong), ('eps', c_float),
-                ('momentum', c_float), ('groups', c_int), ('reserved', c_int)]
+                ('momentum', c_float), ('groups', c_int), ('reserved', c_int), ('mask_bits', c_void_p)]
 
 
 class AugmentDesc(C.Structure):
@@ -145,6 +145,12 @@ PROTOTYPES = {
     'cms_conv_igemm_stats_tile_rows': (c_int, [_P(ConvDesc)]),
     'cms_bn_finalize_tiles': (c_int, [c_void_p, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cms_bn_apply_groups_bits': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_size_t, c_int, c_int,
+                                         c_void_p, c_void_p]),
+    'cms_bn_reduce_ws_bits': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,
+                                      c_void_p, c_void_p]),
+    'cms_bn_bwd_apply_groups_bits': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, C.c_double, c_size_t, c_int, c_int, c_void_p]),
     'cms_conv_set_trace': (c_int, [c_void_p, c_int]),
     'cms_conv_set_wgrad8': (c_int, [c_int]),
     'cms_loss_set_deterministic': (c_int, [c_int]),

@@ -420,18 +420,28 @@ class DeepLabHipExecutor(object):
                       running_mean=a.view(c.bn + '.running_mean'), running_var=a.view(c.bn + '.running_var'),
                       counter=bn.num_batches_tracked)
         y = torch.empty_like(u)
+        # (round 5) the ReLU mask of the backward passes as BITS beside y: they then stream u, dy and 1/16 of a tensor instead of y
+        bits = torch.empty(npix * C // 8, dtype=torch.uint8, device=dev) if (relu and save and _bn_mask_bits()) else None
         ops.bn_op('apply', c=C, dtype=self.dtype, n_pixels=npix, groups=G, relu=relu, x=u, res=res, y=y, scale=scale,
-                  shift=shift)
-        return y, (u, y if relu else None, mean, rstd, bsums, ws, G)
+                  shift=shift, mask_bits=bits)
+        return y, (u, (y if bits is None else bits) if relu else None, mean, rstd, bsums, ws, G)
 
-    def _bwd_unit_bn(self, dy, saved, c, want_res):
+    def _bwd_unit_bn(self, dy, saved, c, want_res, dy_bits=None):
         """Backward of the normalisation of one unit: dy (gradient wrt y) -> (du = gradient wrt the convolution output,
         dres = gradient wrt the residual input or None). The ReLU mask comes from the stored y."""
         u, y, mean, rstd, sums, ws, G = saved   # `sums` is overwritten by the reduction; `ws`: the unit's workspace
         C = c.cout
         npix = u.numel() // C
+        bits = None
+        if y is not None and y.dtype == torch.uint8:        # the mask as bits (`_fwd_unit_bn`)
+            bits, y = y, None
+        if dy_bits is not None:
+            # `dy` arrives UNMASKED with the mask of the tensor it is the gradient of (the downsample unit behind a block output
+            # whose masked gradient `dres` is no longer materialised): this unit has no ReLU of its own, the bits take its place
+            assert y is None and bits is None
+            bits = dy_bits
         ops.bn_op('reduce_bwd', c=C, dtype=self.dtype, n_pixels=npix, groups=G, x=u, dy=dy, y=y, mean=mean, rstd=rstd, sums=sums,
-                  ws=ws)
+                  ws=ws, mask_bits=bits)
         grp = self._dist_group()
         world = ops._world(grp)
         if world > 1:                        # SyncBN: (sum dy', sum dy' xhat) of every group over all ranks
@@ -439,7 +449,7 @@ class DeepLabHipExecutor(object):
         du = torch.empty_like(u)
         dres = torch.empty_like(u) if want_res else None
         ops.bn_op('bwd_apply', c=C, dtype=self.dtype, n_pixels=npix, groups=G, count=(npix // G) * world, x=u, dy=dy, y=y, dx=du, dres=dres,
-                  mean=mean,
+                  mask_bits=bits, mean=mean,
                   rstd=rstd, gamma=self.arena.view(c.bn + '.weight'), sums=sums)
         return du, dres
 
@@ -471,10 +481,14 @@ class DeepLabHipExecutor(object):
             self._pack_plan_bn = ops.PackTransposePlan(triples)
         self._pack_plan_bn.run()
 
-    def _dgrad_raw(self, du, c, res=None, in_hw=None):
+    def _dgrad_raw(self, du, c, res=None, in_hw=None, res_bits=None):
+        """Data gradient of one convolution (+ res). `res_bits`: res is the UNMASKED gradient of a ReLU output and the bits are that
+        ReLU's mask -- added as (bit ? res : 0) in the epilogue (cms_conv_desc.mask_gates_res)."""
         n, ho, wo, _ = du.shape
         if c.stride == 1:
-            return ops.conv_igemm(du, c.wT_raw, c.neg_taps, res=res, mode=1, tile=self._tile(c.cin))
+            return ops.conv_igemm(du, c.wT_raw, c.neg_taps, res=res, mode=1, tile=self._tile(c.cin), mask_bits=res_bits,
+                                  mask_gates_res=res_bits is not None)
+        assert res_bits is None
         return ops.conv_igemm(du, c.wT_raw, c.neg_taps, res=res, mode=1, out_hw=(ho, wo), out_stride=c.stride,
                               out_full_hw=in_hw, tile=self._tile(c.cin))
 
@@ -501,14 +515,19 @@ class DeepLabHipExecutor(object):
             b = self.blocks[bi]
             xin, a1, a2, s1, s2, s3, sd = saved[bi]
             in_hw = (xin.shape[1], xin.shape[2])
-            du3, dres = self._bwd_unit_bn(dOut, s3, b.c3, True)
+            # (round 5) with the block output's ReLU mask as bits, its masked gradient `dres` (the widest tensor of the block) is
+            # never written: the identity shortcut adds (bit ? dOut : 0) in conv1's data-gradient epilogue, the downsample unit's
+            # backward passes read dOut through the same bits
+            bits3 = s3[1] if (s3[1] is not None and s3[1].dtype == torch.uint8 and _bn_gate_shortcut()
+                              and (b.cd is not None or b.c1.stride == 1)) else None
+            du3, dres = self._bwd_unit_bn(dOut, s3, b.c3, bits3 is None)
             da2 = self._dgrad_raw(du3, b.c3)
             du2, _ = self._bwd_unit_bn(da2, s2, b.c2, False)
             da1 = self._dgrad_raw(du2, b.c2)
             du1, _ = self._bwd_unit_bn(da1, s1, b.c1, False)
             dud = None
             if b.cd is not None:
-                dud, _ = self._bwd_unit_bn(dres, sd, b.cd, False)
+                dud, _ = self._bwd_unit_bn(dres if bits3 is None else dOut, sd, b.cd, False, dy_bits=bits3)
             if want_w:
                 jobs = [(du3, a2, b.c3), (du2, a1, b.c2)] + ([(dud, xin, b.cd)] if b.cd is not None else []) + [(du1, xin, b.c1)]
                 if sides:
@@ -527,8 +546,11 @@ class DeepLabHipExecutor(object):
                     for du_, x_, c_ in jobs:
                         self._wgrad_raw(du_, x_, c_)
                     hook(bi)
-            dx = dres if b.cd is None else self._dgrad_raw(dud, b.cd, in_hw=in_hw)
-            dOut = self._dgrad_raw(du1, b.c1, res=dx, in_hw=in_hw)
+            if b.cd is None and bits3 is not None:
+                dOut = self._dgrad_raw(du1, b.c1, res=dOut, in_hw=in_hw, res_bits=bits3)
+            else:
+                dx = dres if b.cd is None else self._dgrad_raw(dud, b.cd, in_hw=in_hw)
+                dOut = self._dgrad_raw(du1, b.c1, res=dx, in_hw=in_hw)
         if not self.defer_wgrad_join:
             for sd_ in sides:
                 ops.stream_wait(main, sd_)
@@ -1403,6 +1425,17 @@ def _fused_bn_stats():
     """CMS_BN_FUSED_STATS (default 1; A/B switch, read per recording): batch-statistics units take their statistics from the tile
     sums the convolution's epilogue writes (`_fwd_unit_bn`); 0 = the round-3/4 pass over the convolution output."""
     return os.environ.get('CMS_BN_FUSED_STATS', '1') != '0'
+
+
+def _bn_mask_bits():
+    """CMS_BN_MASK_BITS (default 1; A/B switch, read per recording): the normalising launch of a batch-statistics unit writes its
+    ReLU mask as bits and the unit's backward passes read those instead of y."""
+    return os.environ.get('CMS_BN_MASK_BITS', '1') != '0'
+
+
+def _bn_gate_shortcut():
+    """CMS_BN_GATE_SHORTCUT (default 1; A/B switch): batch-statistics backward without the `dres` tensor (`_backward_chain_bn`)."""
+    return os.environ.get('CMS_BN_GATE_SHORTCUT', '1') != '0'
 
 
 def _auto_keeps_library():

@@ -53,6 +53,21 @@ __device__ __forceinline__ void store8(uint16_t* p, const float (&v)[8]) {
     *reinterpret_cast<uint4*>(p) = o;
 }
 
+// [stored value > 0] of 8 outputs as one byte (bit e = channel e of the vector): the ReLU mask the backward kernels test, taken
+// from what store8 writes (a positive fp32 below bf16's smallest subnormal is stored as 0)
+__device__ __forceinline__ unsigned stored_positive_bits(const float*, const float (&v)[8]) {
+    unsigned b = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b |= (v[e] > 0.0f ? 1u : 0u) << e;
+    return b;
+}
+__device__ __forceinline__ unsigned stored_positive_bits(const uint16_t*, const float (&v)[8]) {
+    unsigned b = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b |= ((int16_t)f32_to_bf16(v[e]) > 0 ? 1u : 0u) << e;
+    return b;
+}
+
 // MODE 0: (sum x, sum x^2).  MODE 1: (sum dy', sum dy' * xhat) with dy' = dy * [y > 0] (y == nullptr: no ReLU)
 template <class T, int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
@@ -212,7 +227,8 @@ __global__ __launch_bounds__(256) void bn_reduce_tiled_kernel(const T* __restric
                                                               const T* __restrict__ y, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, double* __restrict__ sums,
                                                               unsigned* counters, float* part,
-                                                              size_t Pg, int C, int tiles, int S, BnFin fin, int fenced) {
+                                                              size_t Pg, int C, int tiles, int S, BnFin fin, int fenced,
+                                                              const uint8_t* __restrict__ bits) {
     __shared__ float red[4][2 * BN_CT];
     __shared__ double redd[8][2 * BN_CT];
     __shared__ int last_flag;
@@ -231,45 +247,54 @@ __global__ __launch_bounds__(256) void bn_reduce_tiled_kernel(const T* __restric
             load8(mean + (size_t)grp * C + c0, mu);
             load8(rstd + (size_t)grp * C + c0, rs);
         }
-        auto accumulate = [&](const float (&xv)[8], const float (&dv)[8], const float (&yv)[8]) {
+        // the ReLU mask: the stored output y, or (round 5) the BITS bn_apply wrote beside it -- one byte per 8-channel vector,
+        // 1/16 of the bytes of y ([pixel rows][C / 8], bit e = channel e of the vector)
+        auto accumulate = [&](const float (&xv)[8], const float (&dv)[8], const float (&yv)[8], unsigned mb) {
             if (MODE == 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { a0[e] += xv[e]; a1[e] = fmaf(xv[e], xv[e], a1[e]); }
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float d = (y == nullptr || yv[e] > 0.0f) ? dv[e] : 0.0f;
+                    const bool on = bits ? ((mb >> e) & 1u) != 0 : (y == nullptr || yv[e] > 0.0f);
+                    const float d = on ? dv[e] : 0.0f;
                     a0[e] += d;
                     a1[e] = fmaf(d, (xv[e] - mu[e]) * rs[e], a1[e]);
                 }
             }
         };
         const size_t base = (size_t)grp * Pg * (size_t)C + (size_t)c0;
+        const uint8_t* brow = bits ? bits + (size_t)grp * Pg * (size_t)(C >> 3) + (size_t)(c0 >> 3) : nullptr;
+        const size_t bstride = (size_t)(C >> 3);
         const size_t stride = (size_t)S * 32;
         size_t p = (size_t)split * 32 + slot;
         for (; p + 3 * stride < Pg; p += 4 * stride) {
             float xv[4][8], dv[4][8], yv[4][8];
+            unsigned mb[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const size_t o = base + (p + u * stride) * (size_t)C;
                 load8(x + o, xv[u]);
                 if (MODE == 1) {
                     load8(dy + o, dv[u]);
-                    if (y) load8(y + o, yv[u]);
+                    if (bits) mb[u] = brow[(p + u * stride) * bstride];
+                    else if (y) load8(y + o, yv[u]);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) accumulate(xv[u], dv[u], yv[u]);
+            for (int u = 0; u < 4; ++u) accumulate(xv[u], dv[u], yv[u], mb[u]);
         }
         for (; p < Pg; p += stride) {
             const size_t o = base + p * (size_t)C;
             float xv[8], dv[8], yv[8];
+            unsigned mb = 0u;
             load8(x + o, xv);
             if (MODE == 1) {
                 load8(dy + o, dv);
-                if (y) load8(y + o, yv);
+                if (bits) mb = brow[p * bstride];
+                else if (y) load8(y + o, yv);
             }
-            accumulate(xv, dv, yv);
+            accumulate(xv, dv, yv, mb);
         }
     }
     // the 8 pixel rows of a wave that share a channel group (lane bits 3..5), then the 4 waves through LDS
@@ -398,10 +423,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
 template <class T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       int relu, size_t P, int C) {
+                                                       int relu, size_t P, int C, uint8_t* __restrict__ bits_out) {
     const int CG = C / 8;
     const size_t total = P * CG;
     const size_t gbase = (size_t)blockIdx.y * total * 8;
+    if (bits_out) bits_out += (size_t)blockIdx.y * total;
     scale += (size_t)blockIdx.y * C;
     shift += (size_t)blockIdx.y * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -419,6 +445,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
             xv[e] = relu ? fmaxf(v, 0.0f) : v;
         }
         store8(y + o, xv);
+        if (bits_out) bits_out[i] = (uint8_t)stored_positive_bits(y, xv);      // consecutive lanes: consecutive bytes
     }
 }
 
@@ -432,10 +459,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ y, T* __restrict__ dx, T* __restrict__ dres,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const double* __restrict__ sums,
-                                                           double count, size_t P, int C) {
+                                                           double count, size_t P, int C, const uint8_t* __restrict__ bits) {
     const int CG = C / 8;
     const size_t total = P * CG;
     const size_t gbase = (size_t)blockIdx.y * total * 8;
+    if (bits) bits += (size_t)blockIdx.y * total;
     mean += (size_t)blockIdx.y * C;
     rstd += (size_t)blockIdx.y * C;
     sums += (size_t)blockIdx.y * 2 * C;
@@ -455,11 +483,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             grs[e] = (gamma ? gamma[c] : 1.0f) * rs[e];
         }
     }
-    auto one = [&](const float (&xv)[8], const float (&dv)[8], const float (&yv)[8], size_t o) {
+    auto one = [&](const float (&xv)[8], const float (&dv)[8], const float (&yv)[8], unsigned mb, size_t o) {
         float out[8], dr[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float d = (y == nullptr || yv[e] > 0.0f) ? dv[e] : 0.0f;
+            const bool on = bits ? ((mb >> e) & 1u) != 0 : (y == nullptr || yv[e] > 0.0f);
+            const float d = on ? dv[e] : 0.0f;
             const float xh = (xv[e] - mu[e]) * rs[e];
             out[e] = grs[e] * (d - m1[e] - xh * m2[e]);
             dr[e] = d;
@@ -469,17 +498,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     };
     for (; i + stride < total; i += 2 * stride) {                  // two vectors in flight per thread
         float xa[8], da[8], ya[8], xb[8], db[8], yb[8];
+        unsigned ma = 0u, mb = 0u;
         const size_t oa = gbase + i * 8, ob = gbase + (i + stride) * 8;
-        load8(x + oa, xa); load8(dy + oa, da); if (y) load8(y + oa, ya);
-        load8(x + ob, xb); load8(dy + ob, db); if (y) load8(y + ob, yb);
-        one(xa, da, ya, oa);
-        one(xb, db, yb, ob);
+        load8(x + oa, xa); load8(dy + oa, da); if (bits) ma = bits[i]; else if (y) load8(y + oa, ya);
+        load8(x + ob, xb); load8(dy + ob, db); if (bits) mb = bits[i + stride]; else if (y) load8(y + ob, yb);
+        one(xa, da, ya, ma, oa);
+        one(xb, db, yb, mb, ob);
     }
     if (i < total) {
         float xa[8], da[8], ya[8];
+        unsigned ma = 0u;
         const size_t oa = gbase + i * 8;
-        load8(x + oa, xa); load8(dy + oa, da); if (y) load8(y + oa, ya);
-        one(xa, da, ya, oa);
+        load8(x + oa, xa); load8(dy + oa, da); if (bits) ma = bits[i]; else if (y) load8(y + oa, ya);
+        one(xa, da, ya, ma, oa);
     }
 }
 
@@ -566,7 +597,7 @@ extern "C" size_t cms_bn_workspace_bytes(size_t n_pixels, int c, int groups) {
 
 static int bn_reduce_tiled(const void* x, const void* dy, const void* y, int dtype, const float* mean, const float* rstd,
                            double* sums, size_t n_pixels, int c, int groups, int mode, void* ws, const BnFin* fin,
-                           hipStream_t s) {
+                           hipStream_t s, const uint8_t* bits = nullptr) {
     int tiles, S;
     bn_tiling(n_pixels, c, groups, &tiles, &S);
     unsigned* counters = (unsigned*)ws;
@@ -574,7 +605,7 @@ static int bn_reduce_tiled(const void* x, const void* dy, const void* y, int dty
     const dim3 grid((unsigned)(tiles * S), (unsigned)groups);
     const size_t pg = n_pixels / (size_t)groups;
     BnFin f = fin ? *fin : BnFin{};
-#define CMS_BN_TILED(T, M, F) hipLaunchKernelGGL((bn_reduce_tiled_kernel<T, M, F>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, sums, counters, part, pg, c, tiles, S, f, bn_fenced())
+#define CMS_BN_TILED(T, M, F) hipLaunchKernelGGL((bn_reduce_tiled_kernel<T, M, F>), grid, dim3(256), 0, s, (const T*)x, (const T*)dy, (const T*)y, mean, rstd, sums, counters, part, pg, c, tiles, S, f, bn_fenced(), bits)
     if (dtype == CMS_F32) {
         if (mode == 1) CMS_BN_TILED(float, 1, false);
         else if (fin) CMS_BN_TILED(float, 0, true);
@@ -597,6 +628,16 @@ extern "C" int cms_bn_reduce_ws(const void* x, const void* dy, const void* y, in
     CMS_REQUIRE(mode == 0 || (mode == 1 && dy && mean && rstd), "bn_reduce_ws: mode 1 needs dy, mean, rstd");
     bn_reduce_tiled(x, dy, y, dtype, mean, rstd, sums, n_pixels, c, groups, mode, ws, nullptr, (hipStream_t)stream);
     return launch_status("cms_bn_reduce_ws");
+}
+
+extern "C" int cms_bn_reduce_ws_bits(const void* x, const void* dy, const uint8_t* mask_bits, int dtype, const float* mean,
+                                     const float* rstd, double* sums, size_t n_pixels, int c, int groups, void* ws, void* stream) {
+    CMS_REQUIRE(x && dy && mask_bits && mean && rstd && sums && ws, "bn_reduce_ws_bits: NULL pointer");
+    CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_reduce_ws_bits: bad dtype");
+    CMS_REQUIRE(bn_geo_ok(n_pixels, c), "bn_reduce_ws_bits: bad geometry (channels %% 8 == 0)");
+    CMS_REQUIRE(bn_groups_ok(n_pixels, groups), "bn_reduce_ws_bits: %d groups do not divide %zu pixel rows", groups, n_pixels);
+    bn_reduce_tiled(x, dy, nullptr, dtype, mean, rstd, sums, n_pixels, c, groups, 1, ws, nullptr, (hipStream_t)stream, mask_bits);
+    return launch_status("cms_bn_reduce_ws_bits");
 }
 
 extern "C" int cms_bn_stats(const void* x, int dtype, size_t n_pixels, int c, int groups, const float* gamma, const float* beta,
@@ -735,6 +776,11 @@ extern "C" int cms_bn_finalize(const double* sums, double count, const float* ga
 
 extern "C" int cms_bn_apply_groups(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift,
                                    int relu, size_t n_pixels, int c, int groups, void* stream) {
+    return cms_bn_apply_groups_bits(x, res, y, dtype, scale, shift, relu, n_pixels, c, groups, nullptr, stream);
+}
+
+extern "C" int cms_bn_apply_groups_bits(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift,
+                                        int relu, size_t n_pixels, int c, int groups, uint8_t* mask_bits_out, void* stream) {
     CMS_REQUIRE(x && y && scale && shift, "bn_apply: NULL pointer");
     CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_apply: bad dtype");
     CMS_REQUIRE(bn_geo_ok(n_pixels, c), "bn_apply: bad geometry (channels %% 8 == 0)");
@@ -745,10 +791,10 @@ extern "C" int cms_bn_apply_groups(const void* x, const void* res, void* y, int 
     const dim3 grid((unsigned)grid_for(total, 256, std::max(1, 256 * 16 / groups)), (unsigned)groups);
     if (dtype == CMS_F32)
         hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)res, (float*)y, scale,
-                           shift, relu, pg, c);
+                           shift, relu, pg, c, mask_bits_out);
     else
         hipLaunchKernelGGL(bn_apply_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)res,
-                           (uint16_t*)y, scale, shift, relu, pg, c);
+                           (uint16_t*)y, scale, shift, relu, pg, c, mask_bits_out);
     return launch_status("cms_bn_apply");
 }
 
@@ -760,6 +806,12 @@ extern "C" int cms_bn_apply(const void* x, const void* res, void* y, int dtype, 
 extern "C" int cms_bn_bwd_apply_groups(const void* x, const void* dy, const void* y, void* dx, void* dres, int dtype,
                                        const float* mean, const float* rstd, const float* gamma, const double* sums, double count,
                                        size_t n_pixels, int c, int groups, void* stream) {
+    return cms_bn_bwd_apply_groups_bits(x, dy, y, nullptr, dx, dres, dtype, mean, rstd, gamma, sums, count, n_pixels, c, groups, stream);
+}
+
+extern "C" int cms_bn_bwd_apply_groups_bits(const void* x, const void* dy, const void* y, const uint8_t* mask_bits, void* dx, void* dres,
+                                            int dtype, const float* mean, const float* rstd, const float* gamma, const double* sums,
+                                            double count, size_t n_pixels, int c, int groups, void* stream) {
     CMS_REQUIRE(x && dy && dx && mean && rstd && sums, "bn_bwd_apply: NULL pointer");
     CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "bn_bwd_apply: bad dtype");
     CMS_REQUIRE(bn_geo_ok(n_pixels, c) && count > 0, "bn_bwd_apply: bad geometry (channels %% 8 == 0)");
@@ -782,10 +834,10 @@ extern "C" int cms_bn_bwd_apply_groups(const void* x, const void* dy, const void
     const dim3 grid(want, (unsigned)groups);
     if (dtype == CMS_F32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)dy, (const float*)y,
-                           (float*)dx, (float*)dres, mean, rstd, gamma, sums, count, pg, c);
+                           (float*)dx, (float*)dres, mean, rstd, gamma, sums, count, pg, c, mask_bits);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)dy,
-                           (const uint16_t*)y, (uint16_t*)dx, (uint16_t*)dres, mean, rstd, gamma, sums, count, pg, c);
+                           (const uint16_t*)y, (uint16_t*)dx, (uint16_t*)dres, mean, rstd, gamma, sums, count, pg, c, mask_bits);
     return launch_status("cms_bn_bwd_apply");
 }
 

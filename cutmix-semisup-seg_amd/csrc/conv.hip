@@ -75,6 +75,7 @@ struct ConvArgs {
     const uint8_t* mask_bits;     // dgrad: the ReLU mask as such bits instead of mask_src, or NULL
     float* stats_out;             // [pixel tiles][2 slots][2][Cout] per-tile (sum, sum of squares) of the stored output, or NULL
     int stats_rpg;                // pixel rows per sample group (>= the tile's rows; M for one group)
+    int mask_gates_res;           // dgrad with res + mask_bits: out = acc + (bit ? res : 0) instead of bit ? acc + res : 0
 };
 
 
@@ -790,7 +791,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
     // workgroup (wave-uniform), so that the compiler sees 32 independent LDS read -> arithmetic -> LDS write chains
     auto nest = [&](auto RES_, auto MSK_, auto RELU_, auto BITS_) {
         constexpr int RES = decltype(RES_)::value;      // 1: residual / gradient add from the staged tile
-        constexpr int MSK = decltype(MSK_)::value;      // 1: ReLU mask bits (both operands / mask_bits), 2: mask from the staged tile
+        constexpr int MSK = decltype(MSK_)::value;      // 1: ReLU mask bits (both operands / mask_bits), 2: mask from the staged tile,
+                                                        // 3: mask_bits gate the residual only (mask_gates_res)
         constexpr int RELU = decltype(RELU_)::value;
         constexpr int BITS = decltype(BITS_)::value;    // 1: also write [y > 0] of the ROUNDED output as bits (mask_bits_out)
         uint32_t obits[BITS ? TN : 1][BITS ? TM : 1];
@@ -816,7 +818,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
                     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     if constexpr (RES == 1 || MSK == 2) {
                         const uint2 rr = *reinterpret_cast<const uint2*>(cell);
-                        if constexpr (RES == 1) {
+                        if constexpr (RES == 1 && MSK == 3) {
+                            // the mask bits gate the RESIDUAL (gradient of a shortcut whose ReLU mask they are), not the sum
+                            const int bit = ((i * TM + j) * 4 + q) * 4;
+                            const uint32_t m4 = (uint32_t)(mbits[bit >> 6] >> (bit & 63));
+                            v[0] += (m4 & 1u) ? __uint_as_float(rr.x << 16) : 0.0f; v[1] += (m4 & 2u) ? __uint_as_float(rr.x & 0xffff0000u) : 0.0f;
+                            v[2] += (m4 & 4u) ? __uint_as_float(rr.y << 16) : 0.0f; v[3] += (m4 & 8u) ? __uint_as_float(rr.y & 0xffff0000u) : 0.0f;
+                        } else if constexpr (RES == 1) {
                             v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
                             v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
                         } else {
@@ -872,7 +880,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
             else if (a.res) { if (a.relu) nest(K1{}, K0{}, K1{}, K0{}); else nest(K1{}, K0{}, K0{}, K0{}); }
             else { if (a.relu) nest(K0{}, K0{}, K1{}, K0{}); else nest(K0{}, K0{}, K0{}, K0{}); }
         } else {
-            if (both || (bits_in && a.res)) nest(K1{}, K1{}, K0{}, K0{});
+            if (bits_in && a.res && a.mask_gates_res) nest(K1{}, std::integral_constant<int, 3>{}, K0{}, K0{});
+            else if (both || (bits_in && a.res)) nest(K1{}, K1{}, K0{}, K0{});
             else if (bits_in) nest(K0{}, K1{}, K0{}, K0{});
             else if (a.mask_src) nest(K0{}, K2{}, K0{}, K0{});
             else if (a.res) nest(K1{}, K0{}, K0{}, K0{});
@@ -1255,6 +1264,9 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
     a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.y = (uint16_t*)d->y; a.y32 = d->y32;
     a.scale = d->scale; a.bias = d->bias; a.res = (const uint16_t*)d->res; a.mask_src = (const uint16_t*)d->mask_src;
     a.mask_bits_out = d->mask_bits_out; a.mask_bits = d->mask_bits;
+    a.mask_gates_res = d->mask_gates_res;
+    CMS_REQUIRE(d->mask_gates_res == 0 || (d->mode == 1 && d->res && d->mask_bits && d->zeros && d->y),
+                "conv: mask_gates_res belongs to data-gradient launches with a residual and mask bits on the direct-to-LDS kernel");
     a.stats_out = (float*)d->stats_out;
     a.stats_rpg = d->stats_rows_per_group > 0 ? d->stats_rows_per_group : d->n * d->ho * d->wo;
     CMS_REQUIRE(d->stats_out == nullptr || cms_conv_igemm_stats_tile_rows(d) == 128,

@@ -77,6 +77,7 @@ struct Args {
     int N, H, W, Cin, Ho, Wo, Cout, ntaps, stride, out_H, out_W, out_stride, relu, mode, M, plain;
     float* stats_out;          // [pixel tiles][2 slots][2][Cout] per-tile (sum, sum of squares) of the stored output, or NULL
     int stats_rpg;             // pixel rows per sample group (>= 256; M for one group)
+    int mask_gates_res;        // dgrad with res + mask_bits: out = acc + (bit ? res : 0) instead of bit ? acc + res : 0
     int nt_store;              // output rows as non-temporal stores (CMS_CONV8_NT): streaming data must not evict the halo rows
                                // and weights neighbouring tiles of the XCD re-read from its L2 (profiles/r05b: 1.30 x over-fetch)
     int ntn;                   // channel tiles (Cout / 256); tile t = (pixel tile t / ntn, channel tile t % ntn)
@@ -661,7 +662,13 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
                         }
                         if constexpr (RES == 1 || MSK == 2) {
                             const uint2 rr = *reinterpret_cast<const uint2*>(cell);
-                            if constexpr (RES == 1) {
+                            if constexpr (RES == 1 && MSK == 3) {
+                                // the mask bits gate the RESIDUAL (gradient of a shortcut whose ReLU mask they are), not the sum
+                                const int bit = ((i * 2 + j) * 4 + q) * 4;
+                                const uint32_t m4 = (uint32_t)(mbits[bit >> 6] >> (bit & 63));
+                                v01 += f32x2{(m4 & 1u) ? __uint_as_float(rr.x << 16) : 0.0f, (m4 & 2u) ? __uint_as_float(rr.x & 0xffff0000u) : 0.0f};
+                                v23 += f32x2{(m4 & 4u) ? __uint_as_float(rr.y << 16) : 0.0f, (m4 & 8u) ? __uint_as_float(rr.y & 0xffff0000u) : 0.0f};
+                            } else if constexpr (RES == 1) {
                                 v01 += f32x2{__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xffff0000u)};
                                 v23 += f32x2{__uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xffff0000u)};
                             } else {
@@ -725,7 +732,8 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
             else if (a.res) { if (a.relu) nest(IC<1>{}, IC<1>{}, IC<0>{}, IC<1>{}, IC<0>{}); else nest(IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}); }
             else { if (a.relu) nest(IC<1>{}, IC<0>{}, IC<0>{}, IC<1>{}, IC<0>{}); else nest(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}); }
         } else {
-            if (both || (bits_in && a.res)) nest(IC<0>{}, IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{});
+            if (bits_in && a.res && a.mask_gates_res) nest(IC<0>{}, IC<1>{}, IC<3>{}, IC<0>{}, IC<0>{});
+            else if (both || (bits_in && a.res)) nest(IC<0>{}, IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{});
             else if (bits_in) nest(IC<0>{}, IC<0>{}, IC<1>{}, IC<0>{}, IC<0>{});
             else if (a.mask_src) nest(IC<0>{}, IC<0>{}, IC<2>{}, IC<0>{}, IC<0>{});
             else if (a.res) nest(IC<0>{}, IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{});
@@ -827,6 +835,8 @@ int conv8_launch(const cms_conv_desc* d, hipStream_t s, int mode, int grid_cap, 
     CMS_REQUIRE(d->mask_bits == nullptr || (d->mode == 1 && d->mask_src == nullptr), "conv8: mask_bits replaces mask_src of a data gradient");
     CMS_REQUIRE((d->mask_bits_out == nullptr && d->mask_bits == nullptr) || mode == 0,
                 "conv8: ReLU mask bits with whole tiles per workgroup only (not the stream-K launch)");
+    a.mask_gates_res = d->mask_gates_res;
+    CMS_REQUIRE(d->mask_gates_res == 0 || (d->mode == 1 && d->res && d->mask_bits), "conv8: mask_gates_res belongs to data-gradient launches with a residual and mask bits");
     a.stats_out = (float*)d->stats_out;
     a.stats_rpg = d->stats_rows_per_group > 0 ? d->stats_rows_per_group : d->n * d->ho * d->wo;
     CMS_REQUIRE(d->stats_out == nullptr ||

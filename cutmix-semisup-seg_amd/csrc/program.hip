@@ -141,12 +141,16 @@ static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
             return cms_bn_reduce(b.x, nullptr, nullptr, b.dtype, nullptr, nullptr, b.sums, (size_t)b.n_pixels, b.c, 0, s);
         case 1: return cms_bn_finalize_ex(b.sums, b.count, b.gamma, b.beta, b.eps, b.momentum, b.mean, b.rstd, b.scale, b.shift,
                                           b.running_mean, b.running_var, b.c, b.clear_a, b.clear_b, b.counter, s);
-        case 2: return cms_bn_apply_groups(b.x, b.res, b.y, b.dtype, b.scale, b.shift, b.relu, (size_t)b.n_pixels, b.c, g, s);
+        case 2: return cms_bn_apply_groups_bits(b.x, b.res, b.y, b.dtype, b.scale, b.shift, b.relu, (size_t)b.n_pixels, b.c, g,
+                                                (uint8_t*)b.mask_bits, s);
         case 3:
+            if (b.ws && b.mask_bits)
+                return cms_bn_reduce_ws_bits(b.x, b.dy, (const uint8_t*)b.mask_bits, b.dtype, b.mean, b.rstd, b.sums, (size_t)b.n_pixels,
+                                             b.c, g, b.ws, s);
             if (b.ws) return cms_bn_reduce_ws(b.x, b.dy, b.y, b.dtype, b.mean, b.rstd, b.sums, (size_t)b.n_pixels, b.c, g, 1, b.ws, s);
             return cms_bn_reduce(b.x, b.dy, b.y, b.dtype, b.mean, b.rstd, b.sums, (size_t)b.n_pixels, b.c, 1, s);
-        case 4: return cms_bn_bwd_apply_groups(b.x, b.dy, b.y, b.dx, b.dres, b.dtype, b.mean, b.rstd, b.gamma, b.sums, b.count,
-                                               (size_t)b.n_pixels, b.c, g, s);
+        case 4: return cms_bn_bwd_apply_groups_bits(b.x, b.dy, b.y, (const uint8_t*)b.mask_bits, b.dx, b.dres, b.dtype, b.mean, b.rstd,
+                                                    b.gamma, b.sums, b.count, (size_t)b.n_pixels, b.c, g, s);
         case 5: return cms_increment_counter((int64_t*)b.counter, s);
         case 6: return cms_bn_stats(b.x, b.dtype, (size_t)b.n_pixels, b.c, g, b.gamma, b.beta, b.eps, b.momentum, b.mean, b.rstd,
                                     b.scale, b.shift, b.running_mean, b.running_var, b.counter, b.sums, b.ws, s);
@@ -295,6 +299,7 @@ extern "C" int cms_program_add_bn(cms_program* p, const cms_bn_op* op, int strea
     CMS_REQUIRE(op->what >= 0 && op->what <= 7, "program_add_bn: unknown op %d", op->what);
     CMS_REQUIRE(op->what != 7 || (op->ws && op->reserved > 0), "program_add_bn: finalize_tiles needs the tile sums (ws) and the tile rows");
     CMS_REQUIRE(op->groups <= 1 || op->ws || (op->what != 0 && op->what != 3), "program_add_bn: grouped reductions need a workspace");
+    CMS_REQUIRE(op->what != 3 || !op->mask_bits || op->ws, "program_add_bn: the backward reduction reads mask bits on the workspace kernels only");
     CMS_REQUIRE(stream_idx >= 0 && stream_idx < CMS_PROGRAM_MAX_STREAMS, "program_add_bn: stream index %d", stream_idx);
     Op o = {};
     o.kind = OP_BN; o.stream = stream_idx; o.group = group;

@@ -769,7 +769,8 @@ def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, mo
     these. `what`: reduce | finalize | apply | reduce_bwd | bwd_apply | count | stats (= reduce + finalize in one launch) |
     finalize_tiles (statistics from the tile sums the unit's convolution wrote: ws = conv_igemm's stats['tile_sums'], tile_rows);
     tensors by keyword (x, res, y, dy, dx, dres, sums, gamma, beta, mean, rstd, scale, shift, running_mean, running_var,
-    counter, clear_a, clear_b, ws). With `ws` (bn_workspace) the reductions take the atomics-free kernels; `groups` > 1
+    counter, clear_a, clear_b, ws, mask_bits). `mask_bits` (uint8 [pixel rows][c / 8]): 'apply' writes [y > 0] there as bits,
+    'reduce_bwd' (with ws) / 'bwd_apply' read them instead of y (1/16 of its bytes; bit-identical results). With `ws` (bn_workspace) the reductions take the atomics-free kernels; `groups` > 1
     (sample groups normalised separately, include/cutmixseg.h) needs them. `count` = pixels of one group."""
     _need_cuda(*t.values())
     d = _lib.BnOp()
@@ -811,8 +812,11 @@ def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, mo
                                        g('scale'), g('shift'), g('running_mean'), g('running_var'), d.c, g('clear_a'),
                                        g('clear_b'), g('counter'), _stream()), 'cms_bn_finalize_ex')
     elif what == 'apply':
-        check(fn['cms_bn_apply_groups'](g('x'), g('res'), g('y'), d.dtype, g('scale'), g('shift'), d.relu, d.n_pixels, d.c, G,
-                                        _stream()), 'cms_bn_apply')
+        check(fn['cms_bn_apply_groups_bits'](g('x'), g('res'), g('y'), d.dtype, g('scale'), g('shift'), d.relu, d.n_pixels, d.c, G,
+                                             g('mask_bits'), _stream()), 'cms_bn_apply')
+    elif what == 'reduce_bwd' and has_ws and t.get('mask_bits') is not None:
+        check(fn['cms_bn_reduce_ws_bits'](g('x'), g('dy'), g('mask_bits'), d.dtype, g('mean'), g('rstd'), g('sums'), d.n_pixels, d.c,
+                                          G, g('ws'), _stream()), 'cms_bn_reduce_ws_bits')
     elif what == 'reduce_bwd' and has_ws:
         check(fn['cms_bn_reduce_ws'](g('x'), g('dy'), g('y'), d.dtype, g('mean'), g('rstd'), g('sums'), d.n_pixels, d.c, G, 1,
                                      g('ws'), _stream()), 'cms_bn_reduce_ws')
@@ -820,8 +824,9 @@ def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, mo
         check(fn['cms_bn_reduce'](g('x'), g('dy'), g('y'), d.dtype, g('mean'), g('rstd'), g('sums'), d.n_pixels, d.c, 1, _stream()),
               'cms_bn_reduce')
     elif what == 'bwd_apply':
-        check(fn['cms_bn_bwd_apply_groups'](g('x'), g('dy'), g('y'), g('dx'), g('dres'), d.dtype, g('mean'), g('rstd'),
-                                            g('gamma'), g('sums'), d.count, d.n_pixels, d.c, G, _stream()), 'cms_bn_bwd_apply')
+        check(fn['cms_bn_bwd_apply_groups_bits'](g('x'), g('dy'), g('y'), g('mask_bits'), g('dx'), g('dres'), d.dtype, g('mean'),
+                                                 g('rstd'), g('gamma'), g('sums'), d.count, d.n_pixels, d.c, G, _stream()),
+              'cms_bn_bwd_apply')
     else:
         check(fn['cms_increment_counter'](g('counter'), _stream()), 'cms_increment_counter')
 
@@ -1199,7 +1204,8 @@ def conv_taps(kh, kw, dilation, padding):
 
 def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, res=None, relu=False, mode=0,
                mask_src=None, out=None, out_f32_nchw=None, cout_real=None, out_stride=1, out_full_hw=None, tile=0,
-               ksplit=1, variant=0, out_pixel_offset=0, mask_bits_out=None, mask_bits=None, stats=None):
+               ksplit=1, variant=0, out_pixel_offset=0, mask_bits_out=None, mask_bits=None, stats=None,
+               mask_gates_res=False):
     """
     Implicit-GEMM convolution on the MFMA units (csrc/conv.hip).
       x         bf16 NHWC-contiguous tensor of logical shape (N, H, W, Cin)
@@ -1210,6 +1216,7 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     instead of pixel 0 -- residual / mask are read at the same shifted positions (the phases of a transposed convolution).
     `mask_bits_out` (forward + ReLU): uint8 (N, out_h, out_w, Cout / 8) that receives [y > 0] as bits; `mask_bits` (mode 1):
     such a tensor INSTEAD of `mask_src` -- the ReLU mask of a data gradient at 1/16 of the bytes (cms_conv_desc).
+    `mask_gates_res` (mode 1 with `res` and `mask_bits`): the bits gate the residual only, y = acc + (bit ? res : 0).
     `stats` (bf16 forward launches): a dict {'groups': G}; when the kernel that takes the launch can, its epilogue also writes the
     per-channel (sum, sum of squares) of every pixel tile it stores (cms_conv_desc.stats_out) and the dict comes back with
     'tile_rows' (128 / 256) and 'tile_sums' (fp32 [tiles][2][2][Cout]) for bn_op('finalize_tiles'); 'tile_rows' = 0 when it cannot
@@ -1221,6 +1228,8 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
             raise TypeError('conv_igemm: ReLU mask bits are contiguous uint8 tensors of the bf16 entry point')
     if mask_bits is not None and mask_src is not None:
         raise ValueError('conv_igemm: mask_bits replaces mask_src')
+    if mask_gates_res and (mask_bits is None or res is None or int(mode) != 1):
+        raise ValueError('conv_igemm: mask_gates_res needs a data-gradient launch with res and mask_bits')
     if x.dtype not in (torch.bfloat16, torch.float32) or w_packed.dtype != x.dtype or not x.is_contiguous() \
             or not w_packed.is_contiguous():
         raise TypeError('conv_igemm: contiguous NHWC input and packed weights of one dtype (bf16 or fp32) required')
@@ -1256,6 +1265,7 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     bshift = int(out_pixel_offset) * (int(w_packed.shape[1]) // 8) if out_f32_nchw is None else 0
     d.mask_bits_out = mask_bits_out.data_ptr() + bshift if mask_bits_out is not None else None
     d.mask_bits = mask_bits.data_ptr() + bshift if mask_bits is not None else None
+    d.mask_gates_res = int(bool(mask_gates_res))
     d.ho, d.wo, d.cout = ho, wo, cout
     d.cout_real = cout if cout_real is None else int(cout_real)
     d.ntaps = ntaps

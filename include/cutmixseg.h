@@ -292,6 +292,10 @@ typedef struct cms_conv_desc {
      * straddles a boundary). cms_bn_finalize_tiles turns them into mean / rstd / scale / shift and moves the running statistics. */
     float* stats_out;
     int stats_rows_per_group;
+    /* Round 5, data gradients with BOTH res and mask_bits: != 0 -> the bits gate the residual only, y = acc + (bit ? res : 0)
+     * (the masked gradient of an identity shortcut added to a convolution's data gradient: the batch-statistics bottleneck's
+     * `dres` tensor is never written, architectures/deeplab2.py:105-107); 0 -> y = bit ? acc + res : 0 as before.           */
+    int mask_gates_res;
 } cms_conv_desc;
 
 int cms_conv_igemm(const cms_conv_desc* d, void* stream);
@@ -496,6 +500,17 @@ int cms_bn_apply_groups(const void* x, const void* res, void* y, int dtype, cons
 int cms_bn_bwd_apply_groups(const void* x, const void* dy, const void* y, void* dx, void* dres, int dtype, const float* mean,
                             const float* rstd, const float* gamma, const double* sums, double count, size_t n_pixels, int c,
                             int groups, void* stream);
+/* Round 5: the ReLU mask of a unit as BITS beside its output -- uint8 [pixel rows][c / 8], bit e of byte (row, v) = [stored
+ * y[row][8 v + e] > 0], the layout of cms_conv_desc.mask_bits_out. cms_bn_apply_groups_bits writes them (mask_bits_out may be NULL),
+ * the backward passes read them INSTEAD of y: 1/16 of the bytes of one of the three tensors each of them streams.
+ * (cms_bn_bwd_apply_groups_bits: mask_bits == NULL falls back to y.) Results are bit-identical to the y-masked calls. */
+int cms_bn_apply_groups_bits(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
+                             size_t n_pixels, int c, int groups, uint8_t* mask_bits_out, void* stream);
+int cms_bn_reduce_ws_bits(const void* x, const void* dy, const uint8_t* mask_bits, int dtype, const float* mean, const float* rstd,
+                          double* sums, size_t n_pixels, int c, int groups, void* ws, void* stream);
+int cms_bn_bwd_apply_groups_bits(const void* x, const void* dy, const void* y, const uint8_t* mask_bits, void* dx, void* dres,
+                                 int dtype, const float* mean, const float* rstd, const float* gamma, const double* sums,
+                                 double count, size_t n_pixels, int c, int groups, void* stream);
 int cms_bn_apply(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
                  size_t n_pixels, int c, void* stream);
 int cms_bn_bwd_apply(const void* x, const void* dy, const void* y, void* dx, void* dres, int dtype, const float* mean,
@@ -629,6 +644,7 @@ typedef struct cms_bn_op {
     float eps, momentum;
     int groups;                /* sample groups (0 / 1: one); needs `ws` for what 0 / 3                       */
     int reserved;              /* what 7: pixel rows per statistics tile (cms_conv_igemm_stats_tile_rows)      */
+    void* mask_bits;           /* what 2: written ([y > 0] as bits, or NULL); what 3 (with ws) / 4: read instead of y */
 } cms_bn_op;
 int cms_program_add_bn(cms_program* p, const cms_bn_op* op, int stream_idx, int group);
 int cms_program_size(const cms_program* p);

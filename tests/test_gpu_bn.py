@@ -330,3 +330,44 @@ def test_sync_batchnorm_with_sample_groups_two_ranks_equal_one_process():
         np.testing.assert_allclose(res[r][6], want[5], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(res[0][3] + res[1][3], want[2], rtol=5e-4, atol=5e-5)     # local dgamma / dbeta add up
     np.testing.assert_allclose(res[0][4] + res[1][4], want[3], rtol=5e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize('G', [1, 2])
+@pytest.mark.parametrize('C,dtype', [(64, torch.bfloat16), (256, torch.bfloat16), (2048, torch.bfloat16), (72, torch.float32)])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_relu_mask_bits_replace_y_in_the_backward_passes_bit_for_bit(C, dtype, with_res, G):
+    """Round 5: the normalising launch writes [stored y > 0] as bits ([pixel rows][C / 8], bit e = channel 8 v + e) and the two
+    backward passes read those instead of y -- same sums, same dx / dres, to the bit."""
+    from cutmix_semisup_seg_amd import ops
+    g = torch.Generator().manual_seed(C + G)
+    N, H, W = 2 * G, 19, 23
+    P = N * H * W
+    u = (torch.randn(N, H, W, C, generator=g) * 1.3).to(dtype).to(DEV)
+    res = (torch.randn(N, H, W, C, generator=g) * 0.7).to(dtype).to(DEV) if with_res else None
+    dy = torch.randn(N, H, W, C, generator=g).to(dtype).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV)
+    new = lambda n: torch.empty(n, dtype=torch.float32, device=DEV)
+    mean, rstd, scale, shift = new(G * C), new(G * C), new(G * C), new(G * C)
+    ws = ops.bn_workspace(P, C, DEV, G)
+    ops.bn_op('stats', c=C, dtype=dtype, n_pixels=P, groups=G, eps=1e-5, momentum=0.1, x=u, ws=ws, gamma=gamma, beta=beta,
+              mean=mean, rstd=rstd, scale=scale, shift=shift)
+    y, y2 = torch.empty_like(u), torch.empty_like(u)
+    bits = torch.zeros(P * C // 8, dtype=torch.uint8, device=DEV)
+    ops.bn_op('apply', c=C, dtype=dtype, n_pixels=P, groups=G, relu=True, x=u, res=res, y=y, scale=scale, shift=shift)
+    ops.bn_op('apply', c=C, dtype=dtype, n_pixels=P, groups=G, relu=True, x=u, res=res, y=y2, scale=scale, shift=shift,
+              mask_bits=bits)
+    assert torch.equal(y, y2)
+    want_bits = ((y.view(P, C // 8, 8) > 0).to(torch.int32) << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits.view(P, C // 8), want_bits)
+    assert 0.2 < float((y > 0).float().mean()) < 0.8
+    out = {}
+    for key, kw in (('y', dict(y=y)), ('bits', dict(mask_bits=bits))):
+        sums = torch.empty(G * 2 * C, dtype=torch.float64, device=DEV)
+        ops.bn_op('reduce_bwd', c=C, dtype=dtype, n_pixels=P, groups=G, x=u, dy=dy, mean=mean, rstd=rstd, sums=sums, ws=ws, **kw)
+        dx, dres = torch.empty_like(u), torch.empty_like(u)
+        ops.bn_op('bwd_apply', c=C, dtype=dtype, n_pixels=P, groups=G, count=P // G, x=u, dy=dy, dx=dx, dres=dres, mean=mean,
+                  rstd=rstd, gamma=gamma, sums=sums, **kw)
+        torch.cuda.synchronize()
+        out[key] = (sums.clone(), dx, dres)
+    for a, b in zip(out['y'], out['bits']):
+        assert torch.equal(a, b)

@@ -199,5 +199,19 @@ def test_conv8_relu_mask_bits_written_forward_and_read_by_the_data_gradient(ops,
         c = ops.conv_igemm(du, wT, one, res=r, mode=1, mask_bits=bits)                    # the library's own choice of kernel
         torch.cuda.synchronize()
         assert torch.equal(a, b) and torch.equal(a, c)
+    # (round 5) mask_gates_res: the bits gate the RESIDUAL only -- acc + (bit ? res : 0), the masked gradient of an identity
+    # shortcut added in the epilogue; == the plain residual launch on a pre-masked residual, on every kernel
+    gated = torch.where(y > 0, add, torch.zeros_like(add))
+    for kw_cd, wT_ in ((Cd, wT), (64, _mk((1, Cout, 64), g, 0.05))):     # K = 16 tiles: eight-phase kernel; K = 1 tile: 128 x 128 family
+        du_ = du if kw_cd == Cd else _mk((N, H, W, 64), g, 0.1)
+        ref = ops.conv_igemm(du_, wT_, one, res=gated, mode=1, variant=99)
+        got = ops.conv_igemm(du_, wT_, one, res=add, mode=1, mask_bits=bits, mask_gates_res=True)
+        got99 = ops.conv_igemm(du_, wT_, one, res=add, mode=1, mask_bits=bits, mask_gates_res=True, variant=99)
+        torch.cuda.synchronize()
+        assert torch.equal(ref, got) and torch.equal(ref, got99)
+    got90 = ops.conv_igemm(du, wT, one, res=add, mode=1, mask_bits=bits, mask_gates_res=True, variant=90)
+    assert torch.equal(ops.conv_igemm(du, wT, one, res=gated, mode=1, variant=99), got90)
+    with pytest.raises(ValueError):
+        ops.conv_igemm(du, wT, one, mode=1, mask_bits=bits, mask_gates_res=True)          # no residual to gate
     with pytest.raises(ValueError):
         ops.conv_igemm(du, wT, one, mode=1, mask_bits=bits, variant=91)                   # stream-K launch: no bits
