@@ -393,9 +393,7 @@ class DeepLabHipExecutor(object):
         bsums = torch.empty(G * 2 * C, dtype=torch.float64, device=dev) if save else None
         mean, rstd, scale, shift = (torch.empty(G * C, dtype=torch.float32, device=dev) for _ in range(4))
         ws = ops.bn_workspace(npix, C, dev, G)      # this unit's: tile counters + partial sums (forward, then backward)
-        if st is not None and st['tile_rows'] > 0 and os.environ.get('CMS_BN_DIAG_SKIP_FINALIZE') == '1':
-            pass        # TIMING DIAGNOSTIC ONLY (wrong numerics): what a free statistics launch would be worth
-        elif st is not None and st['tile_rows'] > 0:
+        if st is not None and st['tile_rows'] > 0:
             ops.bn_op('finalize_tiles', c=C, dtype=self.dtype, n_pixels=npix, groups=G, eps=bn.eps, momentum=bn.momentum,
                       tile_rows=st['tile_rows'], ws=st['tile_sums'], gamma=a.view(c.bn + '.weight'), beta=a.view(c.bn + '.bias'),
                       mean=mean, rstd=rstd, scale=scale, shift=shift, running_mean=a.view(c.bn + '.running_mean'),
