@@ -67,7 +67,8 @@ class ConvDesc(C.Structure):
                 ('out_h', c_int), ('out_w', c_int), ('out_stride', c_int), ('relu', c_int), ('mode', c_int),
                 ('tile', c_int), ('ksplit', c_int), ('zeros', c_void_p), ('variant', c_int), ('zeros_bytes', c_int),
                 ('workspace', c_void_p), ('workspace_bytes', C.c_longlong), ('mask_bits_out', c_void_p), ('mask_bits', c_void_p),
-                ('stats_out', c_void_p), ('stats_rows_per_group', c_int), ('mask_gates_res', c_int)]
+                ('stats_out', c_void_p), ('stats_rows_per_group', c_int), ('mask_gates_res', c_int),
+                ('bstats_u', c_void_p), ('bstats_bits', c_void_p), ('bstats_mean', c_void_p), ('bstats_rstd', c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -151,6 +152,7 @@ PROTOTYPES = {
                                       c_void_p, c_void_p]),
     'cms_bn_bwd_apply_groups_bits': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                              c_void_p, c_void_p, C.c_double, c_size_t, c_int, c_int, c_void_p]),
+    'cms_bn_bwd_sums_tiles': (c_int, [c_void_p, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p]),
     'cms_conv_set_trace': (c_int, [c_void_p, c_int]),
     'cms_conv_set_wgrad8': (c_int, [c_int]),
     'cms_loss_set_deterministic': (c_int, [c_int]),

@@ -424,7 +424,20 @@ class DeepLabHipExecutor(object):
                   shift=shift, mask_bits=bits)
         return y, (u, (y if bits is None else bits) if relu else None, mean, rstd, bsums, ws, G)
 
-    def _bwd_unit_bn(self, dy, saved, c, want_res, dy_bits=None):
+    def _bstats(self, s, unit):
+        """Descriptor of a unit's backward statistics for the data-gradient launch that writes the gradient of its output
+        (`ops.conv_igemm(..., mode=1, stats=...)`, cms_conv_desc.bstats_*), or None: `s` = the unit's saved tuple, `unit` = 1 / 2 / 3.
+        CMS_BN_BWD_STATS (read per recording): 0 = off, 3 = the wide unit 3 only (default: 329.8 -> 335.1 img/s; every unit: 333 -- for the
+        narrow units the finalising launch costs what the reduction it replaces did, profiles/r05u_*), 1 = every unit."""
+        mode = os.environ.get('CMS_BN_BWD_STATS', '3')
+        if mode == '0' or (mode == '3' and unit != 3) or self.dtype != torch.bfloat16 or ops._world(self._dist_group()) > 1:
+            return None
+        u, yb, mean, rstd, _sums, _ws, G = s
+        if yb is not None and yb.dtype != torch.uint8:
+            return None                         # the mask is the stored activation (CMS_BN_MASK_BITS=0): the reduction kernel reads it
+        return {'groups': G, 'u': u, 'mean': mean, 'rstd': rstd, 'bits': yb}
+
+    def _bwd_unit_bn(self, dy, saved, c, want_res, dy_bits=None, tile_stats=None):
         """Backward of the normalisation of one unit: dy (gradient wrt y) -> (du = gradient wrt the convolution output,
         dres = gradient wrt the residual input or None). The ReLU mask comes from the stored y."""
         u, y, mean, rstd, sums, ws, G = saved   # `sums` is overwritten by the reduction; `ws`: the unit's workspace
@@ -438,8 +451,14 @@ class DeepLabHipExecutor(object):
             # whose masked gradient `dres` is no longer materialised): this unit has no ReLU of its own, the bits take its place
             assert y is None and bits is None
             bits = dy_bits
-        ops.bn_op('reduce_bwd', c=C, dtype=self.dtype, n_pixels=npix, groups=G, x=u, dy=dy, y=y, mean=mean, rstd=rstd, sums=sums,
-                  ws=ws, mask_bits=bits)
+        if tile_stats is not None and tile_stats.get('tile_rows', 0) > 0:
+            # (round 5) the launch that wrote dy left per-tile (sum d, sum d xhat): no pass over u, dy and the mask
+            assert dy_bits is None
+            ops.bn_op('sums_tiles', c=C, dtype=self.dtype, n_pixels=npix, groups=G, tile_rows=tile_stats['tile_rows'],
+                      ws=tile_stats['tile_sums'], sums=sums)
+        else:
+            ops.bn_op('reduce_bwd', c=C, dtype=self.dtype, n_pixels=npix, groups=G, x=u, dy=dy, y=y, mean=mean, rstd=rstd, sums=sums,
+                      ws=ws, mask_bits=bits)
         grp = self._dist_group()
         world = ops._world(grp)
         if world > 1:                        # SyncBN: (sum dy', sum dy' xhat) of every group over all ranks
@@ -479,14 +498,14 @@ class DeepLabHipExecutor(object):
             self._pack_plan_bn = ops.PackTransposePlan(triples)
         self._pack_plan_bn.run()
 
-    def _dgrad_raw(self, du, c, res=None, in_hw=None, res_bits=None):
+    def _dgrad_raw(self, du, c, res=None, in_hw=None, res_bits=None, bstats=None):
         """Data gradient of one convolution (+ res). `res_bits`: res is the UNMASKED gradient of a ReLU output and the bits are that
         ReLU's mask -- added as (bit ? res : 0) in the epilogue (cms_conv_desc.mask_gates_res)."""
         n, ho, wo, _ = du.shape
         if c.stride == 1:
             return ops.conv_igemm(du, c.wT_raw, c.neg_taps, res=res, mode=1, tile=self._tile(c.cin), mask_bits=res_bits,
-                                  mask_gates_res=res_bits is not None)
-        assert res_bits is None
+                                  mask_gates_res=res_bits is not None, stats=bstats)
+        assert res_bits is None and bstats is None
         return ops.conv_igemm(du, c.wT_raw, c.neg_taps, res=res, mode=1, out_hw=(ho, wo), out_stride=c.stride,
                               out_full_hw=in_hw, tile=self._tile(c.cin))
 
@@ -506,7 +525,10 @@ class DeepLabHipExecutor(object):
             ops.conv_wgrad(d, x4, [(0, 0)], dwall)
             if box is not None:
                 box['dwall'] = dwall
-        dOut = ops.conv_igemm(d, self.aspp_wallT, [(0, 0)], mode=1)        # gradient wrt the block OUTPUT: bn3 applies its mask
+        # gradient wrt the block OUTPUT: bn3 applies its mask. `pend`: the backward statistics of that unit 3, left by the launch
+        # that writes the gradient (`_bstats`)
+        pend = self._bstats(saved[len(self.blocks) - 1][5], 3)
+        dOut = ops.conv_igemm(d, self.aspp_wallT, [(0, 0)], mode=1, stats=pend)
         keep = []
         closes = set(self.bucket_starts())
         for bi in range(len(self.blocks) - 1, -1, -1):
@@ -518,11 +540,13 @@ class DeepLabHipExecutor(object):
             # backward passes read dOut through the same bits
             bits3 = s3[1] if (s3[1] is not None and s3[1].dtype == torch.uint8 and _bn_gate_shortcut()
                               and (b.cd is not None or b.c1.stride == 1)) else None
-            du3, dres = self._bwd_unit_bn(dOut, s3, b.c3, bits3 is None)
-            da2 = self._dgrad_raw(du3, b.c3)
-            du2, _ = self._bwd_unit_bn(da2, s2, b.c2, False)
-            da1 = self._dgrad_raw(du2, b.c2)
-            du1, _ = self._bwd_unit_bn(da1, s1, b.c1, False)
+            du3, dres = self._bwd_unit_bn(dOut, s3, b.c3, bits3 is None, tile_stats=pend)
+            st2 = self._bstats(s2, 2)
+            da2 = self._dgrad_raw(du3, b.c3, bstats=st2)
+            du2, _ = self._bwd_unit_bn(da2, s2, b.c2, False, tile_stats=st2)
+            st1 = self._bstats(s1, 1)
+            da1 = self._dgrad_raw(du2, b.c2, bstats=st1)
+            du1, _ = self._bwd_unit_bn(da1, s1, b.c1, False, tile_stats=st1)
             dud = None
             if b.cd is not None:
                 dud, _ = self._bwd_unit_bn(dres if bits3 is None else dOut, sd, b.cd, False, dy_bits=bits3)
@@ -544,11 +568,14 @@ class DeepLabHipExecutor(object):
                     for du_, x_, c_ in jobs:
                         self._wgrad_raw(du_, x_, c_)
                     hook(bi)
+            # the launch that completes the gradient wrt this block's input = the previous block's output also takes that
+            # block's unit-3 backward statistics
+            pend = self._bstats(saved[bi - 1][5], 3) if (bi > 0 and b.c1.stride == 1) else None
             if b.cd is None and bits3 is not None:
-                dOut = self._dgrad_raw(du1, b.c1, res=dOut, in_hw=in_hw, res_bits=bits3)
+                dOut = self._dgrad_raw(du1, b.c1, res=dOut, in_hw=in_hw, res_bits=bits3, bstats=pend)
             else:
                 dx = dres if b.cd is None else self._dgrad_raw(dud, b.cd, in_hw=in_hw)
-                dOut = self._dgrad_raw(du1, b.c1, res=dx, in_hw=in_hw)
+                dOut = self._dgrad_raw(du1, b.c1, res=dx, in_hw=in_hw, bstats=pend)
         if not self.defer_wgrad_join:
             for sd_ in sides:
                 ops.stream_wait(main, sd_)

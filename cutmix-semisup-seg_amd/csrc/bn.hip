@@ -666,7 +666,8 @@ extern "C" int cms_bn_stats(const void* x, int dtype, size_t n_pixels, int c, in
 constexpr int BNT_CH = 16, BNT_LANES = 64, BNT_J = 20;
 
 __global__ __launch_bounds__(BNT_CH * BNT_LANES) void bn_finalize_tiles_kernel(const float* __restrict__ tile_sums, unsigned T, unsigned Pg,
-                                                                               int C, int G, unsigned nt, BnFin fin) {
+                                                                               int C, int G, unsigned nt, BnFin fin,
+                                                                               double* __restrict__ sums_out) {
     __shared__ double red[BNT_LANES / 4][2 * BNT_CH];       // [wave][stat][channel]
     const int tid = threadIdx.x, cl = tid % BNT_CH, k = tid / BNT_CH, wave = tid >> 6;
     const int c = blockIdx.x * BNT_CH + cl;
@@ -731,9 +732,14 @@ __global__ __launch_bounds__(BNT_CH * BNT_LANES) void bn_finalize_tiles_kernel(c
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
             for (int w = 0; w < BNT_LANES / 4; ++w) { a0 += red[w][cl]; a1 += red[w][BNT_CH + cl]; }
-            BnFin f = fin;
-            f.mean += (size_t)g * C; f.rstd += (size_t)g * C; f.scale += (size_t)g * C; f.shift += (size_t)g * C;
-            bn_finalize_channel(f, c, a0, a1);
+            if (sums_out) {                                 // backward statistics: the sums themselves, [G][2][C] (cms_bn_bwd_sums_tiles)
+                sums_out[(size_t)g * 2 * C + c] = a0;
+                sums_out[(size_t)g * 2 * C + C + c] = a1;
+            } else {
+                BnFin f = fin;
+                f.mean += (size_t)g * C; f.rstd += (size_t)g * C; f.scale += (size_t)g * C; f.shift += (size_t)g * C;
+                bn_finalize_channel(f, c, a0, a1);
+            }
         }
     }
     if (blockIdx.x == 0 && tid == 0 && fin.counter) *fin.counter += G;
@@ -753,8 +759,26 @@ extern "C" int cms_bn_finalize_tiles(const float* tile_sums, int tile_rows, size
     const size_t nt = (n_pixels + (size_t)tile_rows - 1) / (size_t)tile_rows;
     BnFin f{gamma, beta, mean, rstd, scale, shift, running_mean, running_var, counter, (double)pg, eps, momentum};
     hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3((c + BNT_CH - 1) / BNT_CH), dim3(BNT_CH * BNT_LANES), 0, (hipStream_t)stream,
-                       tile_sums, (unsigned)tile_rows, (unsigned)pg, c, groups, (unsigned)nt, f);
+                       tile_sums, (unsigned)tile_rows, (unsigned)pg, c, groups, (unsigned)nt, f, (double*)nullptr);
     return launch_status("cms_bn_finalize_tiles");
+}
+
+// Backward: the tile sums (sum d, sum d xhat) a data-gradient launch wrote (cms_conv_desc.bstats_*) -> sums[groups][2][c], what
+// cms_bn_reduce_ws(mode 1) leaves for cms_bn_bwd_apply_groups. Same kernel, same fixed order.
+extern "C" int cms_bn_bwd_sums_tiles(const float* tile_sums, int tile_rows, size_t n_pixels, int c, int groups, double* sums,
+                                     void* stream) {
+    CMS_REQUIRE(tile_sums && sums, "bn_bwd_sums_tiles: NULL pointer");
+    CMS_REQUIRE(n_pixels > 0 && c > 0 && tile_rows > 0, "bn_bwd_sums_tiles: bad geometry");
+    CMS_REQUIRE(n_pixels + (size_t)tile_rows < (1ull << 31), "bn_bwd_sums_tiles: more than 2^31 pixel rows");
+    CMS_REQUIRE(((n_pixels + (size_t)tile_rows - 1) / (size_t)tile_rows) * 16 * (size_t)c < (1ull << 32), "bn_bwd_sums_tiles: tile sums beyond 4 GB");
+    CMS_REQUIRE(bn_groups_ok(n_pixels, groups) && groups <= BNT_LANES, "bn_bwd_sums_tiles: %d groups do not divide %zu pixel rows (or > 64 groups)",
+                groups, n_pixels);
+    const size_t pg = n_pixels / (size_t)groups;
+    CMS_REQUIRE(pg >= (size_t)tile_rows, "bn_bwd_sums_tiles: a sample group (%zu rows) is shorter than a tile (%d rows)", pg, tile_rows);
+    const size_t nt = (n_pixels + (size_t)tile_rows - 1) / (size_t)tile_rows;
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3((c + BNT_CH - 1) / BNT_CH), dim3(BNT_CH * BNT_LANES), 0, (hipStream_t)stream,
+                       tile_sums, (unsigned)tile_rows, (unsigned)pg, c, groups, (unsigned)nt, BnFin{}, sums);
+    return launch_status("cms_bn_bwd_sums_tiles");
 }
 
 extern "C" int cms_bn_finalize_ex(const double* sums, double count, const float* gamma, const float* beta, float eps,

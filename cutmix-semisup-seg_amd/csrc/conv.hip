@@ -76,6 +76,10 @@ struct ConvArgs {
     float* stats_out;             // [pixel tiles][2 slots][2][Cout] per-tile (sum, sum of squares) of the stored output, or NULL
     int stats_rpg;                // pixel rows per sample group (>= the tile's rows; M for one group)
     int mask_gates_res;           // dgrad with res + mask_bits: out = acc + (bit ? res : 0) instead of bit ? acc + res : 0
+    const uint16_t* bstats_u;     // dgrad + stats_out: u of the batch-statistics unit whose output gradient this launch writes, or NULL
+    const uint8_t* bstats_bits;   // ... its ReLU mask bits, or NULL (no ReLU)
+    const float* bstats_mean;     // ... its statistics [groups][Cout]
+    const float* bstats_rstd;
 };
 
 
@@ -917,8 +921,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
         // thread -> LOGICAL chunk ch of rows r0, r0 + RPP, ... (its place in the swizzled LDS row changes with the row): the
         // 8 channels a thread stores are the same in every pass, which is what the statistics below accumulate over
         const int ch = tid % CPR, r0 = tid / CPR;
-        auto rows = [&](auto STATS_, TileStats& ts, int boundary) {
-            constexpr bool STATS = decltype(STATS_)::value;
+        auto rows = [&](auto KIND_, TileStats& ts, int boundary, const float (&mu0)[8], const float (&rs0)[8], const float (&mu1)[8],
+                        const float (&rs1)[8]) {
+            constexpr int KIND = decltype(KIND_)::value;    // 0: store, 1: + forward statistics, 2: + backward statistics
 #pragma unroll
             for (int r = r0; r < BM; r += RPP) {
                 const uint32_t op = lds_row[r].opix;
@@ -930,19 +935,39 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
                     else
 #endif
                         *dst = val;
-                    if constexpr (STATS) ts.add(val.x, val.y, val.z, val.w, (m0 + r) >= boundary);
+                    if constexpr (KIND == 1) ts.add(val.x, val.y, val.z, val.w, (m0 + r) >= boundary);
+                    if constexpr (KIND == 2) {
+                        const u32x4 uv = *reinterpret_cast<const u32x4*>(a.bstats_u + (size_t)op * a.Cout + co0 + ch * 8);
+                        const unsigned byte = a.bstats_bits ? a.bstats_bits[(size_t)op * (a.Cout >> 3) + (co0 >> 3) + ch] : 0xffu;
+                        ts.add_bwd(val.x, val.y, val.z, val.w, uv.x, uv.y, uv.z, uv.w, byte, (m0 + r) >= boundary, mu0, rs0, mu1, rs1);
+                    }
                 }
             }
         };
         TileStats ts;
+        float mu0[8] = {}, rs0[8] = {}, mu1[8] = {}, rs1[8] = {};
         if (a.stats_out == nullptr) {
-            rows(std::false_type{}, ts, 0);
+            rows(std::integral_constant<int, 0>{}, ts, 0, mu0, rs0, mu1, rs1);
         } else {
-            // BatchNorm statistics out of the epilogue (round 5, tile_stats.hpp): per-channel sums of what this tile stores
-            const int boundary = (m0 / a.stats_rpg + 1) * a.stats_rpg;          // first row of the next sample group
+            // BatchNorm statistics out of the epilogue (round 5, tile_stats.hpp): per-channel sums over what this tile stores --
+            // forward launches (sum, sum of squares) of the output; data-gradient launches with bstats_u (sum d, sum d xhat) of the
+            // batch-statistics unit whose output gradient the launch writes
+            const int g0 = m0 / a.stats_rpg;
+            const int boundary = (g0 + 1) * a.stats_rpg;                        // first row of the next sample group
             const int m_end = m0 + BM < a.M ? m0 + BM : a.M;
             ts.zero();
-            rows(std::true_type{}, ts, boundary);
+            if (a.bstats_u == nullptr) {
+                rows(std::integral_constant<int, 1>{}, ts, boundary, mu0, rs0, mu1, rs1);
+            } else {
+                const int g1 = boundary < a.M ? g0 + 1 : g0;
+                const float* p0 = a.bstats_mean + (size_t)g0 * a.Cout + co0 + ch * 8;
+                const float* p1 = a.bstats_mean + (size_t)g1 * a.Cout + co0 + ch * 8;
+                const float* q0 = a.bstats_rstd + (size_t)g0 * a.Cout + co0 + ch * 8;
+                const float* q1 = a.bstats_rstd + (size_t)g1 * a.Cout + co0 + ch * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { mu0[e] = p0[e]; mu1[e] = p1[e]; rs0[e] = q0[e]; rs1[e] = q1[e]; }
+                rows(std::integral_constant<int, 2>{}, ts, boundary, mu0, rs0, mu1, rs1);
+            }
             __syncthreads();                        // the tile has been read by every wave: its LDS is the scratch now
             tile_stats_finish<CPR, NW, NT>(ts, boundary < m_end, reinterpret_cast<float*>(smem),
                                            a.stats_out + (size_t)tile_m * 4 * a.Cout + co0, a.Cout);
@@ -1219,7 +1244,9 @@ extern "C" int cms_conv_igemm_route(const cms_conv_desc* d) {
 extern "C" int cms_conv_igemm_stats_tile_rows(const cms_conv_desc* d) {
     int rc = conv_check(d);
     if (rc) return rc;
-    if (d->y == nullptr || d->mode != 0 || d->ksplit > 1 || d->out_stride != 1 || d->out_h != d->ho || d->out_w != d->wo) return 0;
+    if (d->y == nullptr || d->ksplit > 1 || d->out_stride != 1 || d->out_h != d->ho || d->out_w != d->wo) return 0;
+    // forward launches: statistics of the output; data gradients: only with the unit's u / mean / rstd (backward statistics)
+    if (d->mode == 0 ? d->bstats_u != nullptr : (d->bstats_u == nullptr || d->bstats_mean == nullptr || d->bstats_rstd == nullptr)) return 0;
     const int route = cms_conv_igemm_route(d);
     if (route < 0) return route;
     if (route == CMS_ROUTE_CONV8 && conv8_env(0) != 1) return 0;        // (whole tiles per workgroup only, not the stream-K launch)
@@ -1269,6 +1296,7 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
                 "conv: mask_gates_res belongs to data-gradient launches with a residual and mask bits on the direct-to-LDS kernel");
     a.stats_out = (float*)d->stats_out;
     a.stats_rpg = d->stats_rows_per_group > 0 ? d->stats_rows_per_group : d->n * d->ho * d->wo;
+    a.bstats_u = (const uint16_t*)d->bstats_u; a.bstats_bits = d->bstats_bits; a.bstats_mean = d->bstats_mean; a.bstats_rstd = d->bstats_rstd;
     CMS_REQUIRE(d->stats_out == nullptr || cms_conv_igemm_stats_tile_rows(d) == 128,
                 "conv: stats_out needs a launch cms_conv_igemm_stats_tile_rows() accepts (bf16 output of a forward launch on a default "
                 "tile, sample groups of whole rows no shorter than a tile)");

@@ -78,6 +78,10 @@ struct Args {
     float* stats_out;          // [pixel tiles][2 slots][2][Cout] per-tile (sum, sum of squares) of the stored output, or NULL
     int stats_rpg;             // pixel rows per sample group (>= 256; M for one group)
     int mask_gates_res;        // dgrad with res + mask_bits: out = acc + (bit ? res : 0) instead of bit ? acc + res : 0
+    const uint16_t* bstats_u;  // dgrad + stats_out: u / ReLU mask bits / mean / rstd of the unit whose output gradient this launch writes
+    const uint8_t* bstats_bits;
+    const float* bstats_mean;
+    const float* bstats_rstd;
     int nt_store;              // output rows as non-temporal stores (CMS_CONV8_NT): streaming data must not evict the halo rows
                                // and weights neighbouring tiles of the XCD re-read from its L2 (profiles/r05b: 1.30 x over-fetch)
     int ntn;                   // channel tiles (Cout / 256); tile t = (pixel tile t / ntn, channel tile t % ntn)
@@ -744,8 +748,9 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
         {
             // thread -> LOGICAL chunk ch (8 channels) of rows r0, r0 + 16, ...: the same channels in every pass (tile_stats.hpp)
             const int ch = tid % CPR, r0 = tid / CPR;       // 16 rows per pass
-            auto rows = [&](auto ST_, TileStats& ts, int boundary) {
-                constexpr bool ST = decltype(ST_)::value;
+            auto rows = [&](auto KIND_, TileStats& ts, int boundary, const float (&mu0)[8], const float (&rs0)[8], const float (&mu1)[8],
+                            const float (&rs1)[8]) {
+                constexpr int KIND = decltype(KIND_)::value;        // 0: store, 1: + forward statistics, 2: + backward statistics
 #pragma unroll
                 for (int r = r0; r < BM; r += NT / CPR) {
                     const uint32_t op = lds_row[r].opix;
@@ -757,20 +762,39 @@ __global__ __launch_bounds__(NT, 2) void conv8_kernel(Args a) {
                         else
 #endif
                             *dst = val;
-                        if constexpr (ST) ts.add(val.x, val.y, val.z, val.w, (m0 + r) >= boundary);
+                        if constexpr (KIND == 1) ts.add(val.x, val.y, val.z, val.w, (m0 + r) >= boundary);
+                        if constexpr (KIND == 2) {
+                            const u32x4 uv = *reinterpret_cast<const u32x4*>(a.bstats_u + (size_t)op * a.Cout + co0 + ch * 8);
+                            const unsigned byte = a.bstats_bits ? a.bstats_bits[(size_t)op * (a.Cout >> 3) + (co0 >> 3) + ch] : 0xffu;
+                            ts.add_bwd(val.x, val.y, val.z, val.w, uv.x, uv.y, uv.z, uv.w, byte, (m0 + r) >= boundary, mu0, rs0, mu1, rs1);
+                        }
                     }
                 }
             };
+            float mu0[8] = {}, rs0[8] = {}, mu1[8] = {}, rs1[8] = {};
             if constexpr (!STATS) {
                 TileStats none;
-                rows(std::false_type{}, none, 0);
+                rows(IC<0>{}, none, 0, mu0, rs0, mu1, rs1);
             } else {
                 TileStats ts;
-                // BatchNorm statistics out of the epilogue (round 5): per-channel sums of what this tile stores, [tile][slot][stat][Cout]
-                const int boundary = (m0 / a.stats_rpg + 1) * a.stats_rpg;      // first row of the next sample group
+                // BatchNorm statistics out of the epilogue (round 5): per-channel sums over what this tile stores, [tile][slot][stat][Cout]:
+                // forward launches (sum, sum of squares); data gradients with bstats_u (sum d, sum d xhat) -- see conv.hip
+                const int g0 = m0 / a.stats_rpg;
+                const int boundary = (g0 + 1) * a.stats_rpg;        // first row of the next sample group
                 const int m_end = m0 + BM < a.M ? m0 + BM : a.M;
                 ts.zero();
-                rows(std::true_type{}, ts, boundary);
+                if (a.bstats_u == nullptr) {
+                    rows(IC<1>{}, ts, boundary, mu0, rs0, mu1, rs1);
+                } else {
+                    const int g1 = boundary < a.M ? g0 + 1 : g0;
+                    const float* p0 = a.bstats_mean + (size_t)g0 * a.Cout + co0 + ch * 8;
+                    const float* p1 = a.bstats_mean + (size_t)g1 * a.Cout + co0 + ch * 8;
+                    const float* q0 = a.bstats_rstd + (size_t)g0 * a.Cout + co0 + ch * 8;
+                    const float* q1 = a.bstats_rstd + (size_t)g1 * a.Cout + co0 + ch * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { mu0[e] = p0[e]; mu1[e] = p1[e]; rs0[e] = q0[e]; rs1[e] = q1[e]; }
+                    rows(IC<2>{}, ts, boundary, mu0, rs0, mu1, rs1);
+                }
                 __syncthreads();                    // every wave has read the tile: its LDS is the scratch now
                 tile_stats_finish<CPR, NT / 64, NT>(ts, boundary < m_end, reinterpret_cast<float*>(smem),
                                                     a.stats_out + (size_t)tile_m * 4 * a.Cout + co0, a.Cout);
@@ -839,10 +863,11 @@ int conv8_launch(const cms_conv_desc* d, hipStream_t s, int mode, int grid_cap, 
     CMS_REQUIRE(d->mask_gates_res == 0 || (d->mode == 1 && d->res && d->mask_bits), "conv8: mask_gates_res belongs to data-gradient launches with a residual and mask bits");
     a.stats_out = (float*)d->stats_out;
     a.stats_rpg = d->stats_rows_per_group > 0 ? d->stats_rows_per_group : d->n * d->ho * d->wo;
+    a.bstats_u = (const uint16_t*)d->bstats_u; a.bstats_bits = d->bstats_bits; a.bstats_mean = d->bstats_mean; a.bstats_rstd = d->bstats_rstd;
     CMS_REQUIRE(d->stats_out == nullptr ||
-                    (d->mode == 0 && d->out_stride == 1 && d->out_h == d->ho && d->out_w == d->wo && a.stats_rpg >= c8::BM &&
+                    ((d->mode == 0 ? d->bstats_u == nullptr : (d->bstats_u && d->bstats_mean && d->bstats_rstd)) && d->out_stride == 1 && d->out_h == d->ho && d->out_w == d->wo && a.stats_rpg >= c8::BM &&
                      (d->n * d->ho * d->wo) % a.stats_rpg == 0),
-                "conv8: stats_out is written by forward launches whose sample groups are whole runs of >= 256 pixel rows");
+                "conv8: stats_out needs sample groups of whole runs of >= 256 pixel rows (forward launches; data gradients with bstats_u / _mean / _rstd)");
     a.N = d->n; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.Cout = d->cout;
     a.ntaps = d->ntaps; a.stride = d->stride; a.out_H = d->out_h; a.out_W = d->out_w; a.out_stride = d->out_stride;
     a.relu = d->relu; a.mode = d->mode;

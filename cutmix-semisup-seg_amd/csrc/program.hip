@@ -156,6 +156,7 @@ static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
                                     b.scale, b.shift, b.running_mean, b.running_var, b.counter, b.sums, b.ws, s);
         case 7: return cms_bn_finalize_tiles((const float*)b.ws, b.reserved, (size_t)b.n_pixels, b.c, g, b.gamma, b.beta, b.eps, b.momentum,
                                              b.mean, b.rstd, b.scale, b.shift, b.running_mean, b.running_var, b.counter, s);
+        case 8: return cms_bn_bwd_sums_tiles((const float*)b.ws, b.reserved, (size_t)b.n_pixels, b.c, g, b.sums, s);
         }
         set_error("program: unknown BatchNorm op %d", b.what);
         return CMS_EINVAL;
@@ -296,8 +297,10 @@ extern "C" int cms_program_add_aspp_spread(cms_program* p, const float* dlogits,
 
 extern "C" int cms_program_add_bn(cms_program* p, const cms_bn_op* op, int stream_idx, int group) {
     CMS_REQUIRE(p && op, "program_add_bn: NULL pointer");
-    CMS_REQUIRE(op->what >= 0 && op->what <= 7, "program_add_bn: unknown op %d", op->what);
-    CMS_REQUIRE(op->what != 7 || (op->ws && op->reserved > 0), "program_add_bn: finalize_tiles needs the tile sums (ws) and the tile rows");
+    CMS_REQUIRE(op->what >= 0 && op->what <= 8, "program_add_bn: unknown op %d", op->what);
+    CMS_REQUIRE((op->what != 7 && op->what != 8) || (op->ws && op->reserved > 0),
+                "program_add_bn: finalize_tiles / sums_tiles need the tile sums (ws) and the tile rows");
+    CMS_REQUIRE(op->what != 8 || op->sums, "program_add_bn: sums_tiles writes `sums`");
     CMS_REQUIRE(op->groups <= 1 || op->ws || (op->what != 0 && op->what != 3), "program_add_bn: grouped reductions need a workspace");
     CMS_REQUIRE(op->what != 3 || !op->mask_bits || op->ws, "program_add_bn: the backward reduction reads mask bits on the workspace kernels only");
     CMS_REQUIRE(stream_idx >= 0 && stream_idx < CMS_PROGRAM_MAX_STREAMS, "program_add_bn: stream index %d", stream_idx);

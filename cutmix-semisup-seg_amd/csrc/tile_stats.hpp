@@ -32,6 +32,30 @@ struct TileStats {
             s1[e] += b; q1[e] = fmaf(b, b, q1[e]);
         }
     }
+    // Backward statistics of a batch-statistics unit from the data-gradient launch that writes the gradient dy of its output (round 5):
+    // d = bit ? dy : 0 (the unit's ReLU mask; byte 0xff without a ReLU), xhat = (u - mean) * rstd with the statistics of the row's sample
+    // group -> (sum d, sum d * xhat), the two sums csrc/bn.hip's backward reduction takes over u, dy and the mask.
+    __device__ __forceinline__ void add_bwd(uint32_t dx, uint32_t dy_, uint32_t dz, uint32_t dw, uint32_t ux, uint32_t uy, uint32_t uz,
+                                            uint32_t uw, unsigned byte, bool second, const float (&mu0)[8], const float (&rs0)[8],
+                                            const float (&mu1)[8], const float (&rs1)[8]) {
+        float d[8], u[8];
+        d[0] = __uint_as_float(dx << 16); d[1] = __uint_as_float(dx & 0xffff0000u);
+        d[2] = __uint_as_float(dy_ << 16); d[3] = __uint_as_float(dy_ & 0xffff0000u);
+        d[4] = __uint_as_float(dz << 16); d[5] = __uint_as_float(dz & 0xffff0000u);
+        d[6] = __uint_as_float(dw << 16); d[7] = __uint_as_float(dw & 0xffff0000u);
+        u[0] = __uint_as_float(ux << 16); u[1] = __uint_as_float(ux & 0xffff0000u);
+        u[2] = __uint_as_float(uy << 16); u[3] = __uint_as_float(uy & 0xffff0000u);
+        u[4] = __uint_as_float(uz << 16); u[5] = __uint_as_float(uz & 0xffff0000u);
+        u[6] = __uint_as_float(uw << 16); u[7] = __uint_as_float(uw & 0xffff0000u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dd = ((byte >> e) & 1u) ? d[e] : 0.0f;
+            const float xh = (u[e] - (second ? mu1[e] : mu0[e])) * (second ? rs1[e] : rs0[e]);     // csrc/bn.hip: (x - mean) * rstd
+            const float a = second ? 0.0f : dd, b = second ? dd : 0.0f;
+            s0[e] += a; q0[e] = fmaf(a, xh, q0[e]);
+            s1[e] += b; q1[e] = fmaf(b, xh, q1[e]);
+        }
+    }
 };
 
 // CPR = chunks per tile row (BN / 8), NW = waves of the workgroup, NT = threads. `scratch` = LDS every wave is done with (the tile;

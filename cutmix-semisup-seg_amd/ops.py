@@ -760,14 +760,15 @@ def bn_workspace(n_pixels, c, device, groups=1):
     return ws
 
 
-_BN_WHAT = {'reduce': 0, 'finalize': 1, 'apply': 2, 'reduce_bwd': 3, 'bwd_apply': 4, 'count': 5, 'stats': 6, 'finalize_tiles': 7}
+_BN_WHAT = {'reduce': 0, 'finalize': 1, 'apply': 2, 'reduce_bwd': 3, 'bwd_apply': 4, 'count': 5, 'stats': 6, 'finalize_tiles': 7, 'sums_tiles': 8}
 
 
 def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, momentum=0.1, groups=1, tile_rows=0, **t):
     """One launch of the batch-statistics BatchNorm protocol (csrc/bn.hip) on caller-owned buffers -- issued now, or appended
     to the program being recorded (cms_program_add_bn): the executor's batch-statistics passes (backbone_hip.py) are made of
     these. `what`: reduce | finalize | apply | reduce_bwd | bwd_apply | count | stats (= reduce + finalize in one launch) |
-    finalize_tiles (statistics from the tile sums the unit's convolution wrote: ws = conv_igemm's stats['tile_sums'], tile_rows);
+    finalize_tiles (statistics from the tile sums the unit's convolution wrote: ws = conv_igemm's stats['tile_sums'], tile_rows) |
+    sums_tiles (backward sums from the tile sums of the data-gradient launch that wrote dy: ws, tile_rows -> sums);
     tensors by keyword (x, res, y, dy, dx, dres, sums, gamma, beta, mean, rstd, scale, shift, running_mean, running_var,
     counter, clear_a, clear_b, ws, mask_bits). `mask_bits` (uint8 [pixel rows][c / 8]): 'apply' writes [y > 0] there as bits,
     'reduce_bwd' (with ws) / 'bwd_apply' read them instead of y (1/16 of its bytes; bit-identical results). With `ws` (bn_workspace) the reductions take the atomics-free kernels; `groups` > 1
@@ -807,6 +808,8 @@ def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, mo
         check(fn['cms_bn_finalize_tiles'](g('ws'), int(tile_rows), d.n_pixels, d.c, G, g('gamma'), g('beta'), d.eps, d.momentum,
                                           g('mean'), g('rstd'), g('scale'), g('shift'), g('running_mean'), g('running_var'),
                                           g('counter'), _stream()), 'cms_bn_finalize_tiles')
+    elif what == 'sums_tiles':
+        check(fn['cms_bn_bwd_sums_tiles'](g('ws'), int(tile_rows), d.n_pixels, d.c, G, g('sums'), _stream()), 'cms_bn_bwd_sums_tiles')
     elif what == 'finalize':
         check(fn['cms_bn_finalize_ex'](g('sums'), d.count, g('gamma'), g('beta'), d.eps, d.momentum, g('mean'), g('rstd'),
                                        g('scale'), g('shift'), g('running_mean'), g('running_var'), d.c, g('clear_a'),
@@ -1220,7 +1223,9 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
     `stats` (bf16 forward launches): a dict {'groups': G}; when the kernel that takes the launch can, its epilogue also writes the
     per-channel (sum, sum of squares) of every pixel tile it stores (cms_conv_desc.stats_out) and the dict comes back with
     'tile_rows' (128 / 256) and 'tile_sums' (fp32 [tiles][2][2][Cout]) for bn_op('finalize_tiles'); 'tile_rows' = 0 when it cannot
-    (the statistics then take a pass over the output: bn_op('stats')).
+    (the statistics then take a pass over the output: bn_op('stats')). Data gradients (mode 1): the dict also carries 'u', 'mean',
+    'rstd' and optionally 'bits' of the batch-statistics unit whose OUTPUT gradient the launch writes; the tile sums are then
+    (sum d, sum d * xhat) for bn_op('sums_tiles') (cms_conv_desc.bstats_*).
     """
     _need_cuda(x, w_packed, scale, bias, res, mask_src, out, out_f32_nchw, mask_bits_out, mask_bits)
     for t in (mask_bits_out, mask_bits):
@@ -1289,6 +1294,14 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
         M = n * ho * wo
         if not f32 and out_f32_nchw is None and M % G == 0:
             d.stats_rows_per_group = M // G
+            if stats.get('u') is not None:          # backward statistics of the unit whose output gradient this launch writes
+                u_, mean_, rstd_, bits_ = stats['u'], stats['mean'], stats['rstd'], stats.get('bits')
+                _need_cuda(u_, mean_, rstd_, bits_)
+                if u_.dtype != x.dtype or not u_.is_contiguous() or u_.numel() != M * cout or mean_.numel() != G * cout \
+                        or rstd_.numel() != G * cout or (bits_ is not None and (bits_.dtype != torch.uint8 or bits_.numel() * 8 != M * cout)):
+                    raise ValueError('conv_igemm: backward statistics need u like the output, mean / rstd [groups][Cout], bits [pixels][Cout / 8]')
+                d.bstats_u, d.bstats_mean, d.bstats_rstd = u_.data_ptr(), mean_.data_ptr(), rstd_.data_ptr()
+                d.bstats_bits = bits_.data_ptr() if bits_ is not None else None
             rows = int(fn['cms_conv_igemm_stats_tile_rows'](C.byref(d)))
             if rows < 0:
                 check(rows, 'cms_conv_igemm_stats_tile_rows')
@@ -1303,12 +1316,16 @@ def conv_igemm(x, w_packed, taps, stride=1, out_hw=None, scale=None, bias=None, 
             check(idx, 'cms_program_add_conv')
         prog.keep += [t for t in (x, w_packed, out, out_f32_nchw, scale, bias, res, mask_src, zp, mask_bits_out, mask_bits, tile_sums)
                       if t is not None]
+        if stats is not None:
+            prog.keep += [t for t in (stats.get('u'), stats.get('mean'), stats.get('rstd'), stats.get('bits')) if t is not None]
         esz = x.element_size()
         prog.flops += 2.0 * n * ho * wo * cout * cin * ntaps
         nbytes = esz * (x.numel() + w_packed.numel()) + float(n * ho * wo) * (
             (4.0 * d.cout_real if out_f32_nchw is not None else esz * cout)
             + (esz * cout if res is not None else 0.0) + (esz * cout if mask_src is not None else 0.0)
-            + (cout / 8.0 if mask_bits is not None else 0.0) + (cout / 8.0 if mask_bits_out is not None else 0.0))
+            + (cout / 8.0 if mask_bits is not None else 0.0) + (cout / 8.0 if mask_bits_out is not None else 0.0)
+            + ((esz * cout + (cout / 8.0 if stats.get('bits') is not None else 0.0))
+               if (stats is not None and stats.get('u') is not None and stats.get('tile_rows')) else 0.0))
         # (the head's fp32 Z planes are an intermediate of the single-pass formulation, not algorithmic output: its floor counts
         # the input and the weights here and the logits at the gather)
         fbytes = esz * (x.numel() + w_packed.numel()) if (out_f32_nchw is not None and d.cout_real > 32) else nbytes

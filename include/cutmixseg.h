@@ -296,6 +296,15 @@ typedef struct cms_conv_desc {
      * (the masked gradient of an identity shortcut added to a convolution's data gradient: the batch-statistics bottleneck's
      * `dres` tensor is never written, architectures/deeplab2.py:105-107); 0 -> y = bit ? acc + res : 0 as before.           */
     int mask_gates_res;
+    /* Round 5, data gradients (mode 1) with stats_out: the launch writes the gradient dy of the OUTPUT of a batch-statistics unit
+     * y = relu(bn(u) (+ res)); with that unit's u (bf16, indexed like this launch's output), ReLU mask bits (NULL: no ReLU) and
+     * statistics mean / rstd [groups][cout] it also leaves per-tile (sum d, sum d * xhat), d = bit ? dy : 0, xhat = (u - mean) * rstd --
+     * cms_bn_bwd_sums_tiles adds them into the sums cms_bn_bwd_apply_groups takes: the unit's backward reduction over u, dy and the
+     * mask (cms_bn_reduce_ws mode 1) is not launched. The stored output is unchanged (unmasked dy).                              */
+    const void* bstats_u;
+    const uint8_t* bstats_bits;
+    const float* bstats_mean;
+    const float* bstats_rstd;
 } cms_conv_desc;
 
 int cms_conv_igemm(const cms_conv_desc* d, void* stream);
@@ -607,7 +616,7 @@ int cms_program_add_sync(cms_program* p, int from_stream, int to_stream, int gro
 /* Batch-statistics BatchNorm launches inside a program (round 3: DeepLab v2 WITHOUT --freeze_bn on the executor,
  * architectures/deeplab2.py:72-84 / train_seg_semisup_mask_mt.py:587). `what`: 0 = cms_bn_reduce(mode 0), 1 = cms_bn_finalize,
  * 2 = cms_bn_apply, 3 = cms_bn_reduce(mode 1), 4 = cms_bn_bwd_apply, 5 = cms_increment_counter(counter), 6 = cms_bn_stats,
- * 7 = cms_bn_finalize_tiles (tile sums in `ws`, tile rows in `reserved`); unused pointers NULL. With `ws` set, what 0 / 3
+ * 7 = cms_bn_finalize_tiles (tile sums in `ws`, tile rows in `reserved`), 8 = cms_bn_bwd_sums_tiles (likewise; writes `sums`); unused pointers NULL. With `ws` set, what 0 / 3
  * run cms_bn_reduce_ws.
  * All buffers are the caller's and persistent (a program is replayed many times). */
 /* Statistics of a unit from the tile sums its convolution wrote (cms_conv_desc.stats_out): per group and channel the tiles' sums are
@@ -616,6 +625,9 @@ int cms_program_add_sync(cms_program* p, int from_stream, int to_stream, int gro
 int cms_bn_finalize_tiles(const float* tile_sums, int tile_rows, size_t n_pixels, int c, int groups, const float* gamma,
                           const float* beta, float eps, float momentum, float* mean, float* rstd, float* scale, float* shift,
                           float* running_mean, float* running_var, long long* counter, void* stream);
+
+/* backward counterpart: tile sums of a data-gradient launch with bstats_* -> sums[groups][2][c] (double) for cms_bn_bwd_apply_groups */
+int cms_bn_bwd_sums_tiles(const float* tile_sums, int tile_rows, size_t n_pixels, int c, int groups, double* sums, void* stream);
 
 typedef struct cms_bn_op {
     int what, dtype, c, relu;

@@ -124,3 +124,68 @@ def test_launches_that_cannot_write_tile_sums_say_so():
     st = {'groups': 1}
     ops.conv_igemm(x, w, [(0, 0)], mode=1, stats=st)
     assert st['tile_rows'] == 0
+
+
+# (name, N, H, W, K channels of du, channels of the gradient written, expected tile rows)
+BWD_CASES = [
+    ('conv8', 4, 41, 41, 1024, 256, 256),
+    ('mixed_128', 20, 41, 41, 64, 256, 128),
+    ('tile64', 2, 47, 31, 128, 64, 128),
+]
+
+
+@pytest.mark.parametrize('G', [1, 2])
+@pytest.mark.parametrize('relu,gated', [(True, False), (True, True), (False, False)])
+@pytest.mark.parametrize('case', BWD_CASES, ids=[c[0] for c in BWD_CASES])
+def test_backward_statistics_from_the_data_gradient_epilogue(case, G, relu, gated):
+    """A data-gradient launch that writes the gradient dy of a batch-statistics unit's output also leaves (sum d, sum d xhat) per
+    tile (cms_conv_desc.bstats_*): the stored dy is unchanged, cms_bn_bwd_sums_tiles gives the sums of the reduction kernel
+    (cms_bn_reduce_ws mode 1 over u, dy and the mask bits) within fp32 accumulation error, bit-reproducibly."""
+    from cutmix_semisup_seg_amd import ops
+    name, N, H, W, Cd, C, rows = case
+    g = torch.Generator().manual_seed(len(name) + 7 * G)
+    M = N * H * W
+    du = (torch.randn(N, H, W, Cd, generator=g) * 0.3).to(torch.bfloat16).to(DEV)
+    wT = (torch.randn(1, C, Cd, generator=g) * (1.0 / np.sqrt(Cd))).to(torch.bfloat16).to(DEV)
+    u = (torch.randn(N, H, W, C, generator=g) * 1.1 + 0.4).to(torch.bfloat16).to(DEV)
+    res = (torch.randn(N, H, W, C, generator=g) * 0.5).to(torch.bfloat16).to(DEV) if gated else None
+    gate_bits = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).to(DEV) if gated else None
+    bits = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).to(DEV) if relu else None
+    # the unit's statistics (any consistent mean / rstd will do: take the real ones)
+    flat = u.view(G, M // G, C).float()
+    mean = flat.mean(1).reshape(-1).contiguous()
+    rstd = (1.0 / torch.sqrt(flat.var(1, unbiased=False) + 1e-5)).reshape(-1).contiguous()
+    one = [(0, 0)]
+    plain = ops.conv_igemm(du, wT, one, res=res, mode=1, mask_bits=gate_bits, mask_gates_res=gated)
+    st = {'groups': G, 'u': u, 'mean': mean, 'rstd': rstd, 'bits': bits}
+    dy = ops.conv_igemm(du, wT, one, res=res, mode=1, mask_bits=gate_bits, mask_gates_res=gated, stats=st)
+    torch.cuda.synchronize()
+    assert st['tile_rows'] == rows
+    assert torch.equal(plain.view(torch.int16), dy.view(torch.int16))
+    got = torch.empty(G * 2 * C, dtype=torch.float64, device=DEV)
+    ops.bn_op('sums_tiles', c=C, dtype=torch.bfloat16, n_pixels=M, groups=G, tile_rows=rows, ws=st['tile_sums'], sums=got)
+    want = torch.empty(G * 2 * C, dtype=torch.float64, device=DEV)
+    ws = ops.bn_workspace(M, C, DEV, G)
+    if relu:
+        ops.bn_op('reduce_bwd', c=C, dtype=torch.bfloat16, n_pixels=M, groups=G, x=u, dy=dy, mean=mean, rstd=rstd, sums=want, ws=ws,
+                  mask_bits=bits)
+    else:
+        ops.bn_op('reduce_bwd', c=C, dtype=torch.bfloat16, n_pixels=M, groups=G, x=u, dy=dy, y=None, mean=mean, rstd=rstd, sums=want,
+                  ws=ws)
+    torch.cuda.synchronize()
+    # scale of the error: fp32 accumulation over <= 256 rows per tile of terms |d| and |d xhat|
+    d = dy.view(G, M // G, C).double()
+    if relu:
+        on = ((bits.view(M, C // 8, 1).to(torch.int32) >> torch.arange(8, device=DEV, dtype=torch.int32)) & 1).view(G, M // G, C)
+        d = d * on
+    xh = (u.view(G, M // G, C).double() - mean.view(G, 1, C).double()) * rstd.view(G, 1, C).double()
+    l1 = torch.stack([d.abs().sum(1), (d * xh).abs().sum(1)], 1).reshape(-1)
+    exact = torch.stack([d.sum(1), (d * xh).sum(1)], 1).reshape(-1)
+    assert ((got - exact).abs() <= 2e-6 * l1 + 1e-6).all()
+    assert ((want - exact).abs() <= 2e-6 * l1 + 1e-6).all()
+    st2 = {'groups': G, 'u': u, 'mean': mean, 'rstd': rstd, 'bits': bits}
+    ops.conv_igemm(du, wT, one, res=res, mode=1, mask_bits=gate_bits, mask_gates_res=gated, stats=st2)
+    again = torch.empty_like(got)
+    ops.bn_op('sums_tiles', c=C, dtype=torch.bfloat16, n_pixels=M, groups=G, tile_rows=rows, ws=st2['tile_sums'], sums=again)
+    torch.cuda.synchronize()
+    assert torch.equal(got, again)
