@@ -197,7 +197,11 @@ __device__ __forceinline__ void wait_vmcnt_lds() {
 // out-of-range offsets: the hardware bounds check writes zeros, no zero page.
 // The kernel body is a device function of (logical block id, number of blocks, first pixel tile), so that ONE launch
 // can run two tile shapes (conv_igemm_mixed_kernel below).
-template <int WN, int WM, int TN, int TM, bool GLDS, int NS, int BK = CONV_BK, bool PF = false, int OCC = 0, bool BUFA = false>
+// ST = the store loop can also take BatchNorm statistics (ConvArgs.stats_out, tile_stats.hpp): separate instantiations of the
+// default tiles, so that the statistics' ~40 registers cost the plain kernels nothing (the 32-channel tile went from 6 to 4
+// workgroups per CU with the code folded in).
+template <int WN, int WM, int TN, int TM, bool GLDS, int NS, int BK = CONV_BK, bool PF = false, int OCC = 0, bool BUFA = false,
+          bool ST = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, const int nblk_in, const int m_tile_base) {
     // NS = LDS stages of the direct-to-LDS loader. 1: load -> barrier -> MFMA -> barrier; memory and MFMA phases only
     // overlap ACROSS the (up to 4) workgroups of a CU. 2: the loads of K-step k+1 are in flight during the MFMAs of
@@ -921,9 +925,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
         // thread -> LOGICAL chunk ch of rows r0, r0 + RPP, ... (its place in the swizzled LDS row changes with the row): the
         // 8 channels a thread stores are the same in every pass, which is what the statistics below accumulate over
         const int ch = tid % CPR, r0 = tid / CPR;
-        auto rows = [&](auto KIND_, TileStats& ts, int boundary, const float (&mu0)[8], const float (&rs0)[8], const float (&mu1)[8],
-                        const float (&rs1)[8]) {
-            constexpr int KIND = decltype(KIND_)::value;    // 0: store, 1: + forward statistics, 2: + backward statistics
+        if constexpr (!ST) {
 #pragma unroll
             for (int r = r0; r < BM; r += RPP) {
                 const uint32_t op = lds_row[r].opix;
@@ -935,42 +937,60 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
                     else
 #endif
                         *dst = val;
-                    if constexpr (KIND == 1) ts.add(val.x, val.y, val.z, val.w, (m0 + r) >= boundary);
-                    if constexpr (KIND == 2) {
-                        const u32x4 uv = *reinterpret_cast<const u32x4*>(a.bstats_u + (size_t)op * a.Cout + co0 + ch * 8);
-                        const unsigned byte = a.bstats_bits ? a.bstats_bits[(size_t)op * (a.Cout >> 3) + (co0 >> 3) + ch] : 0xffu;
-                        ts.add_bwd(val.x, val.y, val.z, val.w, uv.x, uv.y, uv.z, uv.w, byte, (m0 + r) >= boundary, mu0, rs0, mu1, rs1);
-                    }
                 }
             }
-        };
-        TileStats ts;
-        float mu0[8] = {}, rs0[8] = {}, mu1[8] = {}, rs1[8] = {};
-        if (a.stats_out == nullptr) {
-            rows(std::integral_constant<int, 0>{}, ts, 0, mu0, rs0, mu1, rs1);
         } else {
             // BatchNorm statistics out of the epilogue (round 5, tile_stats.hpp): per-channel sums over what this tile stores --
             // forward launches (sum, sum of squares) of the output; data-gradient launches with bstats_u (sum d, sum d xhat) of the
             // batch-statistics unit whose output gradient the launch writes
-            const int g0 = m0 / a.stats_rpg;
-            const int boundary = (g0 + 1) * a.stats_rpg;                        // first row of the next sample group
-            const int m_end = m0 + BM < a.M ? m0 + BM : a.M;
-            ts.zero();
-            if (a.bstats_u == nullptr) {
-                rows(std::integral_constant<int, 1>{}, ts, boundary, mu0, rs0, mu1, rs1);
-            } else {
-                const int g1 = boundary < a.M ? g0 + 1 : g0;
-                const float* p0 = a.bstats_mean + (size_t)g0 * a.Cout + co0 + ch * 8;
-                const float* p1 = a.bstats_mean + (size_t)g1 * a.Cout + co0 + ch * 8;
-                const float* q0 = a.bstats_rstd + (size_t)g0 * a.Cout + co0 + ch * 8;
-                const float* q1 = a.bstats_rstd + (size_t)g1 * a.Cout + co0 + ch * 8;
+            auto rows = [&](auto KIND_, TileStats& ts, int boundary, const float (&mu0)[8], const float (&rs0)[8],
+                            const float (&mu1)[8], const float (&rs1)[8]) {
+                constexpr int KIND = decltype(KIND_)::value;    // 0: store, 1: + forward statistics, 2: + backward statistics
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { mu0[e] = p0[e]; mu1[e] = p1[e]; rs0[e] = q0[e]; rs1[e] = q1[e]; }
-                rows(std::integral_constant<int, 2>{}, ts, boundary, mu0, rs0, mu1, rs1);
+                for (int r = r0; r < BM; r += RPP) {
+                    const uint32_t op = lds_row[r].opix;
+                    if (op != 0xffffffffu) {
+                        const u32x4 val = *reinterpret_cast<const u32x4*>(smem + r * EROW + ((ch ^ (r & (CPR - 1))) << 4));
+                        u32x4* dst = reinterpret_cast<u32x4*>(a.y + (size_t)op * a.Cout + co0 + ch * 8);
+#if defined(__HIP_DEVICE_COMPILE__)
+                        if (a.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(dst), "v"(val) : "memory");
+                        else
+#endif
+                            *dst = val;
+                        if constexpr (KIND == 1) ts.add(val.x, val.y, val.z, val.w, (m0 + r) >= boundary);
+                        if constexpr (KIND == 2) {
+                            const u32x4 uv = *reinterpret_cast<const u32x4*>(a.bstats_u + (size_t)op * a.Cout + co0 + ch * 8);
+                            const unsigned byte = a.bstats_bits ? a.bstats_bits[(size_t)op * (a.Cout >> 3) + (co0 >> 3) + ch] : 0xffu;
+                            ts.add_bwd(val.x, val.y, val.z, val.w, uv.x, uv.y, uv.z, uv.w, byte, (m0 + r) >= boundary, mu0, rs0, mu1, rs1);
+                        }
+                    }
+                }
+            };
+            TileStats ts;
+            float mu0[8] = {}, rs0[8] = {}, mu1[8] = {}, rs1[8] = {};
+            if (a.stats_out == nullptr) {
+                rows(std::integral_constant<int, 0>{}, ts, 0, mu0, rs0, mu1, rs1);
+            } else {
+                const int g0 = m0 / a.stats_rpg;
+                const int boundary = (g0 + 1) * a.stats_rpg;                    // first row of the next sample group
+                const int m_end = m0 + BM < a.M ? m0 + BM : a.M;
+                ts.zero();
+                if (a.bstats_u == nullptr) {
+                    rows(std::integral_constant<int, 1>{}, ts, boundary, mu0, rs0, mu1, rs1);
+                } else {
+                    const int g1 = boundary < a.M ? g0 + 1 : g0;
+                    const float* p0 = a.bstats_mean + (size_t)g0 * a.Cout + co0 + ch * 8;
+                    const float* p1 = a.bstats_mean + (size_t)g1 * a.Cout + co0 + ch * 8;
+                    const float* q0 = a.bstats_rstd + (size_t)g0 * a.Cout + co0 + ch * 8;
+                    const float* q1 = a.bstats_rstd + (size_t)g1 * a.Cout + co0 + ch * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { mu0[e] = p0[e]; mu1[e] = p1[e]; rs0[e] = q0[e]; rs1[e] = q1[e]; }
+                    rows(std::integral_constant<int, 2>{}, ts, boundary, mu0, rs0, mu1, rs1);
+                }
+                __syncthreads();                    // the tile has been read by every wave: its LDS is the scratch now
+                tile_stats_finish<CPR, NW, NT>(ts, boundary < m_end, reinterpret_cast<float*>(smem),
+                                               a.stats_out + (size_t)tile_m * 4 * a.Cout + co0, a.Cout);
             }
-            __syncthreads();                        // the tile has been read by every wave: its LDS is the scratch now
-            tile_stats_finish<CPR, NW, NT>(ts, boundary < m_end, reinterpret_cast<float*>(smem),
-                                           a.stats_out + (size_t)tile_m * 4 * a.Cout + co0, a.Cout);
         }
     }
     if (tracing) {                                  // diagnostic dump: header + stamps of thread 0 (tools/conv_trace.py)
@@ -991,11 +1011,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
     }
 }
 
-template <int WN, int WM, int TN, int TM, bool GLDS, int NS, int BK = CONV_BK, bool PF = false, int OCC = 0, bool BUFA = false>
+template <int WN, int WM, int TN, int TM, bool GLDS, int NS, int BK = CONV_BK, bool PF = false, int OCC = 0, bool BUFA = false,
+          bool ST = false>
 __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
                                            : ((GLDS && WN * WM == 4 && TN * TM == 4) ? ((NS == 1 || BK == 32) ? 4 : 2)
                                               : ((WN * WM == 4 && TN * TM == 8) ? 2 : 1))) void conv_igemm_kernel(ConvArgs a) {
-    conv_body<WN, WM, TN, TM, GLDS, NS, BK, PF, OCC, BUFA>(a, (int)blockIdx.x, (int)gridDim.x, 0);
+    conv_body<WN, WM, TN, TM, GLDS, NS, BK, PF, OCC, BUFA, ST>(a, (int)blockIdx.x, (int)gridDim.x, 0);
 }
 
 // Two tile shapes in one launch. A layer of T = pixel tiles x channel tiles workgroups of the 128 x 128 tile leaves
@@ -1004,13 +1025,13 @@ __global__ __launch_bounds__(64 * WN * WM, OCC > 0 ? (OCC * WN * WM + 3) / 4
 // of 256 workgroups run the 128 x 128 tile over pixel tiles [0, rem_tile_base), and the pixel tiles behind them are cut
 // into 32-channel slices (128 pixels x 32 channels, a quarter of the work each): four times as many, four times
 // shorter, spread over four times as many CUs.
-template <bool BUFA>
+template <bool BUFA, bool ST = false>
 __global__ __launch_bounds__(256, 4) void conv_igemm_mixed_kernel(ConvArgs a) {
     if ((int)blockIdx.x < a.n_main)
-        conv_body<2, 2, 2, 2, true, 1, CONV_BK, false, 0, BUFA>(a, (int)blockIdx.x, a.n_main, 0);
+        conv_body<2, 2, 2, 2, true, 1, CONV_BK, false, 0, BUFA, ST>(a, (int)blockIdx.x, a.n_main, 0);
     else
-        conv_body<1, 4, 1, 1, true, 1, CONV_BK, false, 0, BUFA>(a, (int)blockIdx.x - a.n_main, (int)gridDim.x - a.n_main,
-                                                               a.rem_tile_base);
+        conv_body<1, 4, 1, 1, true, 1, CONV_BK, false, 0, BUFA, ST>(a, (int)blockIdx.x - a.n_main, (int)gridDim.x - a.n_main,
+                                                                   a.rem_tile_base);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1125,7 +1146,7 @@ static void conv_launch_ring(const ConvArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, a);
 }
 
-template <int WN, int WM, int TN, int TM>
+template <int WN, int WM, int TN, int TM, bool STATS_TILE = false>
 static void conv_launch(const ConvArgs& a, hipStream_t s, int loader) {      // loader: 0 registers, 1 / 2 = glds stages,
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;                       //         3 = two glds stages of BK = 32
     const int grid = (a.Cout / BN) * ((a.M + BM - 1) / BM) * a.ksplit;
@@ -1144,6 +1165,13 @@ static void conv_launch(const ConvArgs& a, hipStream_t s, int loader) {      // 
     } else if (loader == 3 && BN % (16 * WN * WM) == 0 && BM % (16 * WN * WM) == 0) {
         if constexpr (BN % (16 * WN * WM) == 0 && BM % (16 * WN * WM) == 0)       // 64-byte rows: 16 rows per wave load
             hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 2, 32>), dim3(grid), dim3(NT), lds, s, a);
+    } else if (STATS_TILE && a.stats_out != nullptr && (loader == 4 || loader == 1)) {     // (the caller has checked the loader)
+        if constexpr (STATS_TILE) {
+            if (loader == 4)
+                hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 1, CONV_BK, false, 0, true, true>), dim3(grid), dim3(NT), lds, s, a);
+            else
+                hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 1, CONV_BK, false, 0, false, true>), dim3(grid), dim3(NT), lds, s, a);
+        }
     } else if (loader == 4) {                    // direct-to-LDS with buffer addressing
         hipLaunchKernelGGL((conv_igemm_kernel<WN, WM, TN, TM, true, 1, CONV_BK, false, 0, true>), dim3(grid), dim3(NT), lds, s, a);
     } else if (loader == 1 || loader == 3) {
@@ -1244,7 +1272,7 @@ extern "C" int cms_conv_igemm_route(const cms_conv_desc* d) {
 extern "C" int cms_conv_igemm_stats_tile_rows(const cms_conv_desc* d) {
     int rc = conv_check(d);
     if (rc) return rc;
-    if (d->y == nullptr || d->ksplit > 1 || d->out_stride != 1 || d->out_h != d->ho || d->out_w != d->wo) return 0;
+    if (d->y == nullptr || d->zeros == nullptr || d->ksplit > 1 || d->out_stride != 1 || d->out_h != d->ho || d->out_w != d->wo) return 0;
     // forward launches: statistics of the output; data gradients: only with the unit's u / mean / rstd (backward statistics)
     if (d->mode == 0 ? d->bstats_u != nullptr : (d->bstats_u == nullptr || d->bstats_mean == nullptr || d->bstats_rstd == nullptr)) return 0;
     const int route = cms_conv_igemm_route(d);
@@ -1361,6 +1389,7 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
                      : ((d->variant == 4 || d->variant == 6 || d->variant == 7) ? 2
                         : (d->variant == 5 ? 3 : ((small && d->variant != 43) ? 4 : 1)));      // 43: flat addresses (round-1 loader)
     const int tile = d->tile;   // 0 = auto
+    CMS_REQUIRE(d->stats_out == nullptr || glds == 4 || glds == 1, "conv: stats_out needs the direct-to-LDS kernels (a zero run in the descriptor)");
     if (d->variant >= 80 && d->variant <= 85) {
         // Round 3 experiment: 256 (co) x 128 (pixels) on FOUR waves (each 128 co x 64 pixels): 48 KB staged and 96 KB of fragment
         // reads per 2x the MFMA work of the default tile, one workgroup per CU for layers of ~263 pixel tiles
@@ -1461,16 +1490,19 @@ extern "C" int cms_conv_igemm(const cms_conv_desc* d_in, void* stream) {
             a.rem_tile_base = a.n_main / ntn;
             const int n_rem = (mtiles - a.rem_tile_base) * (d->cout / 32);
             const size_t lds = 32768 + 80 + 128 * 16 + 2 * 128 * 4 + (a.trace ? CONV_TRACE_DWORDS * 4 : 0);
-            if (glds == 4) hipLaunchKernelGGL(conv_igemm_mixed_kernel<true>, dim3(a.n_main + n_rem), dim3(256), lds, s, a);
+            if (a.stats_out) {
+                if (glds == 4) hipLaunchKernelGGL((conv_igemm_mixed_kernel<true, true>), dim3(a.n_main + n_rem), dim3(256), lds, s, a);
+                else hipLaunchKernelGGL((conv_igemm_mixed_kernel<false, true>), dim3(a.n_main + n_rem), dim3(256), lds, s, a);
+            } else if (glds == 4) hipLaunchKernelGGL(conv_igemm_mixed_kernel<true>, dim3(a.n_main + n_rem), dim3(256), lds, s, a);
             else hipLaunchKernelGGL(conv_igemm_mixed_kernel<false>, dim3(a.n_main + n_rem), dim3(256), lds, s, a);
             return launch_status("cms_conv_igemm");
         }
-        conv_launch<2, 2, 2, 2>(a, s, glds);
+        conv_launch<2, 2, 2, 2, true>(a, s, glds);
     } else if ((tile == 0 && d->cout % 64 == 0) || tile == 64) {
         CMS_REQUIRE(d->cout % 64 == 0, "conv: tile 64 needs Cout %% 64 == 0");
-        conv_launch<1, 4, 2, 1>(a, s, glds);     // 64 co x 128 pixels
+        conv_launch<1, 4, 2, 1, true>(a, s, glds);     // 64 co x 128 pixels
     } else {
-        conv_launch<1, 4, 1, 1>(a, s, glds);     // 32 co x 128 pixels
+        conv_launch<1, 4, 1, 1, true>(a, s, glds);     // 32 co x 128 pixels
     }
     return launch_status("cms_conv_igemm");
 }
