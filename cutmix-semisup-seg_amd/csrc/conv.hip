@@ -943,9 +943,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
             // BatchNorm statistics out of the epilogue (round 5, tile_stats.hpp): per-channel sums over what this tile stores --
             // forward launches (sum, sum of squares) of the output; data-gradient launches with bstats_u (sum d, sum d xhat) of the
             // batch-statistics unit whose output gradient the launch writes
-            auto rows = [&](auto KIND_, TileStats& ts, int boundary, const float (&mu0)[8], const float (&rs0)[8],
-                            const float (&mu1)[8], const float (&rs1)[8]) {
-                constexpr int KIND = decltype(KIND_)::value;    // 0: store, 1: + forward statistics, 2: + backward statistics
+            auto rows = [&](auto KIND_, auto TWO_, TileStats& ts, int boundary, const ts_f32x2 (&mu0)[4], const ts_f32x2 (&rs0)[4],
+                            const ts_f32x2 (&mu1)[4], const ts_f32x2 (&rs1)[4]) {
+                constexpr int KIND = decltype(KIND_)::value;              // 0: store, 1: + forward statistics, 2: + backward statistics
+                constexpr bool TWO = decltype(TWO_)::value != 0;          // the tile straddles a sample-group boundary (both slots)
 #pragma unroll
                 for (int r = r0; r < BM; r += RPP) {
                     const uint32_t op = lds_row[r].opix;
@@ -957,26 +958,27 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
                         else
 #endif
                             *dst = val;
-                        if constexpr (KIND == 1) ts.add(val.x, val.y, val.z, val.w, (m0 + r) >= boundary);
+                        if constexpr (KIND == 1) ts.template add<TWO>(val.x, val.y, val.z, val.w, (m0 + r) >= boundary);
                         if constexpr (KIND == 2) {
                             const u32x4 uv = *reinterpret_cast<const u32x4*>(a.bstats_u + (size_t)op * a.Cout + co0 + ch * 8);
                             const unsigned byte = a.bstats_bits ? a.bstats_bits[(size_t)op * (a.Cout >> 3) + (co0 >> 3) + ch] : 0xffu;
-                            ts.add_bwd(val.x, val.y, val.z, val.w, uv.x, uv.y, uv.z, uv.w, byte, (m0 + r) >= boundary, mu0, rs0, mu1, rs1);
+                            ts.template add_bwd<TWO>(val.x, val.y, val.z, val.w, uv.x, uv.y, uv.z, uv.w, byte, (m0 + r) >= boundary, mu0, rs0, mu1, rs1);
                         }
                     }
                 }
             };
             TileStats ts;
-            float mu0[8] = {}, rs0[8] = {}, mu1[8] = {}, rs1[8] = {};
+            ts_f32x2 mu0[4] = {}, rs0[4] = {}, mu1[4] = {}, rs1[4] = {};      // (mu = MINUS the mean)
             if (a.stats_out == nullptr) {
-                rows(std::integral_constant<int, 0>{}, ts, 0, mu0, rs0, mu1, rs1);
+                rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ts, 0, mu0, rs0, mu1, rs1);
             } else {
                 const int g0 = m0 / a.stats_rpg;
                 const int boundary = (g0 + 1) * a.stats_rpg;                    // first row of the next sample group
                 const int m_end = m0 + BM < a.M ? m0 + BM : a.M;
                 ts.zero();
                 if (a.bstats_u == nullptr) {
-                    rows(std::integral_constant<int, 1>{}, ts, boundary, mu0, rs0, mu1, rs1);
+                    if (boundary < m_end) rows(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, ts, boundary, mu0, rs0, mu1, rs1);
+                    else rows(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, ts, boundary, mu0, rs0, mu1, rs1);
                 } else {
                     const int g1 = boundary < a.M ? g0 + 1 : g0;
                     const float* p0 = a.bstats_mean + (size_t)g0 * a.Cout + co0 + ch * 8;
@@ -984,8 +986,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, const int bid_raw, 
                     const float* q0 = a.bstats_rstd + (size_t)g0 * a.Cout + co0 + ch * 8;
                     const float* q1 = a.bstats_rstd + (size_t)g1 * a.Cout + co0 + ch * 8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { mu0[e] = p0[e]; mu1[e] = p1[e]; rs0[e] = q0[e]; rs1[e] = q1[e]; }
-                    rows(std::integral_constant<int, 2>{}, ts, boundary, mu0, rs0, mu1, rs1);
+                    for (int i = 0; i < 4; ++i) {
+                        mu0[i] = ts_f32x2{-p0[2 * i], -p0[2 * i + 1]}; mu1[i] = ts_f32x2{-p1[2 * i], -p1[2 * i + 1]};
+                        rs0[i] = ts_f32x2{q0[2 * i], q0[2 * i + 1]}; rs1[i] = ts_f32x2{q1[2 * i], q1[2 * i + 1]};
+                    }
+                    if (boundary < m_end) rows(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, ts, boundary, mu0, rs0, mu1, rs1);
+                    else rows(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, ts, boundary, mu0, rs0, mu1, rs1);
                 }
                 __syncthreads();                    // the tile has been read by every wave: its LDS is the scratch now
                 tile_stats_finish<CPR, NW, NT>(ts, boundary < m_end, reinterpret_cast<float*>(smem),

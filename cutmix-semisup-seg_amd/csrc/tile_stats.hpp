@@ -11,49 +11,62 @@
 
 namespace cms {
 
+typedef float ts_f32x2 __attribute__((ext_vector_type(2)));     // packed fp32 pairs: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32
+
+// Cost matters: the loop is pure vector ALU work in the epilogue of EVERY tile (a wave instruction is 4 cycles, two waves share a
+// SIMD: the first version's ~7 scalar operations per element were +3-9 us per launch, tools/conv_stats_bench.py). Hence packed
+// pairs (a dword of the chunk = two adjacent channels = one pair) and a one-slot path for the tiles that do not straddle a group
+// boundary (all but G - 1 of them): 2 + 2 operations per pair.
 struct TileStats {
-    float s0[8], q0[8], s1[8], q1[8];      // (sum, sum of squares) of slot 0 / slot 1, per channel of the chunk
+    ts_f32x2 s0[4], q0[4], s1[4], q1[4];   // (sum, second sum) of slot 0 / slot 1, per channel pair of the chunk
     __device__ __forceinline__ void zero() {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s0[e] = q0[e] = s1[e] = q1[e] = 0.0f;
+        for (int i = 0; i < 4; ++i) s0[i] = q0[i] = s1[i] = q1[i] = ts_f32x2{0.0f, 0.0f};
     }
-    // the 8 bf16 values of a chunk (4 dwords). Branch-free: an if / else over the slot is turned into a dynamically indexed
-    // array by the compiler, i.e. into scratch memory.
+    static __device__ __forceinline__ ts_f32x2 pair(uint32_t d) { return ts_f32x2{__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)}; }
+    // Forward: the 8 bf16 values of a chunk (4 dwords) -> (sum, sum of squares). TWO: the tile straddles a boundary, `second` = the row
+    // belongs to the next group (branch-free: an if / else over the slot becomes a dynamically indexed array, i.e. scratch memory).
+    template <bool TWO>
     __device__ __forceinline__ void add(uint32_t x, uint32_t y, uint32_t z, uint32_t w, bool second) {
-        float v[8];
-        v[0] = __uint_as_float(x << 16); v[1] = __uint_as_float(x & 0xffff0000u);
-        v[2] = __uint_as_float(y << 16); v[3] = __uint_as_float(y & 0xffff0000u);
-        v[4] = __uint_as_float(z << 16); v[5] = __uint_as_float(z & 0xffff0000u);
-        v[6] = __uint_as_float(w << 16); v[7] = __uint_as_float(w & 0xffff0000u);
+        const ts_f32x2 v[4] = {pair(x), pair(y), pair(z), pair(w)};
+        if constexpr (!TWO) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float a = second ? 0.0f : v[e], b = second ? v[e] : 0.0f;
-            s0[e] += a; q0[e] = fmaf(a, a, q0[e]);
-            s1[e] += b; q1[e] = fmaf(b, b, q1[e]);
+            for (int i = 0; i < 4; ++i) { s0[i] += v[i]; q0[i] = v[i] * v[i] + q0[i]; }
+        } else {
+            const float m = second ? 0.0f : 1.0f;
+            const ts_f32x2 mm = {m, m};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const ts_f32x2 a = v[i] * mm, b = v[i] - a;        // exact: (v, 0) or (0, v)
+                s0[i] += a; q0[i] = a * a + q0[i];
+                s1[i] += b; q1[i] = b * b + q1[i];
+            }
         }
     }
     // Backward statistics of a batch-statistics unit from the data-gradient launch that writes the gradient dy of its output (round 5):
     // d = bit ? dy : 0 (the unit's ReLU mask; byte 0xff without a ReLU), xhat = (u - mean) * rstd with the statistics of the row's sample
-    // group -> (sum d, sum d * xhat), the two sums csrc/bn.hip's backward reduction takes over u, dy and the mask.
+    // group -> (sum d, sum d * xhat), the two sums csrc/bn.hip's backward reduction takes over u, dy and the mask. nmu = -mean.
+    template <bool TWO>
     __device__ __forceinline__ void add_bwd(uint32_t dx, uint32_t dy_, uint32_t dz, uint32_t dw, uint32_t ux, uint32_t uy, uint32_t uz,
-                                            uint32_t uw, unsigned byte, bool second, const float (&mu0)[8], const float (&rs0)[8],
-                                            const float (&mu1)[8], const float (&rs1)[8]) {
-        float d[8], u[8];
-        d[0] = __uint_as_float(dx << 16); d[1] = __uint_as_float(dx & 0xffff0000u);
-        d[2] = __uint_as_float(dy_ << 16); d[3] = __uint_as_float(dy_ & 0xffff0000u);
-        d[4] = __uint_as_float(dz << 16); d[5] = __uint_as_float(dz & 0xffff0000u);
-        d[6] = __uint_as_float(dw << 16); d[7] = __uint_as_float(dw & 0xffff0000u);
-        u[0] = __uint_as_float(ux << 16); u[1] = __uint_as_float(ux & 0xffff0000u);
-        u[2] = __uint_as_float(uy << 16); u[3] = __uint_as_float(uy & 0xffff0000u);
-        u[4] = __uint_as_float(uz << 16); u[5] = __uint_as_float(uz & 0xffff0000u);
-        u[6] = __uint_as_float(uw << 16); u[7] = __uint_as_float(uw & 0xffff0000u);
+                                            uint32_t uw, unsigned byte, bool second, const ts_f32x2 (&nmu0)[4], const ts_f32x2 (&rs0)[4],
+                                            const ts_f32x2 (&nmu1)[4], const ts_f32x2 (&rs1)[4]) {
+        const uint32_t dd[4] = {dx, dy_, dz, dw}, uu[4] = {ux, uy, uz, uw};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float dd = ((byte >> e) & 1u) ? d[e] : 0.0f;
-            const float xh = (u[e] - (second ? mu1[e] : mu0[e])) * (second ? rs1[e] : rs0[e]);     // csrc/bn.hip: (x - mean) * rstd
-            const float a = second ? 0.0f : dd, b = second ? dd : 0.0f;
-            s0[e] += a; q0[e] = fmaf(a, xh, q0[e]);
-            s1[e] += b; q1[e] = fmaf(b, xh, q1[e]);
+        for (int i = 0; i < 4; ++i) {
+            // the mask on the PACKED pair: bit 2 i -> low half, bit 2 i + 1 -> high half
+            const uint32_t keep = (0u - ((byte >> (2 * i)) & 1u)) & 0x0000ffffu, keep_hi = (0u - ((byte >> (2 * i + 1)) & 1u)) & 0xffff0000u;
+            const ts_f32x2 d = pair(dd[i] & (keep | keep_hi)), u = pair(uu[i]);
+            if constexpr (!TWO) {
+                const ts_f32x2 xh = (u + nmu0[i]) * rs0[i];         // csrc/bn.hip: (x - mean) * rstd
+                s0[i] += d; q0[i] = d * xh + q0[i];
+            } else {
+                const ts_f32x2 xh = second ? (u + nmu1[i]) * rs1[i] : (u + nmu0[i]) * rs0[i];
+                const float m = second ? 0.0f : 1.0f;
+                const ts_f32x2 mm = {m, m};
+                const ts_f32x2 a = d * mm, b = d - a;
+                s0[i] += a; q0[i] = a * xh + q0[i];
+                s1[i] += b; q1[i] = b * xh + q1[i];
+            }
         }
     }
 };
@@ -64,26 +77,31 @@ template <int CPR, int NW, int NT>
 __device__ __forceinline__ void tile_stats_finish(TileStats& t, bool straddle, float* scratch, float* dst, int Cout) {
     constexpr int BN = CPR * 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // lanes l, l + CPR, l + 2 CPR ... of a wave hold the same chunk
+    // lanes l, l + CPR, l + 2 CPR ... of a wave hold the same chunk (a non-straddling tile carries zeros in slot 1: not exchanged)
 #pragma unroll
     for (int off = 32; off >= CPR; off >>= 1) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            t.s0[e] += __shfl_xor(t.s0[e], off, 64);
-            t.q0[e] += __shfl_xor(t.q0[e], off, 64);
-            t.s1[e] += __shfl_xor(t.s1[e], off, 64);
-            t.q1[e] += __shfl_xor(t.q1[e], off, 64);
+        for (int i = 0; i < 4; ++i) {
+            t.s0[i].x += __shfl_xor(t.s0[i].x, off, 64); t.s0[i].y += __shfl_xor(t.s0[i].y, off, 64);
+            t.q0[i].x += __shfl_xor(t.q0[i].x, off, 64); t.q0[i].y += __shfl_xor(t.q0[i].y, off, 64);
+        }
+        if (straddle) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                t.s1[i].x += __shfl_xor(t.s1[i].x, off, 64); t.s1[i].y += __shfl_xor(t.s1[i].y, off, 64);
+                t.q1[i].x += __shfl_xor(t.q1[i].x, off, 64); t.q1[i].y += __shfl_xor(t.q1[i].y, off, 64);
+            }
         }
     }
     if (lane < CPR) {
         // scratch[wave][slot][stat][BN]
         float* p = scratch + (size_t)wave * 4 * BN + lane * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            p[e] = t.s0[e];
-            p[BN + e] = t.q0[e];
-            p[2 * BN + e] = t.s1[e];
-            p[3 * BN + e] = t.q1[e];
+        for (int i = 0; i < 4; ++i) {
+            p[2 * i] = t.s0[i].x; p[2 * i + 1] = t.s0[i].y;
+            p[BN + 2 * i] = t.q0[i].x; p[BN + 2 * i + 1] = t.q0[i].y;
+            p[2 * BN + 2 * i] = t.s1[i].x; p[2 * BN + 2 * i + 1] = t.s1[i].y;
+            p[3 * BN + 2 * i] = t.q1[i].x; p[3 * BN + 2 * i + 1] = t.q1[i].y;
         }
     }
     __syncthreads();
