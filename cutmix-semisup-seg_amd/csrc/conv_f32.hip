@@ -463,6 +463,9 @@ extern "C" int cms_conv_igemm_f32(const cms_conv_desc* d, void* stream) {
     CMS_REQUIRE(d->x && d->w && (d->y || d->y32), "conv_f32: NULL tensor");
     CMS_REQUIRE(d->n > 0 && d->h > 0 && d->w_in > 0 && d->cin > 0 && d->ho > 0 && d->wo > 0 && d->cout > 0,
                 "conv_f32: bad geometry");
+    CMS_REQUIRE(d->stats_out == nullptr && d->bstats_u == nullptr && d->mask_gates_res == 0 && d->mask_bits == nullptr &&
+                    d->mask_bits_out == nullptr,
+                "conv_f32: ReLU mask bits and epilogue statistics exist on the bf16 entry point only (cms_conv_igemm)");
     CMS_REQUIRE(d->cin % F32_BK == 0, "conv_f32: Cin (%d) must be a multiple of %d", d->cin, F32_BK);
     CMS_REQUIRE(d->cout % 32 == 0, "conv_f32: Cout (%d) must be a multiple of 32 (pad the weight tensor)", d->cout);
     CMS_REQUIRE(d->ntaps > 0 && d->ntaps <= CMS_CONV_MAX_TAPS, "conv_f32: 1..%d taps", CMS_CONV_MAX_TAPS);
