@@ -375,9 +375,11 @@ class DeepLabHipExecutor(object):
         return m
 
     def _fwd_unit_bn(self, x, c, relu, res=None, save=True, groups=1):
-        """y = relu(batch_norm(conv(x)) (+ res)) as THREE launches on persistent buffers: raw convolution, statistics (one
-        atomics-free reduction whose last blocks also finalise: scale / shift, running statistics, batch counter), normalise +
-        residual + ReLU. -> (y, saved), saved = (u, y, mean, rstd, backward sums, workspace) for `_bwd_unit_bn`."""
+        """y = relu(batch_norm(conv(x)) (+ res)) as THREE launches on persistent buffers: raw convolution (round 5: its epilogue
+        leaves per-tile channel sums), statistics (round 5: adds the tile sums and finalises -- scale / shift, running statistics,
+        batch counter; under data parallelism or in fp32: the atomics-free reduction over u of rounds 3-4), normalise + residual +
+        ReLU (+ the ReLU mask as bits). -> (y, saved), saved = (u, mask bits or y or None, mean, rstd, backward sums, workspace,
+        groups) for `_bwd_unit_bn`. (/root/reference/architectures/deeplab2.py:72-84 in training mode.)"""
         n, h, w, _ = x.shape
         ho, wo = self._out_hw(h, w, c.stride)
         G = int(groups)
