@@ -228,6 +228,8 @@ def run_workload(key, args, world, rank, dev):
 
     wl = WORKLOADS[key]
     B, H, W, C = wl['batch'], wl['H'], wl['W'], wl['classes']
+    if os.environ.get('CMS_BENCH_BATCH'):       # EXPERIMENT (tile-quantisation studies): another batch size -- not the headline config
+        B = int(os.environ['CMS_BENCH_BATCH'])
     if os.environ.get('CMS_BENCH_HW_' + key.upper()):       # EXPERIMENT ONLY (tile-fit studies): another crop size, e.g. 313x313
         H, W = (int(v) for v in os.environ['CMS_BENCH_HW_' + key.upper()].split('x'))
         wl = dict(wl, H=H, W=W, name=wl['name'] + ' [EXPERIMENT: crop {}x{}]'.format(H, W))
