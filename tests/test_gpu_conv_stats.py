@@ -30,6 +30,8 @@ CASES = [
 
 def _run(name, N, H, W, Cin, Cout, k, dil, rows, G):
     from cutmix_semisup_seg_amd import ops
+    if (N * H * W) % G != 0 or (N * H * W) // G < rows:
+        pytest.skip('{} sample groups do not fit this case'.format(G))
     g = torch.Generator().manual_seed(len(name) * 131 + G)
     x = (torch.randn(N, H, W, Cin, generator=g) * 0.8 + 0.1).to(torch.bfloat16).to(DEV)
     w = (torch.randn(k * k, Cout, Cin, generator=g) * (1.5 / np.sqrt(Cin * k * k))).to(torch.bfloat16).to(DEV)
@@ -41,7 +43,7 @@ def _run(name, N, H, W, Cin, Cout, k, dil, rows, G):
     return ops, x, w, taps, plain, u, st
 
 
-@pytest.mark.parametrize('G', [1, 2])
+@pytest.mark.parametrize('G', [1, 2, 4])
 @pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
 def test_epilogue_tile_sums_match_fp64_sums_of_the_stored_output(case, G):
     name, N, H, W, Cin, Cout, k, dil, rows = case
@@ -78,7 +80,7 @@ def test_epilogue_tile_sums_match_fp64_sums_of_the_stored_output(case, G):
     assert torch.equal(a.view(torch.int32), b2.view(torch.int32))
 
 
-@pytest.mark.parametrize('G', [1, 2])
+@pytest.mark.parametrize('G', [1, 2, 4])      # 4: three boundaries, three straddling tiles (their slot-1 sums come from lanes 0 .. 2)
 @pytest.mark.parametrize('case', [CASES[0], CASES[2], CASES[4], CASES[6]], ids=[CASES[0][0], CASES[2][0], CASES[4][0], CASES[6][0]])
 def test_finalize_tiles_equals_the_statistics_pass_over_the_output(case, G):
     name, N, H, W, Cin, Cout, k, dil, rows = case
@@ -134,7 +136,7 @@ BWD_CASES = [
 ]
 
 
-@pytest.mark.parametrize('G', [1, 2])
+@pytest.mark.parametrize('G', [1, 2, 4])
 @pytest.mark.parametrize('relu,gated', [(True, False), (True, True), (False, False)])
 @pytest.mark.parametrize('case', BWD_CASES, ids=[c[0] for c in BWD_CASES])
 def test_backward_statistics_from_the_data_gradient_epilogue(case, G, relu, gated):
@@ -145,6 +147,8 @@ def test_backward_statistics_from_the_data_gradient_epilogue(case, G, relu, gate
     name, N, H, W, Cd, C, rows = case
     g = torch.Generator().manual_seed(len(name) + 7 * G)
     M = N * H * W
+    if M % G != 0 or M // G < rows:
+        pytest.skip('{} sample groups do not fit this case'.format(G))
     du = (torch.randn(N, H, W, Cd, generator=g) * 0.3).to(torch.bfloat16).to(DEV)
     wT = (torch.randn(1, C, Cd, generator=g) * (1.0 / np.sqrt(Cd))).to(torch.bfloat16).to(DEV)
     u = (torch.randn(N, H, W, C, generator=g) * 1.1 + 0.4).to(torch.bfloat16).to(DEV)
