@@ -493,3 +493,65 @@ def test_library_convolution_engine_needs_an_explicit_enable():
         assert tuple(eng.conv2d(torch.zeros(1, 8, 4, 4), conv).shape) == (1, 8, 4, 4)      # (the engine itself is plain torch)
     finally:
         deeplab2.enable_library_engine(was)
+
+
+def test_bench_final_line_is_compact_and_strict_json():
+    """the driver keeps a bounded tail of stdout, a 33 KB line lost its head and nothing parsed. The LAST stdout line of
+    bench.py is built by `bench.compact_line` from the complete result object: scalars and short objects only, <= 4096 bytes,
+    strict JSON (no NaN / Infinity), carrying `roofline` and `cpu_baseline`."""
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    import bench
+    long_name = 'void cms::conv_igemm_kernel<2, 2, 2, 2, true, 1, 64, false, 0, true, false>(cms::ConvArgs)' * 3
+    per_wl = {'workload': 'pascal', 'value': 626.7657951795444, 'config': {'x': list(range(500))},
+              'roofline': {'by_kernel': {long_name + str(i): {'a': 1.0} for i in range(40)}}}
+    full = {
+        'metric': 'train images/sec (student+teacher step)', 'value': 626.7657951795444, 'unit': 'images/sec', 'n_gpus': 1,
+        'rccl_world_size': 1, 'steps': 20, 'warmup': 5, 'ms_per_step': 15.954922998207621, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic ' * 40,
+        'config': {'workload': 'deeplab2-resnet101 cutmix mean-teacher step, 10x3x321x321, 21 classes (BASELINE configs[1])',
+                   'per_gpu_batch': 10, 'global_batch': 10, 'crop': [321, 321], 'parallelism': 'dp1',
+                   'stream_probe': [[0, 0.09, [[0] * 7] * 7, [1, 2, 3]]] * 4, 'parity_config': 'p' * 400,
+                   'last_losses': {'sup_loss': float('nan')}, 'value_512x1024': 132.5, 'ms_per_step_512x1024': 30.17,
+                   'also_v3plus_513x513_img_s': 150.8, 'also_no_freeze_bn_321x321_img_s': 342.6,
+                   'host_enqueue_ms_per_step': float('inf')},
+        'roofline': {'bound': 'mfma', 'kernel': 'k' * 300, 'achieved': 381.6, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': 0.1526,
+                     'traffic': 112636718.7, 'avg_launch_ms': 0.0737, 'algorithmic_flops_per_launch': 28153523563.35,
+                     'algorithmic_bytes_per_launch': 95933171.2, 'mixed_frac': 0.416, 'step_mfma_frac': 0.295,
+                     'isolated_frac': float('nan'), 'hbm_group_frac': 0.146, 'mixed_frac_512x1024': 0.439,
+                     'mixed': {'frac': 0.416, 'basis': 'b' * 200}, 'by_kernel': per_wl['roofline']['by_kernel'],
+                     'traffic_by_kernel': {long_name: {'ratio': 1.29, 'pmc_bytes_per_launch': 1.0},
+                                           'cms::w8::wgrad8_kernel(cms::w8::Args)': {'ratio': 2.06},
+                                           'void cms::c8::conv8_kernel<false, false>(cms::c8::Args)': {'ratio': 1.3}},
+                     'traffic_source': 's' * 300, 'sampling': 'every 5th launch'},
+        'roofline_hbm': {'bound': 'hbm', 'peak': 8000.0, 'unit': 'GB/s', 'achieved': 1169.0, 'frac': 0.146, 'basis': 'b' * 300,
+                         'ms_per_step': 0.867, 'parts': {str(i): {'ms_per_step': 0.1} for i in range(6)}, 'traffic': None},
+        'cpu_baseline': {'value': 1.0156, 'unit': 'images/sec', 'cores': 32, 'kind': 'port', 'sample': 'oracle/step.py ' * 30},
+        'value_321x321': 626.7657951795444, 'value_512x1024': 132.5, 'configs': [per_wl] * 2, 'also': [per_wl] * 2,
+        'detail': 'bench_detail.json'}
+    assert len(json.dumps(full)) > 32768                         # the kind of object that broke round 5's record
+    line = bench.compact_line(full)
+    assert '\n' not in line and len(line) <= 4096 == bench.LINE_LIMIT
+
+    def strict(tok):
+        raise AssertionError('non-standard JSON constant ' + tok)
+    d = json.loads(line, parse_constant=strict)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['data'] == 'synthetic' and d['config']['workload'].startswith('deeplab2-resnet101')
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'mixed_frac', 'step_mfma_frac', 'hbm_group_frac',
+              'mixed_frac_512x1024', 'traffic_ratio_wgrad8', 'traffic_ratio_conv8', 'traffic_ratio'):
+        assert k in d['roofline'], k
+    assert len(d['roofline']['kernel']) <= 80 and d['roofline']['isolated_frac'] is None
+    assert d['config']['value_512x1024'] == 132.5 and d['config']['also_v3plus_513x513_img_s'] == 150.8
+    assert set(d['cpu_baseline']) == {'value', 'unit', 'cores', 'kind', 'sample'}
+    assert not any(isinstance(v, (dict, list)) for o in (d['config'], d['roofline'], d['roofline_hbm'], d['cpu_baseline'])
+                   for v in o.values())
+    # the committed complete object of round 5 (33 KB, the one the driver could not keep) through the same function
+    r5 = os.path.join(repo, 'profiles', 'r05zz_bench_default.json')
+    if os.path.exists(r5):
+        l5 = bench.compact_line(json.load(open(r5)))
+        assert len(l5) <= 4096 and json.loads(l5, parse_constant=strict)['value'] == pytest.approx(626.766, rel=1e-5)
