@@ -92,31 +92,14 @@ class Classifier_Module(nn.Module):
         return eng.aspp_head(x, [self.conv2d_list[i] for i in range(ASPP_LIVE)])
 
 
-# The library (MIOpen) convolution engine below is a COMPARISON engine: the tests hold the hand-written kernels against it and
-# A/B runs time it. The product never selects it by itself (round 5: engine_kind 'auto' is the hand-written engine for every
-# layer, in bf16 and fp32), and a process that wants it says so: `enable_library_engine()` / CMS_LIBRARY_ENGINE=1 (tests/conftest.py
-# does). Without that, every library convolution raises -- so "no library kernel ran" is a property of the product, not a habit.
-_LIBRARY_ENGINE = [os.environ.get('CMS_LIBRARY_ENGINE', '0') not in ('0', '')]
-
-
-def enable_library_engine(on=True):
-    _LIBRARY_ENGINE[0] = bool(on)
-
-
-def _library_conv_guard(what):
-    if not _LIBRARY_ENGINE[0]:
-        raise RuntimeError('cutmix-semisup-seg_amd: {} would run on the LIBRARY (MIOpen) convolution engine, which is the comparison '
-                           'engine of the tests -- call architectures.deeplab2.enable_library_engine() (or set CMS_LIBRARY_ENGINE=1) '
-                           'to use it; the default engines run every convolution on the hand-written kernels'.format(what))
-
-
-class TorchEngine(object):
+class LayerEngine(object):
     """
-    Executes conv(+BatchNorm)(+residual)(+ReLU) units layer by layer with LIBRARY convolutions (MIOpen via torch) in
-    `dtype`, channels-last; batch-statistics BatchNorm on csrc/bn.hip. What it is for: the comparison engine of the GPU
-    tests (`engine_kind = 'torch'`), and the base class of deeplab3plus.HipConvEngine, which re-routes the convolutions
-    to the hand-written kernels (all of them with `engine_kind = 'hip'`). The frozen-BatchNorm DeepLab v2 does not come
-    here at all: it runs on the static MFMA executor (backbone_hip.py).
+    Base of the engines that execute conv(+BatchNorm)(+residual)(+ReLU) units layer by layer in `dtype`, channels-last. It owns what
+    every such engine shares -- batch-statistics BatchNorm (+ residual + ReLU) on csrc/bn.hip, frozen statistics as an affine,
+    input preparation, the stem's ceil-mode pool -- and leaves the CONVOLUTIONS to the subclass: `deeplab3plus.HipConvEngine` runs
+    them on the hand-written kernels. There is no library (MIOpen) convolution engine in this package (round 6): the comparison
+    engine the GPU tests A/B against lives in tests/_library_engine.py and is plugged in through `net.engine = ...`. The
+    frozen-BatchNorm DeepLab v2 does not come here at all: it runs on the static MFMA executor (backbone_hip.py).
     """
 
     def __init__(self, dtype=torch.bfloat16):
@@ -132,72 +115,58 @@ class TorchEngine(object):
         return x.to(dtype=self.dtype, memory_format=torch.channels_last)
 
     def conv2d(self, x, conv):
-        _library_conv_guard('convolution {}'.format(conv))
-        return F.conv2d(x, self._weight(conv), None, conv.stride, conv.padding, conv.dilation)
+        raise NotImplementedError('{} executes no convolutions: use deeplab3plus.HipConvEngine (the hand-written kernels)'.format(
+            type(self).__name__))
+
+    def aspp_head(self, x, convs):
+        raise NotImplementedError('{} has no ASPP head'.format(type(self).__name__))
 
     def conv_bn_act(self, x, conv, bn, relu, residual=None):
         return self.bn_act(self.conv2d(x, conv), bn, relu, residual)
+
+    def _bn_on_hip(self, y, bn):
+        """True when csrc/bn.hip takes this batch-statistics BatchNorm: device tensor, channels-last, channels % 8 == 0, running
+        statistics with a momentum."""
+        return (y.is_cuda and y.permute(0, 2, 3, 1).is_contiguous() and y.shape[1] % 8 == 0 and bn.momentum is not None
+                and bn.running_mean is not None)
 
     def bn_act(self, y, bn, relu, residual=None):
         """relu(bn(y) (+ residual)): batch statistics (training mode) on csrc/bn.hip, frozen statistics as an affine."""
         if bn is not None:
             if bn.training:
+                if not self._bn_on_hip(y, bn):
+                    raise RuntimeError('BatchNorm over {} channels ({}) has no hand-written kernel (device tensor, channels-last, '
+                                       'channels % 8 == 0, running statistics needed); there is no library fallback'.format(
+                                           y.shape[1], bn))
+                # batch-statistics BatchNorm (+ residual + ReLU) on csrc/bn.hip; under torch.distributed its statistics are
+                # all-reduced (SyncBN, SURVEY.md 8(e))
                 yh = y.permute(0, 2, 3, 1)                 # NHWC view of the channels-last tensor
-                if y.is_cuda and yh.is_contiguous() and y.shape[1] % 8 == 0 and bn.momentum is not None \
-                        and bn.running_mean is not None:
-                    # batch-statistics BatchNorm (+ residual + ReLU) on csrc/bn.hip; under torch.distributed its
-                    # statistics are all-reduced (SyncBN, SURVEY.md 8(e))
-                    rh = None
-                    if residual is not None:
-                        rh = residual.permute(0, 2, 3, 1)
-                        rh = rh if rh.is_contiguous() else rh.contiguous()
-                    groups = int(getattr(self, 'bn_groups', 1))    # sample groups normalised apart (step.py, grouped passes)
-                    out = ops.batch_norm_act(yh, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                             relu=relu, res=rh, groups=groups)
-                    if bn.num_batches_tracked is not None:
-                        bn.num_batches_tracked += groups
-                    return out.permute(0, 3, 1, 2)
-                # (odd channel counts / non-channels-last inputs: the library, in fp32)
-                if int(getattr(self, 'bn_groups', 1)) != 1:
-                    raise RuntimeError('grouped batch statistics need the csrc/bn.hip path (channels-last, channels % 8 == 0)')
-                y = F.batch_norm(y.float(), bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum,
-                                 bn.eps).to(y.dtype)
+                rh = None
+                if residual is not None:
+                    rh = residual.permute(0, 2, 3, 1)
+                    rh = rh if rh.is_contiguous() else rh.contiguous()
+                groups = int(getattr(self, 'bn_groups', 1))    # sample groups normalised apart (step.py, grouped passes)
+                out = ops.batch_norm_act(yh, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                         relu=relu, res=rh, groups=groups)
                 if bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked += 1
-            else:
-                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
-                shift = bn.bias - bn.running_mean * scale
-                y = torch.addcmul(shift.to(y.dtype).view(1, -1, 1, 1), y, scale.to(y.dtype).view(1, -1, 1, 1))
+                    bn.num_batches_tracked += groups
+                return out.permute(0, 3, 1, 2)
+            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            shift = bn.bias - bn.running_mean * scale
+            y = torch.addcmul(shift.to(y.dtype).view(1, -1, 1, 1), y, scale.to(y.dtype).view(1, -1, 1, 1))
         if residual is not None:
             y = y + residual
         if relu:
             y = F.relu(y, inplace=True)
         return y
 
-    def aspp_head(self, x, convs):
-        _library_conv_guard('the ASPP head')
-        out = None
-        for conv in convs:
-            y = F.conv2d(x, self._weight(conv), None, conv.stride, conv.padding, conv.dilation)
-            out = y if out is None else out + y
-        bias = sum(c.bias for c in convs)
-        return out.float() + bias.view(1, -1, 1, 1)
-
     def maxpool(self, x):
         return F.max_pool2d(x, kernel_size=3, stride=2, padding=1, ceil_mode=True)
 
 
-_ENGINES = {}
-
-
 def _default_engine(x):
-    if not x.is_cuda:
-        raise RuntimeError('cutmix-semisup-seg_amd networks run on the GPU only (input on {}); there is no CPU '
-                           'fallback'.format(x.device))
-    key = ('torch', x.dtype if x.dtype in (torch.bfloat16, torch.float32) else torch.bfloat16)
-    if key not in _ENGINES:
-        _ENGINES[key] = TorchEngine(key[1])
-    return _ENGINES[key]
+    raise RuntimeError('a Bottleneck / Classifier_Module of this build is executed by its network\'s engine (forward(x, eng)); '
+                       'call the network, or pass an engine object')
 
 
 class ResNetDeepLab(nn.Module):
@@ -232,10 +201,11 @@ class ResNetDeepLab(nn.Module):
         d = self.__dict__
         d.setdefault('compute_dtype', torch.bfloat16)
         d.setdefault('engine', None)          # set to an engine object to override the default executor
-        # 'auto': hand-written MFMA executor (backbone_hip.py) whenever BatchNorm is frozen (bf16 = throughput
-        # configuration, fp32 = parity configuration), library engine otherwise; 'torch' / 'hip' force one
+        # 'auto' / 'hip': hand-written MFMA executor (backbone_hip.py) for the body (bf16 = throughput configuration, fp32 =
+        # parity configuration), the hand-written layer engine for the passes it does not take; 'hip' additionally refuses
+        # anything it cannot express. (The library comparison engine of the tests is an `engine` OBJECT: tests/_library_engine.py)
         d.setdefault('engine_kind', 'auto')
-        d.setdefault('stem_kind', 'hip')      # 'torch': stem through the library engine (comparison runs)
+        d.setdefault('stem_kind', 'hip')      # 'engine': the stem through the layer engine instead of csrc/stem.hip (comparison runs)
         d.setdefault('_hip_executor', None)   # the executor used last
         d.setdefault('_hip_executors', {})    # compute dtype -> executor
         d.setdefault('_hip_engine', None)     # the layer-by-layer engine used last (batch-statistics passes)
@@ -265,7 +235,7 @@ class ResNetDeepLab(nn.Module):
         reference CLI's default, no --freeze_bn: deeplab2.py:72-84, train_seg_semisup_mask_mt.py:268-275,587). 'auto' in
         bf16: MFMA kernels for the convolutions that fit them well, csrc/bn.hip for BatchNorm; 'hip': every convolution
         (stem as tap chunks, strided 1x1s, the class-wide head) and every BatchNorm on the hand-written kernels, in bf16
-        or fp32, or an error; 'torch': library convolutions (the comparison engine of the tests)."""
+        or fp32, or an error. An explicit `self.engine` object overrides both (the tests' library comparison engine)."""
         from .deeplab3plus import _engine_of
         return _engine_of(self, x)
 
@@ -285,7 +255,7 @@ class ResNetDeepLab(nn.Module):
         goes through the layer engine. Under torch.distributed the units all-reduce their per-group sums between the reduction
         and the finalisation (SyncBN: a host op between two launches of the recorded pass); `batchstat_executor = False` forces
         the layer engine."""
-        if self.engine_kind == 'torch' or self.engine is not None:
+        if self.engine is not None:
             return False
         ok = self.compute_dtype in (torch.bfloat16, torch.float32) and self.num_classes <= 32
         if self._frozen_bn():

@@ -18,7 +18,7 @@ oracle/deeplab3plus.py is the checker):
              (:120-121), `pretraining=None` => pretrained_parameters() == [] and every parameter trains at the full
              learning rate (:138-151, factory :162-164)
 
-Execution: bf16 channels-last through the library engine (architectures/deeplab2.py: TorchEngine); the low-resolution
+Execution: bf16 channels-last through the layer engine (HipConvEngine below: hand-written kernels); the low-resolution
 logits (1/4 of the input) are handed to the fused loss / evaluation kernels, which apply the final bilinear upsample
 (align_corners=False, deeplab3plus.py:77) in-kernel. With batch-statistics BatchNorm and dropout in the head the
 samples of a batch are not independent, so the training step keeps the reference's separate passes
@@ -32,7 +32,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .util import freeze_bn_module
-from .deeplab2 import TorchEngine, _ENGINES
+from .deeplab2 import LayerEngine
 
 
 class Bottleneck(nn.Module):
@@ -191,14 +191,9 @@ class DeepLabHeadV3Plus(nn.Module):
         y = eng.conv_bn_act(y, self.classifier[3], self.classifier[4], relu=True)
         last = self.classifier[6]
         clf = getattr(eng, 'classifier', None)
-        if clf is not None and y.is_cuda and y.dtype == eng.dtype and last.out_channels <= 64 and last.in_channels % 64 == 0:
-            return clf(y, last)                                 # MFMA kernel, fp32 NCHW logits from the epilogue
-        if getattr(eng, 'strict', False):
-            raise RuntimeError('engine_kind = "hip": classifier {} has no hand-written kernel'.format(last))
-        from .deeplab2 import _library_conv_guard
-        _library_conv_guard('classifier {}'.format(last))
-        y = F.conv2d(y, last.weight.to(y.dtype), None)
-        return y.float() + last.bias.view(1, -1, 1, 1)
+        if clf is None:
+            raise RuntimeError('engine {} has no classifier kernel for {}'.format(type(eng).__name__, last))
+        return clf(y, last)                                     # MFMA kernel, fp32 NCHW logits from the epilogue
 
 
 class DeepLabV3Plus(nn.Module):
@@ -221,17 +216,16 @@ class _ToChannelsLast(torch.autograd.Function):
         return g.contiguous()
 
 
-class HipConvEngine(TorchEngine):
-    """The engine of the networks that run layer by layer (DeepLab v3+ head, the U-Nets), in bf16 (throughput) or fp32
-    (parity configuration, csrc/conv_f32.hip):
+class HipConvEngine(LayerEngine):
+    """The engine of the networks that run layer by layer (DeepLab v3+ head, the U-Nets, batch-statistics passes the executor does
+    not take), in bf16 (throughput) or fp32 (parity configuration, csrc/conv_f32.hip). EVERY convolution runs on the hand-written
+    kernels (backbone_hip.hip_conv2d: MFMA implicit GEMM; channel padding, tap chunks, strided phases for the layers that need them)
+    and every batch-statistics BatchNorm on csrc/bn.hip; a layer neither can express raises -- there is no library fallback in this
+    package (round 6).
 
-      strict = False ('auto')  convolutions the MFMA kernels run well (stride 1, 'same' padding, wide channel counts: the
-                               ASPP branches and projection, the decoder 3x3s, DenseNet's bottleneck 1x1s) go there, the
-                               rest (stems, strided and narrow layers) to the library;
-      strict = True  ('hip')   EVERY convolution runs on the hand-written kernels (backbone_hip._HipConvGeneralFn: channel
-                               padding, tap chunks, strided phases) and every batch-statistics BatchNorm on csrc/bn.hip --
-                               a layer that cannot raises instead of reaching the library. This is what the oracle
-                               comparisons of these networks run on.
+      strict = False ('auto')  the default engine;
+      strict = True  ('hip')   additionally refuses convolutions that are not registered layers of the network and checks the
+                               BatchNorm preconditions up front. This is what the oracle comparisons of these networks run on.
     """
 
     def __init__(self, dtype, wrapper, strict=False):
@@ -241,7 +235,7 @@ class HipConvEngine(TorchEngine):
         self.arena = ensure_arena(wrapper, with_grad=any(p.requires_grad for p in wrapper.parameters()),
                                   with_bf16=(dtype == torch.bfloat16))
         self.keys = {id(m): name + '.weight' for name, m in wrapper.named_modules() if isinstance(m, nn.Conv2d)}
-        self.library_convs = 0          # convolutions this engine handed to the library (0 in strict mode, by construction)
+        self.library_convs = 0          # convolutions handed to a library: none, by construction (kept for the tests' asserts)
 
     def prepare_input(self, x):
         return x.to(dtype=self.dtype, memory_format=torch.channels_last)
@@ -249,21 +243,12 @@ class HipConvEngine(TorchEngine):
     def conv2d(self, x, conv):
         from ..backbone_hip import hip_conv2d, hip_conv2d_eligible
         key = self.keys.get(id(conv))
-        if self.strict:
-            if key is None:
-                raise RuntimeError('engine_kind = "hip": convolution {} is not a registered layer of this network'.format(conv))
-            return hip_conv2d(x, conv, self.arena, key, self.dtype)
-        if key is not None and hip_conv2d_eligible(x, conv, self.dtype):
-            return hip_conv2d(x, conv, self.arena, key, self.dtype)
-        self.library_convs += 1
-        seen = self.__dict__.setdefault('_library_warned', set())
-        if (key, tuple(x.shape)) not in seen:            # one line per layer and input shape, not per call
-            seen.add((key, tuple(x.shape)))
-            import warnings
-            warnings.warn('cutmix-semisup-seg_amd: convolution {} on input {} goes to the LIBRARY (MIOpen) -- engine_kind "auto" '
-                          'keeps the hand-written MFMA kernels for stride-1 / same-padding / wide layers; engine_kind = "hip" '
-                          'runs every convolution on them'.format(key or conv, tuple(x.shape)), RuntimeWarning, stacklevel=2)
-        return super(HipConvEngine, self).conv2d(x, conv)
+        if key is None:
+            raise RuntimeError('convolution {} is not a registered layer of this network (no weight slice in its arena)'.format(conv))
+        if not self.strict and not hip_conv2d_eligible(x, conv, self.dtype):
+            raise RuntimeError('convolution {} on input {} cannot be expressed by the hand-written kernels (ungrouped, square kernel, '
+                               'symmetric stride / padding / dilation needed); there is no library fallback'.format(key, tuple(x.shape)))
+        return hip_conv2d(x, conv, self.arena, key, self.dtype)
 
     def bn_act(self, y, bn, relu, residual=None):
         if self.strict and bn is not None and bn.training:
@@ -277,8 +262,6 @@ class HipConvEngine(TorchEngine):
         """DeepLab v2's head (deeplab2.py:124-128: the live dilated 3x3 branches, class axis padded to 64, summed; biases
         added in fp32) on the hand-written kernels."""
         from ..backbone_hip import hip_conv2d
-        if not self.strict and not all(id(c) in self.keys for c in convs):
-            return super(HipConvEngine, self).aspp_head(x, convs)
         out = None
         for conv in convs:
             y = hip_conv2d(x, conv, self.arena, self.keys[id(conv)], self.dtype).float()
@@ -289,14 +272,17 @@ class HipConvEngine(TorchEngine):
     def classifier(self, x, conv):
         """1x1 convolution with bias to <= 64 classes -> fp32 NCHW logits (convolution epilogue)."""
         from ..backbone_hip import hip_classifier
+        if not (x.is_cuda and x.dtype == self.dtype and conv.out_channels <= 64 and conv.in_channels % 64 == 0):
+            raise RuntimeError('classifier {} has no hand-written kernel (<= 64 classes, input channels % 64 == 0, {} input '
+                               'needed)'.format(conv, self.dtype))
         key = self.keys[id(conv)]
         return hip_classifier(x, conv, self.arena, key, key[:-len('weight')] + 'bias', self.dtype)
 
 
 def _engine_of(net, x, strict=None):
-    """Engine selection shared by DeepLabv3Wrapper and the U-Nets (`EngineNetMixin`): an explicit `net.engine`, the
-    library engine for engine_kind 'torch', otherwise the HipConvEngine of (compute dtype, strictness). `strict=True`
-    asks for the all-hand-written engine whatever `engine_kind` says."""
+    """Engine selection shared by DeepLabv3Wrapper and the U-Nets (`EngineNetMixin`): an explicit `net.engine` object (how the
+    tests plug in their library comparison engine), otherwise the HipConvEngine of (compute dtype, strictness). `strict=True`
+    asks for the strict engine whatever `engine_kind` says."""
     if net.engine is not None and strict is None:
         return net.engine
     if not x.is_cuda:
@@ -304,14 +290,11 @@ def _engine_of(net, x, strict=None):
                            'fallback'.format(x.device))
     if net.compute_dtype not in (torch.bfloat16, torch.float32):
         raise TypeError('compute_dtype must be torch.bfloat16 or torch.float32')
-    if net.engine_kind == 'torch' and strict is None:
-        key = ('torch', net.compute_dtype)
-        if key not in _ENGINES:
-            _ENGINES[key] = TorchEngine(net.compute_dtype)
-        return _ENGINES[key]
+    if net.engine_kind == 'torch':
+        raise RuntimeError("engine_kind 'torch' (library convolutions) is not part of this package any more: the comparison engine "
+                           "lives in tests/_library_engine.py -- `net.engine = LibraryEngine(dtype)`")
     strict = (net.engine_kind == 'hip') if strict is None else bool(strict)
-    # (round 5: 'auto' in fp32 is the hand-written fp32 engine too -- csrc/conv_f32.hip; the library engine runs only when it is
-    # asked for by name, engine_kind = 'torch', as the comparison engine of the tests)
+    # ('auto' in fp32 is the hand-written fp32 engine too -- csrc/conv_f32.hip)
     engines = net.__dict__.setdefault('_hip_engines', {})
     ek = (net.compute_dtype, strict)
     eng = engines.get(ek)
@@ -333,8 +316,8 @@ class EngineNetMixin(object):
         d = self.__dict__
         d.setdefault('compute_dtype', torch.bfloat16)
         d.setdefault('engine', None)            # set to an engine object to override the default
-        # 'auto': MFMA kernels where a layer fits them well, the library for the rest; 'hip': hand-written kernels for
-        # every convolution and BatchNorm, or an error; 'torch': library convolutions only
+        # 'auto' / 'hip': hand-written kernels for every convolution and BatchNorm ('hip' = strict checks); an explicit
+        # `engine` object overrides (the tests' library comparison engine)
         d.setdefault('engine_kind', 'auto')
         d.setdefault('_hip_engine', None)
         d.setdefault('_hip_engines', {})
@@ -365,9 +348,8 @@ class DeepLabv3Wrapper(nn.Module):
         d = self.__dict__
         d.setdefault('compute_dtype', torch.bfloat16)
         d.setdefault('engine', None)
-        # 'auto': hand-written kernels wherever a layer fits them, the library for the rest; 'hip': hand-written kernels
-        # or an error (no library convolution / BatchNorm may run); 'torch': library engine for every pass;
-        # 'hip_nograd': backbone executor only for passes without gradients
+        # 'auto' / 'hip': hand-written kernels for every convolution and BatchNorm ('hip' = strict checks);
+        # 'hip_nograd': backbone executor only for passes without gradients; an explicit `engine` object overrides
         d.setdefault('engine_kind', 'auto')
         d.setdefault('_hip_executor', None)
         d.setdefault('_hip_executors', {})
@@ -385,9 +367,9 @@ class DeepLabv3Wrapper(nn.Module):
     def _use_hip_backbone(self):
         """The MFMA executor (backbone_hip.DeepLabV3PlusBackboneExecutor) runs the backbone whenever its BatchNorm
         statistics are frozen -- training passes included -- in bf16 (throughput) or, with engine_kind 'hip', in fp32
-        (parity configuration); `engine_kind = 'hip_nograd'` restricts it to passes that need no gradient, 'torch'
-        switches it off. With engine_kind 'hip' a backbone on batch statistics runs layer by layer on the strict engine."""
-        if self.engine is not None or self.engine_kind == 'torch':
+        (parity configuration); `engine_kind = 'hip_nograd'` restricts it to passes that need no gradient, an explicit
+        `engine` object switches it off. With engine_kind 'hip' a backbone on batch statistics runs layer by layer on the strict engine."""
+        if self.engine is not None:
             return False
         if self.compute_dtype == torch.float32 and self.engine_kind not in ('hip', 'auto'):
             return False

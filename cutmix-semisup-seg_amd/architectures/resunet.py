@@ -53,14 +53,9 @@ def unet_tail(net, x, eng):
     x = eng.bn_act(x, net.final_dec_bn, relu=True)
     clf = net.final_clf
     hip_clf = getattr(eng, 'classifier', None)
-    if hip_clf is not None and x.is_cuda and x.dtype == eng.dtype and clf.out_channels <= 64 and clf.in_channels % 64 == 0:
-        return hip_clf(x, clf)                                  # MFMA kernel, fp32 NCHW logits from the epilogue
-    if getattr(eng, 'strict', False):
-        raise RuntimeError('engine_kind = "hip": classifier {} has no hand-written kernel'.format(clf))
-    from .deeplab2 import _library_conv_guard
-    _library_conv_guard('classifier {}'.format(clf))
-    y = F.conv2d(x, clf.weight.to(x.dtype), None)
-    return y.float() + clf.bias.view(1, -1, 1, 1)
+    if hip_clf is None:
+        raise RuntimeError('engine {} has no classifier kernel for {}'.format(type(eng).__name__, clf))
+    return hip_clf(x, clf)                                      # MFMA kernel, fp32 NCHW logits from the epilogue
 
 
 class ResUNet(EngineNetMixin, nn.Module):

@@ -5,7 +5,7 @@ same module tree, same state_dict keys (incl. the unused ImageNet classifier `fc
 checkpoints load by name. torchvision itself is not part of this build -- PARITY UNPINNED for these rows (SURVEY.md 8(c));
 oracle/unets.py is the independent CPU restatement the tests check against.
 
-Execution goes through an engine object (architectures/deeplab2.py: TorchEngine / deeplab3plus.py: HipConvEngine):
+Execution goes through an engine object (architectures/deeplab2.py: LayerEngine -> deeplab3plus.py: HipConvEngine):
 BatchNorm on batch statistics runs on csrc/bn.hip (+ ReLU fused, SyncBN under torch.distributed), convolutions that fit
 the MFMA kernels (stride 1, 'same' padding, >= 128 input channels, output channels in multiples of 64) on csrc/conv.hip,
 the rest on the library.

@@ -540,8 +540,9 @@ class DeepLabHipExecutor(object):
             # (round 5) with the block output's ReLU mask as bits, its masked gradient `dres` (the widest tensor of the block) is
             # never written: the identity shortcut adds (bit ? dOut : 0) in conv1's data-gradient epilogue, the downsample unit's
             # backward passes read dOut through the same bits
+            # (the gated shortcut `mask_gates_res` exists in the bf16 data-gradient kernels only: an fp32 identity block keeps `dres`)
             bits3 = s3[1] if (s3[1] is not None and s3[1].dtype == torch.uint8 and _bn_gate_shortcut()
-                              and (b.cd is not None or b.c1.stride == 1)) else None
+                              and (b.cd is not None or (b.c1.stride == 1 and self.dtype == torch.bfloat16))) else None
             du3, dres = self._bwd_unit_bn(dOut, s3, b.c3, bits3 is None, tile_stats=pend)
             st2 = self._bstats(s2, 2)
             da2 = self._dgrad_raw(du3, b.c3, bstats=st2)
@@ -1465,32 +1466,12 @@ def _bn_gate_shortcut():
     return os.environ.get('CMS_BN_GATE_SHORTCUT', '1') != '0'
 
 
-def _auto_keeps_library():
-    """CMS_AUTO_LIBRARY=1 (A/B switch, read once): engine_kind 'auto' as in rounds 2-4 -- stems, strided and narrow layers go
-    to the library (MIOpen), see `hip_conv2d_eligible`."""
-    v = _auto_keeps_library.__dict__.get('v')
-    if v is None:
-        v = _auto_keeps_library.__dict__['v'] = os.environ.get('CMS_AUTO_LIBRARY', '0') not in ('0', '')
-    return v
-
-
 def hip_conv2d_eligible(x, conv, dtype=torch.bfloat16):
-    """The layers the 'auto' engine sends to the MFMA kernels: stride 1, 'same' padding, >= 128 input channels (padded to
-    a multiple of 64 if need be), output channels in multiples of 64 (or >= 32, padded), >= 64 pixels -- where the
-    padding copies cost less than the kernels gain (round 3: the pixel count is that of the BATCH, which brings
-    DenseNet-161's fourth dense block, 7 x 7 maps at a 224 crop, to the MFMA kernels). (`engine_kind = 'hip'` sends EVERY convolution there.)"""
-    kh, kw = conv.kernel_size
-    if not _auto_keeps_library():
-        # (round 5) 'auto' = the hand-written kernels for EVERY convolution the general path can express (strided layers as
-        # phases, 7 x 7 stems as tap chunks, narrow / odd channel counts padded): a library dispatch is not an implementation,
-        # and the one library kernel left in DeepLab v3+'s step (the pooled branch's 1 x 1-map GEMM) made it irreproducible
-        return x.is_cuda and x.dtype == dtype and hip_conv_geometry(conv) is not None
-    return (x.is_cuda and x.dtype == dtype and conv.groups == 1
-            and conv.stride == (1, 1) and kh == kw and kh * kw <= 18
-            and conv.padding == (conv.dilation[0] * (kh - 1) // 2,) * 2 and conv.dilation[0] == conv.dilation[1]
-            and (conv.in_channels % 64 == 0 or conv.in_channels >= 128)
-            and (conv.out_channels % 64 == 0 or conv.out_channels >= 32)
-            and x.shape[0] * x.shape[2] * x.shape[3] >= 64)
+    """True when the hand-written general path (`hip_conv2d`) can express this convolution: any ungrouped square-kernel convolution
+    with symmetric stride / padding / dilation (strided layers as phases, 7 x 7 stems as tap chunks, narrow / odd channel counts
+    padded). A library dispatch is not an implementation: since round 6 a layer that fails this test RAISES in every engine (none of
+    the reference's networks has one); rounds 2-4 sent stems, strided and narrow layers to MIOpen here."""
+    return x.is_cuda and x.dtype == dtype and hip_conv_geometry(conv) is not None
 
 
 class _StemFn(torch.autograd.Function):

@@ -33,11 +33,13 @@ struct TileStats {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { s0[i] += v[i]; q0[i] = v[i] * v[i] + q0[i]; }
         } else {
-            const float m = second ? 0.0f : 1.0f;
-            const ts_f32x2 mm = {m, m};
+            // (v, 0) or (0, v) by a SELECT on the packed dwords, not by a product with 0 / 1: an Inf / NaN of one sample group must
+            // not reach the neighbouring group's slot (Inf * 0 = NaN)
+            const uint32_t k0 = second ? 0u : 0xffffffffu, k1 = ~k0;
+            const uint32_t raw[4] = {x, y, z, w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const ts_f32x2 a = v[i] * mm, b = v[i] - a;        // exact: (v, 0) or (0, v)
+                const ts_f32x2 a = pair(raw[i] & k0), b = pair(raw[i] & k1);
                 s0[i] += a; q0[i] = a * a + q0[i];
                 s1[i] += b; q1[i] = b * b + q1[i];
             }
@@ -61,11 +63,11 @@ struct TileStats {
                 s0[i] += d; q0[i] = d * xh + q0[i];
             } else {
                 const ts_f32x2 xh = second ? (u + nmu1[i]) * rs1[i] : (u + nmu0[i]) * rs0[i];
-                const float m = second ? 0.0f : 1.0f;
-                const ts_f32x2 mm = {m, m};
-                const ts_f32x2 a = d * mm, b = d - a;
-                s0[i] += a; q0[i] = a * xh + q0[i];
-                s1[i] += b; q1[i] = b * xh + q1[i];
+                const uint32_t k0 = second ? 0u : 0xffffffffu, dm = dd[i] & (keep | keep_hi);
+                // selects, not `d * 0` / `0 * xhat`: the groups stay isolated under Inf / NaN
+                const ts_f32x2 a = pair(dm & k0), b = pair(dm & ~k0), z2 = {0.0f, 0.0f};
+                s0[i] += a; q0[i] = a * (second ? z2 : xh) + q0[i];
+                s1[i] += b; q1[i] = b * (second ? xh : z2) + q1[i];
             }
         }
     }

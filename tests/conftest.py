@@ -2,9 +2,9 @@ import os
 import sys
 import json
 
-# the library (MIOpen) convolution engine is the COMPARISON engine of these tests (engine_kind = 'torch'); the product refuses to
-# run it unless a process asks for it (architectures/deeplab2.py: enable_library_engine) -- the tests do, before the package loads
-os.environ.setdefault('CMS_LIBRARY_ENGINE', '1')
+# (round 6) the library (MIOpen) comparison engine is tests/_library_engine.py, plugged in by the tests that A/B against it
+# (`net.engine = LibraryEngine(dtype)`); nothing in the product package calls a library convolution, and no environment switch
+# enables one
 
 import numpy as np
 import pytest

@@ -6,7 +6,7 @@ independent statements of the published structure against each other, the state-
 wrapper, and the wrapper's API (architectures/deeplab3plus.py:104-164).
 
 The product networks have no CPU path; the wiring check drives the module tree with a test-only fp32 engine
-(`net.engine = TorchEngine(float32)`), which is how the module lets a caller replace its executor.
+(`net.engine = LibraryEngine(float32)`, tests/_library_engine.py), which is how the module lets a caller replace its executor.
 """
 import pytest
 import torch
@@ -16,9 +16,9 @@ from oracle import deeplab3plus as o3
 
 def _net(num_classes=5, layers=(1, 1, 2, 1)):
     from cutmix_semisup_seg_amd.architectures import deeplab3plus as d3
-    from cutmix_semisup_seg_amd.architectures.deeplab2 import TorchEngine
+    from _library_engine import LibraryEngine
     net = d3.DeepLabv3Wrapper(d3._deeplabv3plus(num_classes, 8, layers))
-    net.engine = TorchEngine(torch.float32)
+    net.engine = LibraryEngine(torch.float32)
     return net
 
 

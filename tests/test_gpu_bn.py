@@ -65,7 +65,7 @@ def test_batch_norm_act_vs_fp64(C, dtype, relu, with_res):
         torch.testing.assert_close(rg.grad.float().cpu(), want[6].float(), rtol=gtol, atol=gtol)
 
 
-def test_library_engine_training_mode_layers_use_the_hip_batchnorm():
+def test_layer_engine_training_mode_layers_use_the_hip_batchnorm():
     """DeepLab v2 WITHOUT --freeze_bn (BatchNorm on batch statistics, affine parameters frozen, deeplab2.py:72-84):
     forward, running statistics and gradients vs the oracle."""
     from architectures import deeplab2

@@ -134,6 +134,46 @@ def test_batch_statistics_iteration_on_the_hand_written_kernels_matches_the_orac
     assert int(sd_s['bn1.num_batches_tracked']) == 2
 
 
+def test_fp32_batch_statistics_backward_through_identity_shortcut_blocks(no_library_convolutions):
+    """with layers [1, 1, 1, 1] every bottleneck has a downsample branch, so the fp32 backward never took the
+    IDENTITY-shortcut path -- where the block output's mask bits would have asked the fp32 data gradient for the gated shortcut
+    (`mask_gates_res`) that only the bf16 kernels implement (TypeError). Layers [2, 1, 2, 1]: two identity blocks; fp32 keeps the
+    materialised `dres` there. One iteration vs the oracle step on batch statistics."""
+    from cutmix_semisup_seg_amd import ops
+    from cutmix_semisup_seg_amd.step import UnsupBatch
+    from oracle import step as ostep, boxmask as obox
+    import mask_gen
+    C, layers, N, H, W = 5, [2, 1, 2, 1], 3, 49, 65
+    st, stu, tea, opt, step = _setup(torch.float32, 'hip', C, layers)
+    assert stu._use_hip_body()
+    g = torch.Generator().manual_seed(22)
+    x, ux0, ux1 = (torch.randn(N, 3, H, W, generator=g) for _ in range(3))
+    y = torch.randint(0, C, (N, 1, H, W), generator=g)
+    y[torch.rand(N, 1, H, W, generator=g) < 0.05] = 255
+    ranges = mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(N, (H, W), rng=np.random.RandomState(4))
+    m = torch.tensor(obox.rasterise(ranges, (H, W), True).astype(np.float32))
+    ones = torch.ones(N, 1, H, W)
+    S = ostep.StepState(st, C, layers, opt='adam', lr=1e-3, teacher_alpha=0.99)
+    grads = {}
+    ref = ostep.train_iteration(S, x, y, ux0, ux1, ones, ones, m, conf_thresh=0.2, frozen_bn=False, grads_out=grads)
+    with no_library_convolutions:
+        res = step(x.to(DEV), y.to(torch.uint8).to(DEV), [UnsupBatch(ux0.to(DEV), ops.ranges_to_device(ranges, DEV),
+                                                                    x1_tea=ux1.to(DEV))])
+    got = {k: float(v) for k, v in res.items()}
+    assert no_library_convolutions.refused == 0
+    assert stu._hip_executor is not None and stu._hip_executor.dtype == torch.float32 and stu._hip_executor.batch_statistics()
+    assert abs(got['sup_loss'] - ref['sup_loss']) <= 1e-4 * abs(ref['sup_loss'])
+    assert abs(got['consistency_loss'] - ref['consistency_loss']) <= 2e-3 * abs(ref['consistency_loss']) + 1e-9
+    rels = {k: _rel(p.grad, grads[k]) for k, p in stu.named_parameters() if grads.get(k) is not None}
+    ident = [k for k in rels if k.startswith('layer1.1.') or k.startswith('layer3.1.')]
+    assert len(ident) >= 6, sorted(rels)
+    print('\nPARITY fp32 batch-statistics iteration, identity-shortcut blocks: got {} ref {} gradients max {:.2e} mean {:.2e} identity '
+          'blocks {}'.format(got, ref, max(rels.values()), float(np.mean(list(rels.values()))),
+                             {k: float('{:.1e}'.format(rels[k])) for k in ident}))
+    # same bounds as the [1, 1, 1, 1] test above (a ReLU tie at a zero pre-activation moves everything below it by ~3e-3)
+    assert max(rels.values()) <= 1.5e-2 and float(np.mean(list(rels.values()))) <= 6e-3, sorted(rels.items(), key=lambda kv: -kv[1])[:4]
+
+
 def test_bf16_batch_statistics_iteration_runs_on_the_mfma_engine():
     """The default ('auto') engine in bf16: eligible convolutions on csrc/conv.hip, BatchNorm on csrc/bn.hip; the loss falls."""
     from cutmix_semisup_seg_amd import ops

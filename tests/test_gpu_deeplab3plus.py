@@ -214,7 +214,8 @@ def test_no_grad_passes_run_the_backbone_on_the_mfma_executor():
     g = torch.Generator().manual_seed(9)
     x = torch.randn(3, 3, 97, 129, generator=g)
     hip, lib = _net(C, layers, torch.bfloat16, st), _net(C, layers, torch.bfloat16, st)
-    lib.engine_kind = 'torch'
+    from _library_engine import LibraryEngine
+    lib.engine = LibraryEngine(torch.bfloat16)
     for net in (hip, lib):
         net.train()
         net.freeze_batchnorm()                     # the teacher's state in the training loop (Q4): head in train mode
@@ -231,9 +232,8 @@ def test_no_grad_passes_run_the_backbone_on_the_mfma_executor():
     # The two taps themselves against the fp32 oracle backbone (the random-weight head in eval mode amplifies any input
     # difference by an order of magnitude, so the logits are no yardstick there): one rounding per fused layer makes
     # the hand-written path slightly MORE accurate than the library's conv / BN / add / ReLU sequence.
-    from cutmix_semisup_seg_amd.architectures.deeplab2 import TorchEngine
     import torch.nn.functional as F
-    eng = TorchEngine(torch.bfloat16)
+    eng = LibraryEngine(torch.bfloat16)
 
     def taps(net, use_hip):
         bb = net.deeplab.backbone

@@ -43,12 +43,18 @@ def _state(layers, C, active_relus):
     return st
 
 
-def _build(layers, C, kind, active_relus=False):
+def _build(layers, C, kind, active_relus=False, dtype=torch.bfloat16):
+    """kind 'library': the MIOpen comparison engine of tests/_library_engine.py plugged in as the network's engine object."""
     from architectures import deeplab2
     net = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
     net.load_state_dict(_state(layers, C, active_relus))
     net = net.to(DEV)
-    net.engine_kind = kind
+    net.compute_dtype = dtype
+    if kind == 'library':
+        from _library_engine import LibraryEngine
+        net.engine = LibraryEngine(dtype)
+    else:
+        net.engine_kind = kind
     net.train()
     net.freeze_batchnorm()
     return net
@@ -66,7 +72,7 @@ def test_executor_forward_backward_matches_library_engine(layers, C, shape, acti
     from oracle import deeplab2 as odl
     n, H, W = shape
     x = _cf_input(n, H, W, 0.7).bfloat16().to(DEV)
-    hip, ref = _build(layers, C, 'hip', active), _build(layers, C, 'torch', active)
+    hip, ref = _build(layers, C, 'hip', active), _build(layers, C, 'library', active)
     lo_h = hip.forward_lowres(x)
     lo_r = ref.forward_lowres(x)
     assert lo_h.shape == lo_r.shape and lo_h.dtype == torch.float32 and lo_h.is_contiguous()
@@ -78,9 +84,9 @@ def test_executor_forward_backward_matches_library_engine(layers, C, shape, acti
     e_h, e_r = _rel(lo_h.cpu(), want), _rel(lo_r.cpu(), want)
     assert e_h <= 6e-2, (e_h, e_r)
     assert e_h <= 1.5 * e_r + 5e-3, (e_h, e_r)
-    # backward with the same upstream gradient; truth = the fp32 library engine, yardstick = the bf16 library engine
-    ref32 = _build(layers, C, 'torch', active)
-    ref32.compute_dtype = torch.float32
+    # backward with the same upstream gradient; truth = the fp32 LIBRARY engine (an independent implementation); the bf16 library
+    # engine's error is printed beside it for orientation only
+    ref32 = _build(layers, C, 'library', active, dtype=torch.float32)
     lo_32 = ref32.forward_lowres(x)
     g = torch.randn(lo_h.shape, generator=torch.Generator(device=DEV).manual_seed(1), device=DEV)
     hip._cms_arena.zero_grad()
@@ -97,15 +103,17 @@ def test_executor_forward_backward_matches_library_engine(layers, C, shape, acti
         assert gh is not None and gr is not None, k
         errs[k] = (round(_rel(gh, gt), 4), round(_rel(gr.float(), gt), 4))
     print('gradient rel. errors vs fp32 (hand-written, library bf16):', errs)
-    # bf16 activations / gradients through up to 101 layers: both bf16 paths deviate from the fp32 gradients by the
-    # same order (a few % at the head, tens of % at the stem); the hand-written executor must not be worse than the
-    # library's bf16 path (in practice it is slightly better: one rounding per fused layer instead of three)
-    # (the yardstick itself moves: the library's bf16 gradient of layer1.0.conv1 came out at 0.27 and at 0.15 of the fp32 one in two
-    # runs of the same tree -- MIOpen picks its algorithm per process -- while the hand-written value was 0.2951 both times: the
-    # factor leaves room for that)
-    assert all(eh <= max(2.5 * er, 5e-2) for eh, er in errs.values()), errs
-    assert np.mean([eh for eh, _ in errs.values()]) <= 1.15 * np.mean([er for _, er in errs.values()]) + 1e-2, errs
-    assert errs['layer5.conv2d_list.0.weight'][0] <= 2e-2 and errs['layer4.0.conv3.weight'][0] <= 0.15, errs
+    # bf16 activations / gradients through up to 101 layers deviate from the fp32 gradients by a few % at the head and tens of % at
+    # the stem -- storage noise (the per-layer teacher-forced test is the tight statement). ADVICE r5: the bound is
+    # ABSOLUTE per layer group, not a multiple of the library's bf16 error (a yardstick that moved between 0.15 and 0.27 from process
+    # to process with MIOpen's algorithm choice while the hand-written value stayed at 0.2951). Hand-written values measured over
+    # rounds 2-5: head <= 0.0095, layer4.0.conv3 <= 0.101, body <= 0.137 (tiny) / <= 0.352 (ResNet-101).
+    body_cap = 0.20 if sum(layers) == 4 else 0.45
+    body = [k for k in keys if not k.startswith('layer5.') and k != 'layer4.0.conv3.weight']
+    assert all(errs[k][0] <= body_cap for k in body), errs
+    assert float(np.mean([errs[k][0] for k in body])) <= 0.75 * body_cap, errs
+    assert errs['layer4.0.conv3.weight'][0] <= 0.15, errs
+    assert all(errs[k][0] <= 2e-2 for k in keys if k.startswith('layer5.')), errs
     assert float(named_h['layer5.conv2d_list.2.weight'].grad.abs().max()) == 0.0     # never receives a gradient
 
 

@@ -356,31 +356,20 @@ def test_which_convolutions_of_the_v3plus_head_are_routed_to_the_mfma_kernels():
     x65 = lambda c: FakeCuda((10, c, 65, 65))
     stem = torch.nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
     grouped = torch.nn.Conv2d(64, 64, 3, padding=1, groups=2, bias=False)
-    saved = backbone_hip._auto_keeps_library.__dict__.get('v')
-    try:
-        # round 5 default: 'auto' sends EVERY convolution the general hand-written path can express to it -- the pooled
-        # branch's 1 x 1-map GEMM (the last library kernel of the cfg 4 step), strided layers, the 7 x 7 stem included
-        backbone_hip._auto_keeps_library.__dict__['v'] = False
-        assert all(hip_conv2d_eligible(x65(2048), head.aspp.convs[i][0]) for i in range(4))
-        assert hip_conv2d_eligible(FakeCuda((10, 2048, 1, 1)), head.aspp.convs[4][1])
-        assert hip_conv2d_eligible(FakeCuda((10, 3, 513, 513)), stem)
-        assert hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), torch.float32), head.aspp.convs[1][0], torch.float32)
-        assert not hip_conv2d_eligible(FakeCuda((10, 64, 65, 65)), grouped)                  # no hand-written grouped convolution
-        assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), torch.float32), head.aspp.convs[1][0])      # engine dtype differs
-        assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), cuda=False), head.aspp.convs[1][0])
-        # CMS_AUTO_LIBRARY=1: the rule of rounds 2-4 (A/B switch)
-        backbone_hip._auto_keeps_library.__dict__['v'] = True
-        assert all(hip_conv2d_eligible(x65(2048), head.aspp.convs[i][0]) for i in range(4))     # 1x1 + three dilated 3x3
-        assert hip_conv2d_eligible(x65(1280), head.aspp.project[0])
-        assert hip_conv2d_eligible(FakeCuda((10, 304, 129, 129)), head.classifier[0])            # padded to 320 channels
-        assert hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.classifier[3])
-        assert not hip_conv2d_eligible(FakeCuda((10, 2048, 1, 1)), head.aspp.convs[4][1])        # pooled branch: 1 pixel
-        assert hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.project[0])               # 48 outputs, padded to 64
-        assert not hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.classifier[6])        # bias, 21 outputs
-        assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), torch.float32), head.aspp.convs[1][0])
-        assert not hip_conv2d_eligible(FakeCuda((10, 3, 513, 513)), stem)
-    finally:
-        backbone_hip._auto_keeps_library.__dict__['v'] = saved
+    # 'auto' sends EVERY convolution the general hand-written path can express to it -- the pooled branch's 1 x 1-map GEMM (the
+    # last library kernel of the cfg 4 step until round 5), strided layers, the 7 x 7 stem included; what it cannot express raises
+    # in the engine (round 6: there is no library fallback, and no CMS_AUTO_LIBRARY switch any more)
+    assert not hasattr(backbone_hip, '_auto_keeps_library')
+    assert all(hip_conv2d_eligible(x65(2048), head.aspp.convs[i][0]) for i in range(4))
+    assert hip_conv2d_eligible(x65(1280), head.aspp.project[0])
+    assert hip_conv2d_eligible(FakeCuda((10, 304, 129, 129)), head.classifier[0])            # padded to 320 channels
+    assert hip_conv2d_eligible(FakeCuda((10, 256, 129, 129)), head.project[0])               # 48 outputs, padded to 64
+    assert hip_conv2d_eligible(FakeCuda((10, 2048, 1, 1)), head.aspp.convs[4][1])
+    assert hip_conv2d_eligible(FakeCuda((10, 3, 513, 513)), stem)
+    assert hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), torch.float32), head.aspp.convs[1][0], torch.float32)
+    assert not hip_conv2d_eligible(FakeCuda((10, 64, 65, 65)), grouped)                  # no hand-written grouped convolution
+    assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), torch.float32), head.aspp.convs[1][0])      # engine dtype differs
+    assert not hip_conv2d_eligible(FakeCuda((10, 2048, 65, 65), cuda=False), head.aspp.convs[1][0])
 
 
 def test_v3plus_engine_selection_flags():
@@ -394,8 +383,9 @@ def test_v3plus_engine_selection_flags():
     assert not w._use_hip_backbone()
     with torch.no_grad():
         assert w._use_hip_backbone()
-    w.engine_kind = 'torch'
+    w.engine = object()                                    # an explicit engine object (the tests' library engine) switches it off
     assert not w._use_hip_backbone()
+    w.engine = None
     w.engine_kind, w.compute_dtype = 'auto', torch.float32
     assert w._use_hip_backbone()                           # round 5: 'auto' in fp32 is the hand-written fp32 configuration too
     w.engine_kind = 'hip_nograd'
@@ -478,21 +468,42 @@ def test_gaussian_kernels_match_the_reference_vectors():
     assert g['auto'].shape == (4, 33) and g['wide'].shape == (4, 37)
 
 
-def test_library_convolution_engine_needs_an_explicit_enable():
-    """Round 5: the library (MIOpen) engine is the tests' comparison engine; the product refuses to run a
-    library convolution unless the process enabled it (tests/conftest.py does, through CMS_LIBRARY_ENGINE=1)."""
-    from cutmix_semisup_seg_amd.architectures import deeplab2
-    conv = torch.nn.Conv2d(8, 8, 3, padding=1, bias=False)
-    eng = deeplab2.TorchEngine(torch.float32)
-    was = deeplab2._LIBRARY_ENGINE[0]
-    try:
-        deeplab2.enable_library_engine(False)
-        with pytest.raises(RuntimeError, match='LIBRARY'):
-            eng.conv2d(torch.zeros(1, 8, 4, 4), conv)
-        deeplab2.enable_library_engine(True)
-        assert tuple(eng.conv2d(torch.zeros(1, 8, 4, 4), conv).shape) == (1, 8, 4, 4)      # (the engine itself is plain torch)
-    finally:
-        deeplab2.enable_library_engine(was)
+def test_product_package_has_no_library_convolution_or_batchnorm_call():
+    """the MIOpen comparison engine lives under tests/ (tests/_library_engine.py); the product package holds no
+    `F.conv2d` / `F.batch_norm` call, no guarded library branch and no environment switch that enables one. `engine_kind = 'torch'`
+    (how rounds 2-5 selected the library engine) now raises and says where the engine went."""
+    import re
+    from architectures import deeplab2
+    from cutmix_semisup_seg_amd.architectures import deeplab3plus as d3
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'cutmix-semisup-seg_amd')
+    bad = re.compile(r'F\.conv2d|F\.batch_norm|torch\.conv2d|conv_transpose2d|cudnn|miopen_|CMS_LIBRARY_ENGINE|CMS_AUTO_LIBRARY')
+    hits = []
+    for root, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                for i, line in enumerate(open(os.path.join(root, f)), 1):
+                    if bad.search(line):
+                        hits.append('{}:{}: {}'.format(os.path.relpath(os.path.join(root, f), pkg), i, line.strip()))
+    assert not hits, hits
+    assert not hasattr(deeplab2, 'TorchEngine') and not hasattr(deeplab2, 'enable_library_engine')
+    eng = deeplab2.LayerEngine(torch.float32)
+    with pytest.raises(NotImplementedError, match='HipConvEngine'):
+        eng.conv2d(torch.zeros(1, 3, 8, 8), torch.nn.Conv2d(3, 8, 3))
+    bn = torch.nn.BatchNorm2d(8).train()
+    with pytest.raises(RuntimeError, match='no library fallback'):            # CPU tensor: no csrc/bn.hip, and nothing else
+        eng.bn_act(torch.zeros(2, 8, 4, 4), bn, relu=True)
+
+    class FakeCuda(object):
+        is_cuda = True
+    w = d3.DeepLabv3Wrapper(d3._deeplabv3plus(3, 8, (1, 1, 1, 1)))
+    w.engine_kind = 'torch'
+    with pytest.raises(RuntimeError, match='tests/_library_engine.py'):
+        w._engine(FakeCuda())
+    # and the comparison engine itself works where the tests use it on the CPU (fp32 wiring check of the v3+ module tree)
+    from _library_engine import LibraryEngine
+    lib = LibraryEngine(torch.float32)
+    y = lib.conv_bn_act(torch.randn(2, 3, 8, 8), torch.nn.Conv2d(3, 8, 3, padding=1, bias=False), bn, relu=True)
+    assert tuple(y.shape) == (2, 8, 8, 8) and float(y.min()) >= 0.0 and int(bn.num_batches_tracked) == 1
 
 
 def test_bench_final_line_is_compact_and_strict_json():

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch, torch.nn.functional as F
 from test_gpu_deeplab3plus import _he_state, _net
 from oracle import deeplab3plus as o3
-from cutmix_semisup_seg_amd.architectures.deeplab2 import TorchEngine
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+from _library_engine import LibraryEngine as TorchEngine
 DEV = 'cuda:0'
 layers, C = (2, 2, 3, 2), 6
 st = _he_state(C, layers)
