@@ -243,7 +243,9 @@ def measure_traffic(key):
         if 'FETCH_SIZE' not in cs or 'WRITE_SIZE' not in cs:
             continue
         pmc = (2.0 * cs['FETCH_SIZE'][0] / cs['FETCH_SIZE'][1] + cs['WRITE_SIZE'][0] / cs['WRITE_SIZE'][1]) * 1024.0
-        entry = {'pmc_bytes_per_launch': pmc, 'launches': cs['FETCH_SIZE'][1]}
+        entry = {'pmc_bytes_per_launch': pmc, 'launches': cs['FETCH_SIZE'][1],
+                 'fetch_bytes_per_launch': 2.0 * cs['FETCH_SIZE'][0] / cs['FETCH_SIZE'][1] * 1024.0,
+                 'write_bytes_per_launch': cs['WRITE_SIZE'][0] / cs['WRITE_SIZE'][1] * 1024.0}
         for route, info in (sub_by_kernel or {}).items():
             if route in kn:
                 entry['algorithmic_bytes_per_launch'] = info['algorithmic_bytes_per_launch']
@@ -869,6 +871,10 @@ def main():
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)                     # RCCL really spans `world` ranks
         rccl_world = int(probe.item())
+        # RCCL's internal stream exists from here on and sits on one of the four hardware queues: probe the side streams NOW so that
+        # the step's roles (teacher | two weight-gradient streams) avoid it
+        from cutmix_semisup_seg_amd import ops as _ops
+        _ops.probe_streams(dev, again=True)
     else:
         rccl_world = 1
 

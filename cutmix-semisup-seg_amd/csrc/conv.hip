@@ -1213,8 +1213,10 @@ static int conv_default_variant() {
 // move at the ~10 B/clk a CU gets from memory), CMS_CONV8_MIN_KT = fewest 64-deep K tiles per output tile it is used for
 // (default 16), CMS_CONV8_GRID = workgroup cap of mode 2, CMS_CONV8_PASSES = bit 0 forward / bit 1 data-gradient launches.
 static int conv8_env(int which) {
-    static int mode = -1, min_kt = 0, grid = 0, passes = 3;
+    static int mode = -1, min_kt = 0, grid = 0, passes = 3, min_tiles = 0;
     if (mode < 0) {
+        const char* mt = getenv("CMS_CONV8_MIN_TILES");        // fewest 256 x 256 output tiles of a launch it is used for (round 6)
+        min_tiles = mt ? atoi(mt) : 0;
         const char* e = getenv("CMS_CONV8");
         const char* k = getenv("CMS_CONV8_MIN_KT");
         const char* g = getenv("CMS_CONV8_GRID");
@@ -1224,7 +1226,7 @@ static int conv8_env(int which) {
         passes = p ? atoi(p) : 3;
         mode = e ? atoi(e) : 1;
     }
-    return which == 0 ? mode : (which == 1 ? min_kt : (which == 2 ? grid : passes));
+    return which == 0 ? mode : (which == 1 ? min_kt : (which == 2 ? grid : (which == 3 ? passes : min_tiles)));
 }
 
 extern "C" long long cms_conv_igemm_workspace_bytes(void) {
@@ -1238,7 +1240,8 @@ static bool conv_takes_conv8(const cms_conv_desc* d) {
     return d->variant == 0 && d->tile == 0 && conv8_env(0) > 0 && cms::conv8_supported(d) &&
            ((d->mask_bits == nullptr && d->mask_bits_out == nullptr) || conv8_env(0) == 1) &&     // (bits: whole tiles only)
            d->ntaps * (d->cin / 64) >= conv8_env(1) && conv_default_variant() == 0 &&
-           ((conv8_env(3) >> (d->mode == 0 ? 0 : 1)) & 1);
+           ((conv8_env(3) >> (d->mode == 0 ? 0 : 1)) & 1) &&
+           (conv8_env(4) <= 0 || (long long)((d->n * d->ho * d->wo + 255) / 256) * (d->cout / 256) >= conv8_env(4));
 }
 
 static int conv_mixed_env() {                       // balanced launch; CMS_CONV_MIXED=0 switches it off (A/B, read once)

@@ -59,6 +59,7 @@ struct Args {
     int dw_cout;               // rows per tap of the dw tensor
     int nco, nci, ntiles;      // channel tiles; ntiles = nco * nci * ntaps
     int kt_total, kt_per_slice;// K tiles (64 pixels) of the layer / per pixel slice (even)
+    int ksplit, xcd_slices;    // pixel slices; 1 = slice s on XCD s % 8 (padded grid; CMS_WGRAD8_XCD=1), 0 = 8 equal runs (default)
     int q64, r64;              // 64 / Wo, 64 % Wo
     uint32_t* trace;           // diagnostic (cms_conv_set_trace): 16 dwords per workgroup, or NULL
     int trace_wgs;
@@ -104,14 +105,26 @@ __global__ __launch_bounds__(NT, 2) void wgrad8_kernel(Args a) {
     const int wn = wave >> 2, wm = wave & 3;          // 128-channel half of the co tile, 64-channel quarter of the ci tile
     const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD: the two groups run one barrier apart
 
-    // XCD-aware order: all (co, ci, tap) tiles of one pixel slice are consecutive logical ids and run on one XCD, which then
-    // fetches that slice of dU / X from HBM once
-    int b = (int)blockIdx.x;
-    {
+    // XCD-aware order. Default (rounds 4-6): the logical ids (slice-major) are cut into 8 equal runs, one per XCD -- the launch's
+    // workgroups spread EVENLY over the XCDs, neighbouring tiles of a slice share an L2. With 54 = 6 slices x 9 taps that is 6.75
+    // tiles per XCD: every slice straddles two XCDs and is fetched twice (2.06 x the algorithmic bytes by the TCC counters).
+    // CMS_WGRAD8_XCD=1 (round 6 experiment, measured and NOT the default): slice s entirely on XCD s % 8 (grid padded to
+    // 8 * ceil(slices / 8) * tiles, workgroups of slices that do not exist return at once) -- each slice then leaves HBM once, but
+    // the launch's 54-56 one-per-CU workgroups land 9 + 9 + ... on six XCDs instead of 7 on each of eight, and next to the
+    // data-gradient stream's 16.5 conv8 tiles per XCD some XCDs are over-subscribed (34.5 workgroups for 32 CUs) while others idle:
+    // 546 vs 630 img/s at cfg 2, twice in alternation on one box (profiles/r06a_*). Balance across XCDs is worth more than the bytes.
+    int tile, ks;
+    if (a.xcd_slices) {
+        const int b = (int)blockIdx.x, xcd = b & 7, idx = b >> 3;
+        tile = idx % a.ntiles;
+        ks = xcd + 8 * (idx / a.ntiles);
+        if (ks >= a.ksplit) return;
+    } else {
+        int b = (int)blockIdx.x;
         const int G = (int)gridDim.x, q = G / 8, r = G % 8, xcd = b % 8, idx = b / 8;
         b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile = b % a.ntiles; ks = b / a.ntiles;
     }
-    const int tile = b % a.ntiles, ks = b / a.ntiles;
     const int tco = tile % a.nco, tci = (tile / a.nco) % a.nci, tap = tile / (a.nco * a.nci);
     const int co0 = tco * BCO, ci0 = tci * BCI;
     int dy = 0, dx = 0;
@@ -447,7 +460,12 @@ int wgrad8_launch(const cms_wgrad_desc* d, hipStream_t s, void* trace, int trace
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(w8::wgrad8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised = true;
     }
-    hipLaunchKernelGGL(w8::wgrad8_kernel, dim3(a.ntiles * ksplit), dim3(w8::NT), w8::LDS_BYTES, s, a);
+    static int xcd_mode = -1;
+    if (xcd_mode < 0) xcd_mode = wgrad8_env("CMS_WGRAD8_XCD", 0);
+    a.ksplit = ksplit;
+    a.xcd_slices = (xcd_mode != 0 && ksplit > 1) ? 1 : 0;
+    const int grid = a.xcd_slices ? 8 * ((ksplit + 7) / 8) * a.ntiles : a.ntiles * ksplit;
+    hipLaunchKernelGGL(w8::wgrad8_kernel, dim3(grid), dim3(w8::NT), w8::LDS_BYTES, s, a);
     if (use_slab) wgrad_reduce_launch(a.slab, d->dw, ksplit, slice_elems, d->ntaps, d->cout, d->cin, d->cout, a.dw_cout, s);
     return launch_status("cms_conv_wgrad (8-phase)");
 }

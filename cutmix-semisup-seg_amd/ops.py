@@ -376,12 +376,17 @@ def _probe_side_streams(dev):
             with torch.cuda.stream(st_):
                 torch.cuda._sleep(1000)
         pair_ms(cur, cands[0])                            # warm-up
-        alone = max(pair_ms(cur, None), 1e-3)
+        alone = max(min(pair_ms(cur, None) for _ in range(3)), 1e-3)
         n = len(streams)
         clash = [[False] * n for _ in range(n)]
+
+        def clashes(a, b):
+            # noise (another process on the GPU, a second rank on the same device) only ever LENGTHENS a trial: a pair shares a queue
+            # only if every one of three trials says so (one 0.1 ms timing per pair marked false clashes on a busy GPU)
+            return all(pair_ms(a, b) >= 1.5 * alone for _ in range(3))
         for i in range(n):
             for j in range(i + 1, n):
-                clash[i][j] = clash[j][i] = pair_ms(streams[i], streams[j]) >= 1.5 * alone
+                clash[i][j] = clash[j][i] = clashes(streams[i], streams[j])
     # greedy: candidates in creation order that clash neither with the current stream nor with one already chosen
     chosen = []
     for j in range(1, n):
@@ -389,10 +394,33 @@ def _probe_side_streams(dev):
             chosen.append(j)
     _STREAM_PROBE_LOG.append((dev.index, round(alone, 4), [[int(v) for v in row] for row in clash], [j - 1 for j in chosen]))
     good = [streams[j] for j in chosen]
+    if len(good) < 3:
+        # the step wants three side queues (teacher | two weight-gradient streams); say so instead of degrading silently
+        import warnings
+        warnings.warn('cutmix-semisup-seg_amd: the stream probe found {} side stream(s) that run beside the current stream and one '
+                      'another (3 wanted){}; expect a slower step (roles share hardware queues). Clash matrix: {}'.format(
+                          len(good), '' if len(good) >= 2 else ' -- falling back to creation order', _STREAM_PROBE_LOG[-1][2]),
+                      RuntimeWarning, stacklevel=2)
     if len(good) < 2:                                     # a runtime this model does not fit: keep the creation order
         good = cands
     _GOOD_STREAMS[dev.index] = good
     return good
+
+
+def probe_streams(device=None, again=False):
+    """Run the side-stream probe NOW (instead of lazily inside the first step / recording) and return the clash log entry.
+    `again=True` forgets the previous result AND the pooled role streams: call it after anything that creates streams of its own --
+    `torch.distributed.init_process_group` + the first collective (RCCL's internal stream then exists and occupies a hardware queue,
+    so the probe steers the step's roles away from it) -- and before the first step records its programs."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    if again:
+        _GOOD_STREAMS.pop(dev.index, None)
+        for key in [k for k in _STREAM_POOL if k[0] == dev.index]:
+            del _STREAM_POOL[key]
+    _probe_side_streams(dev)
+    return _STREAM_PROBE_LOG[-1] if _STREAM_PROBE_LOG else None
 
 
 def pooled_stream(device, role):

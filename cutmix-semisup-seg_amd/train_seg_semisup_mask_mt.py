@@ -76,6 +76,14 @@ def train_seg_semisup_mask_mt(submit_config, dataset, model, arch, freeze_bn,
     torch_device = torch.device('cuda', local_rank)
     if world > 1 and not dist.is_initialized():
         dist.init_process_group('nccl')
+    if world > 1:
+        # RCCL creates its internal stream with the first collective; it occupies one of the four hardware queues. Probe the side
+        # streams AFTER that, so the step's roles avoid the queue RCCL sits on (ops.probe_streams)
+        from cutmix_semisup_seg_amd import ops as _ops
+        _t = torch.ones(1, device=torch_device)
+        dist.all_reduce(_t)
+        torch.cuda.synchronize(torch_device)
+        _ops.probe_streams(torch_device, again=True)
 
     n_classes = int(synthetic_n_classes)
     if bin_fill_holes and n_classes != 2:

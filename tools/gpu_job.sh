@@ -45,6 +45,7 @@ for step in "$@"; do
       ( IFS=','; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done; unset IFS
         timeout 900 python bench.py $args ) > $OUT/${TAG}_bench_$name.log 2> $OUT/${TAG}_bench_$name.err
       echo "bench[$name] rc=$?" | tee -a $SUM
+      [ -f bench_detail.json ] && cp bench_detail.json $OUT/${TAG}_bench_${name}_detail.json
       grep '^{"metric"' $OUT/${TAG}_bench_$name.log | python -c "
 import sys, json
 for l in sys.stdin:

@@ -62,6 +62,7 @@ def main():
     assert int(probe.item()) == world, 'the process group spans {} ranks, expected {}'.format(int(probe.item()), world)
 
     from cutmix_semisup_seg_amd import ops, optim as fo
+    print('rank {}: stream probe after the first collective: {}'.format(rank, ops.probe_streams(dev, again=True)), flush=True)
     from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
     from architectures import deeplab2
     import mask_gen
