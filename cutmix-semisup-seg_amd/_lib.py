@@ -124,10 +124,15 @@ PROTOTYPES = {
     'cms_consistency_fwd': (c_int, [_P(ConsistencyDesc), c_void_p, c_void_p, c_void_p]),
     'cms_consistency_finalize': (c_int, [c_void_p, c_void_p, c_float, c_int, c_float, c_float, c_void_p, c_void_p]),
     'cms_consistency_bwd': (c_int, [_P(ConsistencyDesc), c_void_p, c_void_p, c_void_p]),
+    'cms_consistency_fused_supported': (c_int, [_P(ConsistencyDesc)]),
+    'cms_consistency_fwd_bwd': (c_int, [_P(ConsistencyDesc), c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cms_scale_by_scalar': (c_int, [c_void_p, C.c_longlong, c_void_p, c_int, c_float, c_void_p]),
     'cms_ce_workspace_bytes': (c_size_t, [_P(CeDesc)]),
     'cms_ce_fwd': (c_int, [_P(CeDesc), c_void_p, c_void_p, c_void_p]),
     'cms_ce_finalize': (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
     'cms_ce_bwd': (c_int, [_P(CeDesc), c_void_p, c_void_p, c_void_p]),
+    'cms_ce_fused_supported': (c_int, [_P(CeDesc)]),
+    'cms_ce_fwd_bwd': (c_int, [_P(CeDesc), c_void_p, c_void_p, c_void_p, c_void_p]),
     'cms_upsample_bilinear_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_void_p]),
     'cms_upsample_bilinear_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

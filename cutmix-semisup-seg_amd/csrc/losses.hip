@@ -613,6 +613,80 @@ __global__ __launch_bounds__(256) void cons_bwd_tiled_kernel(ConsArgs a, const f
     tiled_scatter(g, stage, pixel_grad, grad, smem);
 }
 
+// ---- forward + backward in ONE launch (round 6) -----------------------------------------------------------------------
+// The backward kernel recomputes everything the forward kernel computed (the tile's logit rectangles, both softmaxes of every
+// pixel) and needs from it only ONE scalar: the factor of the gradient. That factor is  ramp * weight / P * um  [* per-pixel
+// confidence]  -- known up front -- times, in the default confidence mode, the scalar RATE (train_seg_semisup_mask_mt.py:415-418:
+// the confidence mask is replaced by its mean), in which the gradient is LINEAR. So one pass computes the loss partial sums AND
+// the gradient with the rate left out (`grad_unit` = ramp * weight / P), the finalising launch derives the scalars, and
+// cms_scale_by_scalar multiplies the gradient rows by the rate afterwards (a 350 k-float pass). The chain between the forward and
+// the backward pass of the step loses a launch of 0.10-0.12 ms and a second staging of all rectangles; under data parallelism
+// the gradient no longer waits for the all-reduce of the confidence count either. Per-pixel values are those of the two
+// kernels (same functions on the same registers).
+template <int CT, int LF>
+__global__ __launch_bounds__(256, (LF >= 0 && CT > 0) ? 4 : 1) void cons_fused_tiled_kernel(ConsArgs a, float grad_unit, float* __restrict__ grad,
+                                                               int patch_stride, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Geo& g = a.g;
+    const size_t plane = (size_t)g.h * g.w;
+    const bool pp = a.tau > 0.0f && a.d.conf_per_pixel;
+    const int pstride = patch_stride;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    auto stage = [&](int n, const Patch& p, float* P) {
+        const size_t sample = (size_t)n * g.c * plane;
+        stage_patch(P, a.d.l_stu + sample, g.c, plane, g.w, p);
+        stage_patch(P + pstride, a.d.l_tea0 + sample, g.c, plane, g.w, p);
+        if (a.d.mode == MODE_MIX) stage_patch(P + 2 * pstride, a.d.l_tea1 + sample, g.c, plane, g.w, p);
+    };
+    auto pixel_grad = [&](int n, int y, int x, const Tap& ty, const Tap& tx, const Patch& p, const float* P, auto emit) -> bool {
+        const ConsPixel px = cons_pixel_inputs(a, n, y, x);
+        const float base_f = grad_unit * px.um;
+        // (no early-out on base_f == 0, see cons_bwd_ident_kernel)
+        Gather<false> gs, gt;
+        gs.base = P;
+        gt.base = P + (px.which ? 2 * pstride : pstride);
+        gs.plane = gt.plane = (size_t)p.n_rows * p.n_cols;
+        gs.w_in = gt.w_in = p.n_cols;
+        gs.ty = gt.ty = ty;                      // (taps already rebased to the rectangle)
+        gs.tx = gt.tx = tx;
+        PixelFwd r;
+        if (CT > 0) {
+            RegVec<CT> rs, rt;
+            fill<CT, false>(rs, gs);
+            fill<CT, false>(rt, gt);
+            r = consistency_pixel_fwd_bwd<(CT > 0 ? CT : 1), LF>(
+                rs, rt, a.d.loss_fn, a.inv_root_c,
+                [&](float conf) -> float { return (pp && !(conf >= a.tau)) ? 0.0f : base_f; },
+                [&](int k, float v) { emit(k, v); });
+        } else {
+            r = consistency_pixel_fwd<0>(gs, gt, g.c, a.d.loss_fn, a.inv_root_c);
+            const float f = (pp && !(r.conf >= a.tau)) ? 0.0f : base_f;
+            consistency_pixel_bwd<0>(gs, gt, g.c, a.d.loss_fn, a.inv_root_c, [&](int k, float v) { emit(k, f * v); });
+        }
+        const float lm = r.loss * px.um;
+        const float cf = (a.tau > 0.0f && r.conf >= a.tau) ? 1.0f : 0.0f;
+        acc[0] += lm;
+        acc[1] += lm * cf;
+        acc[2] += cf;
+        return true;
+    };
+    tiled_scatter(g, stage, pixel_grad, grad, smem);
+    __shared__ float red[3 * 16];
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 3 + 0] = acc[0];
+        partials[blockIdx.x * 3 + 1] = acc[1];
+        partials[blockIdx.x * 3 + 2] = acc[2];
+    }
+}
+
+// x[i] *= scalars[idx] * factor for i < n (the deferred factor of the fused loss launches: a device scalar)
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(float* __restrict__ x, size_t n, const float* __restrict__ scalars,
+                                                              int idx, float factor) {
+    const float f = scalars[idx] * factor;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= f;
+}
+
 // ------------------------------------------------------------------------------------------------ cross entropy
 struct CeArgs {
     cms_ce_desc d;
@@ -793,6 +867,51 @@ __global__ __launch_bounds__(256) void ce_bwd_tiled_kernel(CeArgs a, const float
     tiled_scatter(g, stage, pixel_grad, grad, smem);
 }
 
+// forward + backward of the cross entropy in one launch (round 6): the gradient is (softmax - onehot) * weight / n_valid, linear
+// in the one scalar the forward pass contributes (the count of valid labels, global under data parallelism) -- computed here
+// with that factor left out, scaled by cms_scale_by_scalar behind cms_ce_finalize.
+template <int CT>
+__global__ __launch_bounds__(256) void ce_fused_tiled_kernel(CeArgs a, float* __restrict__ grad, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Geo& g = a.g;
+    const size_t plane = (size_t)g.h * g.w;
+    float acc[2] = {0.0f, 0.0f};
+    auto stage = [&](int n, const Patch& p, float* P) {
+        stage_patch(P, a.d.logits + (size_t)n * g.c * plane, g.c, plane, g.w, p);
+    };
+    auto pixel_grad = [&](int n, int y, int x, const Tap& ty, const Tap& tx, const Patch& p, const float* P, auto emit) -> bool {
+        const size_t pix = ((size_t)n * g.H + y) * g.W + x;
+        const int label = load_label(a, pix);
+        if (label == a.d.ignore_index || label < 0 || label >= g.c) return false;
+        Gather<false> gl;
+        gl.base = P;
+        gl.plane = (size_t)p.n_rows * p.n_cols;
+        gl.w_in = p.n_cols;
+        gl.ty = ty;                              // (taps already rebased to the rectangle)
+        gl.tx = tx;
+        float v;
+        if (CT > 0) {
+            RegVec<CT> r;
+            fill<CT, false>(r, gl);
+            // (the label is a run-time index: its logit is re-gathered instead of indexing registers, as in ce_fwd_tiled_kernel)
+            v = ce_pixel_fwd_bwd<(CT > 0 ? CT : 1)>(r, gl(label), label, [&](int k, float gv) { emit(k, gv); });
+        } else {
+            v = ce_pixel_fwd<0>(gl, g.c, label);
+            ce_pixel_bwd<0>(gl, g.c, label, [&](int k, float gv) { emit(k, gv); });
+        }
+        acc[0] += v;
+        acc[1] += 1.0f;
+        return true;
+    };
+    tiled_scatter(g, stage, pixel_grad, grad, smem);
+    __shared__ float red[2 * 16];
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 2 + 0] = acc[0];
+        partials[blockIdx.x * 2 + 1] = acc[1];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static Geo make_geo(int n, int c, int h, int w, int H, int W, int align) {
     Geo g;
@@ -850,6 +969,21 @@ static int fwd_blocks(const Geo& g, int n_patches) {
     return t > 0 ? t : fwd_grid((size_t)g.n * g.H * g.W);
 }
 
+// the fused forward + backward launches: one workgroup per 64 x TILE_H tile of one sample, all tiles in ONE launch (0 = not
+// available: identity geometry, rectangles beyond the LDS, or the deterministic mode, whose colour-class launches stay unfused)
+static int fused_tiles(const Geo& g, int n_patches) {
+    if (g.h == g.H && g.w == g.W) return 0;
+    if (loss_deterministic()) return 0;
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("CMS_LOSS_FUSED");         // A/B switch, read once
+        on = e ? (atoi(e) != 0) : 1;
+    }
+    if (!on) return 0;
+    if (tile_lds_bytes(g.c, g.sy, g.sx, n_patches) > 160 * 1024 - 4096) return 0;
+    return ((g.W + TILE_W - 1) / TILE_W) * ((g.H + TILE_H - 1) / TILE_H) * g.n;
+}
+
 #define CMS_DISPATCH_C(C, ...)                    \
     switch (C) {                                  \
         case 2: { constexpr int CT = 2; __VA_ARGS__; } break;   \
@@ -866,7 +1000,44 @@ using namespace cms;
 extern "C" size_t cms_consistency_workspace_bytes(const cms_consistency_desc* d) {
     if (!d) return 0;
     const Geo g = make_geo(d->n, d->c, d->h, d->w, d->H, d->W, d->align_corners);
-    return (size_t)fwd_blocks(g, 3) * 3 * sizeof(float);
+    return (size_t)std::max(fwd_blocks(g, 3), fused_tiles(g, 3)) * 3 * sizeof(float);
+}
+
+extern "C" int cms_consistency_fused_supported(const cms_consistency_desc* d) {
+    if (check_cons(d)) return 0;
+    return fused_tiles(make_geo(d->n, d->c, d->h, d->w, d->H, d->W, d->align_corners), 3) > 0 ? 1 : 0;
+}
+
+extern "C" int cms_consistency_fwd_bwd(const cms_consistency_desc* d, float grad_unit, void* workspace, double* stats_out,
+                                       float* grad_l_stu, void* stream) {
+    int rc = check_cons(d);
+    if (rc) return rc;
+    CMS_REQUIRE(workspace && stats_out && grad_l_stu, "consistency_fwd_bwd: workspace / stats_out / grad NULL");
+    ConsArgs a = make_cons_args(d);
+    const int tiles = fused_tiles(a.g, 3);
+    CMS_REQUIRE(tiles > 0, "consistency_fwd_bwd: not available for this geometry / mode (ask cms_consistency_fused_supported)");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = tile_lds_bytes(d->c, a.g.sy, a.g.sx, 3);
+    const int pstride = (int)patch_floats(d->c, a.g.sy, a.g.sx, TILE_H);
+    float* partials = (float*)workspace;
+    CMS_DISPATCH_C(d->c, {
+        // the default loss (`var`) as a compile-time constant: its own register allocation (see consistency_pixel_fwd_bwd)
+        auto kern = d->loss_fn == CMS_LOSS_VAR ? cons_fused_tiled_kernel<CT, LOSS_VAR> : cons_fused_tiled_kernel<CT, -1>;
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, s, a, grad_unit, grad_l_stu, pstride, partials);
+    });
+    hipLaunchKernelGGL((reduce_partials_kernel<3>), dim3(1), dim3(256), 0, s, partials, tiles, stats_out,
+                       (double)((size_t)d->n * d->H * d->W), 3);
+    return launch_status("cms_consistency_fwd_bwd");
+}
+
+extern "C" int cms_scale_by_scalar(float* x, long long n, const float* scalars, int index, float factor, void* stream) {
+    CMS_REQUIRE(x && scalars && n >= 0 && index >= 0, "scale_by_scalar: bad argument");
+    if (n == 0) return CMS_OK;
+    const int grid = (int)std::min<long long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, scalars, index, factor);
+    return launch_status("cms_scale_by_scalar");
 }
 
 extern "C" int cms_consistency_fwd(const cms_consistency_desc* d, void* workspace, double* stats_out, void* stream) {
@@ -952,7 +1123,33 @@ static int check_ce(const cms_ce_desc* d) {
 extern "C" size_t cms_ce_workspace_bytes(const cms_ce_desc* d) {
     if (!d) return 0;
     const Geo g = make_geo(d->n, d->c, d->h, d->w, d->H, d->W, d->align_corners);
-    return (size_t)fwd_blocks(g, 1) * 2 * sizeof(float);
+    return (size_t)std::max(fwd_blocks(g, 1), fused_tiles(g, 1)) * 2 * sizeof(float);
+}
+
+extern "C" int cms_ce_fused_supported(const cms_ce_desc* d) {
+    if (check_ce(d)) return 0;
+    return fused_tiles(make_geo(d->n, d->c, d->h, d->w, d->H, d->W, d->align_corners), 1) > 0 ? 1 : 0;
+}
+
+extern "C" int cms_ce_fwd_bwd(const cms_ce_desc* d, void* workspace, double* stats_out, float* grad_logits, void* stream) {
+    int rc = check_ce(d);
+    if (rc) return rc;
+    CMS_REQUIRE(workspace && stats_out && grad_logits, "ce_fwd_bwd: workspace / stats_out / grad NULL");
+    CeArgs a;
+    a.d = *d;
+    a.g = make_geo(d->n, d->c, d->h, d->w, d->H, d->W, d->align_corners);
+    const int tiles = fused_tiles(a.g, 1);
+    CMS_REQUIRE(tiles > 0, "ce_fwd_bwd: not available for this geometry / mode (ask cms_ce_fused_supported)");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = tile_lds_bytes(d->c, a.g.sy, a.g.sx, 1);
+    float* partials = (float*)workspace;
+    CMS_DISPATCH_C(d->c, {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)ce_fused_tiled_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ce_fused_tiled_kernel<CT>), dim3(tiles), dim3(256), lds, s, a, grad_logits, partials);
+    });
+    hipLaunchKernelGGL((reduce_partials_kernel<2>), dim3(1), dim3(256), 0, s, partials, tiles, stats_out, 0.0, -1);
+    return launch_status("cms_ce_fwd_bwd");
 }
 
 extern "C" int cms_ce_fwd(const cms_ce_desc* d, void* workspace, double* stats_out, void* stream) {

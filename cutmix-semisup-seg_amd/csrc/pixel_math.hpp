@@ -258,6 +258,114 @@ CMS_HD float consistency_pixel_bwd(LS ls, LT lt, int crt, int loss_fn, float inv
     return conf;
 }
 
+// forward AND backward of one pixel from ONE pair of softmaxes (round 6: the one-launch loss kernels; compile-time class count).
+// Every formula is the one of consistency_pixel_fwd / consistency_pixel_bwd, evaluated on the same e[] / rz registers in the same
+// order, so loss, confidence and gradient come out bit for bit as from the two functions -- what is saved is the second pair of
+// softmaxes (2 C expf, two reciprocals) and, in the caller, the second gather of both logit vectors.
+template <int CT, int LF, class LS, class LT, class F, class E>
+CMS_HD PixelFwd consistency_pixel_fwd_bwd(LS ls, LT lt, int loss_fn_rt, float inv_root_c, F factor_of_conf, E emit) {
+    // LF >= 0: the loss function as a compile-time constant (the default `var` gets its own instantiation: with a run-time switch
+    // the register allocation is that of the hungriest branch -- KLD keeps both logit vectors alive beside both probability
+    // vectors: 176 VGPRs, two waves per SIMD); LF < 0: `loss_fn_rt` decides
+    const int loss_fn = LF >= 0 ? LF : loss_fn_rt;
+    // `factor_of_conf(conf)` -> the pixel's gradient factor (known as soon as the teacher's softmax is); `emit(k, factor * g_k)`
+    // goes straight to its destination: no gradient vector is kept (register budget: 128 for four waves per SIMD)
+    static_assert(CT > 0, "compile-time class count only (the generic path calls the two functions)");
+    SoftmaxRegs<CT> ss, st;
+    softmax_regs<CT>(lt, CT, st);
+    PixelFwd out;
+    out.conf = st.rz;
+    const float f = factor_of_conf(out.conf);
+    float acc = 0.0f;
+    if (loss_fn == LOSS_LOGITS_VAR) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float d = ls(c) - lt(c);
+            acc += d * d;
+            emit(c, f * (2.0f * (ls(c) - lt(c)) * inv_root_c));
+        }
+        out.loss = acc * inv_root_c;
+        return out;
+    }
+    if (loss_fn == LOSS_LOGITS_SMOOTHL1) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float d = ls(c) - lt(c);
+            acc += smooth_l1(d);
+            const float g = fabsf(d) < 1.0f ? d : (d > 0.0f ? 1.0f : -1.0f);
+            emit(c, f * (g * inv_root_c));
+        }
+        out.loss = acc * inv_root_c;
+        return out;
+    }
+    softmax_regs<CT>(ls, CT, ss);
+    // probabilities IN PLACE of the exponentials: p_c = e_c * (1 / z), the rounded product softmax_prob returns
+    float log_zs = 0.0f, log_zt = 0.0f;
+    if (loss_fn == LOSS_KLD) {
+        log_zs = logf(ss.z);
+        log_zt = logf(st.z);
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        ss.e[c] = softmax_prob<CT>(ss, ls, c);
+        st.e[c] = softmax_prob<CT>(st, lt, c);
+    }
+    const float* p = ss.e;
+    const float* t = st.e;
+    // ---- the per-pixel loss (consistency_pixel_fwd) and the two sums of the gradient (consistency_pixel_bwd)
+    float dot = 0.0f;
+    float tsum = 0.0f;
+    if (loss_fn == LOSS_VAR) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float d = p[c] - t[c];
+            acc += d * d;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float fp = 2.0f * (p[c] - t[c]);
+            dot += fp * p[c];
+        }
+    } else if (loss_fn == LOSS_BCE) {
+        const float eps = 1e-6f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc += -(t[c] * logf(p[c] + eps) + (1.0f - t[c]) * logf(1.0f - p[c] + eps));
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float fp = -t[c] / (p[c] + eps) + (1.0f - t[c]) / (1.0f - p[c] + eps);
+            dot += fp * p[c];
+        }
+    } else {  // LOSS_KLD
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const float logp = (ls(c) - ss.mx) - log_zs;
+            const float logt = (lt(c) - st.mx) - log_zt;
+            acc += t[c] > 0.0f ? t[c] * (logt - logp) : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            dot += 0.0f * p[c];
+            tsum += t[c];
+        }
+    }
+    out.loss = acc;
+    // ---- dl_k = p_k * (f'_k - sum_c f'_c p_c)
+#pragma unroll
+    for (int k = 0; k < CT; ++k) {
+        float g;
+        if (loss_fn == LOSS_VAR) {
+            g = p[k] * (2.0f * (p[k] - t[k]) - dot);
+        } else if (loss_fn == LOSS_BCE) {
+            const float eps = 1e-6f;
+            g = p[k] * ((-t[k] / (p[k] + eps) + (1.0f - t[k]) / (1.0f - p[k] + eps)) - dot);
+        } else {  // KLD: -t_k + p_k * sum_c t_c
+            g = p[k] * tsum - t[k];
+        }
+        emit(k, f * g);
+    }
+    return out;
+}
+
 // ---------------------------------------------------------------------------------------------- cross entropy
 // returns -log_softmax(l)[label]
 template <int CT, class L>
@@ -274,6 +382,18 @@ CMS_HD void ce_pixel_bwd(L l, int crt, int label, E emit) {
     softmax_regs<CT>(l, crt, s);
 #pragma unroll
     for (int k = 0; k < C; ++k) emit(k, softmax_prob<CT>(s, l, k) - (k == label ? 1.0f : 0.0f));
+}
+
+// -log_softmax(l)[label] and its gradient from ONE softmax (round 6, compile-time class count): the value as ce_fwd computes it
+// (max, sum of exponentials in class order, one logf), the gradient as ce_pixel_bwd (e_k * (1 / z) - onehot).
+template <int CT, class L, class E>
+CMS_HD float ce_pixel_fwd_bwd(L l, float l_label, int label, E emit) {
+    static_assert(CT > 0, "compile-time class count only");
+    SoftmaxRegs<CT> s;
+    softmax_regs<CT>(l, CT, s);
+#pragma unroll
+    for (int k = 0; k < CT; ++k) emit(k, softmax_prob<CT>(s, l, k) - (k == label ? 1.0f : 0.0f));
+    return -((l_label - s.mx) - logf(s.z));
 }
 
 // ---------------------------------------------------------------------------------------------- EMA (3 roundings)

@@ -193,6 +193,47 @@ def consistency_backward(ctx, scalars, grad_out=None, samples=None):
     return grad_out
 
 
+def consistency_fused(cfg, l_stu, l_tea0, l_tea1, out_size, grad_out, ranges=None, mask=None, um0=None, um1=None,
+                      ramp_val=1.0, cons_weight=1.0, group=None, sync_conf_rate=True):
+    """(round 6) `consistency_forward` + `consistency_backward` as ONE loss launch (cms_consistency_fwd_bwd): returns the same
+    scalars and ADDS d unsup_loss / d l_stu to `grad_out` (f32 (N,C,h,w), its rows must be ZERO on entry: the deferred scalar factor
+    -- the confidence rate of the default mode, in which the gradient is linear -- is applied to the rows afterwards). Falls back to
+    the two launches where the fused one does not exist (identity geometry, deterministic mode, CMS_LOSS_FUSED=0)."""
+    _need_cuda(l_stu, l_tea0, l_tea1, ranges, mask, um0, um1, grad_out)
+    l_stu, l_tea0, l_tea1 = _f32c(l_stu), _f32c(l_tea0), _f32c(l_tea1)
+    mask, um0, um1 = _f32c(mask), _f32c(um0), _f32c(um1)
+    if l_tea0.shape != l_stu.shape or (l_tea1 is not None and l_tea1.shape != l_stu.shape):
+        raise ValueError('consistency: student / teacher logits shapes differ')
+    if grad_out.dtype != torch.float32 or tuple(grad_out.shape) != tuple(l_stu.shape) or not grad_out.is_contiguous():
+        raise ValueError('consistency_fused: grad_out must be a contiguous f32 tensor of the logits\' shape')
+    d = _cons_desc(cfg, l_stu, l_tea0, l_tea1, ranges, mask, um0, um1, out_size)
+    if not fn['cms_consistency_fused_supported'](C.byref(d)):
+        sc, cctx = consistency_forward(cfg, l_stu, l_tea0, l_tea1, out_size, ranges, mask, um0, um1, ramp_val, cons_weight, group,
+                                       sync_conf_rate)
+        consistency_backward(cctx, sc, grad_out)
+        return sc
+    dev = l_stu.device
+    ws = torch.empty(max(int(fn['cms_consistency_workspace_bytes'](C.byref(d))), 16), dtype=torch.uint8, device=dev)
+    stats = torch.empty(4, dtype=torch.float64, device=dev)
+    P = float(d.n) * float(d.H) * float(d.W)
+    grad_unit = float(ramp_val) * float(cons_weight) / P
+    check(fn['cms_consistency_fwd_bwd'](C.byref(d), grad_unit, _ptr(ws), _ptr(stats), _ptr(grad_out), _stream()),
+          'cms_consistency_fwd_bwd')
+    stats_g = stats
+    if sync_conf_rate and cfg.conf_thresh > 0.0:
+        g = stats.clone()
+        if _allreduce_sum(g, group):
+            stats_g = g
+    scalars = torch.empty(4, dtype=torch.float32, device=dev)
+    check(fn['cms_consistency_finalize'](_ptr(stats), _ptr(stats_g), cfg.conf_thresh, int(cfg.conf_per_pixel),
+                                         float(ramp_val), float(cons_weight), _ptr(scalars), _stream()),
+          'cms_consistency_finalize')
+    if cfg.conf_thresh > 0.0 and not cfg.conf_per_pixel:
+        # default confidence mode (:415-418): the loss mask is the scalar RATE -- the factor the launch above left out
+        check(fn['cms_scale_by_scalar'](_ptr(grad_out), grad_out.numel(), _ptr(scalars), 1, 1.0, _stream()), 'cms_scale_by_scalar')
+    return scalars
+
+
 class _ConsistencyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, l_stu, l_tea0, l_tea1, ranges, mask, um0, um1, cfg, out_size, ramp_val, cons_weight, group):
@@ -265,6 +306,42 @@ def ce_forward(logits, labels, out_size=None, ignore_index=255, align_corners=Tr
     scalars = torch.empty(2, dtype=torch.float32, device=dev)
     check(fn['cms_ce_finalize'](_ptr(stats), float(loss_weight), _ptr(scalars), _stream()), 'cms_ce_finalize')
     return scalars, (d, (logits, labels), stats)
+
+
+def ce_fused(logits, labels, grad_out, out_size=None, ignore_index=255, align_corners=True, loss_weight=1.0, group=None,
+             sync_count=False):
+    """(round 6) `ce_forward` + `ce_backward` as ONE loss launch (cms_ce_fwd_bwd): returns the scalars f32[2] = [loss, grad_scale]
+    and ADDS the gradient to `grad_out` (f32 (N,C,h,w), rows ZERO on entry: the factor loss_weight / count is applied afterwards)."""
+    _need_cuda(logits, labels, grad_out)
+    logits = _f32c(logits)
+    labels = labels.contiguous()
+    if labels.dim() == 4:
+        labels = labels[:, 0].contiguous()
+    if out_size is None:
+        out_size = labels.shape[1:3]
+    if tuple(labels.shape) != (logits.shape[0], int(out_size[0]), int(out_size[1])):
+        raise ValueError('ce: labels shape {} does not match (N,H,W)=({}, {}, {})'.format(
+            tuple(labels.shape), logits.shape[0], out_size[0], out_size[1]))
+    if grad_out.dtype != torch.float32 or tuple(grad_out.shape) != tuple(logits.shape) or not grad_out.is_contiguous():
+        raise ValueError('ce_fused: grad_out must be a contiguous f32 tensor of the logits\' shape')
+    d = _ce_desc(logits, labels, ignore_index, out_size, align_corners)
+    if not fn['cms_ce_fused_supported'](C.byref(d)):
+        sc, cctx = ce_forward(logits, labels, out_size, ignore_index, align_corners, loss_weight, group, sync_count)
+        ce_backward(cctx, sc, grad_out)
+        return sc
+    dev = logits.device
+    ws = torch.empty(max(int(fn['cms_ce_workspace_bytes'](C.byref(d))), 16), dtype=torch.uint8, device=dev)
+    stats = torch.empty(2, dtype=torch.float64, device=dev)
+    check(fn['cms_ce_fwd_bwd'](C.byref(d), _ptr(ws), _ptr(stats), _ptr(grad_out), _stream()), 'cms_ce_fwd_bwd')
+    if sync_count:
+        import torch.distributed as dist
+        cnt = stats[1:2].clone()
+        if _allreduce_sum(cnt, group):
+            stats = torch.stack([stats[0], cnt[0] / dist.get_world_size(group)])
+    scalars = torch.empty(2, dtype=torch.float32, device=dev)
+    check(fn['cms_ce_finalize'](_ptr(stats), float(loss_weight), _ptr(scalars), _stream()), 'cms_ce_finalize')
+    check(fn['cms_scale_by_scalar'](_ptr(grad_out), grad_out.numel(), _ptr(scalars), 1, 1.0, _stream()), 'cms_scale_by_scalar')
+    return scalars
 
 
 def ce_backward(ctx, scalars, grad_out=None):

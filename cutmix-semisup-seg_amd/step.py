@@ -73,6 +73,9 @@ class StepConfig(object):
         # (measured: 626.1 vs 629.2 img/s at cfg 2, 134.2 vs 134.9 at cfg 3 WITHOUT it, profiles/r05f_*: the two halves slow each other
         # and the cross entropy down by more than the overlap buys -- off; CMS_SPLIT_CONS_BWD=1 switches it on)
         self.split_cons_bwd = os.environ.get('CMS_SPLIT_CONS_BWD', '0') not in ('0', '')
+        # (round 6) each loss as ONE launch (forward + backward, the gradient's scalar factor applied afterwards: ops.consistency_fused
+        # / ops.ce_fused) in the fused-batch step; CMS_FUSED_LOSSES=0 = the forward / backward launch pairs of rounds 1-5 (A/B)
+        self.fused_losses = os.environ.get('CMS_FUSED_LOSSES', '1') != '0'
         self.compute_dtype = compute_dtype
         self.cons = ops.ConsistencyConfig(mode='mix' if self.mix else 'cut', loss_fn=cons_loss_fn,
                                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, invert=invert)
@@ -462,6 +465,16 @@ class CutMixMeanTeacherStep(object):
                     l0 = tea_lo[t_off:t_off + n]
                     l1 = tea_lo[t_off + n:t_off + 2 * n] if cfg.mix else None
                     t_off += 2 * n if cfg.mix else n
+                    if self.cfg.fused_losses and not (split and self.cfg.split_cons_bwd and n >= 2):
+                        # (round 6) loss + gradient in ONE launch; grad_lo's rows are zero here (filled above, disjoint per branch)
+                        sc = ops.consistency_fused(cfg.cons, lo_det[s_off:s_off + n], l0, l1, out_size, grad_lo[s_off:s_off + n],
+                                                   ranges=ub.ranges, um0=ub.um0, um1=ub.um1, ramp_val=ramp,
+                                                   cons_weight=cfg.cons_weight, group=self.group)
+                        s_off += n
+                        if split and isinstance(sc, torch.Tensor):
+                            sc.record_stream(main)
+                        cons_vals.append(sc)
+                        continue
                     sc, cctx = ops.consistency_forward(cfg.cons, lo_det[s_off:s_off + n], l0, l1, out_size,
                                                        ranges=ub.ranges, um0=ub.um0, um1=ub.um1, ramp_val=ramp,
                                                        cons_weight=cfg.cons_weight, group=self.group)
@@ -479,8 +492,11 @@ class CutMixMeanTeacherStep(object):
             if split:
                 with torch.cuda.stream(side):
                     consistency_branch()
-            ce_sc, ce_ctx = ops.ce_forward(lo_det[:n_sup], sup_y, out_size, 255, self.align_corners, group=self.group)
-            ops.ce_backward(ce_ctx, ce_sc, grad_lo[:n_sup])
+            if self.cfg.fused_losses:
+                ce_sc = ops.ce_fused(lo_det[:n_sup], sup_y, grad_lo[:n_sup], out_size, 255, self.align_corners, group=self.group)
+            else:
+                ce_sc, ce_ctx = ops.ce_forward(lo_det[:n_sup], sup_y, out_size, 255, self.align_corners, group=self.group)
+                ops.ce_backward(ce_ctx, ce_sc, grad_lo[:n_sup])
             for cctx, sc, rows, rng_, ev in deferred:
                 main.wait_event(ev)
                 ops.consistency_backward(cctx, sc, rows, samples=rng_)

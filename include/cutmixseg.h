@@ -116,6 +116,21 @@ int cms_consistency_finalize(const double* stats_local, const double* stats_glob
 /* grad_l_stu f32 (N,C,h,w) += d unsup_loss / d l_stu (caller zero-fills when it wants `=`); reads scalars[2] */
 int cms_consistency_bwd(const cms_consistency_desc* d, const float* scalars, float* grad_l_stu, void* stream);
 
+/* (round 6) Forward AND backward in one launch (train_seg_semisup_mask_mt.py:363-367, 407-459 and their autograd twins). The
+ * backward pass needs ONE scalar of the forward pass -- the confidence rate of the default mode (:415-418) -- and is linear in
+ * it: this launch writes stats_out (as cms_consistency_fwd) and ADDS to grad_l_stu the gradient with that scalar left out,
+ *     grad_unit * um * [conf >= thresh, --conf_per_pixel only] * d per-pixel loss / d l_stu,   grad_unit = ramp * weight / (N*H*W);
+ * behind cms_consistency_finalize the caller multiplies the rows by the rate (default mode with a threshold only):
+ *     cms_scale_by_scalar(grad_l_stu, n*c*h*w, scalars, 1, 1.0f, stream).
+ * So grad_l_stu must hold nothing else yet (zero-filled rows). cms_consistency_fused_supported: 1 when the launch exists for
+ * the descriptor (an upsampling geometry whose tile rectangles fit the LDS, not the deterministic mode); the workspace is
+ * cms_consistency_workspace_bytes as before. CMS_LOSS_FUSED=0 in the environment switches both fused launches off. */
+int cms_consistency_fused_supported(const cms_consistency_desc* d);
+int cms_consistency_fwd_bwd(const cms_consistency_desc* d, float grad_unit, void* workspace, double* stats_out,
+                            float* grad_l_stu, void* stream);
+/* x[i] *= scalars[index] * factor, i < n: the deferred scalar factor of the fused loss launches (a device scalar, no host sync) */
+int cms_scale_by_scalar(float* x, long long n, const float* scalars, int index, float factor, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Supervised cross entropy, fused: bilinear upsample + log-softmax + NLL(ignore_index)
  *                               (nn.CrossEntropyLoss(ignore_index=255), train_seg_semisup_mask_mt.py:126, 299-301)
@@ -135,6 +150,11 @@ int cms_ce_fwd(const cms_ce_desc* d, void* workspace, double* stats_out, void* s
  * stats */
 int cms_ce_finalize(const double* stats, float loss_weight, float* scalars_out, void* stream);
 int cms_ce_bwd(const cms_ce_desc* d, const float* scalars, float* grad_logits, void* stream);
+/* (round 6) forward AND backward in one launch (autograd of :126, 299-301): stats_out as cms_ce_fwd; grad_logits += (softmax -
+ * onehot) of every valid pixel through the adjoint of the upsample, WITHOUT the factor loss_weight / count -- behind
+ * cms_ce_finalize: cms_scale_by_scalar(grad_logits, n*c*h*w, scalars, 1, 1.0f, stream). Rows must be zero on entry. */
+int cms_ce_fused_supported(const cms_ce_desc* d);
+int cms_ce_fwd_bwd(const cms_ce_desc* d, void* workspace, double* stats_out, float* grad_logits, void* stream);
 /* The backward kernels of both losses scatter through tiles that share low-resolution cells with their neighbours. on = 1:
  * the tiles are issued as colour classes that never share a cell (four launches, run-to-run reproducible gradients -- what
  * `--deterministic` asks for); 0 (default; CMS_LOSS_DETERMINISTIC=1 in the environment flips it): one launch, fp32 atomics in a

@@ -716,3 +716,118 @@ def test_loss_backward_one_launch_equals_colour_classes(ops):
         fn['cms_loss_set_deterministic'](1 if ops.deterministic_wgrad() else 0)
     assert float((c1 - a1).abs().max()) <= 1e-6 * float(a1.abs().max())
     assert float((c2 - a2).abs().max()) <= 1e-6 * float(a2.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 6: each loss as ONE launch (forward + backward; the gradient's scalar factor applied afterwards)
+@pytest.mark.parametrize('geo', [
+    dict(N=2, C=5, h=6, w=7, H=41, W=50, ac=True),
+    dict(N=2, C=21, h=41, w=41, H=321, W=321, ac=True),       # cfg 2 geometry (Pascal crop)
+    dict(N=1, C=19, h=65, w=129, H=512, W=1024, ac=True),     # cfg 3 geometry (Cityscapes)
+    dict(N=2, C=7, h=9, w=9, H=33, W=33, ac=False),           # generic class count, align_corners=False
+])
+@pytest.mark.parametrize('fn,mode,tau,pp', [('var', 'mix', 0.5, False), ('var', 'mix', 0.6, True),
+                                            ('kld', 'cut', 0.5, True), ('bce', 'mix', 0.0, False),
+                                            ('logits_var', 'cut', 0.0, False), ('logits_smoothl1', 'mix', 0.4, True)])
+def test_consistency_one_launch_vs_oracle_and_vs_the_launch_pair(ops, geo, fn, mode, tau, pp):
+    """ops.consistency_fused (cms_consistency_fwd_bwd + finalize + deferred rate) against the oracle's autograd (the bounds of
+    test_consistency_fused_upsample_vs_oracle) and against the forward / backward launch pair: same scalars to 1e-6 (the partial
+    sums meet in another order), same gradient to 2e-6 of its scale (rate applied after the adjoint sums instead of before)."""
+    from oracle import boxmask, losses as olosses
+    from cutmix_semisup_seg_amd._lib import fn as cfn
+    N, C, h, w, H, W, ac = (geo[k] for k in ('N', 'C', 'h', 'w', 'H', 'W', 'ac'))
+    gen = torch.Generator().manual_seed(C * H + w + 1)
+    ls = torch.randn(N, C, h, w, generator=gen) * 2
+    l0 = torch.randn(N, C, h, w, generator=gen) * 3
+    l1 = torch.randn(N, C, h, w, generator=gen) * 3
+    um0 = (torch.rand(N, 1, H, W, generator=gen) > 0.2).float()
+    um1 = (torch.rand(N, 1, H, W, generator=gen) > 0.2).float()
+    ranges = boxmask.rects_to_ranges(boxmask.draw_rects(N, (H, W), 0.5, rng=np.random.RandomState(5)), (H, W))
+    m = torch.tensor(boxmask.rasterise(ranges, (H, W), True).astype(np.float32))
+    ls_o = ls.clone().requires_grad_(True)
+    up = lambda t: olosses.upsample(t, (H, W), align_corners=ac)
+    kw = dict(loss_fn=fn, conf_thresh=tau, conf_per_pixel=pp, cons_weight=0.7)
+    r = (olosses.mix_mode_loss(up(ls_o), up(l0), up(l1), m, um0, um1, **kw) if mode == 'mix'
+         else olosses.cut_mode_loss(up(ls_o), up(l0), m, um0, **kw))
+    r['unsup_loss'].backward()
+    cfg = ops.ConsistencyConfig(mode=mode, loss_fn=fn, conf_thresh=tau, conf_per_pixel=pp, align_corners=ac)
+    args = (cfg, cu(ls), cu(l0), cu(l1) if mode == 'mix' else None, (H, W))
+    kwd = dict(ranges=ops.ranges_to_device(ranges, DEV), um0=cu(um0), um1=cu(um1), ramp_val=0.9, cons_weight=0.7)
+    d = ops._cons_desc(cfg, args[1], args[2], args[3], kwd['ranges'], None, kwd['um0'], kwd['um1'], (H, W))
+    import ctypes
+    assert cfn['cms_consistency_fused_supported'](ctypes.byref(d)) == 1
+    g_one = torch.zeros(N, C, h, w, device=DEV)
+    sc_one = ops.consistency_fused(*args, g_one, **kwd)
+    sc_two, ctx = ops.consistency_forward(*args, **kwd)
+    g_two = ops.consistency_backward(ctx, sc_two)
+    torch.cuda.synchronize()
+    a, b = sc_one.cpu().numpy(), sc_two.cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-12, equal_nan=True)
+    scale = float(g_two.abs().max())
+    assert float((g_one - g_two).abs().max()) <= 2e-6 * scale + 1e-12, (float((g_one - g_two).abs().max()), scale)
+    # oracle (ramp 1.0 there: the device ran with ramp_val 0.9, a plain factor of loss and gradient)
+    assert float(sc_one[3]) == pytest.approx(0.9 * float(r['unsup_loss'].detach()), rel=1e-4, abs=1e-9)
+    if tau > 0:
+        assert float(sc_one[1]) == pytest.approx(float(r['conf_rate']), abs=3.0 / (N * H * W))
+    want = 0.9 * ls_o.grad.numpy()
+    np.testing.assert_allclose(g_one.cpu().numpy(), want, rtol=2e-3, atol=3e-5 * np.abs(want).max())
+
+
+@pytest.mark.parametrize('geo', [dict(N=2, C=21, h=41, w=41, H=321, W=321, ac=True),
+                                 dict(N=1, C=19, h=65, w=129, H=512, W=1024, ac=True),
+                                 dict(N=2, C=6, h=9, w=11, H=40, W=57, ac=False)])
+def test_ce_one_launch_vs_oracle_and_vs_the_launch_pair(ops, geo):
+    from oracle import losses as olosses
+    N, C, h, w, H, W, ac = (geo[k] for k in ('N', 'C', 'h', 'w', 'H', 'W', 'ac'))
+    gen = torch.Generator().manual_seed(6)
+    lo = torch.randn(N, C, h, w, generator=gen) * 2
+    y = torch.randint(0, C, (N, H, W), generator=gen)
+    y[torch.rand(N, H, W, generator=gen) < 0.05] = 255
+    lo_o = lo.clone().requires_grad_(True)
+    ce_o = olosses.supervised_ce(olosses.upsample(lo_o, (H, W), ac), y)
+    ce_o.backward()
+    yd = cu(y).to(torch.uint8)
+    g_one = torch.zeros(N, C, h, w, device=DEV)
+    sc_one = ops.ce_fused(cu(lo), yd, g_one, (H, W), 255, ac)
+    sc_two, ctx = ops.ce_forward(cu(lo), yd, (H, W), 255, ac)
+    g_two = ops.ce_backward(ctx, sc_two)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(sc_one.cpu().numpy(), sc_two.cpu().numpy(), rtol=2e-6)
+    assert float((g_one - g_two).abs().max()) <= 2e-6 * float(g_two.abs().max())
+    assert float(sc_one[0]) == pytest.approx(float(ce_o.detach()), rel=2e-5)
+    want = lo_o.grad.numpy()
+    np.testing.assert_allclose(g_one.cpu().numpy(), want, rtol=2e-3, atol=3e-5 * np.abs(want).max())
+
+
+def test_one_launch_losses_fall_back_where_the_launch_does_not_exist(ops):
+    """Identity geometry (full-resolution logits) and the deterministic mode have no fused launch: the wrappers run the launch pair
+    and give its result exactly (identity) / bit-reproducibly (deterministic)."""
+    from cutmix_semisup_seg_amd._lib import fn as cfn
+    import mask_gen
+    N, C, H, W = 2, 5, 33, 47
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    ls, l0, l1 = (torch.randn(N, C, H, W, generator=gen, device=DEV) for _ in range(3))
+    ranges = ops.ranges_to_device(mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(N, (H, W), rng=np.random.RandomState(2)), DEV)
+    cfg = ops.ConsistencyConfig(mode='mix', loss_fn='var', conf_thresh=0.3)
+    g1 = torch.zeros_like(ls)
+    sc1 = ops.consistency_fused(cfg, ls, l0, l1, (H, W), g1, ranges=ranges)
+    sc2, ctx = ops.consistency_forward(cfg, ls, l0, l1, (H, W), ranges=ranges)
+    g2 = ops.consistency_backward(ctx, sc2)
+    assert torch.equal(sc1, sc2) and torch.equal(g1, g2)
+    # deterministic mode at an upsampling geometry
+    h, w, HH, WW = 9, 9, 65, 65
+    ls, l0, l1 = (torch.randn(N, C, h, w, generator=gen, device=DEV) for _ in range(3))
+    ranges = ops.ranges_to_device(mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(N, (HH, WW), rng=np.random.RandomState(3)), DEV)
+    y = torch.randint(0, C, (N, HH, WW), generator=gen, device=DEV).to(torch.uint8)
+    try:
+        cfn['cms_loss_set_deterministic'](1)
+        outs = []
+        for _ in range(2):
+            ga, gb = torch.zeros_like(ls), torch.zeros_like(ls)
+            sa = ops.consistency_fused(cfg, ls, l0, l1, (HH, WW), ga, ranges=ranges)
+            sb = ops.ce_fused(ls, y, gb, (HH, WW), 255, True)
+            torch.cuda.synchronize()
+            outs.append((sa.clone(), ga.clone(), sb.clone(), gb.clone()))
+        assert all(torch.equal(p, q) for p, q in zip(*outs))
+    finally:
+        cfn['cms_loss_set_deterministic'](1 if ops.deterministic_wgrad() else 0)
