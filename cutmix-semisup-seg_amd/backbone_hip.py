@@ -387,7 +387,8 @@ class DeepLabHipExecutor(object):
         world = ops._world(grp)
         # (round 5) single process, bf16: the convolution's epilogue leaves per-tile channel sums of what it stores and the
         # statistics launch only adds those up -- the pass over u it used to be is gone (cms_conv_desc.stats_out)
-        st = {'groups': G} if (world == 1 and self.dtype == torch.bfloat16 and _fused_bn_stats()) else None
+        # (round 6) under data parallelism too: the tile sums become the per-group sums the ranks all-reduce (below)
+        st = {'groups': G} if (self.dtype == torch.bfloat16 and _fused_bn_stats()) else None
         u = ops.conv_igemm(x, self._w(c), c.taps, stride=c.stride, out_hw=(ho, wo), tile=self._tile(c.cout), stats=st)
         a, bn, C = self.arena, self._bn_module(c), c.cout
         npix = n * ho * wo
@@ -395,7 +396,7 @@ class DeepLabHipExecutor(object):
         bsums = torch.empty(G * 2 * C, dtype=torch.float64, device=dev) if save else None
         mean, rstd, scale, shift = (torch.empty(G * C, dtype=torch.float32, device=dev) for _ in range(4))
         ws = ops.bn_workspace(npix, C, dev, G)      # this unit's: tile counters + partial sums (forward, then backward)
-        if st is not None and st['tile_rows'] > 0:
+        if st is not None and st['tile_rows'] > 0 and world == 1:
             ops.bn_op('finalize_tiles', c=C, dtype=self.dtype, n_pixels=npix, groups=G, eps=bn.eps, momentum=bn.momentum,
                       tile_rows=st['tile_rows'], ws=st['tile_sums'], gamma=a.view(c.bn + '.weight'), beta=a.view(c.bn + '.bias'),
                       mean=mean, rstd=rstd, scale=scale, shift=shift, running_mean=a.view(c.bn + '.running_mean'),
@@ -405,7 +406,13 @@ class DeepLabHipExecutor(object):
             # [G][2][C] doubles between two launches of the recorded pass (a host op of the program) -> the groups finalised in
             # order with the pixel count of ALL ranks. The fused single-process launch ('stats') does the same without the exchange.
             fsums = torch.empty(G * 2 * C, dtype=torch.float64, device=dev)
-            ops.bn_op('reduce', c=C, dtype=self.dtype, n_pixels=npix, groups=G, x=u, sums=fsums, ws=ws)
+            if st is not None and st['tile_rows'] > 0:
+                # (round 6) the convolution's epilogue left per-tile (sum x, sum x^2): added up per group in a fixed order (the
+                # finalising kernel with a `sums` output) instead of a second pass over u
+                ops.bn_op('sums_tiles', c=C, dtype=self.dtype, n_pixels=npix, groups=G, tile_rows=st['tile_rows'],
+                          ws=st['tile_sums'], sums=fsums)
+            else:
+                ops.bn_op('reduce', c=C, dtype=self.dtype, n_pixels=npix, groups=G, x=u, sums=fsums, ws=ws)
             ops.host_call(lambda t=fsums, g_=grp: ops._allreduce_sum(t, g_))
             for g in range(G):
                 sl = slice(g * C, (g + 1) * C)
@@ -432,7 +439,9 @@ class DeepLabHipExecutor(object):
         CMS_BN_BWD_STATS (read per recording): 0 = off, 3 = the wide unit 3 only (default: 329.8 -> 335.1 img/s; every unit: 333 -- for the
         narrow units the finalising launch costs what the reduction it replaces did, profiles/r05u_*), 1 = every unit."""
         mode = os.environ.get('CMS_BN_BWD_STATS', '3')
-        if mode == '0' or (mode == '3' and unit != 3) or self.dtype != torch.bfloat16 or ops._world(self._dist_group()) > 1:
+        # (round 6: under data parallelism too -- xhat uses the unit's GLOBAL mean / rstd, the per-tile sums are local and the
+        # per-group sums they add up to are all-reduced like the reduction kernel's, `_bwd_unit_bn`)
+        if mode == '0' or (mode == '3' and unit != 3) or self.dtype != torch.bfloat16:
             return None
         u, yb, mean, rstd, _sums, _ws, G = s
         if yb is not None and yb.dtype != torch.uint8:
@@ -684,6 +693,16 @@ class DeepLabHipExecutor(object):
         for p in self._programs.values():
             out.append(p)
             out += list(p.bwd.values())
+        return out
+
+    def bn_stat_sources(self):
+        """BatchNorm launches of every recorded program by kind: which route the statistics of the batch-statistics passes took
+        ('finalize_tiles' / 'sums_tiles' = from the convolution epilogues' tile sums; 'stats' / 'reduce' / 'reduce_bwd' = passes over
+        the activations)."""
+        out = {}
+        for p in self.programs():
+            for k, v in getattr(p, 'bn_kinds', {}).items():
+                out[k] = out.get(k, 0) + v
         return out
 
     def _stamp(self, prog):

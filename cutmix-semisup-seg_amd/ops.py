@@ -897,6 +897,7 @@ def bn_op(what, c=0, dtype=None, n_pixels=0, count=0.0, relu=False, eps=1e-5, mo
         if idx < 0:
             check(idx, 'cms_program_add_bn')
         prog.keep += [v for v in t.values() if v is not None]
+        prog.bn_kinds[what] = prog.bn_kinds.get(what, 0) + 1
         return
     g = lambda k: _ptr(t.get(k))
     G = max(1, d.groups)
@@ -1075,6 +1076,7 @@ class Program(object):
         self.head_launches = 0
         self.by_route = {}      # kernel route (cms_conv_igemm_route / 'wgrad8' / 'wgrad128') -> [launches, algorithmic bytes, FLOPs]
         self.n_streams = 1
+        self.bn_kinds = {}      # BatchNorm launches recorded, by kind ('stats', 'finalize_tiles', 'sums_tiles', 'reduce', ...)
         self.host_ops = []      # (op index, stream index, callable): host work between two launches of a replay -- the
                                 # all-reduces of SyncBN statistics (recorded with `host_call`); `run` splits around them
 

@@ -197,7 +197,7 @@ def test_bf16_batch_statistics_iteration_runs_on_the_mfma_engine():
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # Round 4: the batch-statistics passes under DATA PARALLELISM stay on the executor (SyncBN with sample groups)
-def _dp_net(C, layers):
+def _dp_net(C, layers, dtype=torch.float32):
     from architectures import deeplab2
     from oracle import deeplab2 as odl
     g = torch.Generator().manual_seed(77)
@@ -218,7 +218,7 @@ def _dp_net(C, layers):
     net = deeplab2.ResNetDeepLab(deeplab2.Bottleneck, layers, C, np.zeros(3), np.ones(3))
     net.load_state_dict(st)
     net = net.to(DEV)
-    net.compute_dtype = torch.float32
+    net.compute_dtype = dtype
     net.engine_kind = 'hip'
     net.train()                                       # batch statistics
     return net
@@ -246,14 +246,17 @@ def _dp_passes(net, x, wsum, groups, iters=2):
             int(sd['layer2.0.bn1.num_batches_tracked']))
 
 
-def _dp_inputs(C):
+def _dp_inputs(C, big=False):
     g = torch.Generator().manual_seed(9)
-    x = torch.randn(4, 3, 49, 65, generator=g)        # two sample groups of two: [s0 s1 | s2 s3]
-    wsum = torch.randn(4, C, 7, 9, generator=g)
+    # two sample groups of two: [s0 s1 | s2 s3]. `big`: 17 x 21 = 357 low-resolution cells per sample, so that one sample (a rank's
+    # share of a group) is longer than a 256-row convolution tile and the per-tile statistics of the epilogues are taken
+    H, W, h, w = (129, 161, 17, 21) if big else (49, 65, 7, 9)
+    x = torch.randn(4, 3, H, W, generator=g)
+    wsum = torch.randn(4, C, h, w, generator=g)
     return x, wsum
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, bf16=False):
     import os
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -262,47 +265,78 @@ def _dp_worker(rank, world, port, q):
     try:
         torch.cuda.set_device(torch.device(DEV))
         C, layers = 5, [1, 1, 1, 1]
-        net = _dp_net(C, layers)
+        net = _dp_net(C, layers, torch.bfloat16 if bf16 else torch.float32)
         assert net._use_hip_body() and net.supports_sample_groups()        # the executor, not the layer-engine fallback
-        x, wsum = _dp_inputs(C)
+        x, wsum = _dp_inputs(C, big=bf16)
         idx = [rank, 2 + rank]                         # this rank's shard: one sample of EACH group
-        out = _dp_passes(net, x[idx].to(DEV), wsum[idx].to(DEV), groups=2)
+        cast = (lambda t: t.bfloat16()) if bf16 else (lambda t: t)
+        out = _dp_passes(net, cast(x[idx].to(DEV)), wsum[idx].to(DEV), groups=2)
         ex = net._hip_executor
         assert ex is not None and any(p.host_ops for p in ex.programs()), 'the recorded passes carry the SyncBN all-reduces'
+        if bf16:
+            # (round 6) the statistics of these passes come from the convolution epilogues' tile sums, forward AND (unit 3) backward
+            kinds = ex.bn_stat_sources()
+            assert kinds.get('sums_tiles', 0) > 0 and kinds.get('finalize_tiles', 0) == 0, kinds
         q.put((rank,) + out)
     finally:
         dist.destroy_process_group()
 
 
-def test_grouped_syncbn_on_the_executor_two_ranks_equal_one_process_on_the_whole_batch():
+@pytest.mark.parametrize('bf16', [False, True], ids=['fp32', 'bf16_tile_sums'])
+def test_grouped_syncbn_on_the_executor_two_ranks_equal_one_process_on_the_whole_batch(bf16):
     """DeepLab v2 without --freeze_bn under data parallelism ("BN statistics"): two ranks (gloo, both on this
     GPU), each with one sample of each of the two sample groups, run the grouped passes ON THE EXECUTOR -- every unit's
     per-group sums are all-reduced between the reduction and the finalisation, inside the recorded programs -- and must
     reproduce ONE process normalising the whole batch with two groups: same logits for their samples, the same running
-    statistics on both ranks, local weight gradients that add up to the single-process ones."""
+    statistics on both ranks, local weight gradients that add up to the single-process ones.
+    bf16 (round 6): the per-group sums come from the convolution epilogues' per-tile sums (forward) and the
+    data-gradient epilogues' (backward, unit 3) instead of reduction passes over the activations -- the path the single-process
+    run takes since round 5, now under data parallelism too; bounds at the bf16 storage-noise level."""
     import socket
     import torch.multiprocessing as mp
     C, layers = 5, [1, 1, 1, 1]
-    net = _dp_net(C, layers)
-    x, wsum = _dp_inputs(C)
-    want = _dp_passes(net, x.to(DEV), wsum.to(DEV), groups=2)
+    dtype = torch.bfloat16 if bf16 else torch.float32
+    net = _dp_net(C, layers, dtype)
+    x, wsum = _dp_inputs(C, big=bf16)
+    want = _dp_passes(net, x.to(DEV).to(dtype), wsum.to(DEV), groups=2)
+    if bf16:
+        kinds = net._hip_executor.bn_stat_sources()
+        assert kinds.get('finalize_tiles', 0) > 0, kinds                  # single process: the tile sums finalised directly
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, bf16)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / (np.linalg.norm(b) + 1e-30))
     for r in (0, 1):
-        np.testing.assert_allclose(res[r][1], want[0][[r, 2 + r]], rtol=2e-4, atol=2e-5)          # logits of the rank's samples
-        for a, b in zip(res[r][3], want[2]):                                                       # global running statistics
-            np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+        if bf16:
+            assert rel(res[r][1], want[0][[r, 2 + r]]) <= 3e-2
+            for a, b in zip(res[r][3], want[2]):
+                np.testing.assert_allclose(a, b, rtol=2e-2, atol=2e-3)
+        else:
+            np.testing.assert_allclose(res[r][1], want[0][[r, 2 + r]], rtol=2e-4, atol=2e-5)      # logits of the rank's samples
+            for a, b in zip(res[r][3], want[2]):                                                   # global running statistics
+                np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
         assert res[r][4] == want[3] == 4                                                            # 2 groups x 2 passes
-    for g0, g1, gw in zip(res[0][2], res[1][2], want[1]):                                           # local gradients add up
-        np.testing.assert_allclose(g0 + g1, gw, rtol=2e-3, atol=2e-4 * float(np.abs(gw).max()))
+    if bf16:
+        print('\nPARITY two-rank bf16 SyncBN from tile sums vs one process: logits {} running statistics {} gradients {}'.format(
+            [round(rel(res[r][1], want[0][[r, 2 + r]]), 5) for r in (0, 1)],
+            [round(rel(a, b), 6) for a, b in zip(res[0][3], want[2])],
+            [round(rel(g0 + g1, gw), 4) for g0, g1, gw in zip(res[0][2], res[1][2], want[1])]))
+    for gi, (g0, g1, gw) in enumerate(zip(res[0][2], res[1][2], want[1])):                          # local gradients add up
+        if bf16:
+            # two bf16 pipelines whose statistics differ in the last bits are one storage-noise sample apart (DESIGN 2.1): measured
+            # 0.111 / 0.108 / 0.0076 (layer1.0.conv1 / layer3.0.conv2 / head) -- and the SAME with the reduction kernels instead
+            # of the tile sums (CMS_BN_BWD_STATS=0: 0.110 / 0.108 / 0.0076, profiles/r06g_*): the route is not what separates them.
+            # For scale: a bf16 pass against its own fp32 twin is 0.13 apart on these layers (tests/test_gpu_executor.py)
+            assert rel(g0 + g1, gw) <= (2e-2 if gi == 2 else 0.2), (gi, rel(g0 + g1, gw))
+        else:
+            np.testing.assert_allclose(g0 + g1, gw, rtol=2e-3, atol=2e-4 * float(np.abs(gw).max()))
