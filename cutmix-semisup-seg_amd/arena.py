@@ -66,6 +66,11 @@ class ParamArena(object):
                                          bool(key in params and params[key].requires_grad)))
             off += (cnt + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
+        # bumped by everything of this package that writes the weights (fused optimizer / EMA steps, refresh_bf16 behind
+        # load_state_dict): derived operands cached per layer (zero-padded weights, transposed data-gradient operands of the general
+        # convolution path, backbone_hip._HipConvGeneralFn) are valid for one version
+        self.version = 0
+        self.derived = {}            # (key, what, dtype) -> (version, tensor)
         self._params = None          # [(segment, parameter)] of the trainable segments, built on first use
         self.by_key = {s.key: s for s in self.segments}
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
@@ -96,8 +101,23 @@ class ParamArena(object):
         return buf[s.offset:s.offset + s.count].view(kh * kw, co, ci)
 
     def refresh_bf16(self):
+        self.version += 1
         if self.bf16 is not None:
             self.bf16.copy_(self.flat)
+
+    def touch(self):
+        """The weights were written (optimizer / EMA step): cached derived operands are stale."""
+        self.version += 1
+
+    def cached(self, key, what, dtype, make):
+        """`make()` once per weight version: a derived operand of layer `key` (padded / transposed copies)."""
+        k = (key, what, dtype)
+        hit = self.derived.get(k)
+        if hit is not None and hit[0] == self.version:
+            return hit[1]
+        t = make()
+        self.derived[k] = (self.version, t)
+        return t
 
     def zero_grad(self):
         if self.grad is not None:

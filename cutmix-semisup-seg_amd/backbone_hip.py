@@ -609,7 +609,17 @@ class DeepLabHipExecutor(object):
         w = self.__dict__.get('_stem_param')
         if w is None:                     # (a walk over all named parameters: once, not per pass)
             w = self.__dict__['_stem_param'] = dict(self.net.named_parameters())[self.stem_wkey]
-        return _StemFn.apply(x.contiguous(), w, self)
+        # `save` of the body pass this stem feeds (run_body / run_body_pair decide the same way): its recorded program's input buffer
+        # is where the pooled map is written (CMS_STEM_DIRECT=0: a new tensor + a copy, as in rounds 2-5)
+        save = (torch.is_grad_enabled() and (self.trainable or x.requires_grad)) if (self.use_programs and _stem_direct()) else None
+        return _StemFn.apply(x.contiguous(), w, self, save)
+
+    def _stem_destination(self, shape, save):
+        """Input buffer of the CACHED forward program for a body input of `shape` (N, h, w, 64), or None (not recorded yet, or a
+        pass the executor runs launch by launch)."""
+        key = ('fwd', tuple(int(v) for v in shape), bool(save), self._tile_key(), self._bn_key())
+        prog = self._programs.get(key)
+        return None if prog is None else prog.x_in
 
     def _prepare_forward(self):
         """Operand tables a forward pass reads (torch ops on the current stream, only when stale)."""
@@ -733,7 +743,8 @@ class DeepLabHipExecutor(object):
             return self.fwd_end(st)
         prog = self.forward_program(x.shape, save)
         self._prepare_forward()
-        prog.x_in.copy_(x)
+        if x.data_ptr() != prog.x_in.data_ptr():
+            prog.x_in.copy_(x)
         prog.run([torch.cuda.current_stream()] + list(getattr(prog, 'extra_streams', [])))
         self._stamp(prog)
         # the logits buffer belongs to the program (the next pass of this shape overwrites it): hand out a copy
@@ -1334,8 +1345,13 @@ class _HipConvGeneralFn(torch.autograd.Function):
         else:
             xh = x.permute(0, 2, 3, 1).contiguous().to(dtype)
         if cpad != cin or opad != cout:
-            wpad = torch.zeros((wp.shape[0], opad, cpad), dtype=dtype, device=x.device)
-            wpad[:, :cout, :cin] = wp
+            # (round 6) the zero-padded operand is made once per weight VERSION, not once per call (two launches per convolution
+            # of DenseNet-161's 48-multiples: the VAT iteration is launch-bound)
+            def _pad():
+                t = torch.zeros((wp.shape[0], opad, cpad), dtype=dtype, device=x.device)
+                t[:, :cout, :cin] = wp
+                return t
+            wpad = arena.cached(key, 'pad', dtype, _pad)
         else:
             wpad = wp
         taps = ops.conv_taps(k, k, dil, pad)
@@ -1346,6 +1362,7 @@ class _HipConvGeneralFn(torch.autograd.Function):
             wc = wpad if (t0 == 0 and t1 == len(taps)) else wpad[t0:t1].contiguous()
             y = ops.conv_igemm(xh, wc, taps[t0:t1], stride=stride, out_hw=(ho, wo), res=y)
         ctx.arena, ctx.key, ctx.geom, ctx.dtype = arena, key, geom, dtype
+        ctx.wversion = arena.version
         ctx.cin, ctx.cout, ctx.in_hw = cin, cout, (h, w)
         ctx.need_w = weight.requires_grad and arena.grad is not None
         ctx.save_for_backward(xh, wpad)
@@ -1369,7 +1386,10 @@ class _HipConvGeneralFn(torch.autograd.Function):
         taps = ops.conv_taps(k, k, dil, pad)
         dx = None
         if ctx.needs_input_grad[0]:
-            wT = ops.conv_pack_transpose(wpad, flip=False, out_dtype=torch.float32 if dtype == torch.float32 else None)
+            mk_T = lambda: ops.conv_pack_transpose(wpad, flip=False, out_dtype=torch.float32 if dtype == torch.float32 else None)
+            # the transposed operand of the weights this pass's FORWARD used: cached while they are still the current version
+            # (the VAT direction pass and the teacher's passes run several backward / forward passes per optimizer step)
+            wT = a.cached(ctx.key, 'padT', dtype, mk_T) if a.version == ctx.wversion else mk_T()
             if stride == 1:
                 dxp = None
                 for t0, t1 in _tap_chunks(ntaps):
@@ -1474,6 +1494,11 @@ def _fused_bn_stats():
     return os.environ.get('CMS_BN_FUSED_STATS', '1') != '0'
 
 
+def _stem_direct():
+    """CMS_STEM_DIRECT (default 1; A/B switch): the stem's max-pool writes into the recorded body pass's input buffer."""
+    return os.environ.get('CMS_STEM_DIRECT', '1') != '0'
+
+
 def _bn_mask_bits():
     """CMS_BN_MASK_BITS (default 1; A/B switch, read per recording): the normalising launch of a batch-statistics unit writes its
     ReLU mask as bits and the unit's backward passes read those instead of y."""
@@ -1495,10 +1520,18 @@ def hip_conv2d_eligible(x, conv, dtype=torch.bfloat16):
 
 class _StemFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, executor):
+    def forward(ctx, x, weight, executor, save=None):
         executor._stem_prepare()
         s = ops.stem_forward(x, executor.stem_w147, executor.stem_scale, executor.stem_bias, executor.dtype)
-        p, idx = ops.maxpool3x3s2_forward(s, ceil_mode=executor.stem_ceil)
+        # (round 6) the pooled map goes STRAIGHT into the input buffer of the recorded body pass that will consume it, when that pass
+        # exists already (every step but the first of a shape): no 17 MB copy per network and step behind the stem
+        dst = None
+        if save is not None:
+            hp, wp = ops._pool_out(int(s.shape[1]), executor.stem_ceil), ops._pool_out(int(s.shape[2]), executor.stem_ceil)
+            dst = executor._stem_destination((int(s.shape[0]), hp, wp, int(s.shape[3])), save)
+        p, idx = ops.maxpool3x3s2_forward(s, ceil_mode=executor.stem_ceil, out=dst)
+        if dst is not None:
+            p = dst.detach()                     # a fresh tensor object over the program's buffer (autograd hangs its node on it)
         ctx.executor = executor
         ctx.x_shape = tuple(x.shape)
         ctx.x_dtype = x.dtype
@@ -1529,7 +1562,7 @@ class _StemFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.stem_dgrad(ds, ex.stem_w147, ex.stem_scale, ctx.x_shape).to(ctx.x_dtype)
-        return dx, None, None
+        return dx, None, None, None
 
 
 class _BodyFn(torch.autograd.Function):
@@ -1562,11 +1595,13 @@ class _BodyPairFn(torch.autograd.Function):
             main = torch.cuda.current_stream()
             ps = ex_stu.forward_program(x_stu.shape, need_grad)
             ex_stu._prepare_forward()
-            ps.x_in.copy_(x_stu)
+            if x_stu.data_ptr() != ps.x_in.data_ptr():           # (the stem wrote there directly: `_StemFn`)
+                ps.x_in.copy_(x_stu)
             with torch.cuda.stream(side):
                 pt = ex_tea.forward_program(x_tea.shape, False)
                 ex_tea._prepare_forward()
-                pt.x_in.copy_(x_tea)
+                if x_tea.data_ptr() != pt.x_in.data_ptr():
+                    pt.x_in.copy_(x_tea)
             if ps.host_ops or pt.host_ops:
                 # SyncBN all-reduces between the launches: the native interleave cannot stop for them -- one pass after the
                 # other (each on its stream; they still overlap where the host runs ahead)

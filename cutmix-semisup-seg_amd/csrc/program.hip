@@ -332,6 +332,24 @@ extern "C" int cms_program_run_pair(cms_program* a, void* const* streams_a, int 
     CMS_REQUIRE(a && b && streams_a && streams_b && na > 0 && nb > 0, "program_run_pair: NULL program / streams");
     size_t ia = 0, ib = 0;
     const size_t ea = a->ops.size(), eb = b->ops.size();
+    // EXPERIMENT (round 6, CMS_PAIR_SYNC=k, read once; 0 = off, the default): every k-th group boundary the FIRST streams of the
+    // two programs wait for each other -- the two passes then walk their bottlenecks in phase (conv1 || conv1, conv2 || conv2,
+    // expansion || expansion: launches of one kind share the machine better than a whole-CU eight-phase launch beside a
+    // four-per-CU expansion). Events come from a small static pool (the pair is issued from one host thread).
+    static int pair_sync = -1;
+    static hipEvent_t sync_ev[64][2];
+    static bool sync_ev_made = false;
+    if (pair_sync < 0) {
+        const char* e = getenv("CMS_PAIR_SYNC");
+        pair_sync = e ? atoi(e) : 0;
+    }
+    if (pair_sync > 0 && !sync_ev_made) {
+        for (auto& pr : sync_ev)
+            for (auto& ev : pr)
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("program_run_pair: event"); return CMS_ELAUNCH; }
+        sync_ev_made = true;
+    }
+    int groups_done = 0, ev_slot = 0;
     while (ia < ea || ib < eb) {
         // next group = the smaller of the two heads' groups (groups are recorded in non-decreasing order)
         const int ga = ia < ea ? a->ops[ia].group : 0x7fffffff;
@@ -346,6 +364,16 @@ extern "C" int cms_program_run_pair(cms_program* a, void* const* streams_a, int 
         while (ib < eb && b->ops[ib].group <= g) {
             const int rc = issue(b, b->ops[ib++], streams_b, nb);
             if (rc != CMS_OK) return rc;
+        }
+        if (pair_sync > 0 && (++groups_done % pair_sync) == 0 && ia < ea && ib < eb) {
+            hipStream_t sa = (hipStream_t)streams_a[0], sb = (hipStream_t)streams_b[0];
+            hipEvent_t* ev = sync_ev[ev_slot];
+            ev_slot = (ev_slot + 1) % 64;
+            if (hipEventRecord(ev[0], sa) != hipSuccess || hipEventRecord(ev[1], sb) != hipSuccess ||
+                hipStreamWaitEvent(sa, ev[1], 0) != hipSuccess || hipStreamWaitEvent(sb, ev[0], 0) != hipSuccess) {
+                set_error("program_run_pair: cross-stream sync failed");
+                return CMS_ELAUNCH;
+            }
         }
     }
     return CMS_OK;

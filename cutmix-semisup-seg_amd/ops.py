@@ -985,12 +985,18 @@ def _pool_out(v, ceil_mode):
     return r - 1 if (r - 1) * 2 >= v + 1 else r
 
 
-def maxpool3x3s2_forward(s, ceil_mode=True):
-    """3x3 / 2 / pad 1 max-pool of an NHWC tensor -> (pooled, argmax uint8)."""
-    _need_cuda(s)
+def maxpool3x3s2_forward(s, ceil_mode=True, out=None):
+    """3x3 / 2 / pad 1 max-pool of an NHWC tensor -> (pooled, argmax uint8). `out`: the pooled tensor's buffer (the persistent
+    input buffer of a recorded body pass: backbone_hip._StemFn), else a new tensor."""
+    _need_cuda(s, out)
     n, hs, ws, c = (int(v) for v in s.shape)
     hp, wp = _pool_out(hs, ceil_mode), _pool_out(ws, ceil_mode)
-    p = torch.empty((n, hp, wp, c), dtype=s.dtype, device=s.device)
+    if out is not None:
+        if tuple(out.shape) != (n, hp, wp, c) or out.dtype != s.dtype or not out.is_contiguous():
+            raise ValueError('maxpool3x3s2_forward: `out` must be a contiguous {} tensor of shape {}'.format(s.dtype, (n, hp, wp, c)))
+        p = out
+    else:
+        p = torch.empty((n, hp, wp, c), dtype=s.dtype, device=s.device)
     idx = torch.empty((n, hp, wp, c), dtype=torch.uint8, device=s.device)
     check(fn['cms_maxpool3x3s2_fwd'](_ptr(s), _ptr(p), _ptr(idx), _dtype_code(s), n, hs, ws, c, int(bool(ceil_mode)),
                                      _stream()), 'cms_maxpool3x3s2_fwd')

@@ -211,6 +211,7 @@ class _FusedOptimizer(object):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(fn['cms_increment_counter'](C.c_void_p(self.step_count.data_ptr()), stream), 'cms_increment_counter')
         from .backbone_hip import executors_of
+        self.arena.touch()
         for ex in executors_of(self.module):
             ex.weights_changed()           # packed backward weights are stale now
         if self._ema is not None:

@@ -50,6 +50,8 @@ class EMAWeightOptimizer(object):
     def _touch_target(self):
         # the teacher's weights (and possibly its BN statistics) moved: packed operands of its executor are stale
         from .backbone_hip import executors_of
+        if getattr(self, 'target_arena', None) is not None:
+            self.target_arena.touch()
         for ex in executors_of(self.target_net):
             ex.weights_changed(bn_too=True)
 

@@ -76,6 +76,8 @@ class StepConfig(object):
         # (round 6) each loss as ONE launch (forward + backward, the gradient's scalar factor applied afterwards: ops.consistency_fused
         # / ops.ce_fused) in the fused-batch step; CMS_FUSED_LOSSES=0 = the forward / backward launch pairs of rounds 1-5 (A/B)
         self.fused_losses = os.environ.get('CMS_FUSED_LOSSES', '1') != '0'
+        # (round 6) the step's gradient clear on the first weight-gradient stream instead of at the head of the main stream (A/B)
+        self.zero_grad_side = os.environ.get('CMS_ZERO_GRAD_SIDE', '1') != '0'
         self.compute_dtype = compute_dtype
         self.cons = ops.ConsistencyConfig(mode='mix' if self.mix else 'cut', loss_fn=cons_loss_fn,
                                           conf_thresh=conf_thresh, conf_per_pixel=conf_per_pixel, invert=invert)
@@ -353,6 +355,26 @@ class CutMixMeanTeacherStep(object):
         self._nan_probe.copy_(sup_loss.reshape(1), non_blocking=True)
         self._nan_event.record()
 
+    def _zero_grad(self, main):
+        """Gradient clear of the step (a 177 MB fill, 36 us): nothing reads or writes the gradient arena before the backward pass,
+        8 ms later, so it goes out on the FIRST WEIGHT-GRADIENT STREAM (idle during the forward passes) instead of in front of the
+        paste / concatenation / stems of the main stream (round 6). Order: the fill waits for the main stream (last
+        step's optimizer has read the gradients), the main stream waits for the fill right before the backward pass -- every
+        gradient writer forks from the main stream behind that point. CMS_ZERO_GRAD_SIDE=0: on the main stream, as in rounds 1-5."""
+        if not self.cfg.zero_grad_side or not torch.cuda.is_available():
+            self.student_optim.zero_grad()
+            return
+        wg = ops.pooled_stream(torch.cuda.current_device(), 'wgrad0')
+        if wg is main:
+            self.student_optim.zero_grad()
+            return
+        wg.wait_stream(main)
+        with torch.cuda.stream(wg):
+            self.student_optim.zero_grad()
+            ev = torch.cuda.Event()
+            ev.record(wg)
+        self.__dict__['_zero_grad_event'] = ev
+
     def _student_inputs(self, ub):
         cfg = self.cfg
         if cfg.mix:
@@ -406,7 +428,7 @@ class CutMixMeanTeacherStep(object):
                     # (round 5) the teacher's inputs are the caller's tensors: its stream forks HERE -- behind last step's optimizer /
                     # EMA writes, in front of this step's gradient clear, paste and concatenation on the main stream, which it does not need
                     side.wait_stream(main)
-                self.student_optim.zero_grad()
+                self._zero_grad(main)
                 for ub in unsup_batches:
                     tea_in.append(ub.x0_tea)
                     if cfg.mix:
@@ -518,6 +540,9 @@ class CutMixMeanTeacherStep(object):
                                                   and hasattr(self.student.hip_executor(), 'join_wgrad')) else None
             if dex is not None:
                 dex.defer_wgrad_join = self.cfg.defer_wgrad_join
+            zev = self.__dict__.pop('_zero_grad_event', None)
+            if zev is not None:
+                main.wait_event(zev)                    # the gradient clear issued on the weight-gradient stream at the head of the step
             try:
                 stu_lo.backward(grad_lo.to(stu_lo.dtype))
             finally:
