@@ -500,6 +500,67 @@ def probe_streams(device=None, again=False):
     return _STREAM_PROBE_LOG[-1] if _STREAM_PROBE_LOG else None
 
 
+_SIDE_WORK = {}     # device index -> side streams holding weight-gradient launches the main stream has not joined yet
+_SIDE_RR = {}       # device index -> round-robin counter over the two weight-gradient streams
+
+
+_SIDE_SLOT = {}     # (device index, layer key) -> 0 / 1: a layer's weight gradients always go to the SAME side stream
+
+
+def layer_wgrad_stream(device, key=None):
+    """(round 6) Stream for ONE weight-gradient launch of the layer engines (backbone_hip._HipConvGeneralFn / _HipClassifierFn: the
+    DeepLab v3+ head, the U-Nets), or None = issue it on the current stream. The autograd backward of those networks used to run
+    data gradient -> weight gradient -> data gradient ... on ONE stream; the head of DeepLab v3+ alone is 10 ms of such a chain per
+    66 ms step with a third of the CUs busy (profiles/r05b_step_timeline_v3plus.txt). Weight gradients feed nothing but the
+    optimizer: they alternate over the two pooled weight-gradient streams, each forked from the current stream here (the operands
+    are ready on it); `join_side_streams` is called by whatever touches the gradient arena next (optimizer launches, gradient
+    clears, the bucketed all-reduce). Off under recording, in the deterministic mode (one shared split-K workspace) and with
+    CMS_LAYER_WGRAD_SIDE=0."""
+    if _REC is not None or _WGRAD_DETERMINISTIC or _os.environ.get('CMS_LAYER_WGRAD_SIDE', '1') == '0':
+        return None
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    # a LAYER keeps its stream (alternating in first-use order): a step with several backward passes (separate passes: cross
+    # entropy, then consistency) adds to the same gradient twice, and the read-modify-write of a padded layer's scratch add is
+    # ordered only within one stream
+    slot = _SIDE_SLOT.get((idx, key))
+    if slot is None:
+        n = _SIDE_RR.get(idx, 0)
+        _SIDE_RR[idx] = n + 1
+        slot = _SIDE_SLOT[(idx, key)] = n & 1
+    st = pooled_stream(dev, 'wgrad{}'.format(slot))
+    cur = torch.cuda.current_stream(idx)
+    if st.cuda_stream == cur.cuda_stream:
+        return None
+    st.wait_stream(cur)
+    pend = _SIDE_WORK.setdefault(idx, [])
+    if not pend:
+        # first side launch of this backward pass: join when the pass ENDS (autograd runs the callback on the thread that called
+        # .backward(), behind the last node), so that whoever reads or updates the gradients afterwards -- this package's fused
+        # optimizers, a torch optimizer, a test -- sees them complete on its stream
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda i=idx: join_side_streams(torch.device('cuda', i)))
+        except RuntimeError:
+            pass                         # (not inside a backward pass: the explicit joins -- optimizer, gradient clear -- remain)
+    if all(p.cuda_stream != st.cuda_stream for p in pend):
+        pend.append(st)
+    return st
+
+
+def join_side_streams(device=None):
+    """The current stream waits for every weight-gradient launch `layer_wgrad_stream` put on a side stream since the last join."""
+    if not _SIDE_WORK:
+        return
+    idx = torch.cuda.current_device() if device is None else (torch.device(device).index if torch.device(device).index is not None
+                                                               else torch.cuda.current_device())
+    pend = _SIDE_WORK.pop(idx, None)
+    if pend:
+        cur = torch.cuda.current_stream(idx)
+        for st in pend:
+            if st.cuda_stream != cur.cuda_stream:
+                cur.wait_stream(st)
+
+
 def pooled_stream(device, role):
     """A process-wide side stream per (device, role): roles 'teacher', 'wgrad0..2', 'side', 'optimizer'. HIP multiplexes its
     streams onto a handful of hardware queues; a process that keeps creating streams (bench.py runs four workloads, a

@@ -23,6 +23,11 @@ from ._lib import fn, check
 from .arena import ensure_arena, build_chunk_table
 
 
+
+def ops_join_side_streams():
+    from . import ops
+    ops.join_side_streams()
+
 class _FusedOptimizer(object):
     KIND = None
     LR_RING = 16
@@ -102,6 +107,7 @@ class _FusedOptimizer(object):
         autograd would create fresh `.grad` tensors outside the arena for the parameters it owns (head, BatchNorm,
         decoder layers) and their updates would be silently lost -- the views are re-homed here, at the start of
         every step, over ALL segments."""
+        ops_join_side_streams()
         self.arena.ensure_grads_attached()
         self.arena.zero_grad()
 
@@ -172,6 +178,7 @@ class _FusedOptimizer(object):
     def _launch(self, first_chunk, n_chunks):
         if n_chunks <= 0:
             return
+        ops_join_side_streams()           # weight gradients the layer engines put on side streams (ops.layer_wgrad_stream)
         d = self._desc()
         self._fill(d)
         d.chunk_seg = self._chunk_seg.data_ptr() + 4 * first_chunk

@@ -129,6 +129,7 @@ class GradBuckets(object):
 
     def _issue(self, lo, hi):
         import torch.distributed as dist
+        ops.join_side_streams()          # weight gradients of the layer engines on side streams (ops.layer_wgrad_stream)
         if self.stage is not None:
             buf = self.stage[lo:hi]
             buf.copy_(self.grad[lo:hi])
@@ -589,6 +590,7 @@ class CutMixMeanTeacherStep(object):
                     ls.backward(ops.consistency_backward(cctx, sc).to(ls.dtype))
                     cons_vals.append(sc)
 
+        ops.join_side_streams()           # weight gradients the layer engines issued on side streams (ops.layer_wgrad_stream)
         self._allreduce_grads()
         if self.__dict__.pop('_early_armed', False):
             torch.cuda.current_stream().wait_stream(self._opt_stream)       # the early slices of this step's update
