@@ -123,6 +123,33 @@ class ASPP(nn.Module):
         self.project = nn.Sequential(nn.Conv2d(len(mods) * out_channels, out_channels, 1, bias=False),
                                      nn.BatchNorm2d(out_channels), nn.ReLU(), nn.Dropout(0.5))
 
+    def _branches(self, xs, convs, eng, on_device):
+        """The 1 x 1 and the three dilated 3 x 3 branches. (round 6) The branches are independent until the concat, and at 33 x 33 a
+        dilated 3 x 3 over 2048 channels is ONE 85-tile launch on 256 CUs (0.9 ms each, forward; 0.65 ms its data gradient): two of
+        the three heavy branches run on the pooled weight-gradient streams (idle in a forward pass), forked from the current
+        stream and joined before the concat. autograd runs a node's backward on the stream its forward ran on, so the branches'
+        backward chains overlap the same way. CMS_ASPP_STREAMS=0: one after the other on the current stream (rounds 1-5)."""
+        import os
+        if not on_device or os.environ.get('CMS_ASPP_STREAMS', '1') == '0' or ops._REC is not None or len(convs) < 3:
+            return [eng.conv_bn_act(xi, m[0], m[1], relu=True) for xi, m in zip(xs, convs)]
+        cur = torch.cuda.current_stream()
+        sides = [ops.pooled_stream(xs[0].device, 'wgrad0'), ops.pooled_stream(xs[0].device, 'wgrad1')]
+        sides = [s for s in sides if s.cuda_stream != cur.cuda_stream]
+        out = [None] * len(convs)
+        for i, (xi, m) in enumerate(zip(xs, convs)):
+            st = sides[(i - 2) % len(sides)] if (i >= 2 and sides) else None      # branches 0 (1 x 1) and 1 stay on the current stream
+            if st is None:
+                out[i] = eng.conv_bn_act(xi, m[0], m[1], relu=True)
+                continue
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                out[i] = eng.conv_bn_act(xi, m[0], m[1], relu=True)
+            xi.record_stream(st)
+            out[i].record_stream(cur)
+        for st in sides:
+            cur.wait_stream(st)
+        return out
+
     def forward(self, x, eng):
         convs = list(self.convs)
         xh = _as_nhwc(x)
@@ -132,7 +159,7 @@ class ASPP(nn.Module):
             xs = [a.permute(0, 3, 1, 2) for a in ops.fanout(xh, len(convs))]
         else:
             xs = [x] * len(convs)
-        br = [eng.conv_bn_act(xi, m[0], m[1], relu=True) for xi, m in zip(xs, convs[:-1])]
+        br = self._branches(xs, convs[:-1], eng, xh is not None)
         pool = convs[-1]
         if xh is not None:
             g = ops.global_avg_pool(xs[-1].permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
