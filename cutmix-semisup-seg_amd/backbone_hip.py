@@ -1187,9 +1187,11 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
             if capture is not None:
                 capture[bi] = (dC, dU2, dU1)
             if side is not None:
-                ops.stream_wait(side, main)
+                # `side`: one stream, or (round 6, CMS_V3_WGRAD_STREAMS=2) a list the blocks alternate over
+                sd = side[bi % len(side)] if isinstance(side, (list, tuple)) else side
+                ops.stream_wait(sd, main)
                 keep.append((dC, dU2, dU1))
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(sd):
                     self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
             else:
                 self._block_wgrads(b, dC, dU2, dU1, xin, a1, a2)
@@ -1206,7 +1208,8 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
                     dres.add_(d_low)
             dC = self._dgrad(dU1, b.c1, res=dres, mask=None if bi == 0 else xin, in_hw=in_hw)
         if side is not None:
-            ops.stream_wait(main, side)
+            for sd in (side if isinstance(side, (list, tuple)) else [side]):
+                ops.stream_wait(main, sd)
         del keep
         return dC
 
@@ -1219,6 +1222,8 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
         track_bn = self.bn_trainable
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else None
+        if side is not None and os.environ.get('CMS_V3_WGRAD_STREAMS', '1') == '2':
+            side = [side, ops.pooled_stream(self.arena.device, 'wgrad1')]     # EXPERIMENT: the blocks' weight gradients alternate over two streams
         recorded = isinstance(saved, tuple) and len(saved) == 2 and isinstance(saved[0], ops.Program)
         if not recorded:
             x4 = saved[-1]
@@ -1233,9 +1238,9 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
                                    'same shape through the same executor (programs keep ONE set of buffers per shape): '
                                    'run backward before the next forward, or set executor.use_programs = False')
             x4 = fprog.saved[-1]
-            key = (d_low is not None, track_bn, side is not None)
+            key = (d_low is not None, track_bn, side is not None, isinstance(side, list))
             prog = fprog.bwd.get(key)
-            streams = [main] + ([side] if side is not None else [])
+            streams = [main] + (list(side) if isinstance(side, list) else ([side] if side is not None else []))
             if prog is None:
                 prog = ops.Program()
                 prog.dC_in = torch.empty_like(x4)
