@@ -551,8 +551,9 @@ def join_side_streams(device=None):
     """The current stream waits for every weight-gradient launch `layer_wgrad_stream` put on a side stream since the last join."""
     if not _SIDE_WORK:
         return
-    idx = torch.cuda.current_device() if device is None else (torch.device(device).index if torch.device(device).index is not None
-                                                               else torch.cuda.current_device())
+    idx = None if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
     pend = _SIDE_WORK.pop(idx, None)
     if pend:
         cur = torch.cuda.current_stream(idx)

@@ -23,10 +23,12 @@ from ._lib import fn, check
 from .arena import ensure_arena, build_chunk_table
 
 
-
 def ops_join_side_streams():
+    """Weight gradients the layer engines issued on side streams (ops.layer_wgrad_stream) must have landed before the gradient arena
+    is read or cleared on the current stream."""
     from . import ops
     ops.join_side_streams()
+
 
 class _FusedOptimizer(object):
     KIND = None
