@@ -377,7 +377,6 @@ struct TileTables {
     float xw1[TILE_W];
     int yi0[TILE_H], yi1[TILE_H];
     float yw1[TILE_H];
-    int x_lo, n_cols, y_lo, n_rows;
     int xbeg[TILE_W + 2], xend[TILE_W + 2];
 };
 
@@ -421,35 +420,53 @@ __device__ __forceinline__ void tiled_scatter(const Geo& g, Stage stage, PixelGr
         tb.yw1[r] = t.w1;
     }
     __syncthreads();
-    if (tid == 0) {
-        tb.x_lo = tb.xi0[0];
-        tb.n_cols = tb.xi1[tw - 1] - tb.xi0[0] + 1;
-        tb.y_lo = tb.yi0[0];
-        tb.n_rows = tb.yi1[th - 1] - tb.yi0[0] + 1;
+    // the tile's rectangle of low-resolution cells: every thread reads it off the tables (four broadcast LDS reads) -- no
+    // single-thread section and no second barrier in front of the staging (round 6)
+    const int r_x_lo = tb.xi0[0], r_n_cols = tb.xi1[tw - 1] - r_x_lo + 1;
+    const int r_y_lo = tb.yi0[0], r_n_rows = tb.yi1[th - 1] - r_y_lo + 1;
+    // contiguous range [xbeg, xend) of tile columns that touch low-res column x_lo + j (i0 is monotone in x). (round 6) every tile
+    // column reports itself to its two cells with LDS atomics -- one step for 64 lanes -- instead of n_cols lanes scanning all 64
+    // columns in a dependent loop while the other three waves of the workgroup wait (same table, bit-identical results)
+    if (tid < r_n_cols) {
+        tb.xbeg[tid] = tw;
+        tb.xend[tid] = 0;
     }
     __syncthreads();
-    if (tid < tb.n_cols) {
-        // contiguous range of tile columns that touch low-res column x_lo + tid (i0 is monotone in x)
-        const int X = tb.x_lo + tid;
-        int lo = tw, hi = 0;
-        for (int c = 0; c < tw; ++c) {
-            if (tb.xi0[c] == X || tb.xi1[c] == X) {
-                lo = min(lo, c);
-                hi = c + 1;
-            }
-        }
-        tb.xbeg[tid] = lo;
-        tb.xend[tid] = hi;
+    if (tid < tw) {
+        const int j0 = tb.xi0[tid] - r_x_lo, j1 = tb.xi1[tid] - r_x_lo;
+        atomicMin(&tb.xbeg[j0], tid);
+        atomicMax(&tb.xend[j0], tid + 1);
+        atomicMin(&tb.xbeg[j1], tid);
+        atomicMax(&tb.xend[j1], tid + 1);
     }
 
     float* G = smem;                                 // [TILE_H][C][G_LD]
     float* R = smem + (size_t)TILE_H * C * G_LD;     // [TILE_H][C][n_cols]
     // (round 5) phase 0: the tile's rectangle of every logit tensor -> LDS behind G and R; phase 1 gathers from there
     Patch patch;
-    patch.x_lo = tb.x_lo; patch.n_cols = tb.n_cols; patch.y_lo = tb.y_lo; patch.n_rows = tb.n_rows;
-    float* P = R + (size_t)TILE_H * C * tb.n_cols;
+    patch.x_lo = r_x_lo; patch.n_cols = r_n_cols; patch.y_lo = r_y_lo; patch.n_rows = r_n_rows;
+    float* P = R + (size_t)TILE_H * C * r_n_cols;
     stage(n, patch, P);
-    __syncthreads();
+    // (round 6) x-adjoint weights as a table: wtab[j][u] = weight of tile column xbeg[j] + u in low-res column j -- phase 2's inner
+    // loop is then two LDS reads and an FMA per term instead of three table reads, two compares and two selects (same values, same
+    // order: bit-identical). Small tables only (the DeepLab scales: 11-19 columns, <= 18 terms); otherwise the comparing loop.
+    constexpr int WT_COLS = 24, WT_SPAN = 20;
+    __shared__ float wtab[WT_COLS * WT_SPAN];
+    const bool wide = tid < r_n_cols && (tb.xend[tid] - tb.xbeg[tid]) > WT_SPAN;
+    const bool table = __syncthreads_or(wide ? 1 : 0) == 0 && r_n_cols <= WT_COLS;      // (also the barrier behind the staging)
+    if (table) {
+        for (int e = tid; e < r_n_cols * WT_SPAN; e += blockDim.x) {
+            const int j = e / WT_SPAN, u = e - j * WT_SPAN;
+            const int c = tb.xbeg[j] + u;
+            float wv = 0.0f;
+            if (c < tb.xend[j]) {
+                const int X = r_x_lo + j;
+                const float w1 = tb.xw1[c];
+                wv = (tb.xi0[c] == X ? 1.0f - w1 : 0.0f) + (tb.xi1[c] == X ? w1 : 0.0f);
+            }
+            wtab[e] = wv;
+        }
+    }
 
     // phase 1
     const int col = tid & (TILE_W - 1);
@@ -473,20 +490,26 @@ __device__ __forceinline__ void tiled_scatter(const Geo& g, Stage stage, PixelGr
     __syncthreads();
 
     // phase 2: items (row, j, class), class fastest across lanes -> stride G_LD reads, conflict-free
-    const int n_cols = tb.n_cols, n_rows = tb.n_rows;
+    const int n_cols = r_n_cols, n_rows = r_n_rows;
     const int items2 = th * n_cols * C;
     for (int it = tid; it < items2; it += blockDim.x) {
         const int k = it % C;
         const int rj = it / C;
         const int j = rj % n_cols;
         const int row = rj / n_cols;
-        const int X = tb.x_lo + j;
+        const int X = r_x_lo + j;
         const float* gr = G + ((size_t)row * C + k) * G_LD;
         float s = 0.0f;
-        for (int c = tb.xbeg[j]; c < tb.xend[j]; ++c) {
-            const float w1 = tb.xw1[c];
-            float wgt = (tb.xi0[c] == X ? 1.0f - w1 : 0.0f) + (tb.xi1[c] == X ? w1 : 0.0f);
-            s += wgt * gr[c];
+        if (table) {
+            const int cb = tb.xbeg[j], nterm = tb.xend[j] - cb;
+            const float* wt = wtab + j * WT_SPAN;
+            for (int u = 0; u < nterm; ++u) s += wt[u] * gr[cb + u];
+        } else {
+            for (int c = tb.xbeg[j]; c < tb.xend[j]; ++c) {
+                const float w1 = tb.xw1[c];
+                float wgt = (tb.xi0[c] == X ? 1.0f - w1 : 0.0f) + (tb.xi1[c] == X ? w1 : 0.0f);
+                s += wgt * gr[c];
+            }
         }
         R[((size_t)row * C + k) * n_cols + j] = s;
     }
@@ -501,14 +524,14 @@ __device__ __forceinline__ void tiled_scatter(const Geo& g, Stage stage, PixelGr
         const int ki = it / n_cols;
         const int i = ki % n_rows;
         const int k = ki / n_rows;
-        const int Y = tb.y_lo + i;
+        const int Y = r_y_lo + i;
         float s = 0.0f;
         for (int row = 0; row < th; ++row) {
             const float w1 = tb.yw1[row];
             float wgt = (tb.yi0[row] == Y ? 1.0f - w1 : 0.0f) + (tb.yi1[row] == Y ? w1 : 0.0f);
             s += wgt * R[((size_t)row * C + k) * n_cols + j];
         }
-        if (s != 0.0f) atomicAdd(out_n + (size_t)k * plane + (size_t)Y * g.w + (tb.x_lo + j), s);
+        if (s != 0.0f) atomicAdd(out_n + (size_t)k * plane + (size_t)Y * g.w + (r_x_lo + j), s);
     }
 }
 
