@@ -170,6 +170,7 @@ PROTOTYPES = {
     'cms_conv_wgrad_group_run': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     'cms_conv_pack_transpose': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'cms_conv_pack_transpose_batch': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    'cms_conv_pack_transpose_batch64': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'cms_augment_batch': (c_int, [_P(AugmentDesc), c_void_p]),
     'cms_augment_luma': (c_int, [_P(AugmentDesc), c_void_p, c_void_p]),
     'cms_bn_reduce': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,

@@ -1115,6 +1115,56 @@ __global__ __launch_bounds__(256) void pack_transpose_batch_kernel(const cms_pac
     }
 }
 
+// (round 6) The same for tensors whose channel counts are multiples of 64 (every body convolution of the DeepLab networks + the
+// head's stacked operand), bf16 -> bf16: a 64 x 64 tile per workgroup, 16-byte global accesses on both sides (8 lanes = one 128-byte
+// row segment; the 32 x 32 kernel above moves 2 bytes per lane in 64-byte segments: 166 us for the 170 MB of a ResNet-101 at 1 TB/s,
+// on the critical path between the losses and the backward pass once the loss kernels got shorter). Padded fp32 LDS tile, the
+// classic two-way-conflict transpose. first_block counts 64 x 64 tiles here.
+__global__ __launch_bounds__(256) void pack_transpose_batch64_kernel(const cms_pack_item* __restrict__ items, int n_items) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = n_items - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                                   // last item with first_block <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const cms_pack_item it = items[lo];
+    const int Cout = it.cout, Cin = it.cin;
+    const int nbx = Cin >> 6, nby = Cout >> 6;
+    int r0 = b - it.first_block;
+    const int bx = r0 % nbx; r0 /= nbx;
+    const int by = r0 % nby;
+    const int tap = r0 / nby;
+    const int co0 = by * 64, ci0 = bx * 64;
+    const size_t base = (size_t)tap * Cout * Cin;
+    const uint16_t* src = (const uint16_t*)it.src + base;
+    uint16_t* dst = (uint16_t*)it.dst + base;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int q = (int)threadIdx.x + 256 * p;
+        const int r = q >> 3, c8 = q & 7;               // source row (co), 8-channel chunk of the row (ci)
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)(co0 + r) * Cin + ci0 + c8 * 8);
+        const float sc = it.scale ? it.scale[co0 + r] : 1.0f;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            tile[r][c8 * 8 + 2 * e] = __uint_as_float(w[e] << 16) * sc;
+            tile[r][c8 * 8 + 2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u) * sc;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int q = (int)threadIdx.x + 256 * p;
+        const int ci = q >> 3, c8 = q & 7;              // destination row (ci), 8-channel chunk of the row (co)
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = (uint32_t)f32_to_bf16(tile[c8 * 8 + 2 * e][ci]) | ((uint32_t)f32_to_bf16(tile[c8 * 8 + 2 * e + 1][ci]) << 16);
+        *reinterpret_cast<uint4*>(dst + (size_t)(ci0 + ci) * Cout + co0 + c8 * 8) = uint4{o[0], o[1], o[2], o[3]};
+    }
+}
+
 }  // namespace cms
 
 using namespace cms;
@@ -1539,6 +1589,12 @@ extern "C" int cms_conv_pack_transpose_batch(const cms_pack_item* items_dev, int
     hipLaunchKernelGGL(pack_transpose_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev,
                        n_items, src_dtype == CMS_F32 ? 1 : 0);
     return launch_status("cms_conv_pack_transpose_batch");
+}
+
+extern "C" int cms_conv_pack_transpose_batch64(const cms_pack_item* items_dev, int n_items, int total_blocks, void* stream) {
+    CMS_REQUIRE(items_dev && n_items > 0 && total_blocks > 0, "conv_pack_transpose_batch64: empty table");
+    hipLaunchKernelGGL(pack_transpose_batch64_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
+    return launch_status("cms_conv_pack_transpose_batch64");
 }
 
 // =================================================================================================================

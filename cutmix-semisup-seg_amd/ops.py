@@ -1557,6 +1557,11 @@ class PackTransposePlan(object):
         if ddt not in (torch.bfloat16, torch.float32) or (ddt == torch.float32 and dt != torch.float32):
             raise TypeError('PackTransposePlan: bf16 destinations, or fp32 destinations from fp32 sources')
         self.dst_f32 = ddt == torch.float32
+        # (round 6) 64 x 64 tiles with 16-byte accesses where every tensor allows it (bf16 -> bf16, channel counts % 64 == 0: the
+        # DeepLab bodies); CMS_PACK64=0 keeps the 32 x 32 kernel (A/B)
+        self.tile64 = (dt == torch.bfloat16 and ddt == torch.bfloat16 and _os.environ.get('CMS_PACK64', '1') != '0'
+                       and all(int(s.shape[1]) % 64 == 0 and int(s.shape[2]) % 64 == 0 for s, _, _ in triples))
+        tl = 64 if self.tile64 else 32
         for i, (src, dst, scale) in enumerate(triples):
             _need_cuda(src, dst, scale)
             ntaps, cout, cin = (int(v) for v in src.shape)
@@ -1567,7 +1572,7 @@ class PackTransposePlan(object):
             items[i].src, items[i].dst = src.data_ptr(), dst.data_ptr()
             items[i].scale = scale.data_ptr() if scale is not None else None
             items[i].ntaps, items[i].cout, items[i].cin, items[i].first_block = ntaps, cout, cin, blk
-            blk += ntaps * ((cout + 31) // 32) * ((cin + 31) // 32)
+            blk += ntaps * ((cout + tl - 1) // tl) * ((cin + tl - 1) // tl)
         self.n_items, self.total_blocks = len(triples), blk
         self.dtype_code = _dtype_code(triples[0][0])
         self.table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(triples[0][0].device)
@@ -1576,6 +1581,10 @@ class PackTransposePlan(object):
         if self.dst_f32:
             check(fn['cms_conv_pack_transpose_batch_f32'](_ptr(self.table), self.n_items, self.total_blocks, _stream()),
                   'cms_conv_pack_transpose_batch_f32')
+            return
+        if self.tile64:
+            check(fn['cms_conv_pack_transpose_batch64'](_ptr(self.table), self.n_items, self.total_blocks, _stream()),
+                  'cms_conv_pack_transpose_batch64')
             return
         check(fn['cms_conv_pack_transpose_batch'](_ptr(self.table), self.n_items, self.total_blocks, self.dtype_code,
                                                   _stream()), 'cms_conv_pack_transpose_batch')

@@ -368,6 +368,9 @@ typedef struct cms_pack_item {
 
 int cms_conv_pack_transpose_batch(const cms_pack_item* items_dev, int n_items, int total_blocks, int src_dtype,
                                   void* stream);
+/* (round 6) The same for bf16 sources whose cout AND cin are multiples of 64 (every body convolution of the DeepLab networks):
+ * 64 x 64 tiles, 16-byte accesses on both sides; item i owns blocks [first_block, first_block + ntaps * (cout/64) * (cin/64)). */
+int cms_conv_pack_transpose_batch64(const cms_pack_item* items_dev, int n_items, int total_blocks, void* stream);
 
 /* dW[tap][co][ci] (fp32) += scale[co] * sum over pixels of dU[pix][co] * X[pix shifted by tap][ci]; K = pixels,
  * split across workgroups and accumulated with atomics (zero the gradient buffer once per step). */

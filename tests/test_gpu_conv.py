@@ -429,3 +429,45 @@ def test_relu_mask_bits_written_by_the_forward_launch_and_read_by_the_data_gradi
         assert torch.equal(a, b)
     with pytest.raises(ValueError):
         ops.conv_igemm(du, wT, one, mode=1, mask_src=y, mask_bits=bits)
+
+
+def test_pack_transpose_plan_64_tiles_equal_the_32_tile_kernel_and_torch(monkeypatch):
+    """`ops.PackTransposePlan`: wT[tap][ci][co] = bf16(w[tap][co][ci] * scale[co]) for many tensors in one launch. Round 6: tensors
+    whose channel counts are multiples of 64 go through 64 x 64 tiles with 16-byte accesses (cms_conv_pack_transpose_batch64) -- bit
+    for bit the result of the 32 x 32 kernel and of the same arithmetic in torch; a plan with an unaligned tensor keeps the old kernel."""
+    from cutmix_semisup_seg_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(4)
+    shapes = [(1, 256, 1024), (9, 256, 256), (1, 2048, 512), (1, 384, 2048), (3, 64, 128)]
+
+    def make(shapes_):
+        tr = []
+        for i, (t, co, ci) in enumerate(shapes_):
+            w = torch.randn(t, co, ci, generator=g, device=DEV).bfloat16()
+            sc = (0.5 + torch.rand(co, generator=g, device=DEV)) if i % 2 == 0 else None
+            tr.append((w, torch.zeros(t, ci, co, dtype=torch.bfloat16, device=DEV), sc))
+        return tr
+
+    def want(w, sc):
+        v = w.float() * (sc.view(1, -1, 1) if sc is not None else 1.0)
+        return v.bfloat16().permute(0, 2, 1).contiguous()
+    tr = make(shapes)
+    plan = ops.PackTransposePlan(tr)
+    assert plan.tile64
+    plan.run()
+    out64 = [d.clone() for _, d, _ in tr]
+    for (w, _, sc), o in zip(tr, out64):
+        assert torch.equal(o, want(w, sc))
+    monkeypatch.setenv('CMS_PACK64', '0')
+    for _, d, _ in tr:
+        d.zero_()
+    plan32 = ops.PackTransposePlan(tr)
+    assert not plan32.tile64
+    plan32.run()
+    assert all(torch.equal(d, o) for (_, d, _), o in zip(tr, out64))
+    monkeypatch.delenv('CMS_PACK64')
+    odd = make(shapes[:2] + [(1, 48, 144)])
+    p3 = ops.PackTransposePlan(odd)
+    assert not p3.tile64
+    p3.run()
+    for w, d, sc in odd:
+        assert torch.equal(d, want(w, sc))
