@@ -219,6 +219,8 @@ PROTOTYPES = {
     'cms_program_add_wgrad_group': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     'cms_program_add_memset': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int]),
     'cms_program_add_sync': (c_int, [c_void_p, c_int, c_int, c_int]),
+    'cms_program_sync_count': (c_int, [c_void_p]),
+    'cms_program_set_sync_flags': (c_int, [c_void_p, c_void_p, c_int]),
     'cms_program_add_aspp_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _P(c_int), _P(c_int), c_int, c_int,
                                             c_int, c_int, c_int, c_int, c_int, c_int]),
     'cms_program_add_aspp_spread': (c_int, [c_void_p, c_void_p, c_void_p, c_int, _P(c_int), _P(c_int), c_int, c_int, c_int,

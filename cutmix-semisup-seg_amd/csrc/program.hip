@@ -11,6 +11,20 @@
 // into a hipGraph by the caller since all it does is launch work and record / wait events.
 //
 // Optional: every k-th convolution launch is bracketed with HIP events on its own stream (bench.py's `roofline`).
+//
+// Cross-stream order WITHOUT events (round 6, cms_program_set_sync_flags). hipEventRecord + hipStreamWaitEvent cost the
+// PRODUCING stream ~11-13 us per pair of waiters (tools/event_cost_probe.hip: a 50 us kernel chain goes from 51.0 to 61.9-63.7 us
+// per link; the marker packet drains the queue and signals through the host-visible path) -- the backward pass has one such point
+// per bottleneck on its data-gradient chain (profiles/r06w_step_timeline.txt: 23 holes of ~12 us in layer 3 alone). With a flag
+// buffer a sync is two one-wave kernels instead: `sync_set_kernel` on the producing stream (release store of a sequence number
+// to the op's flag word, in order behind the producer) and `sync_wait_kernel` on the waiting stream (polls the word through L2
+// with s_sleep, then ends: the next kernel of that stream starts behind it with the usual acquire): 53.0 us per link.
+// Consecutive syncs from one point of a stream share ONE setter. No deadlock: the setter is enqueued before its waiter and
+// whatever precedes it in its hardware queue was enqueued earlier still, i.e. depends on nothing behind the waiter; a waiter
+// holds one wave. Stream capture (hipGraph) keeps the event form: a graph has no queue order to rely on.
+// MEASURED IN THE STEP AND NOT THE DEFAULT: 626.8 / 628.9 img/s with flags against 634.2 / 633.8 with events at cfg 2, alternating legs
+// on one box (profiles/r06ae_*). The hole on the data-gradient stream is not idle machine time -- the weight-gradient streams run in it
+// -- and releasing them ~10 us earlier takes CUs from the chain's next launch. ops.Program hands the flags over only on request.
 #include <cstdlib>
 #include "common.hpp"
 #include <new>
@@ -29,6 +43,24 @@ struct AsppOp {            // arguments of cms_aspp_gather_fwd / cms_aspp_spread
     int n_taps, n, c, zc, h, w;
 };
 
+__global__ __launch_bounds__(64) void sync_set_kernel(int* flag, int v) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// polls until the flag has reached sequence number v (wrap-safe); gives up after ~4 s of wall clock (a lost setter must not hang
+// the device: the word behind the flags then counts the timeouts -- tests read it)
+__global__ __launch_bounds__(64) void sync_wait_kernel(const int* flag, int v, int* timeouts) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while ((int)((unsigned)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)v) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > 400000000LL) {            // 100 MHz
+            atomicAdd(timeouts, 1);
+            return;
+        }
+    }
+}
+
 struct Op {
     int kind;
     int stream;        // OP_SYNC: the stream that WAITS
@@ -42,6 +74,7 @@ struct Op {
     void* ptr;
     size_t bytes;
     hipEvent_t ev;     // OP_SYNC
+    int flag_slot;     // OP_SYNC: index of this op among the program's syncs = its word in the flag buffer
     double flops;
 };
 
@@ -67,6 +100,13 @@ struct cms_program {
     hipEvent_t prev_sync_ev = nullptr;   // the event the PREVIOUS issued op recorded, if that op was a sync from `prev_sync_from`:
     void* prev_sync_from = nullptr;      // consecutive syncs from one stream (both weight-gradient streams waiting for the main
                                          // stream, once per bottleneck) share ONE event record (round 5)
+    int n_syncs = 0;
+    int* flags = nullptr;                // caller-owned, zero-initialised device words: one per sync op + the timeout counter
+    int n_flags = 0;
+    unsigned seq = 0;                    // sequence number of the last setter issued (a flag word only ever grows, modulo 2^32)
+    int prev_flag_slot = -1;             // the setter the PREVIOUS issued op launched from `prev_sync_from` (shared by the next waiter)
+    unsigned prev_flag_val = 0;
+    bool use_flags = false;              // this replay: flags given, switched on, not capturing
 };
 
 using namespace cms;
@@ -86,7 +126,15 @@ static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
     if (share_events && o.kind == OP_SYNC && p->prev_sync_ev != nullptr && o.from >= 0 && o.from < n_streams &&
         p->prev_sync_from == streams[o.from])
         shared_ev = p->prev_sync_ev;         // nothing was issued since that record: the same point of the `from` stream
+    static int share_flags = -1;
+    if (share_flags < 0) {
+        const char* e = getenv("CMS_PROG_FLAG_SHARE");      // A/B switch, read once: 0 = every waiter gets its own setter
+        share_flags = e ? atoi(e) : 1;
+    }
+    const int shared_slot = (share_flags && o.kind == OP_SYNC && p->prev_flag_slot >= 0 && o.from >= 0 && o.from < n_streams &&
+                             p->prev_sync_from == streams[o.from]) ? p->prev_flag_slot : -1;
     p->prev_sync_ev = nullptr;
+    p->prev_flag_slot = -1;
     switch (o.kind) {
     case OP_CONV: {
         Timed* t = nullptr;
@@ -171,6 +219,21 @@ static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
         CMS_REQUIRE(o.from >= 0 && o.from < n_streams, "program: sync from stream %d but only %d streams given", o.from,
                     n_streams);
         if (streams[o.from] == streams[o.stream]) return CMS_OK;      // same stream: already ordered
+        if (p->use_flags && o.flag_slot < p->n_flags - 1) {
+            int slot = shared_slot;
+            unsigned val = p->prev_flag_val;
+            if (slot < 0) {                                           // a new point of the producing stream: its own setter
+                slot = o.flag_slot;
+                val = ++p->seq;
+                hipLaunchKernelGGL(sync_set_kernel, dim3(1), dim3(64), 0, (hipStream_t)streams[o.from], p->flags + slot, (int)val);
+            }
+            hipLaunchKernelGGL(sync_wait_kernel, dim3(1), dim3(64), 0, s, (const int*)(p->flags + slot), (int)val,
+                               p->flags + (p->n_flags - 1));
+            p->prev_flag_slot = slot;
+            p->prev_flag_val = val;
+            p->prev_sync_from = streams[o.from];
+            return launch_status("program: flag sync");
+        }
         if (shared_ev != nullptr) {
             if (hipStreamWaitEvent(s, shared_ev, 0) != hipSuccess) {
                 set_error("program: event wait failed");
@@ -262,6 +325,7 @@ extern "C" int cms_program_add_sync(cms_program* p, int from_stream, int to_stre
                     to_stream < CMS_PROGRAM_MAX_STREAMS, "program_add_sync: stream indices %d -> %d", from_stream, to_stream);
     Op o = {};
     o.kind = OP_SYNC; o.stream = to_stream; o.from = from_stream; o.group = group;
+    o.flag_slot = p->n_syncs++;
     if (hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess) {
         set_error("program_add_sync: hipEventCreate failed");
         return CMS_ELAUNCH;
@@ -312,12 +376,43 @@ extern "C" int cms_program_add_bn(cms_program* p, const cms_bn_op* op, int strea
 
 extern "C" int cms_program_size(const cms_program* p) { return p ? (int)p->ops.size() : 0; }
 
+extern "C" int cms_program_sync_count(const cms_program* p) { return p ? p->n_syncs : 0; }
+
+extern "C" int cms_program_set_sync_flags(cms_program* p, int* flags_dev, int n_flags) {
+    CMS_REQUIRE(p, "program_set_sync_flags: NULL program");
+    CMS_REQUIRE((flags_dev == nullptr && n_flags == 0) || (flags_dev != nullptr && n_flags >= 2),
+                "program_set_sync_flags: a device buffer of >= 2 zeroed ints (one per sync op + the timeout counter), or NULL / 0");
+    p->flags = flags_dev;
+    p->n_flags = n_flags;
+    return CMS_OK;
+}
+
+// flags given + CMS_PROG_FLAG_SYNC != 0 (read once) + the first stream is not being captured into a graph
+static void begin_replay(cms_program* p, void* const* streams) {
+    static int flag_sync = -1;
+    if (flag_sync < 0) {
+        const char* e = getenv("CMS_PROG_FLAG_SYNC");
+        flag_sync = e ? atoi(e) : 1;        // (the Python side only hands flags over with CMS_PROG_FLAG_SYNC=1: measured slower)
+    }
+    p->prev_sync_ev = nullptr;               // (the host may have enqueued anything since the last call)
+    p->prev_flag_slot = -1;
+    p->use_flags = false;
+    if (flag_sync != 0 && p->flags != nullptr && p->n_syncs > 0) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)streams[0], &st) != hipSuccess) {
+            (void)hipGetLastError();
+            st = hipStreamCaptureStatusNone;
+        }
+        p->use_flags = st == hipStreamCaptureStatusNone;
+    }
+}
+
 extern "C" int cms_program_run(cms_program* p, int first, int last, void* const* streams, int n_streams) {
     CMS_REQUIRE(p && streams && n_streams > 0, "program_run: NULL program / streams");
     const int n = (int)p->ops.size();
     if (last < 0 || last > n) last = n;
     CMS_REQUIRE(first >= 0 && first <= last, "program_run: bad range [%d, %d) of %d ops", first, last, n);
-    p->prev_sync_ev = nullptr;               // (the host may have enqueued anything since the last call)
+    begin_replay(p, streams);
     for (int i = first; i < last; ++i) {
         const int rc = issue(p, p->ops[i], streams, n_streams);
         if (rc != CMS_OK) return rc;
@@ -350,17 +445,21 @@ extern "C" int cms_program_run_pair(cms_program* a, void* const* streams_a, int 
         sync_ev_made = true;
     }
     int groups_done = 0, ev_slot = 0;
+    begin_replay(a, streams_a);
+    begin_replay(b, streams_b);
     while (ia < ea || ib < eb) {
         // next group = the smaller of the two heads' groups (groups are recorded in non-decreasing order)
         const int ga = ia < ea ? a->ops[ia].group : 0x7fffffff;
         const int gb = ib < eb ? b->ops[ib].group : 0x7fffffff;
         const int g = ga < gb ? ga : gb;
         a->prev_sync_ev = nullptr;           // (the other program's ops were issued in between, possibly on shared streams)
+        a->prev_flag_slot = -1;
         while (ia < ea && a->ops[ia].group <= g) {
             const int rc = issue(a, a->ops[ia++], streams_a, na);
             if (rc != CMS_OK) return rc;
         }
         b->prev_sync_ev = nullptr;
+        b->prev_flag_slot = -1;
         while (ib < eb && b->ops[ib].group <= g) {
             const int rc = issue(b, b->ops[ib++], streams_b, nb);
             if (rc != CMS_OK) return rc;

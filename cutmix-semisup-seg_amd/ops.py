@@ -1169,9 +1169,32 @@ class Program(object):
             arr[i] = st.cuda_stream
         return arr
 
+    def _ensure_sync_flags(self, force=False):
+        """(round 6) the flag words of the program's cross-stream syncs (csrc/program.hip: a setter + a polling kernel per sync
+        instead of an event record + wait): one zeroed int per sync op + the timeout counter, owned by the program, given to the
+        native side before the first replay (again if ops were recorded since). OPT-IN (CMS_PROG_FLAG_SYNC=1, or `force`): the
+        flag form removes the ~12 us hole per bottleneck from the data-gradient stream and the step gets SLOWER (626.8 / 628.9
+        against 634.2 / 633.8 img/s at cfg 2, profiles/r06ae_*: the weight-gradient streams are released earlier and take CUs the
+        data-gradient chain's next launch was about to get), so the default replay keeps hipEventRecord / hipStreamWaitEvent."""
+        if not force and _os.environ.get('CMS_PROG_FLAG_SYNC', '0') != '1':
+            return
+        n = int(fn['cms_program_sync_count'](self.h))
+        if n > 0 and getattr(self, '_sync_flags_n', 0) != n:
+            if getattr(self, 'sync_flags', None) is not None:
+                self.keep.append(self.sync_flags)       # (waiters of a replay in flight may still poll the old words)
+            self.sync_flags = torch.zeros(n + 1, dtype=torch.int32, device=torch.device('cuda', torch.cuda.current_device()))
+            self._sync_flags_n = n
+            check(fn['cms_program_set_sync_flags'](self.h, self.sync_flags.data_ptr(), n + 1), 'cms_program_set_sync_flags')
+
+    def sync_timeouts(self):
+        """Waiter kernels that gave up (must stay 0; reads the device)."""
+        fl = getattr(self, 'sync_flags', None)
+        return 0 if fl is None else int(fl[-1].item())
+
     def run(self, streams, first=0, last=-1):
         if len(streams) < self.n_streams:
             raise ValueError('program recorded on {} streams, {} given'.format(self.n_streams, len(streams)))
+        self._ensure_sync_flags()
         if self.host_ops:
             # a host op recorded at index i happens after launches [0, i) and before launch i: it belongs to the range that
             # STARTS at i (segmented replays call run(first, i) and then run(i, ...)), or to the last range when i == size
@@ -1212,6 +1235,8 @@ def run_pair(prog_a, streams_a, prog_b, streams_b):
     caller can never drop the exchanges silently (`_BodyPairFn` issues such passes one after the other)."""
     if prog_a.host_ops or prog_b.host_ops:
         raise RuntimeError('run_pair: a program with host operations (SyncBN exchanges) must be replayed with Program.run')
+    prog_a._ensure_sync_flags()
+    prog_b._ensure_sync_flags()
     check(fn['cms_program_run_pair'](prog_a.h, Program._handles(streams_a), len(streams_a), prog_b.h,
                                      Program._handles(streams_b), len(streams_b)), 'cms_program_run_pair')
 

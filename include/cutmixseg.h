@@ -636,6 +636,15 @@ int cms_program_add_aspp_spread(cms_program* p, const float* dlogits, void* d_nh
                                 const int* tap_dx, int n_taps, int n, int c, int zc, int h, int w, int stream_idx, int group);
 /* work enqueued so far on `from_stream` must finish before anything enqueued later on `to_stream` starts */
 int cms_program_add_sync(cms_program* p, int from_stream, int to_stream, int group);
+/* Syncs without events (round 6). With a caller-owned, ZEROED device buffer of n_flags >= cms_program_sync_count(p) + 1 ints
+ * (persistent like every buffer of a program; the last word counts waiter timeouts and stays 0), a sync is replayed as a one-wave
+ * setter kernel on the producing stream + a one-wave polling kernel on the waiting stream instead of hipEventRecord +
+ * hipStreamWaitEvent (which costs the producing stream ~12 us per pair of waiters, tools/event_cost_probe.hip). NULL / 0 = events
+ * again; CMS_PROG_FLAG_SYNC=0 in the environment keeps the events whatever is set; a replay under stream capture uses events.
+ * Opt-in: in the training step the event form is FASTER (profiles/r06ae_*), so ops.Program only sets flags on request.
+ * (The reference has no counterpart: its step is one stream, train_seg_semisup_mask_mt.py:287-476.) */
+int cms_program_sync_count(const cms_program* p);
+int cms_program_set_sync_flags(cms_program* p, int* flags_dev, int n_flags);
 /* Batch-statistics BatchNorm launches inside a program (round 3: DeepLab v2 WITHOUT --freeze_bn on the executor,
  * architectures/deeplab2.py:72-84 / train_seg_semisup_mask_mt.py:587). `what`: 0 = cms_bn_reduce(mode 0), 1 = cms_bn_finalize,
  * 2 = cms_bn_apply, 3 = cms_bn_reduce(mode 1), 4 = cms_bn_bwd_apply, 5 = cms_increment_counter(counter), 6 = cms_bn_stats,

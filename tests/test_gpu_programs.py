@@ -110,3 +110,43 @@ def test_pipelined_conv_variants_equal_default_kernel(tile, variant):
         for _ in range(3):
             out = ops.conv_igemm(x, wp, taps, scale=scale, bias=bias, res=res, relu=True, tile=tile, variant=variant)
             assert torch.equal(out, ref), (tile, variant, N, H, W, Cin, Cout, k)
+
+
+def test_flag_syncs_order_the_streams_like_events():
+    """(round 6) csrc/program.hip replays a cross-stream sync as a one-wave setter kernel + a one-wave polling kernel when the
+    program has its flag words (ops.Program._ensure_sync_flags). A chain that ping-pongs between two streams -- every launch
+    reads what the other stream's previous launch wrote, into buffers that hold stale values from the previous replay -- gives
+    the single-stream result on every replay, and no waiter ever timed out."""
+    from cutmix_semisup_seg_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(4, 33, 33, 256, generator=g, device=DEV).bfloat16()
+    ws = [(torch.randn(1, 256, 256, generator=g, device=DEV) * 0.06).bfloat16() for _ in range(8)]
+    taps = ops.conv_taps(1, 1, 1, 0)
+    bufs = [torch.zeros_like(x) for _ in range(9)]
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    prog = ops.Program()
+    with ops.recording(prog, [main, side]):
+        src = x
+        for i, w in enumerate(ws):
+            st = main if i % 2 == 0 else side
+            other = side if i % 2 == 0 else main
+            if i > 0:
+                ops.stream_wait(st, other)
+            with torch.cuda.stream(st):
+                ops.conv_igemm(src, w, taps, relu=True, out=bufs[i])
+            src = bufs[i]
+        ops.stream_wait(main, side)
+    assert int(ops.fn['cms_program_sync_count'](prog.h)) == len(ws)
+    for rep in range(4):
+        x.copy_(torch.randn(x.shape, generator=g, device=DEV).bfloat16())
+        ref = x
+        for w in ws:
+            ref = ops.conv_igemm(ref, w, taps, relu=True)
+        torch.cuda.synchronize()
+        if rep == 1:
+            prog._ensure_sync_flags(force=True)       # replay 0: events (the default); replays 1..3: flags
+        prog.run([main, side])
+        torch.cuda.synchronize()
+        assert torch.equal(bufs[len(ws) - 1], ref), rep
+    assert prog.sync_flags is not None and int(prog.sync_flags[:-1].max()) >= 3      # the setters ran (sequence numbers grow)
+    assert prog.sync_timeouts() == 0
