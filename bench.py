@@ -876,7 +876,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # CMS_BENCH_FORCE_PG=1: bring the process group (RCCL) up even with ONE rank -- a 1-GPU box then measures the step with RCCL's
+    # internal stream resident on one of the hardware queues, which is how every rank of the 8-GPU run executes it
+    force_pg = world == 1 and os.environ.get('CMS_BENCH_FORCE_PG') == '1'
+    if force_pg:
+        os.environ.setdefault('MASTER_PORT', '29541')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if world > 1 or force_pg:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(os.environ.get('CMS_BENCH_BACKEND', 'nccl'))
         probe = torch.ones(1, device=dev)
@@ -970,7 +977,7 @@ def main():
             print(json.dumps({'bench_detail': out}))
         sys.stdout.flush()
         print(compact_line(out))
-    if world > 1:
+    if world > 1 or force_pg:
         dist.destroy_process_group()
 
 

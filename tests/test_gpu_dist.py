@@ -111,3 +111,24 @@ def test_two_ranks_bucketed_allreduce_and_identical_replicas():
     np.testing.assert_array_equal(red0, red1)                  # both ranks hold the same reduced buffer ...
     np.testing.assert_array_equal(w0, w1)                      # ... and stay identical replicas after Adam + EMA
     np.testing.assert_array_equal(tw0, tw1)
+
+
+def test_rccl_single_rank_exchange_paths():
+    """(round 6) RCCL itself, on one GPU: backend "nccl" with world size 1 in a fresh process (tools/rccl_single_rank.py) -- the
+    stream probe after the first collective, GradBuckets driven from a side stream exactly like the fused step (fp32 and through
+    the bf16 staging arena; late writers, an immediate reader: a missing stream edge shows as stale data), the small statistics
+    all-reduces between launches, three iterations of the fused step with RCCL resident. The gloo tests above cannot see
+    stream-ordering mistakes (gloo's collectives on device tensors synchronise the host)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('LOCAL_RANK', 'GROUP_RANK', 'LOCAL_WORLD_SIZE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_single_rank.py')], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('OK'), (r.stdout[-2000:], r.stderr[-2000:])
