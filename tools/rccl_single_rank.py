@@ -10,8 +10,9 @@ runs on gloo, whose collectives on device tensors are host-synchronous, so strea
      stream -- fp32 and through the bf16 staging arena; with one rank the sum is the identity, so the reader must see exactly what the
      writers wrote (a missing stream edge shows as stale data: the writers are slow kernels, the reader is launched immediately);
   3. the 32-byte loss-statistics all-reduce and an fp64 SyncBN-sized all-reduce issued between two launches on one stream;
-  4. three iterations of the fused CutMix step of a small DeepLab v2 with the process group alive (exchange skipped at world 1), timed
-     with and without RCCL resident is bench.py's job (CMS_BENCH_FORCE_PG=1).
+  4. three iterations of the fused CutMix step of a small DeepLab v2 with the process group alive (exchange skipped at world 1; timing
+     the headline with and without RCCL resident is bench.py's job: CMS_BENCH_FORCE_PG=1);
+  5. the same iterations with the step told it has two ranks: the bucketed exchange then runs inside the recorded backward pass.
     python tools/rccl_single_rank.py"""
 import os
 import sys
@@ -79,32 +80,56 @@ for it in range(5):
     assert float(a[0].item()) == 2.0 * it and float(b[-1].item()) == 2.0 * it + 1.0
 print('3. 16-byte and fp64 statistics all-reduces between launches: exact', flush=True)
 
-# ---- 4. the fused step with the process group alive
+# ---- 4. the fused step with the process group alive; then the SAME iterations with the step told it has two ranks, so that the
+# bucketed exchange really runs inside the recorded backward pass (hooks on the weight-gradient stream -> async all_reduce on RCCL ->
+# finish() in front of the optimizer). With one rank the sum is the identity: the gradient arena must come out the same.
 import numpy as np
 from cutmix_semisup_seg_amd import optim as fo
 from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
 from architectures import deeplab2
 import mask_gen
 import optim_weight_ema
-torch.manual_seed(7)
 C, N, H, W = 5, 2, 65, 65
-mk = lambda: deeplab2.ResNetDeepLab(deeplab2.Bottleneck, [1, 1, 1, 1], C, np.zeros(3), np.ones(3)).to(dev)
-stu, tea = mk(), mk()
-opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=1e-4), dict(params=list(stu.new_parameters()), lr=1e-3)])
-for p in tea.parameters():
-    p.requires_grad = False
-ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
-ema.fuse_into(opt)
-stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()
-step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=0.3))
-g = torch.Generator(device=dev).manual_seed(3)
-for it in range(3):
-    im = lambda: torch.randn(N, 3, H, W, generator=g, device=dev).bfloat16()
-    y = torch.randint(0, C, (N, 1, H, W), generator=g, device=dev).to(torch.uint8)
-    r = mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(N, (H, W), rng=np.random.RandomState(it))
-    res = step(im(), y, [UnsupBatch(im(), ops.ranges_to_device(r, dev), x1_tea=im())])
-torch.cuda.synchronize()
-assert np.isfinite(float(res['sup_loss']))
-print('4. fused step with RCCL resident: 3 iterations, sup_loss {:.4f}'.format(float(res['sup_loss'])), flush=True)
+
+
+def run(pretend_world, allreduce_dtype='fp32'):
+    torch.manual_seed(7)
+    mk = lambda: deeplab2.ResNetDeepLab(deeplab2.Bottleneck, [2, 1, 2, 1], C, np.zeros(3), np.ones(3)).to(dev)
+    stu, tea = mk(), mk()
+    opt = fo.FusedAdam(stu, [dict(params=list(stu.pretrained_parameters()), lr=1e-4), dict(params=list(stu.new_parameters()), lr=1e-3)])
+    for p in tea.parameters():
+        p.requires_grad = False
+    ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
+    ema.fuse_into(opt)
+    stu.train(); tea.train(); stu.freeze_batchnorm(); tea.freeze_batchnorm()
+    step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=0.3, deterministic=True, allreduce_dtype=allreduce_dtype))
+    step.world = pretend_world
+    step.time_buckets = pretend_world > 1
+    g = torch.Generator(device=dev).manual_seed(3)
+    grads = []
+    for it in range(3):
+        im = lambda: torch.randn(N, 3, H, W, generator=g, device=dev).bfloat16()
+        y = torch.randint(0, C, (N, 1, H, W), generator=g, device=dev).to(torch.uint8)
+        r = mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(N, (H, W), rng=np.random.RandomState(it))
+        res = step(im(), y, [UnsupBatch(im(), ops.ranges_to_device(r, dev), x1_tea=im())])
+        grads.append(opt.arena.grad.clone())
+    torch.cuda.synchronize()
+    assert np.isfinite(float(res['sup_loss']))
+    return grads, float(res['sup_loss']), step.bucket_timing()
+
+
+g1, loss1, _ = run(1)
+print('4. fused step with RCCL resident: 3 iterations, sup_loss {:.4f}'.format(loss1), flush=True)
+g2, loss2, tim = run(2)
+# iteration 0 starts from identical weights: identical gradients (deterministic weight gradients); later iterations differ by the
+# optimizer's 1 / world factor, which is the point of pretending -- only iteration 0 is compared
+assert torch.equal(g1[0], g2[0]), float((g1[0] - g2[0]).abs().max())
+print('5. bucketed exchange inside the recorded backward pass over RCCL: gradients of iteration 0 bit-identical to the run without '
+      'exchange; buckets of the last step (bytes, issue-to-wait ms): {}'.format([(t['bytes'], round(t['issue_to_wait_ms'], 3)) for t in tim]),
+      flush=True)
+g3, _, _ = run(2, 'bf16')
+err = float((g3[0] - g1[0]).abs().max() / (g1[0].abs().max() + 1e-30))
+assert err <= 1e-2, err
+print('   ... through the bf16 staging arena: max relative difference {:.2e}'.format(err), flush=True)
 dist.destroy_process_group()
 print('OK')
