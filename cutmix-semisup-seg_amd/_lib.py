@@ -100,6 +100,11 @@ class PackItem(C.Structure):
                 ('ntaps', c_int), ('cout', c_int), ('cin', c_int), ('first_block', c_int)]
 
 
+class WfinishItem(C.Structure):
+    _fields_ = [('scratch', c_void_p), ('grad', c_void_p), ('w', c_void_p), ('scale', c_void_p), ('wdot', c_void_p),
+                ('ntaps', c_int), ('cout', c_int), ('cin', c_int), ('first_block', c_int)]
+
+
 _P = C.POINTER
 
 
@@ -193,6 +198,11 @@ PROTOTYPES = {
                                  c_void_p, C.c_double, c_size_t, c_int, c_void_p]),
     'cms_channel_copy': (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_int, c_int, c_size_t, c_void_p]),
     'cms_add_n': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    'cms_channel_sum': (c_int, [c_void_p, c_int, c_size_t, c_int, c_void_p, c_void_p]),
+    'cms_wgrad_finish_pack': (c_int, [_P(WfinishItem), c_int]),
+    'cms_wgrad_finish_run': (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    'cms_program_add_channel_sum': (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_int, c_void_p, c_int, c_int]),
+    'cms_program_add_wgrad_finish': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     'cms_rows_reduce': (c_int, [c_void_p, c_size_t, c_int, c_size_t, c_int, c_int, c_void_p, c_float, c_void_p]),
     'cms_upsample_nhwc': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p]),

@@ -759,6 +759,15 @@ class DeepLabHipExecutor(object):
             self.arena.packed(c.wkey, self.arena.grad).add_(g * c.scale.view(1, -1, 1))
             c.wdot.add_((g * self._w(c)).sum(dim=(0, 2)))
             c.dbeta.add_(du.sum(dim=(0, 1, 2)))
+        elif c.wdot is not None and self._wfinish_takes(du, x, c):
+            # (round 6) the wide layers of a backbone whose BatchNorm affine trains (DeepLab v3+) on the eight-phase kernel: the
+            # UNSCALED gradient into a scratch tensor, d(beta) by a column sum of dU; `_wfinish_flush` (end of the pass) adds
+            # scale * G to the arena and takes <W, G> (csrc/wfinish.hip)
+            ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self._wscratch()), stride=c.stride, scale=None,
+                           wg_target=self._wg_target())
+            ops.channel_sum(du, c.dbeta)
+            if all(c is not p for p in self._wfinish_pending):
+                self._wfinish_pending.append(c)
         elif c.wdot is not None:
             ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride, scale=c.scale,
                            w_bf16=self._w(c), wdot=c.wdot, dbeta=c.dbeta)
@@ -766,11 +775,48 @@ class DeepLabHipExecutor(object):
             ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self.arena.grad), stride=c.stride, scale=c.scale,
                            wg_target=self._wg_target())
 
+    # ---- trainable BatchNorm affine on the eight-phase weight-gradient kernel (round 6)
+    def _wscratch(self):
+        t = self.__dict__.get('_wscratch_buf')
+        if t is None:
+            t = self.__dict__['_wscratch_buf'] = torch.zeros_like(self.arena.grad)     # cleared again by every finishing launch
+        return t
+
+    @property
+    def _wfinish_pending(self):
+        return self.__dict__.setdefault('_wfinish_list', [])
+
+    def _wfinish_takes(self, du, x, c):
+        """bf16, atomics mode, and the launch WITHOUT side outputs would run on csrc/wgrad8.hip (Cout, Cin multiples of 256, enough
+        pixels). CMS_V3_WGRAD8=0 keeps the side-output kernel everywhere (A/B)."""
+        if self.dtype != torch.bfloat16 or ops.deterministic_wgrad() or os.environ.get('CMS_V3_WGRAD8', '1') == '0':
+            return False
+        key = (c.wkey, tuple(du.shape), tuple(x.shape))
+        hit = self.__dict__.setdefault('_wfinish_ok', {}).get(key)
+        if hit is None:
+            hit = self._wfinish_ok[key] = bool(ops.conv_wgrad(du, x, c.taps, self.arena.packed(c.wkey, self._wscratch()),
+                                                              stride=c.stride, scale=None, wg_target=self._wg_target(),
+                                                              query_kernel=True))
+        return hit
+
+    def _wfinish_flush(self):
+        """ONE finishing launch for the weight gradients `_wgrad` sent to the scratch tensor since the last flush -- on the
+        current stream, which must be ordered behind all of them."""
+        pend = self._wfinish_pending
+        if not pend:
+            return
+        a = self.arena
+        ops.wgrad_finish([(a.packed(c.wkey, self._wscratch()), a.packed(c.wkey, a.grad), self._w(c), c.scale, c.wdot) for c in pend])
+        del pend[:]
+
     def _wg_target(self):
         """CUs a weight-gradient launch of the backward pass aims at (cms_wgrad_desc.wg_target): the launches run on
         `wgrad_streams` side streams beside the data-gradient chain, whose eight-phase convolutions hold 132 CUs."""
         if not self.overlap_wgrad:
             return 0
+        t = os.environ.get('CMS_WG_TARGET')             # experiment: CUs a weight-gradient launch aims at
+        if t:
+            return int(t)
         return 56 if self.wgrad_streams >= 2 else 112
 
     def _dgrad(self, du, c, res=None, mask=None, in_hw=None):
@@ -1208,8 +1254,15 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
                     dres.add_(d_low)
             dC = self._dgrad(dU1, b.c1, res=dres, mask=None if bi == 0 else xin, in_hw=in_hw)
         if side is not None:
-            for sd in (side if isinstance(side, (list, tuple)) else [side]):
+            sds = list(side) if isinstance(side, (list, tuple)) else [side]
+            for sd in sds[1:]:
+                ops.stream_wait(sds[0], sd)
+            with torch.cuda.stream(sds[0]):
+                self._wfinish_flush()
+            for sd in sds:
                 ops.stream_wait(main, sd)
+        else:
+            self._wfinish_flush()
         del keep
         return dC
 
@@ -1222,8 +1275,13 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
         track_bn = self.bn_trainable
         main = torch.cuda.current_stream()
         side = self._side_stream() if self.overlap_wgrad else None
-        if side is not None and os.environ.get('CMS_V3_WGRAD_STREAMS', '1') == '2':
-            side = [side, ops.pooled_stream(self.arena.device, 'wgrad1')]     # EXPERIMENT: the blocks' weight gradients alternate over two streams
+        # (round 6) TWO weight-gradient streams, the blocks alternating over them: with the wide layers on the eight-phase kernel
+        # (`_wfinish_takes`: ~56 workgroups per launch) one stream leaves half the machine idle beside the data-gradient chain --
+        # 148 img/s on one stream, 174 on two, 157.5 with the side-output kernel on one (cfg 4, profiles/r06aj_*). With the side-output
+        # kernel everywhere (CMS_V3_WGRAD8=0) two streams lose (152.8 vs 154.7, profiles/r06o_*): one stream then. CMS_V3_WGRAD_STREAMS overrides.
+        two = self.dtype == torch.bfloat16 and not ops.deterministic_wgrad() and os.environ.get('CMS_V3_WGRAD8', '1') != '0'
+        if side is not None and os.environ.get('CMS_V3_WGRAD_STREAMS', '2' if two else '1') == '2':
+            side = [side, ops.pooled_stream(self.arena.device, 'wgrad1')]
         recorded = isinstance(saved, tuple) and len(saved) == 2 and isinstance(saved[0], ops.Program)
         if not recorded:
             x4 = saved[-1]

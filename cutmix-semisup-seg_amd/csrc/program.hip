@@ -32,7 +32,7 @@
 
 namespace cms {
 
-enum OpKind { OP_CONV = 0, OP_WGRAD = 1, OP_MEMSET = 2, OP_SYNC = 3, OP_ASPP_GATHER = 4, OP_ASPP_SPREAD = 5, OP_BN = 6, OP_WGRAD_GROUP = 7 };
+enum OpKind { OP_CONV = 0, OP_WGRAD = 1, OP_MEMSET = 2, OP_SYNC = 3, OP_ASPP_GATHER = 4, OP_ASPP_SPREAD = 5, OP_BN = 6, OP_WGRAD_GROUP = 7, OP_CHANNEL_SUM = 8, OP_WGRAD_FINISH = 9 };
 
 struct AsppOp {            // arguments of cms_aspp_gather_fwd / cms_aspp_spread_bwd
     const float* src;      // z / dlogits
@@ -180,6 +180,10 @@ static int issue(cms_program* p, Op& o, void* const* streams, int n_streams) {
         return o.f32 ? cms_conv_wgrad_f32(&o.wg, s) : cms_conv_wgrad(&o.wg, s);
     case OP_WGRAD_GROUP:        // ptr = the device-resident item table, bytes = items, from = grid size, f32 = kind
         return cms_conv_wgrad_group_run(o.ptr, (int)o.bytes, o.from, o.f32, s);
+    case OP_CHANNEL_SUM:        // ptr = src, bytes = rows, from = channels, f32 = dtype code, aspp.dst = the fp32 sums
+        return cms_channel_sum(o.ptr, o.f32, o.bytes, o.from, (float*)o.aspp.dst, s);
+    case OP_WGRAD_FINISH:       // ptr = the device-resident item table, bytes = items, from = grid size
+        return cms_wgrad_finish_run(o.ptr, (int)o.bytes, o.from, s);
     case OP_BN: {
         const cms_bn_op& b = o.bn;
         const int g = b.groups > 1 ? b.groups : 1;
@@ -308,6 +312,27 @@ extern "C" int cms_program_add_wgrad_group(cms_program* p, const void* table_dev
     Op o = {};
     o.kind = OP_WGRAD_GROUP; o.stream = stream_idx; o.group = group;
     o.ptr = const_cast<void*>(table_dev); o.bytes = (size_t)n_items; o.from = total_blocks; o.f32 = kind;
+    return push(p, o);
+}
+
+extern "C" int cms_program_add_channel_sum(cms_program* p, const void* src, int dtype, size_t rows, int channels, float* dst,
+                                           int stream_idx, int group) {
+    CMS_REQUIRE(p && src && dst && rows > 0 && channels > 0 && channels % 64 == 0, "program_add_channel_sum: bad arguments");
+    CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "program_add_channel_sum: bad dtype");
+    CMS_REQUIRE(stream_idx >= 0 && stream_idx < CMS_PROGRAM_MAX_STREAMS, "program_add_channel_sum: stream index %d", stream_idx);
+    Op o = {};
+    o.kind = OP_CHANNEL_SUM; o.stream = stream_idx; o.group = group;
+    o.ptr = const_cast<void*>(src); o.bytes = rows; o.from = channels; o.f32 = dtype; o.aspp.dst = dst;
+    return push(p, o);
+}
+
+extern "C" int cms_program_add_wgrad_finish(cms_program* p, const void* items_dev, int n_items, int total_blocks, int stream_idx,
+                                            int group) {
+    CMS_REQUIRE(p && items_dev && n_items > 0 && total_blocks > 0, "program_add_wgrad_finish: bad arguments");
+    CMS_REQUIRE(stream_idx >= 0 && stream_idx < CMS_PROGRAM_MAX_STREAMS, "program_add_wgrad_finish: stream index %d", stream_idx);
+    Op o = {};
+    o.kind = OP_WGRAD_FINISH; o.stream = stream_idx; o.group = group;
+    o.ptr = const_cast<void*>(items_dev); o.bytes = (size_t)n_items; o.from = total_blocks;
     return push(p, o);
 }
 

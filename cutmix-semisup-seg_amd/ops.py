@@ -1720,6 +1720,71 @@ def conv_wgrad(du, x, taps, dw, stride=1, scale=None, cout_real=None, ksplit=0, 
     return dw
 
 
+def channel_sum(src, dst):
+    """dst (fp32 [C], accumulated with atomics) += sum over all leading dimensions of src[..., C] (bf16 / fp32, contiguous,
+    C % 64 == 0): d(beta) = sum_p dU of a trainable BatchNorm affine over frozen statistics (csrc/wfinish.hip). A program op while
+    recording."""
+    _need_cuda(src, dst)
+    c = int(src.shape[-1])
+    if not src.is_contiguous() or src.dtype not in (torch.bfloat16, torch.float32) or dst.dtype != torch.float32 \
+            or not dst.is_contiguous() or int(dst.numel()) != c or c % 64:
+        raise TypeError('channel_sum: contiguous bf16 / fp32 (..., C) input with C % 64 == 0 and an fp32 [C] output required')
+    rows = src.numel() // c
+    if _REC is not None:
+        prog = _REC[0]
+        idx = fn['cms_program_add_channel_sum'](prog.h, _ptr(src), _dtype_code(src), rows, c, _ptr(dst), _rec_stream_index(), prog.group)
+        if idx < 0:
+            check(idx, 'cms_program_add_channel_sum')
+        prog.keep += [src, dst]
+        return dst
+    check(fn['cms_channel_sum'](_ptr(src), _dtype_code(src), rows, c, _ptr(dst), _stream()), 'cms_channel_sum')
+    return dst
+
+
+def wgrad_finish(items):
+    """ONE launch behind the weight gradients of a backward pass whose BatchNorm affine trains over frozen statistics
+    (csrc/wfinish.hip): `items` = list of (scratch, grad, w_bf16, scale, wdot) with scratch / grad fp32 (ntaps, Cout, Cin) -- the
+    unscaled gradient G the eight-phase kernel wrote and the arena's slice --, w_bf16 the weight in the same layout, scale fp32
+    [Cout] or None, wdot fp32 [Cout]: grad += scale * G, wdot += <W, G> per output channel, G cleared. A program op while recording
+    (the device-resident item table then belongs to the program)."""
+    if not items:
+        return
+    arr = (_lib.WfinishItem * len(items))()
+    keep = []
+    for i, (scratch, grad, w, scale, wdot) in enumerate(items):
+        _need_cuda(scratch, grad, w, scale, wdot)
+        nt, co, ci = (int(v) for v in w.shape)
+        if not (scratch.dtype == grad.dtype == wdot.dtype == torch.float32 and w.dtype == torch.bfloat16 and scratch.is_contiguous()
+                and grad.is_contiguous() and w.is_contiguous() and tuple(scratch.shape) == tuple(grad.shape) == (nt, co, ci)
+                and int(wdot.numel()) == co and wdot.is_contiguous() and ci % 4 == 0
+                and (scale is None or (scale.dtype == torch.float32 and int(scale.numel()) == co and scale.is_contiguous()))):
+            raise TypeError('wgrad_finish: item {}: fp32 scratch / grad (ntaps, Cout, Cin), bf16 weight of that shape, fp32 [Cout] '
+                            'scale / wdot, Cin % 4 == 0 required'.format(i))
+        m = arr[i]
+        m.scratch, m.grad, m.w, m.wdot = scratch.data_ptr(), grad.data_ptr(), w.data_ptr(), wdot.data_ptr()
+        m.scale = scale.data_ptr() if scale is not None else None
+        m.ntaps, m.cout, m.cin = nt, co, ci
+        keep += [t for t in (scratch, grad, w, scale, wdot) if t is not None]
+    total = int(fn['cms_wgrad_finish_pack'](arr, len(items)))
+    if total < 0:
+        check(total, 'cms_wgrad_finish_pack')
+    nbytes = C.sizeof(_lib.WfinishItem) * len(items)
+    host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    C.memmove(host.data_ptr(), C.addressof(arr), nbytes)
+    dev = items[0][0].device
+    table = host.to(dev, non_blocking=True)
+    if _REC is not None:
+        prog = _REC[0]
+        idx = fn['cms_program_add_wgrad_finish'](prog.h, C.c_void_p(table.data_ptr()), len(items), total, _rec_stream_index(), prog.group)
+        if idx < 0:
+            check(idx, 'cms_program_add_wgrad_finish')
+        prog.keep += keep + [table, host]
+        torch.cuda.current_stream().synchronize()      # (recorded once: the table is in place before any replay, on whatever stream)
+        return
+    check(fn['cms_wgrad_finish_run'](C.c_void_p(table.data_ptr()), len(items), total, _stream()), 'cms_wgrad_finish_run')
+    table.record_stream(torch.cuda.current_stream())
+
+
 def conv_wgrad_group(jobs, target_workgroups=0):
     """The weight gradients of MANY layers as one grid per kind (cms_conv_wgrad_group_*): `jobs` = list of
     (du, x, taps, dw, stride, scale) as for `conv_wgrad`. Launches that cannot join a group (channel counts that are not

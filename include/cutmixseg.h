@@ -661,6 +661,30 @@ int cms_bn_finalize_tiles(const float* tile_sums, int tile_rows, size_t n_pixels
 /* backward counterpart: tile sums of a data-gradient launch with bstats_* -> sums[groups][2][c] (double) for cms_bn_bwd_apply_groups */
 int cms_bn_bwd_sums_tiles(const float* tile_sums, int tile_rows, size_t n_pixels, int c, int groups, double* sums, void* stream);
 
+/* Trainable BatchNorm affine over frozen statistics on the eight-phase weight-gradient kernel (csrc/wfinish.hip; the torchvision
+ * backbone of architectures/deeplab3plus.py:96-98 + autograd): the weight-gradient launch writes the UNSCALED gradient G into a
+ * scratch tensor of the weight's shape, cms_channel_sum takes d(beta) = sum_p dU, and one finishing launch per backward pass does,
+ * per item and output channel co:  grad += scale[co] * G,  wdot[co] += <W[co], G[co]>,  G = 0.  All buffers are the caller's. */
+typedef struct cms_wfinish_item {
+    float* scratch;            /* fp32 [ntaps][cout][cin]: G of this pass, cleared by the launch                         */
+    float* grad;               /* fp32 [ntaps][cout][cin]: the gradient arena's slice of the weight                      */
+    const uint16_t* w;         /* bf16 [ntaps][cout][cin]: the weight                                                    */
+    const float* scale;        /* [cout] gamma * rstd, or NULL (1)                                                        */
+    float* wdot;               /* [cout], accumulated                                                                     */
+    int ntaps, cout, cin;      /* cin % 4 == 0                                                                            */
+    int first_block;           /* filled by cms_wgrad_finish_pack                                                         */
+} cms_wfinish_item;
+/* dst[c] (fp32, accumulated with atomics) += sum over `rows` rows of src[row][c]; channels % 64 == 0 */
+int cms_channel_sum(const void* src, int dtype, size_t rows, int channels, float* dst, void* stream);
+/* host: lays the items out over the grid (first_block) -> total workgroups, or a negative error code */
+int cms_wgrad_finish_pack(cms_wfinish_item* items, int n_items);
+/* items_dev: the packed table in device memory */
+int cms_wgrad_finish_run(const void* items_dev, int n_items, int total_blocks, void* stream);
+/* ... as program ops */
+int cms_program_add_channel_sum(cms_program* p, const void* src, int dtype, size_t rows, int channels, float* dst, int stream_idx,
+                                int group);
+int cms_program_add_wgrad_finish(cms_program* p, const void* items_dev, int n_items, int total_blocks, int stream_idx, int group);
+
 typedef struct cms_bn_op {
     int what, dtype, c, relu;
     const void* x;             /* conv output u, NHWC                                                          */

@@ -131,4 +131,6 @@ def test_rccl_single_rank_exchange_paths():
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_single_rank.py')], env=env, capture_output=True, text=True,
                        timeout=600)
+    if r.returncode == 77:
+        pytest.skip('RCCL did not come up on this box: ' + r.stdout.strip()[-300:])
     assert r.returncode == 0 and r.stdout.strip().endswith('OK'), (r.stdout[-2000:], r.stderr[-2000:])

