@@ -26,28 +26,30 @@ __device__ __forceinline__ void ld8f(const uint16_t* p, float (&v)[8]) {
     v[6] = bf16_to_f32((uint16_t)(u.w & 0xffffu)); v[7] = bf16_to_f32((uint16_t)(u.w >> 16));
 }
 
-// dst[c] += sum_rows src[row][c]: block = (slab of rows, 64-channel tile), 32 rows side by side, 16 bytes / 32 bytes per lane;
-// one fp32 atomic per block and channel
-template <class T>
+// dst[c] += sum_rows src[row][c]: block = (slab of rows, TILE-channel tile); LPR = TILE / 8 lanes side by side read one row's
+// TILE channels (16 bytes / 32 bytes per lane: 512 contiguous bytes per row of a 256-channel bf16 tile), 256 / LPR rows per pass,
+// four passes in flight; one fp32 atomic per block and channel
+template <class T, int TILE>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ src, size_t rows, int C, float* __restrict__ dst, int slabs) {
-    __shared__ float red[32][64 + 1];
-    const int tiles = C / 64;
+    constexpr int LPR = TILE / 8, RPP = 256 / LPR;           // lanes per row, rows per pass
+    __shared__ float red[RPP][TILE + 1];
+    const int tiles = C / TILE;
     const int slab = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    const int cgl = threadIdx.x & 7, slot = threadIdx.x >> 3;
+    const int cgl = threadIdx.x % LPR, slot = threadIdx.x / LPR;
     const size_t r0 = rows * (size_t)slab / (size_t)slabs, r1 = rows * (size_t)(slab + 1) / (size_t)slabs;
-    const T* base = src + (size_t)tile * 64 + cgl * 8;
+    const T* base = src + (size_t)tile * TILE + cgl * 8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     size_t p = r0 + slot;
-    for (; p + 96 < r1; p += 128) {
+    for (; p + 3 * RPP < r1; p += 4 * RPP) {
         float v[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ld8f(base + (p + 32 * u) * (size_t)C, v[u]);
+        for (int u = 0; u < 4; ++u) ld8f(base + (p + RPP * u) * (size_t)C, v[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += v[u][e];
     }
-    for (; p < r1; p += 32) {
+    for (; p < r1; p += RPP) {
         float v[8];
         ld8f(base + p * (size_t)C, v);
 #pragma unroll
@@ -56,10 +58,11 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[slot][cgl * 8 + e] = acc[e];
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < TILE) {
         float s = 0.0f;
-        for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
-        atomicAdd(dst + tile * 64 + threadIdx.x, s);
+#pragma unroll
+        for (int k = 0; k < RPP; ++k) s += red[k][threadIdx.x];
+        atomicAdd(dst + tile * TILE + threadIdx.x, s);
     }
 }
 
@@ -100,17 +103,22 @@ using namespace cms;
 extern "C" int cms_channel_sum(const void* src, int dtype, size_t rows, int channels, float* dst, void* stream) {
     CMS_REQUIRE(src && dst && rows > 0 && channels > 0 && channels % 64 == 0, "channel_sum: NULL pointer / channels %% 64 != 0");
     CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "channel_sum: bad dtype");
-    const int tiles = channels / 64;
-    size_t want = rows / 256;                                   // >= 256 rows per slab (8 trips of the unrolled loop)
+    const int tile = channels % 256 == 0 ? 256 : 64;            // (the wide layers: 512 contiguous bytes per row and pass)
+    const int tiles = channels / tile;
+    size_t want = rows / 256;                                   // >= 256 rows per slab
     int slabs = (int)(want < 1 ? 1 : want);
     const int cap = 1024 / tiles > 1 ? 1024 / tiles : 1;        // ~1 k workgroups per launch
     if (slabs > cap) slabs = cap;
     const dim3 grid((unsigned)(slabs * tiles));
-    if (dtype == CMS_F32)
-        hipLaunchKernelGGL(channel_sum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, rows, channels, dst, slabs);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CMS_F32 && tile == 256)
+        hipLaunchKernelGGL((channel_sum_kernel<float, 256>), grid, dim3(256), 0, s, (const float*)src, rows, channels, dst, slabs);
+    else if (dtype == CMS_F32)
+        hipLaunchKernelGGL((channel_sum_kernel<float, 64>), grid, dim3(256), 0, s, (const float*)src, rows, channels, dst, slabs);
+    else if (tile == 256)
+        hipLaunchKernelGGL((channel_sum_kernel<uint16_t, 256>), grid, dim3(256), 0, s, (const uint16_t*)src, rows, channels, dst, slabs);
     else
-        hipLaunchKernelGGL(channel_sum_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, rows, channels, dst,
-                           slabs);
+        hipLaunchKernelGGL((channel_sum_kernel<uint16_t, 64>), grid, dim3(256), 0, s, (const uint16_t*)src, rows, channels, dst, slabs);
     return launch_status("cms_channel_sum");
 }
 
