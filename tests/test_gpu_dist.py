@@ -133,4 +133,5 @@ def test_rccl_single_rank_exchange_paths():
                        timeout=600)
     if r.returncode == 77:
         pytest.skip('RCCL did not come up on this box: ' + r.stdout.strip()[-300:])
-    assert r.returncode == 0 and r.stdout.strip().endswith('OK'), (r.stdout[-2000:], r.stderr[-2000:])
+    # (RCCL prints its version banner through C stdio when the process ends: 'OK' is a line of the output, not its last one)
+    assert r.returncode == 0 and 'OK' in r.stdout.splitlines(), (r.stdout[-2000:], r.stderr[-2000:])
