@@ -130,7 +130,7 @@ class ASPP(nn.Module):
         stream and joined before the concat. autograd runs a node's backward on the stream its forward ran on, so the branches'
         backward chains overlap the same way. CMS_ASPP_STREAMS=0: one after the other on the current stream (rounds 1-5)."""
         import os
-        if not on_device or os.environ.get('CMS_ASPP_STREAMS', '1') == '0' or ops._REC is not None or len(convs) < 3:
+        if not on_device or os.environ.get('CMS_ASPP_STREAMS', '1') == '0' or ops._REC is not None or not ops.side_streams_enabled() or len(convs) < 3:
             return [eng.conv_bn_act(xi, m[0], m[1], relu=True) for xi, m in zip(xs, convs)]
         cur = torch.cuda.current_stream()
         sides = [ops.pooled_stream(xs[0].device, 'wgrad0'), ops.pooled_stream(xs[0].device, 'wgrad1')]

@@ -1201,7 +1201,7 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
                 ks = [(ky, kx) for ky in sel[py] for kx in sel[px]]
                 ent = self._phase_w.get((id(c), py, px))
                 if ent is None:
-                    idx = torch.tensor([ky * 3 + kx for ky, kx in ks], dtype=torch.long, device=du.device)
+                    idx = _index_tensor(tuple(ky * 3 + kx for ky, kx in ks), du.device)
                     ent = (c, idx, c.wT[idx].contiguous())                   # (taps, Cin, Cout), BN scale folded
                     self._phase_w[(id(c), py, px)] = ent
                 taps = [((py + 1 - ky) // 2, (px + 1 - kx) // 2) for ky, kx in ks]
@@ -1491,7 +1491,7 @@ class _HipConvGeneralFn(torch.autograd.Function):
                                if (py + pad - ky * dil) % stride == 0 and (px + pad - kx * dil) % stride == 0]
                         if not sel:
                             continue                       # pixels of this phase receive nothing: they stay zero
-                        idx = torch.tensor([ky * k + kx for ky, kx in sel], dtype=torch.long, device=dy.device)
+                        idx = _index_tensor(tuple(ky * k + kx for ky, kx in sel), dy.device)
                         wsub = wT.index_select(0, idx)
                         offs = [((py + pad - ky * dil) // stride, (px + pad - kx * dil) // stride) for ky, kx in sel]
                         first = True
@@ -1502,6 +1502,19 @@ class _HipConvGeneralFn(torch.autograd.Function):
                             first = False
             dx = (dxp[..., :cin] if cpad != cin else dxp).permute(0, 3, 1, 2)
         return dx, None, None, None, None, None
+
+
+_INDEX_TENSORS = {}
+
+
+def _index_tensor(values, device):
+    """A small int64 index tensor on the device, made ONCE per (values, device): a host -> device copy from pageable memory
+    synchronises, which a pass being captured into a hipGraph may not do (vat.VATMeanTeacherStep._graphed_grads)."""
+    key = (values, str(device))
+    t = _INDEX_TENSORS.get(key)
+    if t is None:
+        t = _INDEX_TENSORS[key] = torch.tensor(list(values), dtype=torch.long, device=device)
+    return t
 
 
 class _HipClassifierFn(torch.autograd.Function):

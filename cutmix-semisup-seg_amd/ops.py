@@ -507,6 +507,21 @@ _SIDE_RR = {}       # device index -> round-robin counter over the two weight-gr
 _SIDE_SLOT = {}     # (device index, layer key) -> 0 / 1: a layer's weight gradients always go to the SAME side stream
 
 
+_SIDE_ENABLED = True
+
+
+def set_side_streams_enabled(on):
+    """Switch the layer engines' side streams (weight gradients, ASPP branches) on / off; -> the previous setting. Off while a pass
+    is captured into a hipGraph on ONE stream (vat.VATMeanTeacherStep._graphed_grads)."""
+    global _SIDE_ENABLED
+    prev, _SIDE_ENABLED = _SIDE_ENABLED, bool(on)
+    return prev
+
+
+def side_streams_enabled():
+    return _SIDE_ENABLED
+
+
 def layer_wgrad_stream(device, key=None):
     """(round 6) Stream for ONE weight-gradient launch of the layer engines (backbone_hip._HipConvGeneralFn / _HipClassifierFn: the
     DeepLab v3+ head, the U-Nets), or None = issue it on the current stream. The autograd backward of those networks used to run
@@ -516,7 +531,7 @@ def layer_wgrad_stream(device, key=None):
     are ready on it); `join_side_streams` is called by whatever touches the gradient arena next (optimizer launches, gradient
     clears, the bucketed all-reduce). Off under recording, in the deterministic mode (one shared split-K workspace) and with
     CMS_LAYER_WGRAD_SIDE=0."""
-    if _REC is not None or _WGRAD_DETERMINISTIC or _os.environ.get('CMS_LAYER_WGRAD_SIDE', '1') == '0':
+    if _REC is not None or _WGRAD_DETERMINISTIC or not _SIDE_ENABLED or _os.environ.get('CMS_LAYER_WGRAD_SIDE', '1') == '0':
         return None
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()

@@ -25,6 +25,7 @@ What runs where:
   * quirk kept: the network used for the direction is put in eval mode and stays there (:237).
 """
 import math
+import os
 
 import torch
 
@@ -149,12 +150,23 @@ class VATMeanTeacherStep(object):
         cfg.cons.align_corners = self.align_corners
         import torch.distributed as dist
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # (round 6) the gradient passes as one hipGraph launch (see _graphed_grads)
+        # Default ('auto'): ON for networks that run layer by layer through the Python layer engines (the U-Nets: 51.7 -> 76.4 img/s on
+        # the DenseNet-161 U-Net, 185.8 -> 209.4 on the ResNet-50 U-Net, profiles/r06bc_*), OFF for the DeepLab networks, whose passes
+        # are recorded programs already (114.3 eager vs 108.2 captured). CMS_VAT_GRAPH=0 / 1 forces it.
+        env = os.environ.get('CMS_VAT_GRAPH', 'auto')
+        layerwise = not any(hasattr(student_net, a) for a in ('_use_hip_body', '_use_hip_backbone'))
+        self.use_graph = env == '1' or (env not in ('0', '1') and layerwise)
+        self.graph_warmup = 2
+        self._graphs = {}
 
-    def __call__(self, sup_x, sup_y, unsup_batches, ramp_val=1.0, eps0=None):
+    # ------------------------------------------------------------------------------------------ the gradient passes
+    def _grads(self, sup_x, sup_y, unsup_batches, ramp, eps0):
+        """Everything of the iteration in front of the gradient exchange / optimizer: gradient clear, supervised pass, VAT
+        direction, teacher pass, perturbed student pass. -> (ce scalars, [consistency scalars]) on the device."""
         cfg = self.cfg
         out_size = sup_x.shape[2:4]
         self.student_optim.zero_grad()
-        ramp = ramp_val if cfg.rampup > 0 else 1.0
         lo = self.student.forward_lowres(sup_x)
         ce_sc, ce_ctx = ops.ce_forward(lo.detach(), sup_y, out_size, 255, self.align_corners, group=self.group)
         lo.backward(ops.ce_backward(ce_ctx, ce_sc).to(lo.dtype))
@@ -172,6 +184,90 @@ class VATMeanTeacherStep(object):
                                                    ramp_val=ramp, cons_weight=cfg.cons_weight, group=self.group)
                 l_stu.backward(ops.consistency_backward(cctx, sc).to(l_stu.dtype))
                 cons_vals.append(sc)
+        ops.join_side_streams()
+        return ce_sc, cons_vals
+
+    # ------------------------------------------------------------------------------------------ hipGraph replay (round 6)
+    def _graph_key(self, sup_x, sup_y, unsup_batches, ramp, eps0):
+        def sig(t):
+            return None if t is None else (tuple(t.shape), t.dtype, t.device.index)
+        return (sig(sup_x), sig(sup_y), tuple((sig(u.x_tea), sig(u.x_stu), sig(u.um), u.x_stu is u.x_tea) for u in unsup_batches),
+                float(ramp), sig(eps0), self.student.training, self.teacher.training, self.vat_dir_net.training,
+                getattr(self.student, 'compute_dtype', None), getattr(self.teacher, 'compute_dtype', None))
+
+    def _graphed_grads(self, sup_x, sup_y, unsup_batches, ramp, eps0):
+        """The gradient passes as ONE hipGraph launch. The layer engines of the U-Nets issue ~9 000 launches per VAT iteration
+        through Python autograd: 169 ms of host work per 213 ms step of the DenseNet-161 U-Net (profiles/r06i_*) -- the GPU waits
+        for the host. After `graph_warmup` eager iterations of a (shapes, modes, ramp) signature (lazy initialisation, stream probe,
+        BatchNorm modes settled: the direction network goes to eval() in its first iteration and stays there, :237) the passes
+        are captured once into a torch.cuda.CUDAGraph over static input buffers and replayed: everything inside -- random
+        direction (the generator is registered with the graph), batch-statistics BatchNorm incl. running statistics, weight
+        gradients into the arena -- is device work of the same kernels. Outside the graph: gradient exchange, optimizer, EMA.
+        Not captured: a ramp that still changes (`rampup > 0` while ramp < 1 would need a graph per value: those iterations run
+        eagerly), data parallelism (SyncBN host operations)."""
+        key = self._graph_key(sup_x, sup_y, unsup_batches, ramp, eps0)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = {'seen': 0}
+        if 'graph' not in ent:
+            ent['seen'] += 1
+            if ent['seen'] <= self.graph_warmup or ent.get('failed'):
+                return self._grads(sup_x, sup_y, unsup_batches, ramp, eps0)
+            # static inputs
+            st = {'sup_x': sup_x.clone(), 'sup_y': sup_y.clone(), 'eps0': None if eps0 is None else eps0.clone(), 'ubs': []}
+            for u in unsup_batches:
+                xt = u.x_tea.clone()
+                xs = xt if u.x_stu is u.x_tea else u.x_stu.clone()
+                st['ubs'].append(VATUnsupBatch(xt, xs, None if u.um is None else u.um.clone()))
+            # operands derived from the weights (padded / transposed copies) are cached per weight version by the eager path: the
+            # capture must contain their refresh, so both arenas are marked stale first
+            for net in (self.student, self.teacher):
+                a = getattr(net, '_cms_arena', None)
+                if a is not None:
+                    a.touch()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            if self.generator is not None and hasattr(g, 'register_generator_state'):
+                g.register_generator_state(self.generator)
+            # one capture stream by default; CMS_VAT_GRAPH_SIDE=1: the layer engines' side streams fork / join inside the capture
+            prev = ops.set_side_streams_enabled(os.environ.get('CMS_VAT_GRAPH_SIDE', '0') == '1')
+            try:
+                with torch.cuda.graph(g):
+                    ce_sc, cons_vals = self._grads(st['sup_x'], st['sup_y'], st['ubs'], ramp, st['eps0'])
+            except Exception as e:               # noqa: BLE001 -- an operation the capture cannot hold (nothing ran on the device)
+                import warnings
+                warnings.warn('cutmix-semisup-seg_amd: the VAT gradient passes could not be captured into a hipGraph ({}: {}); this '
+                              'signature keeps running launch by launch'.format(type(e).__name__, str(e).splitlines()[0] if str(e) else ''),
+                              RuntimeWarning, stacklevel=2)
+                ent['failed'] = True
+                torch.cuda.synchronize()
+                return self._grads(sup_x, sup_y, unsup_batches, ramp, eps0)
+            finally:
+                ops.set_side_streams_enabled(prev)
+            ent.update(graph=g, static=st, out=(ce_sc, cons_vals))
+        st = ent['static']
+        st['sup_x'].copy_(sup_x)
+        st['sup_y'].copy_(sup_y)
+        if eps0 is not None:
+            st['eps0'].copy_(eps0)
+        for su, u in zip(st['ubs'], unsup_batches):
+            su.x_tea.copy_(u.x_tea)
+            if su.x_stu is not su.x_tea:
+                su.x_stu.copy_(u.x_stu)
+            if u.um is not None:
+                su.um.copy_(u.um)
+        ent['graph'].replay()
+        ce_sc, cons_vals = ent['out']
+        return ce_sc.clone(), [c.clone() for c in cons_vals]
+
+    def __call__(self, sup_x, sup_y, unsup_batches, ramp_val=1.0, eps0=None):
+        cfg = self.cfg
+        ramp = ramp_val if cfg.rampup > 0 else 1.0
+        use_graph = self.use_graph and self.world == 1 and sup_x.is_cuda and (cfg.rampup <= 0 or float(ramp) >= 1.0)
+        if use_graph:
+            ce_sc, cons_vals = self._graphed_grads(sup_x, sup_y, unsup_batches, ramp, eps0)
+        else:
+            ce_sc, cons_vals = self._grads(sup_x, sup_y, unsup_batches, ramp, eps0)
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.student_optim.arena.grad, op=dist.ReduceOp.SUM, group=self.group)

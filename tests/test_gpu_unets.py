@@ -135,6 +135,54 @@ def test_config4_vat_step_denseunet():
     assert vals[-1]['sup_loss'] < vals[0]['sup_loss']
 
 
+def test_vat_gradient_passes_as_hipgraph_match_eager_launches():
+    """(round 6) vat.VATMeanTeacherStep replays the gradient passes of a layer-engine network (the U-Nets: ~9 000 launches through
+    Python autograd per iteration, host-bound) as ONE hipGraph launch after two eager iterations. Three identically seeded runs on
+    the ResNet-50 U-Net with the same inputs and initial noise: eager, eager again (the yardstick: fp32 atomics reorder run to run)
+    and graph -- the graph run really captured, replays with NEW inputs, and differs from the eager run no more than the eager runs
+    differ from each other."""
+    from architectures import network_architectures
+    from cutmix_semisup_seg_amd import optim as fo, vat
+    import optim_weight_ema
+    B, H, W, C = 4, 64, 96, 2
+    g = torch.Generator(device=DEV).manual_seed(1)
+    data = []
+    for _ in range(6):
+        y = (torch.rand(B, 1, H, W, generator=g, device=DEV) < 0.4).to(torch.uint8)
+        x = (torch.randn(B, 3, H, W, generator=g, device=DEV) + 1.5 * y.float()).bfloat16()
+        u = torch.randn(B, 3, H, W, generator=g, device=DEV).bfloat16()
+        data.append((x, y, u, vat.normalized_noise_like(u, 1.0e-6 * H * W / 1000, g)))
+
+    def run(use_graph):
+        torch.manual_seed(0)
+        Net = network_architectures.seg.get('resnet50unet_imagenet')
+        stu, tea = Net(C, pretrained=False).to(DEV), Net(C, pretrained=False).to(DEV)
+        opt = fo.FusedSGD(stu, [dict(params=list(stu.pretrained_parameters()), lr=0.01), dict(params=list(stu.new_parameters()), lr=0.1)],
+                          momentum=0.9, nesterov=True, weight_decay=5e-4)
+        for p in tea.parameters():
+            p.requires_grad = False
+        ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
+        ema.fuse_into(opt)
+        stu.train(); tea.train()
+        step = vat.VATMeanTeacherStep(stu, tea, opt, ema, vat.VATConfig(vat_radius=1.0, adaptive_vat_radius=True, cons_loss_fn='kld',
+                                                                       cons_weight=0.001, conf_thresh=0.0))
+        assert step.use_graph                      # 'auto': a layer-engine network
+        step.use_graph = use_graph
+        losses = [float(step(x, y, [vat.VATUnsupBatch(u)], eps0=e)['sup_loss']) for x, y, u, e in data]
+        torch.cuda.synchronize()
+        return losses, opt.arena.flat.clone(), step
+
+    la, wa, _ = run(False)
+    lb, wb, _ = run(False)
+    lg, wg, sg = run(True)
+    assert sum(1 for v in sg._graphs.values() if 'graph' in v) == 1 and not any(v.get('failed') for v in sg._graphs.values())
+    rel = lambda p, q: float((p - q).abs().max() / (p.abs().max() + 1e-30))
+    dl = lambda p, q: max(abs(a - b) / abs(a) for a, b in zip(p, q))
+    print('\nVAT hipGraph vs eager: losses {} | {}; weights graph-eager {:.2e}, eager-eager {:.2e}'.format(la, lg, rel(wa, wg), rel(wa, wb)))
+    assert all(np.isfinite(lg)) and lg[-1] < lg[0]
+    assert dl(la, lg) <= max(1e-3, 4 * dl(la, lb)) and rel(wa, wg) <= max(1e-3, 4 * rel(wa, wb))
+
+
 @pytest.mark.parametrize('arch,shape', [('resnet50unet_imagenet', (4, 3, 64, 96)), ('densenet161unet', (2, 3, 64, 64))])
 def test_bf16_engine_every_unit_teacher_forced_vs_the_bf16_storage_unit_oracle(arch, shape, no_library_convolutions):
     """The bf16 configuration of the U-Nets held like the timed DeepLab configurations (round 4): whole-network outputs of two

@@ -42,11 +42,11 @@ step = vat.VATMeanTeacherStep(stu, tea, opt, ema, cfg, generator=g)
 im = lambda: torch.randn(B, 3, H, W, generator=g, device=dev).bfloat16()
 y = torch.randint(0, C, (B, 1, H, W), generator=g, device=dev).to(torch.uint8)
 x, xt = im(), im()
-for _ in range(3):
+for _ in range(int(os.environ.get('VAT_BENCH_WARMUP', '5'))):     # (2 eager iterations + the hipGraph capture + replays)
     step(x, y, [vat.VATUnsupBatch(xt)])
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-K = 8
+K = int(os.environ.get('VAT_BENCH_STEPS', '16'))
 for _ in range(K):
     r = step(x, y, [vat.VATUnsupBatch(xt)])
 torch.cuda.synchronize()
