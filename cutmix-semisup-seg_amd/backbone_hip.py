@@ -1218,6 +1218,7 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
             ops.memset_zero(self._wdot_all)
             ops.memset_zero(self._dbeta_all)
         keep = []
+        wjob = 0
         capture = getattr(self, 'debug_capture', None)      # {block: (dC, dU2, dU1)} of the pass being issued (diagnostics)
         for bi in range(len(self.blocks) - 1, -1, -1):
             if rec is not None:
@@ -1232,8 +1233,20 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
                 dU1 = self._dgrad_strided(dU2, b.c2, a1, (a1.shape[1], a1.shape[2]))
             if capture is not None:
                 capture[bi] = (dC, dU2, dU1)
-            if side is not None:
-                # `side`: one stream, or (round 6, CMS_V3_WGRAD_STREAMS=2) a list the blocks alternate over
+            if isinstance(side, (list, tuple)) and len(side) > 1 and os.environ.get('CMS_V3_WGRAD_PER_JOB', '1') != '0':
+                # (round 6) two weight-gradient streams, the JOBS alternating over them with a counter that runs across the
+                # blocks: per-block alternation left one stream 2.4 ms behind the other at the end of the pass (layer 1's three
+                # blocks at 129 x 129: two of them on one stream) with the main stream idle behind both (profiles/r06al_*)
+                for sd in side:
+                    ops.stream_wait(sd, main)
+                keep.append((dC, dU2, dU1))
+                jobs = [(dC, a2, b.c3), (dU2, a1, b.c2)] + ([(dC, xin, b.cd)] if b.cd is not None else []) + [(dU1, xin, b.c1)]
+                for du_, x_, c_ in jobs:
+                    with torch.cuda.stream(side[wjob % len(side)]):
+                        self._wgrad(du_, x_, c_)
+                    wjob += 1
+            elif side is not None:
+                # `side`: one stream, or a list the blocks alternate over (CMS_V3_WGRAD_PER_JOB=0)
                 sd = side[bi % len(side)] if isinstance(side, (list, tuple)) else side
                 ops.stream_wait(sd, main)
                 keep.append((dC, dU2, dU1))
