@@ -115,6 +115,46 @@ def compact_line(full):
     return line
 
 
+def vat_denseunet_run(dev, warmup=6, steps=12):
+    """One short run of BASELINE configs[4] (tools/vat_bench.py denseunet): -> an `also` entry."""
+    import time
+    import torch
+    from cutmix_semisup_seg_amd import optim as fo, vat
+    from architectures import network_architectures
+    import optim_weight_ema
+    B, H, W, C = 10, 224, 224, 2
+    torch.manual_seed(0)
+    Net = network_architectures.seg.get('densenet161unet_imagenet')
+    stu, tea = Net(C, pretrained=False).to(dev), Net(C, pretrained=False).to(dev)
+    opt = fo.FusedSGD(stu, [dict(params=list(stu.pretrained_parameters()), lr=0.01), dict(params=list(stu.new_parameters()), lr=0.1)],
+                      momentum=0.9, nesterov=True, weight_decay=5e-4)
+    for p in tea.parameters():
+        p.requires_grad = False
+    ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
+    ema.fuse_into(opt)
+    stu.train(); tea.train()
+    g = torch.Generator(device=dev).manual_seed(1)
+    step = vat.VATMeanTeacherStep(stu, tea, opt, ema, vat.VATConfig(vat_radius=1.0, adaptive_vat_radius=True, cons_loss_fn='kld',
+                                                                   cons_weight=0.001, conf_thresh=0.97), generator=g)
+    x = torch.randn(B, 3, H, W, generator=g, device=dev).bfloat16()
+    xt = torch.randn(B, 3, H, W, generator=g, device=dev).bfloat16()
+    y = torch.randint(0, C, (B, 1, H, W), generator=g, device=dev).to(torch.uint8)
+    for _ in range(warmup):                       # 2 eager iterations, the capture, the (slower) first replays
+        step(x, y, [vat.VATUnsupBatch(xt)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = step(x, y, [vat.VATUnsupBatch(xt)])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    captured = sum(1 for v in step._graphs.values() if 'graph' in v)
+    del step, opt, ema, stu, tea
+    torch.cuda.empty_cache()
+    return {'name': 'VAT DenseNet-161 U-Net (BASELINE configs[4])', 'value': B / dt, 'unit': 'images/sec', 'ms_per_step': dt * 1e3,
+            'steps': steps, 'warmup': warmup, 'config': {'workload': 'densenet161unet VAT mean-teacher iteration, 10x3x224x224, 2 classes, SGD',
+                                                        'hipgraph_replay': bool(captured), 'sup_loss': float(r['sup_loss'])}}
+
+
 def write_detail(full, path=None):
     """The complete result object next to the script (or under $TMPDIR when the tree is read-only); returns the path or None."""
     import tempfile
@@ -929,6 +969,13 @@ def main():
             except Exception as e:                  # noqa: BLE001 -- reported, the headline line still goes out
                 also.append({'name': name, 'error': '{}: {}'.format(type(e).__name__, e)})
                 torch.cuda.empty_cache()
+        # BASELINE configs[4]: VAT mean-teacher iteration of the DenseNet-161 U-Net (train_seg_semisup_vat_mt.py), 10 x 3 x 224 x 224,
+        # 2 classes, SGD -- the gradient passes replayed as one hipGraph launch (vat.VATMeanTeacherStep); steady state after the capture
+        try:
+            also.append(vat_denseunet_run(dev))
+        except Exception as e:                      # noqa: BLE001
+            also.append({'name': 'VAT DenseNet-161 U-Net (BASELINE configs[4])', 'error': '{}: {}'.format(type(e).__name__, e)})
+            torch.cuda.empty_cache()
     if rank == 0:
         head = results[0]
         out = {
@@ -966,7 +1013,7 @@ def main():
         out['configs'] = results
         if also:
             out['also'] = also
-            for a_, k_ in zip(also, ('also_v3plus_513x513_img_s', 'also_no_freeze_bn_321x321_img_s')):
+            for a_, k_ in zip(also, ('also_v3plus_513x513_img_s', 'also_no_freeze_bn_321x321_img_s', 'also_vat_denseunet_224x224_img_s')):
                 out['config'][k_] = a_.get('value')
         # the complete object goes to bench_detail.json (and, with --detail_stdout, to an EARLIER stdout line); the LAST stdout
         # line is the compact one the driver parses (<= LINE_LIMIT bytes)

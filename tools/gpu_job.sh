@@ -52,7 +52,7 @@ for l in sys.stdin:
     d = json.loads(l)
     r = d.get('roofline', {})
     c = d.get('config', {})
-    print('   $name: value %.1f %s  ms/step %.2f  512x1024 %s  conv frac %s isolated %s step_mfma %s mixed %s hbm_group %s | also v3+ %s nofreeze %s | line %d B' % (d['value'], d['unit'], d['ms_per_step'], d.get('value_512x1024'), r.get('frac'), r.get('isolated_frac'), r.get('step_mfma_frac'), r.get('mixed_frac'), r.get('hbm_group_frac'), c.get('also_v3plus_513x513_img_s'), c.get('also_no_freeze_bn_321x321_img_s'), len(l)))
+    print('   $name: value %.1f %s  ms/step %.2f  512x1024 %s  conv frac %s isolated %s step_mfma %s mixed %s hbm_group %s | also v3+ %s nofreeze %s vat %s | line %d B' % (d['value'], d['unit'], d['ms_per_step'], d.get('value_512x1024'), r.get('frac'), r.get('isolated_frac'), r.get('step_mfma_frac'), r.get('mixed_frac'), r.get('hbm_group_frac'), c.get('also_v3plus_513x513_img_s'), c.get('also_no_freeze_bn_321x321_img_s'), c.get('also_vat_denseunet_224x224_img_s'), len(l)))
 " | tee -a $SUM ;;
     rocprof)
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o bench -- python $ROOT/bench.py $rest ) > $OUT/${TAG}_rocprof.log 2>&1
