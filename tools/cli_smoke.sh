@@ -19,4 +19,7 @@ run vat train_seg_semisup_vat_mt.py --job_desc v --synthetic --arch resnet101_de
 # round 5: the U-Nets through the default ('auto' = all hand-written) engine -- no library convolution may be reached (it would raise)
 run resunet_cutmix train_seg_semisup_mask_mt.py --job_desc ru --synthetic --arch resnet50unet_imagenet --batch_size 2 --crop_size 64,64 --learning_rate 3e-5 --num_epochs 1 --iters_per_epoch 2 --synthetic_val_batches 1
 run denseunet_vat train_seg_semisup_vat_mt.py --job_desc dv --synthetic --arch densenet161unet_imagenet --batch_size 2 --crop_size 64,64 --num_epochs 1 --iters_per_epoch 2 --synthetic_val_batches 1
+# round 6: the VAT trainer of a U-Net long enough for the hipGraph replay of the gradient passes (two eager iterations, the capture,
+# replays) across an evaluation in between (train -> eval -> train: same signature, the graph is replayed again in epoch 2)
+run denseunet_vat_graph train_seg_semisup_vat_mt.py --job_desc dvg --synthetic --arch densenet161unet_imagenet --batch_size 2 --crop_size 64,64 --num_epochs 2 --iters_per_epoch 5 --synthetic_val_batches 1
 echo "cli_smoke OK"
