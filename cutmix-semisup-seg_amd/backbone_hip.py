@@ -1293,8 +1293,9 @@ class DeepLabV3PlusBackboneExecutor(DeepLabHipExecutor):
         # 148 img/s on one stream, 174 on two, 157.5 with the side-output kernel on one (cfg 4, profiles/r06aj_*). With the side-output
         # kernel everywhere (CMS_V3_WGRAD8=0) two streams lose (152.8 vs 154.7, profiles/r06o_*): one stream then. CMS_V3_WGRAD_STREAMS overrides.
         two = self.dtype == torch.bfloat16 and not ops.deterministic_wgrad() and os.environ.get('CMS_V3_WGRAD8', '1') != '0'
-        if side is not None and os.environ.get('CMS_V3_WGRAD_STREAMS', '2' if two else '1') == '2':
-            side = [side, ops.pooled_stream(self.arena.device, 'wgrad1')]
+        nws = os.environ.get('CMS_V3_WGRAD_STREAMS', '2' if two else '1')
+        if side is not None and nws in ('2', '3'):
+            side = [side] + [ops.pooled_stream(self.arena.device, 'wgrad{}'.format(i)) for i in range(1, int(nws))]
         recorded = isinstance(saved, tuple) and len(saved) == 2 and isinstance(saved[0], ops.Program)
         if not recorded:
             x4 = saved[-1]
