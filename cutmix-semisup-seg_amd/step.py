@@ -382,6 +382,121 @@ class CutMixMeanTeacherStep(object):
             return ops.cutmix_paste(ub.x0_stu, ub.x1_stu, ranges=ub.ranges, invert=cfg.cons.invert)
         return ops.cutmix_paste(None, ub.x0_stu, ranges=ub.ranges, invert=cfg.cons.invert)      # x * m
 
+    # ------------------------------------------------------------------------------------------ separate passes (+ hipGraph replay)
+    def _separate_passes(self, sup_x, sup_y, unsup_batches, ramp, out_size, use_unsup, allow_overlap=True):
+        """The gradient passes in the reference's order (batch-statistics BN couples the samples of a pass: no concatenation). The
+        teacher's passes depend on nothing the student does within the iteration (its weights only move in the EMA at the end),
+        so they are issued FIRST, on the side stream, and run concurrently with the student's supervised forward / backward and
+        mixed forward; the teacher's own two passes keep their order (they update the same running statistics).
+        -> (ce scalars, [consistency scalars])"""
+        cfg = self.cfg
+        main = torch.cuda.current_stream()
+        self.student_optim.zero_grad()
+        tea_out = []
+        overlap = allow_overlap and use_unsup and cfg.overlap_teacher and self.teacher is not self.student
+        if overlap:
+            side = self._teacher_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                for ub in unsup_batches:
+                    tea_out.append((self.teacher.forward_lowres(ub.x0_tea),
+                                    self.teacher.forward_lowres(ub.x1_tea) if cfg.mix else None))
+        lo = self.student.forward_lowres(sup_x)
+        ce_sc, ce_ctx = ops.ce_forward(lo.detach(), sup_y, out_size, 255, self.align_corners, group=self.group)
+        lo.backward(ops.ce_backward(ce_ctx, ce_sc).to(lo.dtype))
+        cons_vals = []
+        if use_unsup:
+            for bi, ub in enumerate(unsup_batches):
+                x_stu = self._student_inputs(ub)
+                if overlap:
+                    l0, l1 = tea_out[bi]
+                else:
+                    with torch.no_grad():
+                        l0 = self.teacher.forward_lowres(ub.x0_tea)
+                        l1 = self.teacher.forward_lowres(ub.x1_tea) if cfg.mix else None
+                ls = self.student.forward_lowres(x_stu)
+                if overlap and bi == 0:
+                    main.wait_stream(side)
+                sc, cctx = ops.consistency_forward(cfg.cons, ls.detach(), l0, l1, out_size, ranges=ub.ranges,
+                                                   um0=ub.um0, um1=ub.um1, ramp_val=ramp,
+                                                   cons_weight=cfg.cons_weight, group=self.group)
+                ls.backward(ops.consistency_backward(cctx, sc).to(ls.dtype))
+                cons_vals.append(sc)
+        return ce_sc, cons_vals
+
+    def _graph_wanted(self):
+        """hipGraph replay of the separate passes ('auto'): single process, both networks layer-engine networks (the U-Nets: every
+        launch goes through Python autograd and the step is HOST-bound -- 51.9 ms of enqueue per 51.9 ms step on the ResNet-50
+        U-Net, 158 per 158 on the DenseNet-161 U-Net, tools/unet_cutmix_bench.py). CMS_STEP_GRAPH=0 / 1 forces it."""
+        env = os.environ.get('CMS_STEP_GRAPH', 'auto')
+        if env in ('0', '1'):
+            return env == '1' and self.world == 1
+        layerwise = not any(hasattr(n, a) for n in (self.student, self.teacher) for a in ('_use_hip_body', '_use_hip_backbone'))
+        return layerwise and self.world == 1
+
+    def _separate_or_graphed(self, sup_x, sup_y, unsup_batches, ramp, out_size, use_unsup):
+        """`_separate_passes`, or -- after two eager iterations of a (shapes, modes, ramp) signature -- its capture into ONE
+        torch.cuda.CUDAGraph over static input buffers, replayed (see vat.VATMeanTeacherStep._graphed_grads, whose rules apply:
+        weight-derived operands marked stale before the capture, one capture stream, no teacher side stream inside, dropout draws
+        from the default generator the graph registers; a ramp that still changes runs eagerly; an operation the capture cannot hold
+        -> warning + launches). Gradient exchange, optimizer, EMA and the NaN probe stay outside."""
+        cfg = self.cfg
+        if not (sup_x.is_cuda and self._graph_wanted() and (cfg.rampup <= 0 or float(ramp) >= 1.0)):
+            return self._separate_passes(sup_x, sup_y, unsup_batches, ramp, out_size, use_unsup)
+        ubs = list(unsup_batches) if use_unsup else []
+        flat = [sup_x, sup_y]
+        for u in ubs:
+            flat += [u.x0_tea, u.x1_tea, u.x0_stu, u.x1_stu, u.ranges, u.um0, u.um1]
+        sig = lambda t: None if t is None else (tuple(t.shape), t.dtype, t.device.index)
+        alias = tuple(next(j for j, q in enumerate(flat) if q is t) if t is not None else -1 for t in flat)   # which inputs are ONE tensor
+        key = (tuple(sig(t) for t in flat), alias, float(ramp), tuple(out_size), bool(use_unsup), self.student.training, self.teacher.training,
+               getattr(self.student, 'compute_dtype', None), getattr(self.teacher, 'compute_dtype', None))
+        store = self.__dict__.setdefault('_graphs', {})
+        ent = store.setdefault(key, {'seen': 0})
+
+        def rebuild(ts):
+            out, i = [], 2
+            for _ in ubs:
+                x0t, x1t, x0s, x1s, rg, m0, m1 = ts[i:i + 7]
+                out.append(UnsupBatch(x0t, rg, um0=m0, x1_tea=x1t, um1=m1, x0_stu=x0s, x1_stu=x1s))
+                i += 7
+            return out
+
+        if 'graph' not in ent:
+            ent['seen'] += 1
+            if ent['seen'] <= 2 or ent.get('failed'):
+                return self._separate_passes(sup_x, sup_y, unsup_batches, ramp, out_size, use_unsup)
+            static = []
+            for j, t in enumerate(flat):
+                static.append(None if t is None else (static[alias[j]] if alias[j] != j else t.clone()))
+            for net in (self.student, self.teacher):
+                a = getattr(net, '_cms_arena', None)
+                if a is not None:
+                    a.touch()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            prev = ops.set_side_streams_enabled(False)
+            try:
+                with torch.cuda.graph(g):
+                    outs = self._separate_passes(static[0], static[1], rebuild(static), ramp, out_size, use_unsup, allow_overlap=False)
+            except Exception as e:               # noqa: BLE001 -- nothing ran on the device
+                import warnings
+                warnings.warn('cutmix-semisup-seg_amd: the gradient passes of the step could not be captured into a hipGraph ({}: {}); '
+                              'this signature keeps running launch by launch'.format(type(e).__name__, str(e).splitlines()[0] if str(e) else ''),
+                              RuntimeWarning, stacklevel=2)
+                ent['failed'] = True
+                torch.cuda.synchronize()
+                return self._separate_passes(sup_x, sup_y, unsup_batches, ramp, out_size, use_unsup)
+            finally:
+                ops.set_side_streams_enabled(prev)
+            ent.update(graph=g, static=static, out=outs)
+        for j, (st, t) in enumerate(zip(ent['static'], flat)):
+            if t is not None and alias[j] == j:
+                st.copy_(t)
+        ent['graph'].replay()
+        ce_sc, cons_vals = ent['out']
+        return ce_sc.clone(), [c.clone() for c in cons_vals]
+
     # ------------------------------------------------------------------------------------------ the iteration
     def __call__(self, sup_x, sup_y, unsup_batches, ramp_val=1.0):
         """
@@ -553,42 +668,7 @@ class CutMixMeanTeacherStep(object):
                     dex.defer_wgrad_join = False
                     dex.join_wgrad()
         else:
-            # reference order, separate passes (batch-statistics BN). The teacher's passes depend on nothing the student
-            # does within the iteration (its weights only move in the EMA at the end), so they are issued FIRST, on
-            # the side stream, and run concurrently with the student's supervised forward / backward and mixed
-            # forward; the teacher's own two passes keep their order (they update the same running statistics).
-            main = torch.cuda.current_stream()
-            self.student_optim.zero_grad()
-            tea_out = []
-            overlap = use_unsup and cfg.overlap_teacher and self.teacher is not self.student
-            if overlap:
-                side = self._teacher_stream()
-                side.wait_stream(main)
-                with torch.cuda.stream(side), torch.no_grad():
-                    for ub in unsup_batches:
-                        tea_out.append((self.teacher.forward_lowres(ub.x0_tea),
-                                        self.teacher.forward_lowres(ub.x1_tea) if cfg.mix else None))
-            lo = self.student.forward_lowres(sup_x)
-            ce_sc, ce_ctx = ops.ce_forward(lo.detach(), sup_y, out_size, 255, self.align_corners, group=self.group)
-            lo.backward(ops.ce_backward(ce_ctx, ce_sc).to(lo.dtype))
-            cons_vals = []
-            if use_unsup:
-                for bi, ub in enumerate(unsup_batches):
-                    x_stu = self._student_inputs(ub)
-                    if overlap:
-                        l0, l1 = tea_out[bi]
-                    else:
-                        with torch.no_grad():
-                            l0 = self.teacher.forward_lowres(ub.x0_tea)
-                            l1 = self.teacher.forward_lowres(ub.x1_tea) if cfg.mix else None
-                    ls = self.student.forward_lowres(x_stu)
-                    if overlap and bi == 0:
-                        main.wait_stream(side)
-                    sc, cctx = ops.consistency_forward(cfg.cons, ls.detach(), l0, l1, out_size, ranges=ub.ranges,
-                                                       um0=ub.um0, um1=ub.um1, ramp_val=ramp,
-                                                       cons_weight=cfg.cons_weight, group=self.group)
-                    ls.backward(ops.consistency_backward(cctx, sc).to(ls.dtype))
-                    cons_vals.append(sc)
+            ce_sc, cons_vals = self._separate_or_graphed(sup_x, sup_y, unsup_batches, ramp, out_size, use_unsup)
 
         ops.join_side_streams()           # weight gradients the layer engines issued on side streams (ops.layer_wgrad_stream)
         self._allreduce_grads()

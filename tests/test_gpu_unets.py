@@ -135,6 +135,61 @@ def test_config4_vat_step_denseunet():
     assert vals[-1]['sup_loss'] < vals[0]['sup_loss']
 
 
+def test_cutmix_step_separate_passes_as_hipgraph_match_eager_launches():
+    """(round 6) step.CutMixMeanTeacherStep replays the separate passes of a layer-engine network (train_seg_semisup_mask_mt.py:287-476
+    on a U-Net: batch-statistics BatchNorm, so no concatenation; host-bound launch by launch) as ONE hipGraph launch after two eager
+    iterations: eager, eager again (yardstick) and graph runs of the ResNet-50 U-Net with new inputs and new box masks every iteration."""
+    from architectures import network_architectures
+    from cutmix_semisup_seg_amd import ops, optim as fo
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig, UnsupBatch
+    import mask_gen
+    import optim_weight_ema
+    B, H, W, C = 4, 64, 96, 2
+    g = torch.Generator(device=DEV).manual_seed(1)
+    rng = np.random.RandomState(5)
+    data = []
+    for _ in range(6):
+        y = (torch.rand(B, 1, H, W, generator=g, device=DEV) < 0.4).to(torch.uint8)
+        x = (torch.randn(B, 3, H, W, generator=g, device=DEV) + 1.5 * y.float()).bfloat16()
+        x0 = torch.randn(B, 3, H, W, generator=g, device=DEV).bfloat16()
+        x1 = torch.randn(B, 3, H, W, generator=g, device=DEV).bfloat16()
+        r = ops.ranges_to_device(mask_gen.BoxMaskGenerator(0.5, invert=True).generate_ranges(B, (H, W), rng=rng), torch.device(DEV))
+        data.append((x, y, x0, x1, r))
+
+    def run(mode):
+        torch.manual_seed(0)
+        Net = network_architectures.seg.get('resnet50unet_imagenet')
+        stu, tea = Net(C, pretrained=False).to(DEV), Net(C, pretrained=False).to(DEV)
+        opt = fo.FusedSGD(stu, [dict(params=list(stu.pretrained_parameters()), lr=0.01), dict(params=list(stu.new_parameters()), lr=0.1)],
+                          momentum=0.9, nesterov=True, weight_decay=5e-4)
+        for p in tea.parameters():
+            p.requires_grad = False
+        ema = optim_weight_ema.EMAWeightOptimizer(tea, stu, 0.99)
+        ema.fuse_into(opt)
+        stu.train(); tea.train()
+        step = CutMixMeanTeacherStep(stu, tea, opt, ema, StepConfig(conf_thresh=0.0))
+        assert step._graph_wanted()                 # 'auto': layer-engine networks, one process
+        os.environ['CMS_STEP_GRAPH'] = mode
+        try:
+            losses = [float(step(x, y, [UnsupBatch(x0, r, x1_tea=x1)])['sup_loss']) for x, y, x0, x1, r in data]
+        finally:
+            os.environ.pop('CMS_STEP_GRAPH', None)
+        torch.cuda.synchronize()
+        return losses, opt.arena.flat.clone(), step
+
+    import os
+    la, wa, _ = run('0')
+    lb, wb, _ = run('0')
+    lg, wg, sg = run('1')
+    ents = list(sg.__dict__.get('_graphs', {}).values())
+    assert sum(1 for v in ents if 'graph' in v) == 1 and not any(v.get('failed') for v in ents)
+    rel = lambda p, q: float((p - q).abs().max() / (p.abs().max() + 1e-30))
+    dl = lambda p, q: max(abs(a - b) / abs(a) for a, b in zip(p, q))
+    print('\nCutMix step hipGraph vs eager: losses {} | {}; weights graph-eager {:.2e}, eager-eager {:.2e}'.format(la, lg, rel(wa, wg), rel(wa, wb)))
+    assert all(np.isfinite(lg)) and lg[-1] < lg[0]
+    assert dl(la, lg) <= max(1e-3, 4 * dl(la, lb)) and rel(wa, wg) <= max(1e-3, 4 * rel(wa, wb))
+
+
 def test_vat_gradient_passes_as_hipgraph_match_eager_launches():
     """(round 6) vat.VATMeanTeacherStep replays the gradient passes of a layer-engine network (the U-Nets: ~9 000 launches through
     Python autograd per iteration, host-bound) as ONE hipGraph launch after two eager iterations. Three identically seeded runs on
