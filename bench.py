@@ -386,6 +386,10 @@ def run_workload(key, args, world, rank, dev):
     if args.tile_rule and has_ex:
         rules = {int(a): int(b) for a, b in (kv.split(':') for kv in args.tile_rule.split(','))}
         stu.hip_executor().tile_rules = tea.hip_executor().tile_rules = rules
+    if os.environ.get('CMS_TEACHER_TILE_RULE') and has_ex:
+        # EXPERIMENT (round 6): the TEACHER's K-deep convolutions on the 128 x 128 family (e.g. "256-128+512-128") while the student's
+        # stay on the eight-phase kernel -- two eight-phase launches of 132 tiles are 264 whole-CU workgroups for 256 CUs
+        tea.hip_executor().tile_rules = {int(a): int(b) for a, b in (kv.split('-') for kv in os.environ['CMS_TEACHER_TILE_RULE'].split('+'))}
 
     gen = torch.Generator(device=dev).manual_seed(12345 + rank)
     mask_rng = np.random.RandomState(12345 + rank)

@@ -33,3 +33,19 @@ for k1, k2 in (('8', '8'), ('128', '8'), ('8', '128'), ('128', '128'), ('t256', 
         print('   {:<22s} {:10.1f} {:12.1f}'.format(k1 + ' / ' + k2, one, two))
     except Exception as e:            # noqa
         print('   {:<22s} failed: {}'.format(k1 + ' / ' + k2, str(e)[:120]))
+
+# asymmetric pairs: the student's chain on one set of kernels, the teacher's on another -- two eight-phase launches of 132 tiles are 264
+# whole-CU workgroups for 256 CUs; an eight-phase launch beside a 128 x 128 launch (four per CU) has no such collision
+print('== asymmetric pairs (chain A kernels | chain B kernels); us per bottleneck pair')
+for ka, kb in ((('8', '8'), ('128', '128')), (('8', '8'), ('128', '8')), (('8', '8'), ('8', '128')), (('8', '8'), ('t1128', 't1128'))):
+    try:
+        pa_ = (mk(ka[0], 1), mk(ka[1], 2), L.conv3)
+        pb_ = (mk(kb[0], 1), mk(kb[1], 2), L.conv3)
+        for f in pb_[:2]:
+            f(B, 0)
+        torch.cuda.synchronize()
+        ga, gb = L.chain(A, pa, pa_), L.chain(B, pb, pb_)
+        two = L.timed(lambda: (ga(), gb()), [pa, pb]) / L.BLOCKS
+        print('   {:<12s} | {:<14s} {:10.1f}'.format(' / '.join(ka), ' / '.join(kb), two))
+    except Exception as e:            # noqa
+        print('   {} | {} failed: {}'.format(ka, kb, str(e)[:120]))
