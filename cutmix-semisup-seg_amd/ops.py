@@ -452,18 +452,27 @@ def _probe_side_streams(dev):
         for st_ in streams:                               # every stream has run something: its queue is assigned
             with torch.cuda.stream(st_):
                 torch.cuda._sleep(1000)
-        pair_ms(cur, cands[0])                            # warm-up
-        alone = max(min(pair_ms(cur, None) for _ in range(3)), 1e-3)
         n = len(streams)
-        clash = [[False] * n for _ in range(n)]
+        # The spin kernel counts SHADER clocks, so its duration moves with the power state (0.090 ms at 2.2 GHz, 0.150 ms right after
+        # the GPU idled: tests/test_gpu_executor.py met that, round 6). A yardstick taken at a low clock would hide every clash
+        # (2 x 0.09 < 1.5 x 0.15): a few ms of work bring the clock up first, the yardstick is measured before AND after the pairs,
+        # and a probe whose two yardsticks disagree by more than 20 % is taken again (at most twice).
+        for attempt in range(3):
+            torch.cuda._sleep(20 * spin)
+            pair_ms(cur, cands[0])                        # warm-up
+            alone = max(min(pair_ms(cur, None) for _ in range(3)), 1e-3)
+            clash = [[False] * n for _ in range(n)]
 
-        def clashes(a, b):
-            # noise (another process on the GPU, a second rank on the same device) only ever LENGTHENS a trial: a pair shares a queue
-            # only if every one of three trials says so (one 0.1 ms timing per pair marked false clashes on a busy GPU)
-            return all(pair_ms(a, b) >= 1.5 * alone for _ in range(3))
-        for i in range(n):
-            for j in range(i + 1, n):
-                clash[i][j] = clash[j][i] = clashes(streams[i], streams[j])
+            def clashes(a, b):
+                # noise (another process on the GPU, a second rank on the same device) only ever LENGTHENS a trial: a pair shares a
+                # queue only if every one of three trials says so (one 0.1 ms timing per pair marked false clashes on a busy GPU)
+                return all(pair_ms(a, b) >= 1.5 * alone for _ in range(3))
+            for i in range(n):
+                for j in range(i + 1, n):
+                    clash[i][j] = clash[j][i] = clashes(streams[i], streams[j])
+            alone_end = max(min(pair_ms(cur, None) for _ in range(3)), 1e-3)
+            if 0.8 <= alone_end / alone <= 1.25:
+                break
     # greedy: candidates in creation order that clash neither with the current stream nor with one already chosen
     chosen = []
     for j in range(1, n):
