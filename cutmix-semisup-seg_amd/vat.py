@@ -161,24 +161,41 @@ class VATMeanTeacherStep(object):
         self._graphs = {}
 
     # ------------------------------------------------------------------------------------------ the gradient passes
-    def _grads(self, sup_x, sup_y, unsup_batches, ramp, eps0):
+    def _grads(self, sup_x, sup_y, unsup_batches, ramp, eps0, teacher_early=False):
         """Everything of the iteration in front of the gradient exchange / optimizer: gradient clear, supervised pass, VAT
-        direction, teacher pass, perturbed student pass. -> (ce scalars, [consistency scalars]) on the device."""
+        direction, teacher pass, perturbed student pass. -> (ce scalars, [consistency scalars]) on the device.
+        `teacher_early` (the captured form): the teacher's passes over the unperturbed images are issued FIRST, on a side stream,
+        beside everything up to the consistency loss -- only when the teacher is in eval() mode (it is from the second iteration on
+        when it provides the VAT direction, :237; its pass then changes no state and its place in the order is immaterial)."""
         cfg = self.cfg
         out_size = sup_x.shape[2:4]
         self.student_optim.zero_grad()
+        early = None
+        if (teacher_early and cfg.cons_weight > 0.0 and unsup_batches and self.teacher is not self.student and not self.teacher.training
+                and sup_x.is_cuda):
+            main = torch.cuda.current_stream()
+            side = ops.pooled_stream(sup_x.device, 'teacher')
+            if side.cuda_stream != main.cuda_stream:
+                side.wait_stream(main)
+                with torch.cuda.stream(side), torch.no_grad():
+                    early = [self.teacher.forward_lowres(ub.x_tea) for ub in unsup_batches]
         lo = self.student.forward_lowres(sup_x)
         ce_sc, ce_ctx = ops.ce_forward(lo.detach(), sup_y, out_size, 255, self.align_corners, group=self.group)
         lo.backward(ops.ce_backward(ce_ctx, ce_sc).to(lo.dtype))
         cons_vals = []
         if cfg.cons_weight > 0.0:
-            for ub in unsup_batches:
+            for bi, ub in enumerate(unsup_batches):
                 x_perturb, _ = vat_perturbation(self.vat_dir_net, ub.x_tea, ub.x_stu, cfg.vat_radius, cfg.adaptive,
                                                 cfg.cons_loss_fn, eps0=eps0, generator=self.generator)
                 x_adv = (ub.x_stu.float() + x_perturb).to(ub.x_stu.dtype)
-                with torch.no_grad():
-                    l_tea = self.teacher.forward_lowres(ub.x_tea)
+                if early is not None:
+                    l_tea = early[bi]
+                else:
+                    with torch.no_grad():
+                        l_tea = self.teacher.forward_lowres(ub.x_tea)
                 l_stu = self.student.forward_lowres(x_adv)
+                if early is not None and bi == 0:
+                    torch.cuda.current_stream().wait_stream(side)
                 sc, cctx = ops.consistency_forward(cfg.cons, l_stu.detach(), l_tea, None, out_size,
                                                    ranges=_ones_ranges(x_adv.shape[0], x_adv.device), um0=ub.um,
                                                    ramp_val=ramp, cons_weight=cfg.cons_weight, group=self.group)
@@ -233,7 +250,8 @@ class VATMeanTeacherStep(object):
             prev = ops.set_side_streams_enabled(os.environ.get('CMS_VAT_GRAPH_SIDE', '0') == '1')
             try:
                 with torch.cuda.graph(g):
-                    ce_sc, cons_vals = self._grads(st['sup_x'], st['sup_y'], st['ubs'], ramp, st['eps0'])
+                    ce_sc, cons_vals = self._grads(st['sup_x'], st['sup_y'], st['ubs'], ramp, st['eps0'],
+                                                   teacher_early=os.environ.get('CMS_VAT_GRAPH_TEACHER_EARLY', '1') != '0')
             except Exception as e:               # noqa: BLE001 -- an operation the capture cannot hold (nothing ran on the device)
                 import warnings
                 warnings.warn('cutmix-semisup-seg_amd: the VAT gradient passes could not be captured into a hipGraph ({}: {}); this '
