@@ -170,7 +170,7 @@ class VATMeanTeacherStep(object):
         cfg = self.cfg
         out_size = sup_x.shape[2:4]
         self.student_optim.zero_grad()
-        early = None
+        early = adv_early = None
         if (teacher_early and cfg.cons_weight > 0.0 and unsup_batches and self.teacher is not self.student and not self.teacher.training
                 and sup_x.is_cuda):
             main = torch.cuda.current_stream()
@@ -179,22 +179,37 @@ class VATMeanTeacherStep(object):
                 side.wait_stream(main)
                 with torch.cuda.stream(side), torch.no_grad():
                     early = [self.teacher.forward_lowres(ub.x_tea) for ub in unsup_batches]
+                # ... and when the direction comes from the teacher too (the default, :102-105), the whole VAT direction pass goes with
+                # it: nothing on that stream touches the student, whose supervised forward / backward runs beside it on the main stream
+                # (CMS_VAT_GRAPH_DIR_SIDE=0: the direction stays on the main stream)
+                if self.vat_dir_net is self.teacher and os.environ.get('CMS_VAT_GRAPH_DIR_SIDE', '1') != '0':
+                    with torch.cuda.stream(side):
+                        adv_early = []
+                        for ub in unsup_batches:
+                            x_perturb, _ = vat_perturbation(self.vat_dir_net, ub.x_tea, ub.x_stu, cfg.vat_radius, cfg.adaptive,
+                                                            cfg.cons_loss_fn, eps0=eps0, generator=self.generator)
+                            adv_early.append((ub.x_stu.float() + x_perturb).to(ub.x_stu.dtype))
         lo = self.student.forward_lowres(sup_x)
         ce_sc, ce_ctx = ops.ce_forward(lo.detach(), sup_y, out_size, 255, self.align_corners, group=self.group)
         lo.backward(ops.ce_backward(ce_ctx, ce_sc).to(lo.dtype))
         cons_vals = []
         if cfg.cons_weight > 0.0:
+            if adv_early is not None:
+                torch.cuda.current_stream().wait_stream(side)          # the perturbed images (and the teacher's logits)
             for bi, ub in enumerate(unsup_batches):
-                x_perturb, _ = vat_perturbation(self.vat_dir_net, ub.x_tea, ub.x_stu, cfg.vat_radius, cfg.adaptive,
-                                                cfg.cons_loss_fn, eps0=eps0, generator=self.generator)
-                x_adv = (ub.x_stu.float() + x_perturb).to(ub.x_stu.dtype)
+                if adv_early is not None:
+                    x_adv = adv_early[bi]
+                else:
+                    x_perturb, _ = vat_perturbation(self.vat_dir_net, ub.x_tea, ub.x_stu, cfg.vat_radius, cfg.adaptive,
+                                                    cfg.cons_loss_fn, eps0=eps0, generator=self.generator)
+                    x_adv = (ub.x_stu.float() + x_perturb).to(ub.x_stu.dtype)
                 if early is not None:
                     l_tea = early[bi]
                 else:
                     with torch.no_grad():
                         l_tea = self.teacher.forward_lowres(ub.x_tea)
                 l_stu = self.student.forward_lowres(x_adv)
-                if early is not None and bi == 0:
+                if early is not None and adv_early is None and bi == 0:
                     torch.cuda.current_stream().wait_stream(side)
                 sc, cctx = ops.consistency_forward(cfg.cons, l_stu.detach(), l_tea, None, out_size,
                                                    ranges=_ones_ranges(x_adv.shape[0], x_adv.device), um0=ub.um,
