@@ -473,6 +473,9 @@ class CutMixMeanTeacherStep(object):
                 a = getattr(net, '_cms_arena', None)
                 if a is not None:
                     a.touch()
+            # everything lazy that synchronises must have happened BEFORE the capture: the side-stream probe above all (a trainer whose
+            # eager iterations never asked for a pooled stream met it inside the capture: `operation not permitted when stream is capturing`)
+            ops.pooled_stream(sup_x.device, 'teacher')
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             prev = ops.set_side_streams_enabled(False)
@@ -488,7 +491,11 @@ class CutMixMeanTeacherStep(object):
                               'this signature keeps running launch by launch'.format(type(e).__name__, str(e).splitlines()[0] if str(e) else ''),
                               RuntimeWarning, stacklevel=2)
                 ent['failed'] = True
-                torch.cuda.synchronize()
+                try:
+                    torch.cuda.synchronize()
+                except Exception as e2:          # noqa: BLE001 -- a forked stream is still inside the aborted capture: this process cannot launch any more
+                    raise RuntimeError('a failed hipGraph capture left the device in capture mode ({}); restart with {}=0 (launch by launch) '
+                                       'and report the operation named in the warning above'.format(e2, 'CMS_STEP_GRAPH')) from e
                 return self._separate_passes(sup_x, sup_y, unsup_batches, ramp, out_size, use_unsup)
             finally:
                 ops.set_side_streams_enabled(prev)

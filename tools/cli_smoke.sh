@@ -22,4 +22,5 @@ run denseunet_vat train_seg_semisup_vat_mt.py --job_desc dv --synthetic --arch d
 # round 6: the VAT trainer of a U-Net long enough for the hipGraph replay of the gradient passes (two eager iterations, the capture,
 # replays) across an evaluation in between (train -> eval -> train: same signature, the graph is replayed again in epoch 2)
 run denseunet_vat_graph train_seg_semisup_vat_mt.py --job_desc dvg --synthetic --arch densenet161unet_imagenet --batch_size 2 --crop_size 64,64 --num_epochs 2 --iters_per_epoch 5 --synthetic_val_batches 1
+run resunet_cutmix_graph train_seg_semisup_mask_mt.py --job_desc rug --synthetic --arch resnet50unet_imagenet --batch_size 2 --crop_size 64,64 --learning_rate 3e-5 --num_epochs 2 --iters_per_epoch 5 --synthetic_val_batches 1
 echo "cli_smoke OK"
