@@ -566,3 +566,36 @@ def test_bench_final_line_is_compact_and_strict_json():
     if os.path.exists(r5):
         l5 = bench.compact_line(json.load(open(r5)))
         assert len(l5) <= 4096 and json.loads(l5, parse_constant=strict)['value'] == pytest.approx(626.766, rel=1e-5)
+
+
+def test_hipgraph_replay_is_chosen_for_layer_engine_networks_only(monkeypatch):
+    """(round 6) The gradient passes are captured into a hipGraph and replayed where every launch goes through Python (the U-Nets:
+    host-bound), not for the DeepLab networks whose passes are recorded programs; one process only; the environment switches force
+    it either way (vat.VATMeanTeacherStep.use_graph, step.CutMixMeanTeacherStep._graph_wanted)."""
+    from cutmix_semisup_seg_amd.step import CutMixMeanTeacherStep, StepConfig
+    from cutmix_semisup_seg_amd import vat
+    from cutmix_semisup_seg_amd.architectures import deeplab3plus as d3, network_architectures
+    monkeypatch.delenv('CMS_STEP_GRAPH', raising=False)
+    monkeypatch.delenv('CMS_VAT_GRAPH', raising=False)
+    v2 = lambda: deeplab2.ResNetDeepLab(deeplab2.Bottleneck, [1, 1, 1, 1], 3, np.zeros(3), np.ones(3))
+    v3 = lambda: d3.DeepLabv3Wrapper(d3._deeplabv3plus(3, 8, (1, 1, 1, 1)))
+    unet = lambda: network_architectures.seg.get('resnet50unet_imagenet')(2, pretrained=False)
+    for mk, want in ((v2, False), (v3, False), (unet, True)):
+        stu, tea = mk(), mk()
+        assert CutMixMeanTeacherStep(stu, tea, None, None, StepConfig())._graph_wanted() is want
+        assert vat.VATMeanTeacherStep(stu, tea, None, None, vat.VATConfig()).use_graph is want
+    stu, tea = unet(), unet()
+    mixed = CutMixMeanTeacherStep(stu, v2(), None, None, StepConfig())          # one of the two on an executor: launch by launch
+    assert not mixed._graph_wanted()
+    step = CutMixMeanTeacherStep(stu, tea, None, None, StepConfig())
+    step.world = 2                                                              # data parallel: SyncBN exchanges are host operations
+    assert not step._graph_wanted()
+    step.world = 1
+    monkeypatch.setenv('CMS_STEP_GRAPH', '0')
+    assert not step._graph_wanted()
+    monkeypatch.setenv('CMS_STEP_GRAPH', '1')
+    assert CutMixMeanTeacherStep(v2(), v2(), None, None, StepConfig())._graph_wanted()
+    monkeypatch.setenv('CMS_VAT_GRAPH', '0')
+    assert not vat.VATMeanTeacherStep(stu, tea, None, None, vat.VATConfig()).use_graph
+    monkeypatch.setenv('CMS_VAT_GRAPH', '1')
+    assert vat.VATMeanTeacherStep(v2(), v2(), None, None, vat.VATConfig()).use_graph
