@@ -156,6 +156,7 @@ PROTOTYPES = {
     'cms_conv_igemm_stats_tile_rows': (c_int, [_P(ConvDesc)]),
     'cms_bn_finalize_tiles': (c_int, [c_void_p, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cms_frozen_bn_act_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     'cms_bn_apply_groups_bits': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_size_t, c_int, c_int,
                                          c_void_p, c_void_p]),
     'cms_bn_reduce_ws_bits': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int,

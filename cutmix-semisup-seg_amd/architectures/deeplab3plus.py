@@ -25,6 +25,8 @@ samples of a batch are not independent, so the training step keeps the reference
 (step.py: fuse_batches=False). The backbone on the hand-written MFMA convolution kernels is the next step for this
 row.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -283,7 +285,36 @@ class HipConvEngine(LayerEngine):
             if not (yh.is_contiguous() and y.shape[1] % 8 == 0 and bn.momentum is not None and bn.running_mean is not None):
                 raise RuntimeError('engine_kind = "hip": BatchNorm over {} channels ({}) has no hand-written kernel '
                                    '(channels-last input with channels % 8 == 0 needed)'.format(y.shape[1], bn))
+        if bn is not None and bn.training:
+            self.__dict__.get('_frozen_affines', {}).pop(id(bn), None)      # (its running statistics move: a cached affine is stale)
+        if (bn is not None and not bn.training and y.is_cuda and y.shape[1] % 8 == 0 and not bn.weight.requires_grad
+                and not bn.bias.requires_grad and bn.running_mean is not None and y.dtype in (torch.bfloat16, torch.float32)
+                and os.environ.get('CMS_FROZEN_BN_FUSED', '1') != '0'):
+            # (round 6) eval-mode BatchNorm with a non-trainable affine (the teacher of the VAT trainer: three passes over ~170 such
+            # layers per iteration of the DenseNet-161 U-Net) as ONE launch: the tensor-op form below is ~9 launches forward (rsqrt,
+            # two multiplies, subtract, two casts, addcmul, add, ReLU) and 4 backward. scale / shift: once per weight version.
+            yh = y.permute(0, 2, 3, 1)
+            if yh.is_contiguous():
+                rh = None
+                if residual is not None:
+                    rh = residual.permute(0, 2, 3, 1)
+                    rh = rh if rh.is_contiguous() else rh.contiguous()
+                scale, shift = self._frozen_affine(bn)
+                return ops.frozen_bn_act(yh, scale, shift, relu=relu, res=rh).permute(0, 3, 1, 2)
         return super(HipConvEngine, self).bn_act(y, bn, relu, residual)
+
+    def _frozen_affine(self, bn):
+        """fp32 (scale, shift) of an eval-mode BatchNorm, cached per weight version of the network's arena (optimizer / EMA steps
+        `touch()` it; a capture into a hipGraph marks it stale first, so the refresh is part of the graph)."""
+        cache = self.__dict__.setdefault('_frozen_affines', {})
+        hit = cache.get(id(bn))
+        if hit is not None and hit[0] == self.arena.version:
+            return hit[1], hit[2]
+        with torch.no_grad():
+            scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+            shift = bn.bias.float() - bn.running_mean.float() * scale
+        cache[id(bn)] = (self.arena.version, scale, shift)
+        return scale, shift
 
     def aspp_head(self, x, convs):
         """DeepLab v2's head (deeplab2.py:124-128: the live dilated 3x3 branches, class axis padded to 64, summed; biases

@@ -822,6 +822,48 @@ extern "C" int cms_bn_apply_groups_bits(const void* x, const void* res, void* y,
     return launch_status("cms_bn_apply");
 }
 
+// Backward of y = relu(x * scale + shift (+ res)) over FROZEN statistics (eval-mode BatchNorm as an affine, the teacher of the VAT
+// trainer: architectures/deeplab2.py LayerEngine.bn_act): dx = scale * dy', dres = dy' with dy' = dy * [y > 0] (relu) or dy.
+// One launch where the tensor-op form took four (mask, multiply, two casts). y == NULL: no ReLU.
+template <class T>
+__global__ __launch_bounds__(256) void frozen_bn_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                            T* __restrict__ dres, const float* __restrict__ scale, size_t P, int C) {
+    const int CG = C / 8;
+    const size_t total = P * CG;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        float d[8], sc[8], yv[8];
+        load8(dy + i * 8, d);
+        load8(scale + cg * 8, sc);
+        if (y) {
+            load8(y + i * 8, yv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = yv[e] > 0.0f ? d[e] : 0.0f;
+        }
+        if (dres) store8(dres + i * 8, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] *= sc[e];
+        store8(dx + i * 8, d);
+    }
+}
+
+extern "C" int cms_frozen_bn_act_bwd(const void* dy, const void* y, void* dx, void* dres, int dtype, const float* scale,
+                                     size_t n_pixels, int c, void* stream) {
+    CMS_REQUIRE(dy && dx && scale, "frozen_bn_act_bwd: NULL pointer");
+    CMS_REQUIRE(dtype == CMS_F32 || dtype == CMS_BF16, "frozen_bn_act_bwd: bad dtype");
+    CMS_REQUIRE(bn_geo_ok(n_pixels, c), "frozen_bn_act_bwd: bad geometry (channels %% 8 == 0)");
+    const size_t total = n_pixels * (size_t)(c / 8);
+    const dim3 grid((unsigned)grid_for(total, 256, 256 * 16));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CMS_F32)
+        hipLaunchKernelGGL(frozen_bn_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)y, (float*)dx, (float*)dres,
+                           scale, n_pixels, c);
+    else
+        hipLaunchKernelGGL(frozen_bn_bwd_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)dy, (const uint16_t*)y, (uint16_t*)dx,
+                           (uint16_t*)dres, scale, n_pixels, c);
+    return launch_status("cms_frozen_bn_act_bwd");
+}
+
 extern "C" int cms_bn_apply(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
                             size_t n_pixels, int c, void* stream) {
     return cms_bn_apply_groups(x, res, y, dtype, scale, shift, relu, n_pixels, c, 1, stream);

@@ -924,6 +924,46 @@ class _BatchNormActFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None
 
 
+class _FrozenBnActFn(torch.autograd.Function):
+    """relu(x * scale + shift (+ res)) on contiguous NHWC tensors, scale / shift fp32 [C] WITHOUT gradient (an eval-mode BatchNorm whose
+    affine does not train: the teacher of the VAT trainer): one launch forward (cms_bn_apply), one backward (cms_frozen_bn_act_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, res, relu):
+        n_pix = x.numel() // x.shape[-1]
+        c = int(x.shape[-1])
+        y = torch.empty_like(x)
+        check(fn['cms_bn_apply_groups_bits'](_ptr(x), _ptr(res) if res is not None else None, _ptr(y), _dtype_code(x), _ptr(scale), _ptr(shift),
+                                             int(bool(relu)), n_pix, c, 1, None, _stream()), 'cms_bn_apply')
+        ctx.save_for_backward(scale, y if relu else None)
+        ctx.geo = (n_pix, c, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        scale, y = ctx.saved_tensors
+        n_pix, c, has_res = ctx.geo
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(dy)
+        dres = torch.empty_like(dy) if (has_res and ctx.needs_input_grad[3]) else None
+        check(fn['cms_frozen_bn_act_bwd'](_ptr(dy), _ptr(y) if y is not None else None, _ptr(dx), _ptr(dres) if dres is not None else None,
+                                          _dtype_code(dy), _ptr(scale), n_pix, c, _stream()), 'cms_frozen_bn_act_bwd')
+        return dx, None, None, dres, None
+
+
+def frozen_bn_act(x_nhwc, scale, shift, relu=False, res=None):
+    """relu(x * scale + shift (+ res)): an eval-mode BatchNorm (+ residual, + ReLU) with a non-trainable affine on a contiguous NHWC
+    bf16 / fp32 tensor (channels % 8 == 0); scale, shift fp32 [C]."""
+    _need_cuda(x_nhwc, scale, shift, res)
+    if not x_nhwc.is_contiguous() or x_nhwc.shape[-1] % 8 != 0 or x_nhwc.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError('frozen_bn_act: contiguous NHWC bf16 / fp32 tensor with channels % 8 == 0 required')
+    if res is not None and (res.shape != x_nhwc.shape or res.dtype != x_nhwc.dtype or not res.is_contiguous()):
+        raise ValueError('frozen_bn_act: residual must match the input')
+    if scale.dtype != torch.float32 or shift.dtype != torch.float32 or scale.numel() != x_nhwc.shape[-1] or shift.numel() != x_nhwc.shape[-1]:
+        raise ValueError('frozen_bn_act: fp32 scale / shift of one value per channel required')
+    return _FrozenBnActFn.apply(x_nhwc, scale.contiguous(), shift.contiguous(), res, bool(relu))
+
+
 def batch_norm_act(x_nhwc, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=False, res=None,
                    group=None, groups=1):
     """nn.BatchNorm2d in training mode (+ residual add, + ReLU) on a contiguous NHWC tensor (channels %% 8 == 0).

@@ -538,6 +538,11 @@ int cms_bn_bwd_apply_groups(const void* x, const void* dy, const void* y, void* 
  * (cms_bn_bwd_apply_groups_bits: mask_bits == NULL falls back to y.) Results are bit-identical to the y-masked calls. */
 int cms_bn_apply_groups_bits(const void* x, const void* res, void* y, int dtype, const float* scale, const float* shift, int relu,
                              size_t n_pixels, int c, int groups, uint8_t* mask_bits_out, void* stream);
+/* Backward of y = relu(x * scale + shift (+ res)) with FROZEN statistics (an eval-mode BatchNorm as an affine: the forward is
+ * cms_bn_apply with scale = gamma * rstd, shift = beta - mean * scale; architectures/deeplab2.py LayerEngine.bn_act, the teacher of
+ * train_seg_semisup_vat_mt.py:237): dx = scale * dy', dres = dy' (or NULL), dy' = dy * [y > 0] (y = the forward's output; NULL: no ReLU). */
+int cms_frozen_bn_act_bwd(const void* dy, const void* y, void* dx, void* dres, int dtype, const float* scale, size_t n_pixels, int c,
+                          void* stream);
 int cms_bn_reduce_ws_bits(const void* x, const void* dy, const uint8_t* mask_bits, int dtype, const float* mean, const float* rstd,
                           double* sums, size_t n_pixels, int c, int groups, void* ws, void* stream);
 int cms_bn_bwd_apply_groups_bits(const void* x, const void* dy, const void* y, const uint8_t* mask_bits, void* dx, void* dres,

@@ -371,3 +371,30 @@ def test_relu_mask_bits_replace_y_in_the_backward_passes_bit_for_bit(C, dtype, w
         out[key] = (sums.clone(), dx, dres)
     for a, b in zip(out['y'], out['bits']):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32], ids=['bf16', 'fp32'])
+@pytest.mark.parametrize('relu,with_res', [(True, True), (True, False), (False, False), (False, True)])
+def test_frozen_bn_act_one_launch_vs_tensor_ops(dtype, relu, with_res):
+    """(round 6) ops.frozen_bn_act -- an eval-mode BatchNorm with a non-trainable affine (+ residual, + ReLU) as one launch forward and
+    one backward (cms_bn_apply / cms_frozen_bn_act_bwd) -- against the fp64 formula: output, gradient wrt the input and the residual."""
+    from cutmix_semisup_seg_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(11)
+    n, h, w, c = 3, 17, 19, 64
+    x = torch.randn(n, h, w, c, generator=g, device=DEV).to(dtype).requires_grad_(True)
+    res = torch.randn(n, h, w, c, generator=g, device=DEV).to(dtype).requires_grad_(True) if with_res else None
+    scale = torch.rand(c, generator=g, device=DEV) + 0.5
+    shift = torch.randn(c, generator=g, device=DEV)
+    dy = torch.randn(n, h, w, c, generator=g, device=DEV).to(dtype)
+    y = ops.frozen_bn_act(x, scale, shift, relu=relu, res=res)
+    y.backward(dy)
+    xd = x.detach().double()
+    v = xd * scale.double() + shift.double() + (res.detach().double() if with_res else 0.0)
+    want = v.clamp_min(0.0) if relu else v
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert float((y.double() - want).abs().max()) <= tol * (1.0 + float(want.abs().max()))
+    mask = (y.detach() > 0).double() if relu else torch.ones_like(want)        # (the kernel masks with the STORED output)
+    dyd = dy.double() * mask
+    assert float((x.grad.double() - dyd * scale.double()).abs().max()) <= tol * (1.0 + float(dyd.abs().max()) * 1.5)
+    if with_res:
+        assert float((res.grad.double() - dyd).abs().max()) <= tol * (1.0 + float(dyd.abs().max()))
